@@ -1,0 +1,74 @@
+// Shared helpers for the gfx950 kernels behind include/catgan.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/catgan.h"
+
+namespace cg {
+
+// thread-local error string returned by cg_last_error()
+char* err_buf();
+int fail(const char* fmt, ...);
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define CG_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t e__ = (call);                                                  \
+        if (e__ != hipSuccess)                                                    \
+            return cg::fail("%s:%d %s -> %s", __FILE__, __LINE__, #call,          \
+                            hipGetErrorString(e__));                              \
+    } while (0)
+
+#define CG_LAUNCH_CHECK()                                                         \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess)                                                    \
+            return cg::fail("%s:%d kernel launch -> %s", __FILE__, __LINE__,      \
+                            hipGetErrorString(e__));                              \
+    } while (0)
+
+#define CG_REQUIRE(cond, ...)                                                     \
+    do {                                                                          \
+        if (!(cond)) return cg::fail(__VA_ARGS__);                                \
+    } while (0)
+
+constexpr int kNumCU = 256;  // MI355X: 8 XCDs x 32 CUs
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// grid for memory-bound grid-stride kernels: enough blocks to fill 256 CUs x 8
+static inline int ew_grid(long n, int per_block = 256) {
+    long b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > kNumCU * 8) b = kNumCU * 8;
+    return (int)b;
+}
+
+// ---- device-side helpers -------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-wide sum for 256-thread blocks; result valid in thread 0
+__device__ __forceinline__ double block_sum_256(double v, double* sh /*[4]*/) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+
+}  // namespace cg

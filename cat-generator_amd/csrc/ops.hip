@@ -1,0 +1,824 @@
+// Memory-bound kernels of the G+D step (everything that is not a GEMM):
+// activations, BCE, batch-norm, pooling, dropout, layout changes, spatial
+// transformer pieces, fused penalty+clamp+Adam, small reductions.  NHWC fp32.
+// Each kernel cites the reference module it stands in for (see catgan.h).
+#include "common.h"
+#include <stdarg.h>
+
+namespace cg {
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return 1;
+}
+}  // namespace cg
+
+namespace {
+using cg::block_sum_256;
+using cg::wave_sum;
+
+#define GRID_STRIDE(i, n) \
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------- activations
+__global__ void prelu_fwd_k(const float* x, const float* alpha, float* y, long n) {
+    const float a = *alpha;
+    GRID_STRIDE(i, n) {
+        const float v = x[i];
+        y[i] = v > 0.f ? v : a * v;
+    }
+}
+__global__ void prelu_bwd_k(const float* x, const float* dy, const float* alpha, float* dx, float* galpha, float scale,
+                            long n) {
+    __shared__ double sh[4];
+    const float a = *alpha;
+    float s = 0.f;
+    GRID_STRIDE(i, n) {
+        const float v = x[i], g = dy[i];
+        dx[i] = v > 0.f ? g : a * g;
+        if (v <= 0.f) s += v * g;
+    }
+    const double t = block_sum_256((double)s, sh);
+    if (threadIdx.x == 0 && galpha) atomicAdd(galpha, (float)(t * scale));
+}
+__global__ void lrelu_fwd_k(const float* x, float* y, float s, long n) {
+    GRID_STRIDE(i, n) {
+        const float v = x[i];
+        y[i] = v >= 0.f ? v : s * v;
+    }
+}
+__global__ void lrelu_bwd_k(const float* x, const float* dy, float* dx, float s, long n) {
+    GRID_STRIDE(i, n) { dx[i] = x[i] >= 0.f ? dy[i] : s * dy[i]; }
+}
+__global__ void sigmoid_fwd_k(const float* x, float* y, long n) {
+    GRID_STRIDE(i, n) { y[i] = 1.f / (1.f + expf(-x[i])); }
+}
+__global__ void sigmoid_bwd_k(const float* y, const float* dy, float* dx, long n) {
+    GRID_STRIDE(i, n) {
+        const float v = y[i];
+        dx[i] = dy[i] * (1.f - v) * v;
+    }
+}
+
+// ------------------------------------------------------------------------ BCE
+__global__ void bce_fwd_k(const float* p, const float* t, float* loss, long n) {
+    // single block: n is the batch size
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+        const float x = p[i], y = t[i];
+        s -= (double)(logf(x + 1e-12f) * y + logf(1.f - x + 1e-12f) * (1.f - y));
+    }
+    const double tot = block_sum_256(s, sh);
+    if (threadIdx.x == 0) *loss = (float)(tot / (double)n);
+}
+__global__ void bce_bwd_k(const float* p, const float* t, float* dp, long n) {
+    const float norm = 1.f / (float)n;
+    GRID_STRIDE(i, n) {
+        const float x = p[i], y = t[i];
+        dp[i] = -norm * (y - x) / ((1.f - x + 1e-12f) * (x + 1e-12f));
+    }
+}
+
+// ------------------------------------------------------------- column reduces
+// x: [M][C].  grid = (ceil(C/64), row chunks); block = 64 channels x 4 row lanes.
+// MODE 0: (x, x^2)   MODE 1: (dy, dy*xhat)   MODE 2: (dy, 0)
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_k(const float* x, const float* dy, const float* mean,
+                                                   const float* invstd, long M, int C, long rows_per_block,
+                                                   double* sums) {
+    __shared__ double sh1[4][64], sh2[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C) {
+        float s1 = 0.f, s2 = 0.f;
+        float mu = 0.f, is = 0.f;
+        if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+        int cnt = 0;
+        for (long r = r0 + rl; r < r1; r += 4) {
+            const long i = r * C + c;
+            if (MODE == 0) {
+                const float v = x[i];
+                s1 += v; s2 += v * v;
+            } else if (MODE == 1) {
+                const float g = dy[i];
+                s1 += g; s2 += g * ((x[i] - mu) * is);
+            } else {
+                s1 += dy[i];
+            }
+            if (++cnt == 64) {  // bound fp32 partial length
+                a1 += s1; a2 += s2; s1 = 0.f; s2 = 0.f; cnt = 0;
+            }
+        }
+        a1 += s1; a2 += s2;
+    }
+    sh1[rl][cl] = a1; sh2[rl][cl] = a2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const double t1 = sh1[0][cl] + sh1[1][cl] + sh1[2][cl] + sh1[3][cl];
+        const double t2 = sh2[0][cl] + sh2[1][cl] + sh2[2][cl] + sh2[3][cl];
+        atomicAdd(&sums[c], t1);
+        if (MODE != 2) atomicAdd(&sums[C + c], t2);
+    }
+}
+
+__global__ void bias_grad_finish_k(const double* sums, float* gb, int C, float scale) {
+    GRID_STRIDE(c, C) { gb[c] += scale * (float)sums[c]; }
+}
+
+// --------------------------------------------------------------- batch-norm
+__global__ void bn_prepare_k(const double* sums, double count, int C, float eps, float momentum, float* running_mean,
+                             float* running_var, float* save_mean, float* save_invstd) {
+    GRID_STRIDE(c, C) {
+        const double mean = sums[c] / count;
+        double var = sums[C + c] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        save_mean[c] = (float)mean;
+        save_invstd[c] = invstd;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        if (running_var) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+__global__ void bn_apply_k(const float* x, float* y, const float* gamma, const float* beta, const float* mean,
+                           const float* invstd, long total, int C) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        y[i] = (x[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+    }
+}
+__global__ void bn_eval_k(const float* x, float* y, const float* gamma, const float* beta, const float* rm,
+                          const float* rv, long total, int C, float eps) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        y[i] = (x[i] - rm[c]) / sqrtf(rv[c] + eps) * gamma[c] + beta[c];
+    }
+}
+__global__ void bn_bwd_k(const float* x, const float* dy, const float* gamma, const float* mean, const float* invstd,
+                         const double* sums, double count, long total, int C, float* dx) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const float is = invstd[c];
+        const float xh = (x[i] - mean[c]) * is;
+        const float m1 = (float)(sums[c] / count);
+        const float m2 = (float)(sums[C + c] / count);
+        dx[i] = gamma[c] * is * (dy[i] - m1 - xh * m2);
+    }
+}
+__global__ void bn_bwd_param_k(const double* local_sums, int C, float* ggamma, float* gbeta, float scale) {
+    GRID_STRIDE(c, C) {
+        if (gbeta) gbeta[c] += scale * (float)local_sums[c];
+        if (ggamma) ggamma[c] += scale * (float)local_sums[C + c];
+    }
+}
+
+// ------------------------------------------------------- resampling / pooling
+__global__ void ups2_fwd_k(const float* x, float* y, int N, int H, int W, int C) {
+    const long total = (long)N * 2 * H * 2 * W * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int ox = (int)(r % (2 * W)); r /= (2 * W);
+        const int oy = (int)(r % (2 * H));
+        const long n = r / (2 * H);
+        y[i] = x[((n * H + (oy >> 1)) * W + (ox >> 1)) * C + c];
+    }
+}
+__global__ void ups2_bwd_k(const float* dy, float* dx, int N, int H, int W, int C) {
+    const long total = (long)N * H * W * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const long n = r / H;
+        const long W2 = 2 * W;
+        const long b = ((n * 2 * H + 2 * yy) * W2 + 2 * xx) * C + c;
+        dx[i] = (dy[b] + dy[b + C]) + (dy[b + W2 * C] + dy[b + W2 * C + C]);
+    }
+}
+template <bool MAX>
+__global__ void pool2_fwd_k(const float* x, float* y, int N, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)N * Ho * Wo * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const long n = r / Ho;
+        const long b = ((n * H + 2 * oy) * W + 2 * ox) * C + c;
+        const float v00 = x[b], v01 = x[b + C], v10 = x[b + (long)W * C], v11 = x[b + (long)W * C + C];
+        if (MAX) {
+            float m = v00;
+            if (v01 > m) m = v01;
+            if (v10 > m) m = v10;
+            if (v11 > m) m = v11;
+            y[i] = m;
+        } else {
+            y[i] = (v00 + v01 + v10 + v11) * 0.25f;
+        }
+    }
+}
+__global__ void avgpool2_bwd_k(const float* dy, float* dx, int N, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)N * H * W * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const long n = r / H;
+        float v = 0.f;
+        if ((yy >> 1) < Ho && (xx >> 1) < Wo) v = dy[((n * Ho + (yy >> 1)) * Wo + (xx >> 1)) * C + c] * 0.25f;
+        dx[i] = v;
+    }
+}
+__global__ void maxpool2_bwd_k(const float* x, const float* dy, float* dx, int N, int H, int W, int C) {
+    // one thread per pooled output: route the gradient to the first max in scan order
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)N * Ho * Wo * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const long n = r / Ho;
+        const long b = ((n * H + 2 * oy) * W + 2 * ox) * C + c;
+        const long o01 = C, o10 = (long)W * C, o11 = (long)W * C + C;
+        const float v00 = x[b], v01 = x[b + o01], v10 = x[b + o10], v11 = x[b + o11];
+        int arg = 0; float m = v00;
+        if (v01 > m) { m = v01; arg = 1; }
+        if (v10 > m) { m = v10; arg = 2; }
+        if (v11 > m) { m = v11; arg = 3; }
+        const float g = dy[i];
+        dx[b] = arg == 0 ? g : 0.f;
+        dx[b + o01] = arg == 1 ? g : 0.f;
+        dx[b + o10] = arg == 2 ? g : 0.f;
+        dx[b + o11] = arg == 3 ? g : 0.f;
+    }
+}
+
+// -------------------------------------------------------------------- dropout
+__global__ void mask_mul_k(const float* x, const float* mask, float* y, long total, long HWC, int C, int spatial) {
+    GRID_STRIDE(i, total) {
+        float m;
+        if (spatial) {
+            const long n = i / HWC;
+            m = mask[n * C + (i % C)];
+        } else {
+            m = mask[i];
+        }
+        y[i] = x[i] * m;
+    }
+}
+__device__ __forceinline__ float u01(uint64_t seed, uint64_t ctr) {
+    // splitmix64 of (seed, counter); 24-bit mantissa uniform in [0,1)
+    uint64_t z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__global__ void rng_bernoulli_k(float* out, long n, float keep, float value, uint64_t seed, uint64_t offset) {
+    GRID_STRIDE(i, n) { out[i] = u01(seed, offset + (uint64_t)i) < keep ? value : 0.f; }
+}
+__global__ void rng_uniform_k(float* out, long n, float lo, float hi, uint64_t seed, uint64_t offset) {
+    GRID_STRIDE(i, n) { out[i] = lo + (hi - lo) * u01(seed, offset + (uint64_t)i); }
+}
+
+// --------------------------------------------------------------------- layout
+__global__ void nchw_to_nhwc_k(const float* in, float* out, int N, int C, int H, int W) {
+    const long total = (long)N * C * H * W;
+    GRID_STRIDE(i, total) {  // i indexes the NHWC output
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const long n = r / H;
+        out[i] = in[((n * C + c) * H + y) * W + x];
+    }
+}
+__global__ void nhwc_to_nchw_k(const float* in, float* out, int N, int C, int H, int W) {
+    const long total = (long)N * C * H * W;
+    GRID_STRIDE(i, total) {  // i indexes the NCHW output
+        const int x = (int)(i % W);
+        long r = i / W;
+        const int y = (int)(r % H); r /= H;
+        const int c = (int)(r % C);
+        const long n = r / C;
+        out[i] = in[((n * H + y) * W + x) * C + c];
+    }
+}
+__global__ void copy_channels_k(const float* src, float* dst, long M, int Csrc, int so, int Cdst, int dof, int Cc) {
+    const long total = M * Cc;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % Cc);
+        const long m = i / Cc;
+        dst[m * Cdst + dof + c] = src[m * Csrc + so + c];
+    }
+}
+__global__ void gather_rows_k(const float* src, const int32_t* idx, float* dst, long nrows, long rowlen) {
+    const long total = nrows * rowlen;
+    GRID_STRIDE(i, total) {
+        const long r = i / rowlen, j = i - r * rowlen;
+        dst[i] = src[(long)idx[r] * rowlen + j];
+    }
+}
+__global__ void fill_k(float* x, float v, long n) { GRID_STRIDE(i, n) x[i] = v; }
+__global__ void add_k(const float* a, const float* b, float* o, long n) { GRID_STRIDE(i, n) o[i] = a[i] + b[i]; }
+__global__ void axpy_k(float al, const float* x, float* y, long n) { GRID_STRIDE(i, n) y[i] += al * x[i]; }
+__global__ void scale_k(float* x, float al, long n) { GRID_STRIDE(i, n) x[i] *= al; }
+__global__ void clamp_k(float* x, float lo, float hi, long n) {
+    GRID_STRIDE(i, n) { x[i] = fminf(fmaxf(x[i], lo), hi); }
+}
+template <bool SQ>
+__global__ void sumred_k(const float* x, long n, double* out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    GRID_STRIDE(i, n) {
+        const float v = x[i];
+        s += SQ ? (double)v * (double)v : (double)fabsf(v);
+    }
+    const double t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) atomicAdd(out, t);
+}
+
+// -------------------------------------------------------- spatial transformer
+// T = R(theta) * S(s) * Tr(tx,ty); rows: [c*s, -sn*s, c*s*tx - sn*s*ty], [sn*s, c*s, sn*s*tx + c*s*ty]
+__global__ void affine_matrix_fwd_k(const float* params, float* T, int N, int ur, int us, int ut) {
+    const int P = ur + us + 2 * ut;
+    GRID_STRIDE(n, N) {
+        const float* p = params + (long)n * P;
+        int k = 0;
+        float th = 0.f, sc = 1.f, tx = 0.f, ty = 0.f;
+        if (ur) th = p[k++];
+        if (us) sc = p[k++];
+        if (ut) { tx = p[k]; ty = p[k + 1]; }
+        const float c = cosf(th), s = sinf(th);
+        float* t = T + (long)n * 6;
+        t[0] = c * sc;  t[1] = -s * sc; t[2] = c * sc * tx - s * sc * ty;
+        t[3] = s * sc;  t[4] = c * sc;  t[5] = s * sc * tx + c * sc * ty;
+    }
+}
+__global__ void affine_matrix_bwd_k(const float* params, const float* gT, float* gparams, int N, int ur, int us, int ut) {
+    const int P = ur + us + 2 * ut;
+    GRID_STRIDE(n, N) {
+        const float* p = params + (long)n * P;
+        int k = 0;
+        float th = 0.f, sc = 1.f, tx = 0.f, ty = 0.f;
+        if (ur) th = p[k++];
+        if (us) sc = p[k++];
+        if (ut) { tx = p[k]; ty = p[k + 1]; }
+        const float c = cosf(th), s = sinf(th);
+        const float* g = gT + (long)n * 6;
+        float* gp = gparams + (long)n * P;
+        k = 0;
+        if (ur) {
+            // d/dtheta: c -> -s, s -> c
+            const float d0 = -s * sc, d1 = -c * sc, d2 = -s * sc * tx - c * sc * ty;
+            const float d3 = c * sc, d4 = -s * sc, d5 = c * sc * tx - s * sc * ty;
+            gp[k++] = g[0] * d0 + g[1] * d1 + g[2] * d2 + g[3] * d3 + g[4] * d4 + g[5] * d5;
+        }
+        if (us) {
+            gp[k++] = g[0] * c + g[1] * (-s) + g[2] * (c * tx - s * ty) + g[3] * s + g[4] * c + g[5] * (s * tx + c * ty);
+        }
+        if (ut) {
+            gp[k] = g[2] * (c * sc) + g[5] * (s * sc);
+            gp[k + 1] = g[2] * (-s * sc) + g[5] * (c * sc);
+        }
+    }
+}
+__global__ void affine_grid_fwd_k(const float* T, float* grid, int N, int H, int W) {
+    const long total = (long)N * H * W;
+    GRID_STRIDE(i, total) {
+        const int j = (int)(i % W);
+        long r = i / W;
+        const int ii = (int)(r % H);
+        const long n = r / H;
+        const float y = H > 1 ? -1.f + 2.f * (float)ii / (float)(H - 1) : -1.f;
+        const float x = W > 1 ? -1.f + 2.f * (float)j / (float)(W - 1) : -1.f;
+        const float* t = T + n * 6;
+        grid[i * 2 + 0] = t[0] * y + t[1] * x + t[2];
+        grid[i * 2 + 1] = t[3] * y + t[4] * x + t[5];
+    }
+}
+// one block per sample: gT[n][r][:] = sum_{i,j} ggrid[n,i,j,r] * (y_i, x_j, 1)
+__global__ __launch_bounds__(256) void affine_grid_bwd_k(const float* ggrid, float* gT, int N, int H, int W) {
+    __shared__ double sh[4];
+    const int n = blockIdx.x;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const int HW = H * W;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        const int ii = p / W, j = p - ii * W;
+        const float y = H > 1 ? -1.f + 2.f * (float)ii / (float)(H - 1) : -1.f;
+        const float x = W > 1 ? -1.f + 2.f * (float)j / (float)(W - 1) : -1.f;
+        const float g0 = ggrid[((long)n * HW + p) * 2 + 0];
+        const float g1 = ggrid[((long)n * HW + p) * 2 + 1];
+        acc[0] += g0 * y; acc[1] += g0 * x; acc[2] += g0;
+        acc[3] += g1 * y; acc[4] += g1 * x; acc[5] += g1;
+    }
+    for (int k = 0; k < 6; ++k) {
+        const double t = block_sum_256(acc[k], sh);
+        if (threadIdx.x == 0) gT[(long)n * 6 + k] = (float)t;
+    }
+}
+
+struct BilinTaps {
+    int y0, x0;
+    float wy0, wx0;  // weight of the top / left tap
+    bool in00, in01, in10, in11;
+};
+__device__ __forceinline__ BilinTaps bilin_taps(float yf, float xf, int Hi, int Wi) {
+    BilinTaps t;
+    const float xc = (xf + 1.f) * (float)(Wi - 1) * 0.5f;
+    const float yc = (yf + 1.f) * (float)(Hi - 1) * 0.5f;
+    const float x0f = floorf(xc), y0f = floorf(yc);
+    t.x0 = (int)x0f; t.y0 = (int)y0f;
+    t.wx0 = 1.f - (xc - x0f);
+    t.wy0 = 1.f - (yc - y0f);
+    const bool xin0 = t.x0 >= 0 && t.x0 <= Wi - 1, xin1 = t.x0 + 1 >= 0 && t.x0 + 1 <= Wi - 1;
+    const bool yin0 = t.y0 >= 0 && t.y0 <= Hi - 1, yin1 = t.y0 + 1 >= 0 && t.y0 + 1 <= Hi - 1;
+    t.in00 = yin0 && xin0; t.in01 = yin0 && xin1; t.in10 = yin1 && xin0; t.in11 = yin1 && xin1;
+    return t;
+}
+__global__ void bilinear_fwd_k(const float* img, const float* grid, float* out, int N, int Hi, int Wi, int C, int Ho,
+                               int Wo) {
+    const long total = (long)N * Ho * Wo * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        const long pix = i / C;
+        const long n = pix / ((long)Ho * Wo);
+        const BilinTaps t = bilin_taps(grid[pix * 2], grid[pix * 2 + 1], Hi, Wi);
+        const float* b = img + (((n * Hi + t.y0) * (long)Wi + t.x0)) * C + c;
+        float v = 0.f;
+        if (t.in00) v += t.wx0 * t.wy0 * b[0];
+        if (t.in01) v += (1.f - t.wx0) * t.wy0 * b[C];
+        if (t.in10) v += t.wx0 * (1.f - t.wy0) * b[(long)Wi * C];
+        if (t.in11) v += (1.f - t.wx0) * (1.f - t.wy0) * b[(long)Wi * C + C];
+        out[i] = v;
+    }
+}
+// one wave per output pixel; lanes stride the channels
+__global__ __launch_bounds__(256) void bilinear_bwd_k(const float* img, const float* grid, const float* gout,
+                                                      float* gimg, float* ggrid, int N, int Hi, int Wi, int C, int Ho,
+                                                      int Wo) {
+    const long npix = (long)N * Ho * Wo;
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long pix = wave0; pix < npix; pix += nwaves) {
+        const long n = pix / ((long)Ho * Wo);
+        const BilinTaps t = bilin_taps(grid[pix * 2], grid[pix * 2 + 1], Hi, Wi);
+        const long b = ((n * Hi + t.y0) * (long)Wi + t.x0) * C;
+        const long o01 = C, o10 = (long)Wi * C, o11 = (long)Wi * C + C;
+        float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float g = gout[pix * C + c];
+            if (t.in00) { d00 += img[b + c] * g;       atomicAdd(&gimg[b + c], t.wx0 * t.wy0 * g); }
+            if (t.in01) { d01 += img[b + o01 + c] * g; atomicAdd(&gimg[b + o01 + c], (1.f - t.wx0) * t.wy0 * g); }
+            if (t.in10) { d10 += img[b + o10 + c] * g; atomicAdd(&gimg[b + o10 + c], t.wx0 * (1.f - t.wy0) * g); }
+            if (t.in11) { d11 += img[b + o11 + c] * g; atomicAdd(&gimg[b + o11 + c], (1.f - t.wx0) * (1.f - t.wy0) * g); }
+        }
+        d00 = wave_sum(d00); d01 = wave_sum(d01); d10 = wave_sum(d10); d11 = wave_sum(d11);
+        if (lane == 0) {
+            const float gy = -t.wx0 * d00 + t.wx0 * d10 - (1.f - t.wx0) * d01 + (1.f - t.wx0) * d11;
+            const float gx = -t.wy0 * d00 + t.wy0 * d01 - (1.f - t.wy0) * d10 + (1.f - t.wy0) * d11;
+            ggrid[pix * 2 + 0] = gy * (float)(Hi - 1) * 0.5f;
+            ggrid[pix * 2 + 1] = gx * (float)(Wi - 1) * 0.5f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ optimiser
+__global__ void adam_k(float* p, float* g, float* m, float* v, long n, float step, float b1, float b2, float eps,
+                       float l1, float l2, float clampv, int write_back) {
+    GRID_STRIDE(i, n) {
+        const float pi = p[i];
+        float gi = g[i];
+        if (l1 != 0.f || l2 != 0.f) {
+            const float sg = pi > 0.f ? 1.f : (pi < 0.f ? -1.f : 0.f);
+            gi += sg * l1 + pi * l2;
+        }
+        if (clampv > 0.f) gi = fminf(fmaxf(gi, -clampv), clampv);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = pi - step * mi / (sqrtf(vi) + eps);
+        if (write_back) g[i] = gi;
+    }
+}
+__global__ void confusion_k(const float* out, const float* tgt, int32_t* counts, long n) {
+    GRID_STRIDE(i, n) {
+        const int pred = out[i] > 0.5f ? 1 : 0;
+        const int t = tgt[i] > 0.5f ? 1 : 0;
+        atomicAdd(&counts[pred * 2 + t], 1);
+    }
+}
+
+}  // namespace
+
+#define EW_LAUNCH(kern, n, ...)                                                                  \
+    do {                                                                                         \
+        if ((n) > 0) {                                                                           \
+            hipLaunchKernelGGL(kern, dim3(cg::ew_grid(n)), dim3(256), 0, cg::S(stream), __VA_ARGS__); \
+            CG_LAUNCH_CHECK();                                                                   \
+        }                                                                                        \
+    } while (0)
+
+extern "C" {
+
+int cg_abi_version(void) { return CG_ABI_VERSION; }
+const char* cg_last_error(void) { return cg::err_buf(); }
+int cg_device_count(int* count) { CG_REQUIRE(count, "null"); CG_HIP(hipGetDeviceCount(count)); return 0; }
+int cg_set_device(int device) { CG_HIP(hipSetDevice(device)); return 0; }
+int cg_malloc(void** dptr, size_t bytes) { CG_REQUIRE(dptr, "null"); CG_HIP(hipMalloc(dptr, bytes)); return 0; }
+int cg_free(void* dptr) { CG_HIP(hipFree(dptr)); return 0; }
+int cg_memcpy_h2d(void* stream, void* dst, const void* src, size_t bytes) {
+    CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cg::S(stream))); return 0;
+}
+int cg_memcpy_d2h(void* stream, void* dst, const void* src, size_t bytes) {
+    CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cg::S(stream)));
+    CG_HIP(hipStreamSynchronize(cg::S(stream)));
+    return 0;
+}
+int cg_memcpy_d2d(void* stream, void* dst, const void* src, size_t bytes) {
+    CG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, cg::S(stream))); return 0;
+}
+int cg_memset_zero(void* stream, void* dst, size_t bytes) {
+    CG_HIP(hipMemsetAsync(dst, 0, bytes, cg::S(stream))); return 0;
+}
+int cg_stream_create(void** stream) {
+    CG_REQUIRE(stream, "null");
+    hipStream_t s; CG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = (void*)s; return 0;
+}
+int cg_stream_destroy(void* stream) { CG_HIP(hipStreamDestroy(cg::S(stream))); return 0; }
+int cg_stream_sync(void* stream) { CG_HIP(hipStreamSynchronize(cg::S(stream))); return 0; }
+
+int cg_prelu_forward(void* stream, const float* x, const float* alpha, float* y, long n) {
+    CG_REQUIRE(x && alpha && y, "cg_prelu_forward: null pointer");
+    EW_LAUNCH(prelu_fwd_k, n, x, alpha, y, n); return 0;
+}
+int cg_prelu_backward(void* stream, const float* x, const float* dy, const float* alpha, float* dx, float* galpha,
+                      float scale, long n) {
+    CG_REQUIRE(x && dy && alpha && dx, "cg_prelu_backward: null pointer");
+    EW_LAUNCH(prelu_bwd_k, n, x, dy, alpha, dx, galpha, scale, n); return 0;
+}
+int cg_leakyrelu_forward(void* stream, const float* x, float* y, float slope, long n) {
+    CG_REQUIRE(x && y, "cg_leakyrelu_forward: null pointer");
+    EW_LAUNCH(lrelu_fwd_k, n, x, y, slope, n); return 0;
+}
+int cg_leakyrelu_backward(void* stream, const float* x, const float* dy, float* dx, float slope, long n) {
+    CG_REQUIRE(x && dy && dx, "cg_leakyrelu_backward: null pointer");
+    EW_LAUNCH(lrelu_bwd_k, n, x, dy, dx, slope, n); return 0;
+}
+int cg_sigmoid_forward(void* stream, const float* x, float* y, long n) {
+    CG_REQUIRE(x && y, "cg_sigmoid_forward: null pointer");
+    EW_LAUNCH(sigmoid_fwd_k, n, x, y, n); return 0;
+}
+int cg_sigmoid_backward(void* stream, const float* y, const float* dy, float* dx, long n) {
+    CG_REQUIRE(y && dy && dx, "cg_sigmoid_backward: null pointer");
+    EW_LAUNCH(sigmoid_bwd_k, n, y, dy, dx, n); return 0;
+}
+int cg_bce_forward(void* stream, const float* p, const float* t, float* loss, long n) {
+    CG_REQUIRE(p && t && loss && n > 0, "cg_bce_forward: bad args");
+    hipLaunchKernelGGL(bce_fwd_k, dim3(1), dim3(256), 0, cg::S(stream), p, t, loss, n);
+    CG_LAUNCH_CHECK(); return 0;
+}
+int cg_bce_backward(void* stream, const float* p, const float* t, float* dp, long n) {
+    CG_REQUIRE(p && t && dp, "cg_bce_backward: null pointer");
+    EW_LAUNCH(bce_bwd_k, n, p, t, dp, n); return 0;
+}
+
+static int colreduce_launch(void* stream, int mode, const float* x, const float* dy, const float* mean,
+                            const float* invstd, long M, int C, double* sums, int nsums) {
+    CG_HIP(hipMemsetAsync(sums, 0, sizeof(double) * nsums * C, cg::S(stream)));
+    if (M <= 0) return 0;
+    const int cblocks = cg::cdiv(C, 64);
+    long rows_per_block = 256;
+    long chunks = (M + rows_per_block - 1) / rows_per_block;
+    const long max_chunks = (long)cg::kNumCU * 8 / cblocks > 0 ? (long)cg::kNumCU * 8 / cblocks : 1;
+    if (chunks > max_chunks) {
+        rows_per_block = ((M + max_chunks - 1) / max_chunks + 3) / 4 * 4;
+        chunks = (M + rows_per_block - 1) / rows_per_block;
+    }
+    dim3 grid(cblocks, (unsigned)chunks);
+    if (mode == 0) hipLaunchKernelGGL(colreduce_k<0>, grid, dim3(256), 0, cg::S(stream), x, dy, mean, invstd, M, C, rows_per_block, sums);
+    else if (mode == 1) hipLaunchKernelGGL(colreduce_k<1>, grid, dim3(256), 0, cg::S(stream), x, dy, mean, invstd, M, C, rows_per_block, sums);
+    else hipLaunchKernelGGL(colreduce_k<2>, grid, dim3(256), 0, cg::S(stream), x, dy, mean, invstd, M, C, rows_per_block, sums);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cg_bias_grad(void* stream, const float* dy, float* gb, long M, int C, float scale, void* ws, size_t ws_bytes) {
+    CG_REQUIRE(dy && gb && C > 0, "cg_bias_grad: bad args");
+    CG_REQUIRE(ws && ws_bytes >= sizeof(double) * (size_t)C, "cg_bias_grad: workspace too small");
+    double* scratch = (double*)ws;
+    if (colreduce_launch(stream, 2, nullptr, dy, nullptr, nullptr, M, C, scratch, 1)) return 1;
+    EW_LAUNCH(bias_grad_finish_k, (long)C, (const double*)scratch, gb, C, scale);
+    return 0;
+}
+
+int cg_bn_stats(void* stream, const float* x, long M, int C, double* sums) {
+    CG_REQUIRE(x && sums && C > 0, "cg_bn_stats: bad args");
+    return colreduce_launch(stream, 0, x, nullptr, nullptr, nullptr, M, C, sums, 2);
+}
+int cg_bn_forward(void* stream, const float* x, float* y, const float* gamma, const float* beta, const double* sums,
+                  double count, long M, int C, float eps, float momentum, float* running_mean, float* running_var,
+                  float* save_mean, float* save_invstd) {
+    CG_REQUIRE(x && y && gamma && beta && sums && save_mean && save_invstd && C > 0 && count > 0, "cg_bn_forward: bad args");
+    EW_LAUNCH(bn_prepare_k, (long)C, sums, count, C, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+    const long total = M * C;
+    EW_LAUNCH(bn_apply_k, total, x, y, gamma, beta, (const float*)save_mean, (const float*)save_invstd, total, C);
+    return 0;
+}
+int cg_bn_forward_eval(void* stream, const float* x, float* y, const float* gamma, const float* beta,
+                       const float* running_mean, const float* running_var, long M, int C, float eps) {
+    CG_REQUIRE(x && y && gamma && beta && running_mean && running_var && C > 0, "cg_bn_forward_eval: bad args");
+    const long total = M * C;
+    EW_LAUNCH(bn_eval_k, total, x, y, gamma, beta, running_mean, running_var, total, C, eps);
+    return 0;
+}
+int cg_bn_backward_stats(void* stream, const float* x, const float* dy, const float* save_mean, const float* save_invstd,
+                         long M, int C, double* sums) {
+    CG_REQUIRE(x && dy && save_mean && save_invstd && sums && C > 0, "cg_bn_backward_stats: bad args");
+    return colreduce_launch(stream, 1, x, dy, save_mean, save_invstd, M, C, sums, 2);
+}
+int cg_bn_backward(void* stream, const float* x, const float* dy, const float* gamma, const float* save_mean,
+                   const float* save_invstd, const double* sums, double count, const double* local_sums, long M, int C,
+                   float* dx, float* ggamma, float* gbeta, float scale) {
+    CG_REQUIRE(x && dy && gamma && save_mean && save_invstd && sums && local_sums && dx && C > 0 && count > 0,
+               "cg_bn_backward: bad args");
+    const long total = M * C;
+    EW_LAUNCH(bn_bwd_k, total, x, dy, gamma, save_mean, save_invstd, sums, count, total, C, dx);
+    EW_LAUNCH(bn_bwd_param_k, (long)C, local_sums, C, ggamma, gbeta, scale);
+    return 0;
+}
+
+int cg_upsample2x_forward(void* stream, const float* x, float* y, int N, int H, int W, int C) {
+    CG_REQUIRE(x && y, "cg_upsample2x_forward: null pointer");
+    const long total = (long)N * 4 * H * W * C;
+    EW_LAUNCH(ups2_fwd_k, total, x, y, N, H, W, C); return 0;
+}
+int cg_upsample2x_backward(void* stream, const float* dy, float* dx, int N, int H, int W, int C) {
+    CG_REQUIRE(dy && dx, "cg_upsample2x_backward: null pointer");
+    const long total = (long)N * H * W * C;
+    EW_LAUNCH(ups2_bwd_k, total, dy, dx, N, H, W, C); return 0;
+}
+int cg_avgpool2_forward(void* stream, const float* x, float* y, int N, int H, int W, int C) {
+    CG_REQUIRE(x && y, "cg_avgpool2_forward: null pointer");
+    const long total = (long)N * (H / 2) * (W / 2) * C;
+    EW_LAUNCH(pool2_fwd_k<false>, total, x, y, N, H, W, C); return 0;
+}
+int cg_avgpool2_backward(void* stream, const float* dy, float* dx, int N, int H, int W, int C) {
+    CG_REQUIRE(dy && dx, "cg_avgpool2_backward: null pointer");
+    const long total = (long)N * H * W * C;
+    EW_LAUNCH(avgpool2_bwd_k, total, dy, dx, N, H, W, C); return 0;
+}
+int cg_maxpool2_forward(void* stream, const float* x, float* y, int N, int H, int W, int C) {
+    CG_REQUIRE(x && y, "cg_maxpool2_forward: null pointer");
+    const long total = (long)N * (H / 2) * (W / 2) * C;
+    EW_LAUNCH(pool2_fwd_k<true>, total, x, y, N, H, W, C); return 0;
+}
+int cg_maxpool2_backward(void* stream, const float* x, const float* dy, float* dx, int N, int H, int W, int C) {
+    CG_REQUIRE(x && dy && dx, "cg_maxpool2_backward: null pointer");
+    CG_REQUIRE(H % 2 == 0 && W % 2 == 0, "cg_maxpool2_backward: odd spatial size");
+    const long total = (long)N * (H / 2) * (W / 2) * C;
+    EW_LAUNCH(maxpool2_bwd_k, total, x, dy, dx, N, H, W, C); return 0;
+}
+int cg_mask_mul(void* stream, const float* x, const float* mask, float* y, int N, long HW, int C, int spatial) {
+    CG_REQUIRE(x && mask && y, "cg_mask_mul: null pointer");
+    const long total = (long)N * HW * C;
+    EW_LAUNCH(mask_mul_k, total, x, mask, y, total, HW * C, C, spatial); return 0;
+}
+int cg_rng_bernoulli(void* stream, float* out, long n, float keep_prob, float value, uint64_t seed, uint64_t offset) {
+    CG_REQUIRE(out, "cg_rng_bernoulli: null pointer");
+    EW_LAUNCH(rng_bernoulli_k, n, out, n, keep_prob, value, seed, offset); return 0;
+}
+int cg_rng_uniform(void* stream, float* out, long n, float lo, float hi, uint64_t seed, uint64_t offset) {
+    CG_REQUIRE(out, "cg_rng_uniform: null pointer");
+    EW_LAUNCH(rng_uniform_k, n, out, n, lo, hi, seed, offset); return 0;
+}
+int cg_nchw_to_nhwc(void* stream, const float* in, float* out, int N, int C, int H, int W) {
+    CG_REQUIRE(in && out, "cg_nchw_to_nhwc: null pointer");
+    const long total = (long)N * C * H * W;
+    EW_LAUNCH(nchw_to_nhwc_k, total, in, out, N, C, H, W); return 0;
+}
+int cg_nhwc_to_nchw(void* stream, const float* in, float* out, int N, int C, int H, int W) {
+    CG_REQUIRE(in && out, "cg_nhwc_to_nchw: null pointer");
+    const long total = (long)N * C * H * W;
+    EW_LAUNCH(nhwc_to_nchw_k, total, in, out, N, C, H, W); return 0;
+}
+int cg_copy_channels(void* stream, const float* src, float* dst, long M, int Csrc, int src_off, int Cdst, int dst_off,
+                     int Ccopy) {
+    CG_REQUIRE(src && dst, "cg_copy_channels: null pointer");
+    CG_REQUIRE(src_off >= 0 && dst_off >= 0 && src_off + Ccopy <= Csrc && dst_off + Ccopy <= Cdst,
+               "cg_copy_channels: slice out of range");
+    const long total = M * Ccopy;
+    EW_LAUNCH(copy_channels_k, total, src, dst, M, Csrc, src_off, Cdst, dst_off, Ccopy); return 0;
+}
+int cg_gather_rows(void* stream, const float* src, const int32_t* idx, float* dst, long nrows, long rowlen) {
+    CG_REQUIRE(src && idx && dst, "cg_gather_rows: null pointer");
+    const long total = nrows * rowlen;
+    EW_LAUNCH(gather_rows_k, total, src, idx, dst, nrows, rowlen); return 0;
+}
+int cg_fill(void* stream, float* x, float value, long n) {
+    CG_REQUIRE(x, "cg_fill: null pointer");
+    EW_LAUNCH(fill_k, n, x, value, n); return 0;
+}
+int cg_add(void* stream, const float* a, const float* b, float* out, long n) {
+    CG_REQUIRE(a && b && out, "cg_add: null pointer");
+    EW_LAUNCH(add_k, n, a, b, out, n); return 0;
+}
+int cg_axpy(void* stream, float alpha, const float* x, float* y, long n) {
+    CG_REQUIRE(x && y, "cg_axpy: null pointer");
+    EW_LAUNCH(axpy_k, n, alpha, x, y, n); return 0;
+}
+int cg_scale(void* stream, float* x, float alpha, long n) {
+    CG_REQUIRE(x, "cg_scale: null pointer");
+    EW_LAUNCH(scale_k, n, x, alpha, n); return 0;
+}
+int cg_clamp(void* stream, float* x, float lo, float hi, long n) {
+    CG_REQUIRE(x, "cg_clamp: null pointer");
+    EW_LAUNCH(clamp_k, n, x, lo, hi, n); return 0;
+}
+int cg_sumsq(void* stream, const float* x, long n, double* out) {
+    CG_REQUIRE(x && out, "cg_sumsq: null pointer");
+    CG_HIP(hipMemsetAsync(out, 0, sizeof(double), cg::S(stream)));
+    EW_LAUNCH(sumred_k<true>, n, x, n, out); return 0;
+}
+int cg_sumabs(void* stream, const float* x, long n, double* out) {
+    CG_REQUIRE(x && out, "cg_sumabs: null pointer");
+    CG_HIP(hipMemsetAsync(out, 0, sizeof(double), cg::S(stream)));
+    EW_LAUNCH(sumred_k<false>, n, x, n, out); return 0;
+}
+
+int cg_affine_matrix_forward(void* stream, const float* params, float* T, int N, int use_rot, int use_scale,
+                             int use_trans) {
+    CG_REQUIRE(params && T, "cg_affine_matrix_forward: null pointer");
+    CG_REQUIRE(use_rot || use_scale || use_trans, "cg_affine_matrix_forward: fully parametrised form not supported");
+    EW_LAUNCH(affine_matrix_fwd_k, (long)N, params, T, N, use_rot ? 1 : 0, use_scale ? 1 : 0, use_trans ? 1 : 0);
+    return 0;
+}
+int cg_affine_matrix_backward(void* stream, const float* params, const float* gT, float* gparams, int N, int use_rot,
+                              int use_scale, int use_trans) {
+    CG_REQUIRE(params && gT && gparams, "cg_affine_matrix_backward: null pointer");
+    EW_LAUNCH(affine_matrix_bwd_k, (long)N, params, gT, gparams, N, use_rot ? 1 : 0, use_scale ? 1 : 0, use_trans ? 1 : 0);
+    return 0;
+}
+int cg_affine_grid_forward(void* stream, const float* T, float* grid, int N, int H, int W) {
+    CG_REQUIRE(T && grid, "cg_affine_grid_forward: null pointer");
+    const long total = (long)N * H * W;
+    EW_LAUNCH(affine_grid_fwd_k, total, T, grid, N, H, W); return 0;
+}
+int cg_affine_grid_backward(void* stream, const float* ggrid, float* gT, int N, int H, int W) {
+    CG_REQUIRE(ggrid && gT && N > 0, "cg_affine_grid_backward: bad args");
+    hipLaunchKernelGGL(affine_grid_bwd_k, dim3(N), dim3(256), 0, cg::S(stream), ggrid, gT, N, H, W);
+    CG_LAUNCH_CHECK(); return 0;
+}
+int cg_bilinear_sampler_forward(void* stream, const float* img, const float* grid, float* out, int N, int Hi, int Wi,
+                                int C, int Ho, int Wo) {
+    CG_REQUIRE(img && grid && out, "cg_bilinear_sampler_forward: null pointer");
+    const long total = (long)N * Ho * Wo * C;
+    EW_LAUNCH(bilinear_fwd_k, total, img, grid, out, N, Hi, Wi, C, Ho, Wo); return 0;
+}
+int cg_bilinear_sampler_backward(void* stream, const float* img, const float* grid, const float* gout, float* gimg,
+                                 float* ggrid, int N, int Hi, int Wi, int C, int Ho, int Wo) {
+    CG_REQUIRE(img && grid && gout && gimg && ggrid, "cg_bilinear_sampler_backward: null pointer");
+    CG_HIP(hipMemsetAsync(gimg, 0, sizeof(float) * (size_t)N * Hi * Wi * C, cg::S(stream)));
+    const long npix = (long)N * Ho * Wo;
+    long blocks = (npix + 3) / 4;
+    if (blocks > cg::kNumCU * 8) blocks = cg::kNumCU * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bilinear_bwd_k, dim3((unsigned)blocks), dim3(256), 0, cg::S(stream), img, grid, gout, gimg, ggrid,
+                       N, Hi, Wi, C, Ho, Wo);
+    CG_LAUNCH_CHECK(); return 0;
+}
+
+int cg_adam_step(void* stream, float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                 float eps, int t, float l1, float l2, float clamp, int write_back_grad) {
+    CG_REQUIRE(p && g && m && v && t >= 1, "cg_adam_step: bad args");
+    const double bc1 = 1.0 - pow((double)beta1, (double)t);
+    const double bc2 = 1.0 - pow((double)beta2, (double)t);
+    const float step = (float)((double)lr * sqrt(bc2) / bc1);
+    EW_LAUNCH(adam_k, n, p, g, m, v, n, step, beta1, beta2, eps, l1, l2, clamp, write_back_grad);
+    return 0;
+}
+int cg_confusion_update(void* stream, const float* outputs, const float* targets, int32_t* counts, long n) {
+    CG_REQUIRE(outputs && targets && counts, "cg_confusion_update: null pointer");
+    EW_LAUNCH(confusion_k, n, outputs, targets, counts, n); return 0;
+}
+
+}  // extern "C"

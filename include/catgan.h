@@ -1,0 +1,232 @@
+/*
+ * catgan.h — C ABI of the MI355X-native DCGAN step engine (libcatgan_hip.so).
+ *
+ * This is the drop-in boundary for the one hot path of aleju/cat-generator:
+ * the alternating D/G update of adversarial.lua:51-275 on G32up-c / G32up /
+ * D32_st3 (models.lua:196-228, :138-160, :640-711, :814-906).  The reference
+ * reaches its arithmetic through un-vendored Torch7 rocks (nn / cunn /
+ * cudnn.torch / stn / optim); every entry point below replaces the native
+ * call one nn.Module method makes, and cites the reference call site that
+ * constructs / invokes that module.  A LuaJIT `ffi.cdef` of this header is
+ * the binding a maintainer adds.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only.  All tensors fp32.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *    compute entry points are asynchronous on that stream.
+ *  - every function returns 0 on success, non-zero on failure;
+ *    cg_last_error() returns a thread-local message.  No C++ exception
+ *    crosses the ABI (LuaJIT FFI cannot unwind them).
+ *  - feature maps are NHWC in device memory ("BHWD" in stn's vocabulary):
+ *    x[((n*H + y)*W + x)*C + c].  2-D tensors are row-major [rows][cols].
+ *  - parameters and their gradients stay in the Torch7 *canonical* layout
+ *    (conv weight [Cout][Cin][kH][kW], linear weight [out][in], see
+ *    Module:getParameters(), train.lua:184-185); the engine keeps packed
+ *    copies (cg_pack_*) that the GEMM kernels read.
+ *  - "accumulate" outputs (gradWeight/gradBias/gradAlpha) follow Torch7's
+ *    accGradParameters contract: result is ADDED (scaled) to the buffer.
+ */
+#ifndef CATGAN_H
+#define CATGAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CG_ABI_VERSION 1
+
+/* ---- runtime: device memory / streams for hosts without their own (LuaJIT).
+ * Replaces cutorch.setDevice (train.lua:109), CudaTensor storage, and the
+ * nn.Copy('torch.FloatTensor','torch.CudaTensor') layers (models.lua:643,704;
+ * utils/nn_utils.lua:638-643). */
+int         cg_abi_version(void);
+const char* cg_last_error(void);
+int cg_device_count(int* count);
+int cg_set_device(int device);
+int cg_malloc(void** dptr, size_t bytes);
+int cg_free(void* dptr);
+int cg_memcpy_h2d(void* stream, void* dst, const void* src, size_t bytes);
+int cg_memcpy_d2h(void* stream, void* dst, const void* src, size_t bytes);
+int cg_memcpy_d2d(void* stream, void* dst, const void* src, size_t bytes);
+int cg_memset_zero(void* stream, void* dst, size_t bytes);
+int cg_stream_create(void** stream);
+int cg_stream_destroy(void* stream);
+int cg_stream_sync(void* stream);
+
+/* ---- convolution / linear (implicit GEMM on fp32 MFMA) -------------------
+ * Replaces cudnn.SpatialConvolution (models.lua:206,212,218,222),
+ * nn.SpatialConvolution (models.lua:646-685, 844-846) and nn.Linear
+ * (models.lua:199,697,700,850,853); stride 1, zero padding.
+ *
+ * cg_conv2d_forward computes, for packed weights wpk[(ky*kW+kx)*Cin+ci][Cout],
+ *   y[n,oy,ox,co] = bias[co] + sum_{ky,kx,ci} X(n, oy+ky-padH, ox+kx-padW, ci) * wpk[..][co]
+ * with Ho = Hl + 2*padH - kH + 1 (Hl = logical input height).  If ups==1 the
+ * logical input is the nearest-neighbour 2x upsampling of the physical x
+ * (Hl = 2*Hp): X(n,iy,ix,ci) = x[n, iy>>1, ix>>1, ci] — this folds
+ * nn.SpatialUpSamplingNearest(2) (models.lua:205,211,217) into the gather.
+ * The same entry point is updateGradInput when called with the gradOutput as
+ * x and the backward-packed weights (cg_pack_conv_weight's wb), and nn.Linear
+ * when Hp=Wp=kH=kW=1.  bias may be NULL.  ws/ws_bytes: scratch for split-K
+ * partials, cg_conv2d_workspace_bytes() tells how much is needed (may be 0). */
+size_t cg_conv2d_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout,
+                                 int kH, int kW, int padH, int padW, int ups);
+int cg_conv2d_forward(void* stream, const float* x, const float* wpk, const float* bias,
+                      float* y, int N, int Hp, int Wp, int Cin, int Cout,
+                      int kH, int kW, int padH, int padW, int ups,
+                      void* ws, size_t ws_bytes);
+
+/* accGradParameters for the weight: gw_canonical += scale * dW, where
+ *   dW[co][ci][ky][kx] = sum_{n,oy,ox} X(n,oy+ky-padH,ox+kx-padW,ci) * dy[n,oy,ox,co]
+ * (X as above, honouring ups).  gw layout is canonical [Cout][Cin][kH][kW]
+ * (== [out][in] for Linear).  Deterministic two-stage split-K reduction. */
+size_t cg_conv2d_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout,
+                                       int kH, int kW, int padH, int padW, int ups);
+int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw_canonical,
+                    int N, int Hp, int Wp, int Cin, int Cout,
+                    int kH, int kW, int padH, int padW, int ups, float scale,
+                    void* ws, size_t ws_bytes);
+
+/* gb[c] += scale * sum_m dy[m][c]   (gradBias of conv / linear).
+ * ws: scratch of at least 8*C bytes (fp64 column sums). */
+int cg_bias_grad(void* stream, const float* dy, float* gb, long M, int C, float scale,
+                 void* ws, size_t ws_bytes);
+
+/* canonical [Cout][Cin][kH][kW] -> wf[(ky*kW+kx)*Cin+ci][Cout] (forward) and
+ * wb[((kH-1-ky)*kW+(kW-1-kx))*Cout+co][Cin] (updateGradInput; flipped taps).
+ * Either output may be NULL. */
+int cg_pack_conv_weight(void* stream, const float* w_canonical, float* wf, float* wb,
+                        int Cout, int Cin, int kH, int kW);
+
+/* ---- activations --------------------------------------------------------
+ * nn.PReLU(nil,nil,true): one shared slope (models.lua:201,208,214,220,647..698).
+ * y = x>0 ? x : a*x ; dx = x>0 ? dy : a*dy ; *galpha += scale*sum_{x<=0} x*dy. */
+int cg_prelu_forward(void* stream, const float* x, const float* alpha, float* y, long n);
+int cg_prelu_backward(void* stream, const float* x, const float* dy, const float* alpha,
+                      float* dx, float* galpha, float scale, long n);
+/* nn.LeakyReLU (LeakyReLU.lua:13-31): y = x>=0 ? x : s*x ; dx = x>=0 ? dy : s*dy. */
+int cg_leakyrelu_forward(void* stream, const float* x, float* y, float slope, long n);
+int cg_leakyrelu_backward(void* stream, const float* x, const float* dy, float* dx, float slope, long n);
+/* nn.Sigmoid (models.lua:223,701): y = 1/(1+exp(-x)); dx = dy*y*(1-y). */
+int cg_sigmoid_forward(void* stream, const float* x, float* y, long n);
+int cg_sigmoid_backward(void* stream, const float* y, const float* dy, float* dx, long n);
+
+/* nn.BCECriterion (train.lua:181), sizeAverage, eps = 1e-12:
+ * *loss = -(1/n) sum t*log(p+eps) + (1-t)*log(1-p+eps) ;
+ * dp = -(t-p)/((1-p+eps)*(p+eps))/n. */
+int cg_bce_forward(void* stream, const float* p, const float* t, float* loss, long n);
+int cg_bce_backward(void* stream, const float* p, const float* t, float* dp, long n);
+
+/* ---- nn.SpatialBatchNormalization, training mode (models.lua:207,213,219) --
+ * x,y: [M][C] (M = N*H*W).  Statistics are exchanged as fp64 sums so that a
+ * data-parallel host can all-reduce them between the two calls (sync-BN).
+ *   cg_bn_stats:   sums[0..C) = sum_m x, sums[C..2C) = sum_m x^2 (overwrites)
+ *   cg_bn_forward: mean = s1/count, var = s2/count - mean^2 (biased), eps,
+ *                  y = (x-mean)*invstd*gamma + beta; writes save_mean /
+ *                  save_invstd; running stats updated with `momentum`
+ *                  (running_var with the unbiased variance), NULL to skip. */
+int cg_bn_stats(void* stream, const float* x, long M, int C, double* sums);
+int cg_bn_forward(void* stream, const float* x, float* y, const float* gamma, const float* beta,
+                  const double* sums, double count, long M, int C, float eps, float momentum,
+                  float* running_mean, float* running_var, float* save_mean, float* save_invstd);
+/*   cg_bn_backward_stats: sums[0..C) = sum dy, sums[C..2C) = sum dy*xhat
+ *   cg_bn_backward: dx = gamma*invstd*(dy - s1/count - xhat*s2/count);
+ *                   ggamma += scale*s2_local... (uses local_sums for the
+ *                   parameter gradients, global `sums` for dx). */
+int cg_bn_backward_stats(void* stream, const float* x, const float* dy, const float* save_mean,
+                         const float* save_invstd, long M, int C, double* sums);
+int cg_bn_backward(void* stream, const float* x, const float* dy, const float* gamma,
+                   const float* save_mean, const float* save_invstd,
+                   const double* sums, double count, const double* local_sums,
+                   long M, int C, float* dx, float* ggamma, float* gbeta, float scale);
+/* evaluate() mode: y = (x-running_mean)/sqrt(running_var+eps)*gamma+beta. */
+int cg_bn_forward_eval(void* stream, const float* x, float* y, const float* gamma, const float* beta,
+                       const float* running_mean, const float* running_var, long M, int C, float eps);
+
+/* ---- resampling / pooling (NHWC) ---------------------------------------- */
+/* nn.SpatialUpSamplingNearest(2) materialised (only when not folded into a conv);
+ * H,W are the low-res dims.  backward sums each 2x2 block. */
+int cg_upsample2x_forward(void* stream, const float* x, float* y, int N, int H, int W, int C);
+int cg_upsample2x_backward(void* stream, const float* dy, float* dx, int N, int H, int W, int C);
+/* nn.SpatialAveragePooling(2,2,2,2) / nn.SpatialMaxPooling(2,2) (models.lua:650,657,843,848);
+ * H,W are input dims (even). */
+int cg_avgpool2_forward(void* stream, const float* x, float* y, int N, int H, int W, int C);
+int cg_avgpool2_backward(void* stream, const float* dy, float* dx, int N, int H, int W, int C);
+int cg_maxpool2_forward(void* stream, const float* x, float* y, int N, int H, int W, int C);
+int cg_maxpool2_backward(void* stream, const float* x, const float* dy, float* dx, int N, int H, int W, int C);
+
+/* ---- dropout (models.lua:651,658,...,695,699) ---------------------------
+ * y = x * mask.  spatial!=0: mask is [N][C], broadcast over HW (nn.SpatialDropout);
+ * else mask has x's shape (nn.Dropout).  Used for forward and backward. */
+int cg_mask_mul(void* stream, const float* x, const float* mask, float* y,
+                int N, long HW, int C, int spatial);
+/* counter-based generator (own design; TH's MT19937 cannot be reproduced):
+ * out[i] = (u(seed,offset+i) < keep_prob) ? value : 0 ; uniform in [lo,hi). */
+int cg_rng_bernoulli(void* stream, float* out, long n, float keep_prob, float value,
+                     uint64_t seed, uint64_t offset);
+int cg_rng_uniform(void* stream, float* out, long n, float lo, float hi,
+                   uint64_t seed, uint64_t offset);
+
+/* ---- layout / data movement --------------------------------------------- */
+int cg_nchw_to_nhwc(void* stream, const float* in, float* out, int N, int C, int H, int W);
+int cg_nhwc_to_nchw(void* stream, const float* in, float* out, int N, int C, int H, int W);
+/* dst[m][dst_off + c] = src[m][src_off + c], c in [0,Ccopy): nn.Concat(2) fwd/bwd
+ * (models.lua:688-692). */
+int cg_copy_channels(void* stream, const float* src, float* dst, long M,
+                     int Csrc, int src_off, int Cdst, int dst_off, int Ccopy);
+/* dst[i] = src[idx[i]] for rows of rowlen floats: D-batch assembly from the
+ * real-image pool (adversarial.lua:225-230). */
+int cg_gather_rows(void* stream, const float* src, const int32_t* idx, float* dst,
+                   long nrows, long rowlen);
+int cg_fill(void* stream, float* x, float value, long n);
+int cg_add(void* stream, const float* a, const float* b, float* out, long n); /* out = a+b */
+int cg_axpy(void* stream, float alpha, const float* x, float* y, long n);    /* y += alpha*x */
+int cg_scale(void* stream, float* x, float alpha, long n);
+int cg_clamp(void* stream, float* x, float lo, float hi, long n);
+/* *out (double) = sum x^2 / sum |x| : torch.norm(p,2)^2, torch.norm(p,1)
+ * (adversarial.lua:94-95). */
+int cg_sumsq(void* stream, const float* x, long n, double* out);
+int cg_sumabs(void* stream, const float* x, long n, double* out);
+
+/* ---- spatial transformer (stn rock; models.lua:877-878,888) --------------
+ * AffineTransformMatrixGenerator(rot,scale,trans): params[N][P] consumed in the
+ * order [theta][s][tx,ty]; T = R(theta)*S(s)*Tr(tx,ty), top two rows -> T[N][2][3],
+ * acting on (y,x,1).  R = [[c,-s],[s,c]]. */
+int cg_affine_matrix_forward(void* stream, const float* params, float* T, int N,
+                             int use_rot, int use_scale, int use_trans);
+int cg_affine_matrix_backward(void* stream, const float* params, const float* gT, float* gparams,
+                              int N, int use_rot, int use_scale, int use_trans);
+/* AffineGridGeneratorBHWD(H,W): grid[n,i,j,:] = T_n * (y_i, x_j, 1), y_i = -1+2i/(H-1). */
+int cg_affine_grid_forward(void* stream, const float* T, float* grid, int N, int H, int W);
+int cg_affine_grid_backward(void* stream, const float* ggrid, float* gT, int N, int H, int W);
+/* BilinearSamplerBHWD: img[N,Hi,Wi,C], grid[N,Ho,Wo,2] (y,x) in [-1,1], corner aligned,
+ * out-of-range taps contribute 0.  backward overwrites gimg and ggrid. */
+int cg_bilinear_sampler_forward(void* stream, const float* img, const float* grid, float* out,
+                                int N, int Hi, int Wi, int C, int Ho, int Wo);
+int cg_bilinear_sampler_backward(void* stream, const float* img, const float* grid, const float* gout,
+                                 float* gimg, float* ggrid,
+                                 int N, int Hi, int Wi, int C, int Ho, int Wo);
+
+/* ---- optimiser ----------------------------------------------------------
+ * Fuses adversarial.lua:92-98 (L1/L2 penalty on the gradient), :110-112
+ * (clamp) and optim.adam (adversarial.lua:245,262; Torch7 form: eps is added
+ * to sqrt(v) without bias-correcting v) into one pass over the flat vectors:
+ *   g' = clamp(g + l1*sign(p) + l2*p, -clamp, +clamp)   (clamp<=0: no clamp)
+ *   m = b1*m + (1-b1)*g' ; v = b2*v + (1-b2)*g'^2
+ *   p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps)
+ * t is the 1-based step count.  If write_back_grad, g is overwritten with g'
+ * (what GRAD_PARAMETERS holds after fevalD returns). */
+int cg_adam_step(void* stream, float* p, float* g, float* m, float* v, long n,
+                 float lr, float beta1, float beta2, float eps, int t,
+                 float l1, float l2, float clamp, int write_back_grad);
+
+/* counts[pred*2 + target] += 1 with pred = out>0.5 (adversarial.lua:101-106). */
+int cg_confusion_update(void* stream, const float* outputs, const float* targets,
+                        int32_t* counts, long n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CATGAN_H */
