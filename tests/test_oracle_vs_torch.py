@@ -1,0 +1,259 @@
+"""Pins the CPU oracle (oracle/) against PyTorch-CPU, an independent descendant of THNN.
+
+The reference has no tests/golden vectors, so this cross-check plus the
+hand-computable known answers below are what anchor the oracle.  Tolerances are fp32
+summation-order class: |d| <= 1e-5 * (1+|ref|) * sqrt(K/1024) unless stated.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle as O
+
+f32 = np.float32
+
+
+def close(a, b, rtol=1e-5, atol=1e-5, K=1024):
+    s = max(1.0, np.sqrt(K / 1024.0))
+    np.testing.assert_allclose(a, b, rtol=rtol * s, atol=atol * s)
+
+
+@pytest.mark.parametrize("N,Cin,H,Cout,k", [(2, 3, 8, 5, 3), (3, 16, 9, 8, 5), (2, 8, 8, 4, 7), (1, 4, 6, 3, 1)])
+def test_conv_fwd_bwd(N, Cin, H, Cout, k):
+    rs = np.random.RandomState(0)
+    pad = (k - 1) // 2
+    x = rs.randn(N, Cin, H, H + 1).astype(f32)
+    w = rs.randn(Cout, Cin, k, k).astype(f32) * 0.2
+    b = rs.randn(Cout).astype(f32)
+    dy = rs.randn(N, Cout, H, H + 1).astype(f32)
+    xt, wt, bt = (torch.tensor(a, requires_grad=True) for a in (x, w, b))
+    yt = F.conv2d(xt, wt, bt, padding=pad)
+    yt.backward(torch.tensor(dy))
+    K = Cin * k * k
+    close(O.conv2d_forward(x, w, b, pad), yt.detach().numpy(), K=K)
+    close(O.conv2d_backward_data(dy, w, x.shape, pad), xt.grad.numpy(), K=K)
+    gw, gb = np.ones_like(w), np.ones_like(b)  # accumulate semantics: starts at 1
+    O.conv2d_backward_weight(x, dy, gw, gb, pad)
+    close(gw - 1, wt.grad.numpy(), K=N * H * H, atol=1e-4)
+    close(gb - 1, bt.grad.numpy(), K=N * H * H, atol=1e-4)
+
+
+def test_conv_1x1_is_gemm():
+    rs = np.random.RandomState(1)
+    x = rs.randn(2, 6, 4, 4).astype(f32)
+    w = rs.randn(5, 6, 1, 1).astype(f32)
+    y = O.conv2d_forward(x, w, None, 0)
+    ref = np.einsum("oc,nchw->nohw", w[:, :, 0, 0].astype(np.float64), x.astype(np.float64))
+    close(y, ref)
+
+
+def test_linear():
+    rs = np.random.RandomState(2)
+    x = rs.randn(7, 33).astype(f32); w = rs.randn(10, 33).astype(f32); b = rs.randn(10).astype(f32)
+    dy = rs.randn(7, 10).astype(f32)
+    xt, wt, bt = (torch.tensor(a, requires_grad=True) for a in (x, w, b))
+    yt = F.linear(xt, wt, bt); yt.backward(torch.tensor(dy))
+    close(O.linear_forward(x, w, b), yt.detach().numpy())
+    close(O.linear_backward_data(dy, w), xt.grad.numpy())
+    gw, gb = np.zeros_like(w), np.zeros_like(b)
+    O.linear_backward_weight(x, dy, gw, gb)
+    close(gw, wt.grad.numpy()); close(gb, bt.grad.numpy())
+
+
+def test_bn_train_matches_torch():
+    rs = np.random.RandomState(3)
+    rng = O.RNG(1)
+    m = O.SBN(6, rng)
+    x = (rs.randn(4, 6, 5, 5) * 2 + 1).astype(f32); dy = rs.randn(4, 6, 5, 5).astype(f32)
+    xt = torch.tensor(x, requires_grad=True)
+    wt, bt = torch.tensor(m.weight.copy(), requires_grad=True), torch.tensor(m.bias.copy(), requires_grad=True)
+    rm, rv = torch.zeros(6), torch.ones(6)
+    yt = F.batch_norm(xt, rm, rv, wt, bt, training=True, momentum=0.1, eps=1e-5)
+    yt.backward(torch.tensor(dy))
+    y = m.forward(x); dx = m.backward(dy)
+    close(y, yt.detach().numpy(), atol=2e-5)
+    close(dx, xt.grad.numpy(), atol=2e-5)
+    close(m.grad_weight, wt.grad.numpy(), atol=1e-4); close(m.grad_bias, bt.grad.numpy(), atol=1e-4)
+    close(m.running_mean, rm.numpy()); close(m.running_var, rv.numpy())
+
+
+def test_bn_constant_input_known_answer():
+    m = O.SBN(3, O.RNG(1))
+    y = m.forward(np.full((2, 3, 4, 4), 5.0, f32))
+    np.testing.assert_allclose(y, np.broadcast_to(m.bias[None, :, None, None], y.shape), atol=1e-6)
+
+
+def test_prelu_leaky_sigmoid_pool_upsample():
+    rs = np.random.RandomState(4)
+    x = rs.randn(3, 4, 6, 6).astype(f32); dy = rs.randn(3, 4, 6, 6).astype(f32)
+    xt = torch.tensor(x, requires_grad=True); a = torch.tensor([0.25], requires_grad=True)
+    yt = F.prelu(xt, a); yt.backward(torch.tensor(dy))
+    p = O.PReLU(); close(p.forward(x), yt.detach().numpy()); close(p.backward(dy), xt.grad.numpy())
+    close(p.grad_weight, a.grad.numpy(), atol=1e-5)
+    l = O.LeakyReLU(); xt = torch.tensor(x, requires_grad=True)
+    yt = F.leaky_relu(xt, 0.333); yt.backward(torch.tensor(dy))
+    close(l.forward(x), yt.detach().numpy()); close(l.backward(dy), xt.grad.numpy())
+    # x == 0 takes the positive branch (LeakyReLU.lua:24: sign(0)+1 = 1)
+    l.forward(np.zeros((1, 1, 1, 1), f32)); assert l.backward(np.ones((1, 1, 1, 1), f32))[0, 0, 0, 0] == 1.0
+    s = O.Sigmoid(); xt = torch.tensor(x, requires_grad=True)
+    yt = torch.sigmoid(xt); yt.backward(torch.tensor(dy))
+    close(s.forward(x), yt.detach().numpy()); close(s.backward(dy), xt.grad.numpy())
+    for mod, fn in ((O.AvgPool2(), F.avg_pool2d), (O.MaxPool2(), F.max_pool2d)):
+        xt = torch.tensor(x, requires_grad=True); yt = fn(xt, 2); g = rs.randn(*yt.shape).astype(f32)
+        yt.backward(torch.tensor(g))
+        close(mod.forward(x), yt.detach().numpy()); close(mod.backward(g), xt.grad.numpy())
+    u = O.UpSample2(); xt = torch.tensor(x, requires_grad=True)
+    yt = F.interpolate(xt, scale_factor=2, mode="nearest"); g = rs.randn(*yt.shape).astype(f32)
+    yt.backward(torch.tensor(g))
+    close(u.forward(x), yt.detach().numpy()); close(u.backward(g), xt.grad.numpy())
+
+
+def test_bce_and_adam_known_answers():
+    p = np.array([0.9, 0.2, 0.6], f32); t = np.array([1, 0, 1], f32)
+    ref = F.binary_cross_entropy(torch.tensor(p), torch.tensor(t)).item()
+    assert abs(O.bce_forward(p, t) - ref) < 1e-6
+    pt = torch.tensor(p, requires_grad=True); F.binary_cross_entropy(pt, torch.tensor(t)).backward()
+    close(O.bce_backward(p, t), pt.grad.numpy())
+    # Adam step 1: x -= lr * g/(|g| + eps*...) ~ lr*sign(g) for |g| >> eps
+    x = np.array([1.0, -2.0, 3.0], f32); g = np.array([0.5, -0.25, 2.0], f32); st = {}
+    O.adam(x, g, st)
+    np.testing.assert_allclose(x, np.array([1.0, -2.0, 3.0]) - 1e-3 * np.sign(g), atol=1e-6)
+    # Torch7 form differs from torch.optim.Adam in eps placement: step 2 against the closed form
+    O.adam(x, g, st)
+    m = 0.9 * (0.1 * g) + 0.1 * g; v = 0.999 * (0.001 * g * g) + 0.001 * g * g
+    step = 1e-3 * np.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
+    ref2 = (np.array([1.0, -2.0, 3.0]) - 1e-3 * np.sign(g)) - step * m / (np.sqrt(v) + 1e-8)
+    np.testing.assert_allclose(x, ref2, atol=1e-6)
+
+
+def _torch_grid(T, H, W):
+    # F.affine_grid works in (x,y); our T acts on (y,x,1) and emits (y,x)
+    Tx = torch.stack([torch.stack([T[:, 1, 1], T[:, 1, 0], T[:, 1, 2]], 1),
+                      torch.stack([T[:, 0, 1], T[:, 0, 0], T[:, 0, 2]], 1)], 1)
+    return F.affine_grid(Tx, (T.shape[0], 1, H, W), align_corners=True)  # [N,H,W,2] = (x,y)
+
+
+def test_spatial_transformer_pieces_vs_torch():
+    rs = np.random.RandomState(5)
+    N, H, Cc = 3, 8, 4
+    params = (rs.randn(N, 4) * 0.3 + np.array([0, 1, 0, 0])).astype(f32)
+    atm, agg = O.AffineMatrix(True, True, True), O.AffineGrid(H, H)
+    T = atm.forward(params); grid = agg.forward(T)
+    gxy = _torch_grid(torch.tensor(T), H, H).numpy()
+    close(grid[..., 0], gxy[..., 1], atol=1e-5); close(grid[..., 1], gxy[..., 0], atol=1e-5)
+    img = rs.randn(N, H, H, Cc).astype(f32)  # BHWD
+    out = O.bilinear_forward(img, grid)
+    it = torch.tensor(img.transpose(0, 3, 1, 2).copy(), requires_grad=True)
+    pt = torch.tensor(params, requires_grad=True)
+    # torch graph for gradients through params -> T -> grid -> sample
+    th, sc, tx, ty = pt[:, 0], pt[:, 1], pt[:, 2], pt[:, 3]
+    c, s = torch.cos(th), torch.sin(th)
+    Tt = torch.stack([torch.stack([c * sc, -s * sc, c * sc * tx - s * sc * ty], 1),
+                      torch.stack([s * sc, c * sc, s * sc * tx + c * sc * ty], 1)], 1)
+    ot = F.grid_sample(it, _torch_grid(Tt, H, H), mode="bilinear", padding_mode="zeros", align_corners=True)
+    close(out.transpose(0, 3, 1, 2), ot.detach().numpy(), atol=2e-5)
+    g = rs.randn(*out.shape).astype(f32)
+    ot.backward(torch.tensor(g.transpose(0, 3, 1, 2).copy()))
+    gimg, ggrid = O.bilinear_backward(img, grid, g)
+    close(gimg.transpose(0, 3, 1, 2), it.grad.numpy(), atol=5e-5)
+    gp = atm.backward(agg.backward(ggrid))
+    close(gp, pt.grad.numpy(), atol=2e-4, rtol=1e-4)
+
+
+def test_identity_transformer_is_exact_copy():
+    # models.lua:859-860 initialises the localisation net to the identity transform
+    rng = O.RNG(7)
+    st = O.SpatialTransformer(True, True, True, 8, 5, rng)
+    x = np.random.RandomState(6).rand(2, 5, 8, 8).astype(f32)
+    np.testing.assert_allclose(st.forward(x), x, atol=1e-6)
+
+
+def test_model_parameter_counts():
+    rng = O.RNG(1)
+    G = O.create_G32up_c(3, 100, rng); D = O.create_D32_st3(3, 32, rng)
+    pG, _ = O.get_parameters(G); pD, _ = O.get_parameters(D)
+    assert pG.size == 5191687
+    assert pD.size == 6664777
+    G1 = O.create_G32up(1, 100, rng); p1, _ = O.get_parameters(G1)
+    assert p1.size == 2468100
+    # weight-init scoping (weight-init.lua:52): G conv biases zeroed, D Concat children keep default biases
+    assert np.all(G.mods[4].bias == 0)
+    assert np.any(D.mods[7].mods[0].mods[1].bias != 0)
+    assert np.all(D.mods[1].bias == 0)
+
+
+def _finite_diff(f, x, idxs, eps=1e-3):
+    out = []
+    for i in idxs:
+        old = x[i]
+        x[i] = old + eps; fp = f()
+        x[i] = old - eps; fm = f()
+        x[i] = old
+        out.append((fp - fm) / (2 * eps))
+    return np.array(out)
+
+
+def test_full_D_gradient_finite_difference():
+    """Central differences through the whole D32_st3 (16x16 variant for speed) + BCE; eval-free since
+    dropout masks are fixed."""
+    rng = O.RNG(3)
+    D = O.create_D32_st3(3, 16, rng)
+    for m in D.modules():
+        if isinstance(m, (O.SpatialDropout, O.Dropout)):
+            m.fixed = None
+    pD, gD = O.get_parameters(D)
+    rs = np.random.RandomState(0)
+    x = rs.rand(4, 3, 16, 16).astype(f32); t = np.array([1, 0, 1, 0], f32)
+    # fix masks by drawing them once
+    out = D.forward(x)
+    for m in D.modules():
+        if isinstance(m, (O.SpatialDropout, O.Dropout)):
+            m.fixed = m.mask
+    gD[...] = 0
+    out = D.forward(x)
+    gin = D.backward(O.bce_backward(out, t.reshape(out.shape)))
+
+    def loss():
+        return O.bce_forward(D.forward(x), t)
+
+    # parameter gradient check on a spread of indices (fp32 forward => loose tolerance)
+    idxs = np.linspace(0, pD.size - 1, 24).astype(int)
+    fd = _finite_diff(loss, pD, idxs, eps=2e-3)
+    np.testing.assert_allclose(gD[idxs], fd, rtol=0.08, atol=3e-4)
+    xi = [(0, 1, 5, 7), (2, 0, 9, 3), (3, 2, 15, 15)]
+    fdx = _finite_diff(loss, x, xi, eps=2e-3)
+    np.testing.assert_allclose([gin[i] for i in xi], fdx, rtol=0.08, atol=3e-4)
+
+
+def test_full_G_matches_torch_autograd():
+    rng = O.RNG(5)
+    G = O.create_G32up_c(3, 100, rng)
+    pG, gG = O.get_parameters(G)
+    rs = np.random.RandomState(1)
+    z = (rs.rand(4, 100) * 2 - 1).astype(f32); dy = rs.randn(4, 3, 32, 32).astype(f32)
+    y = G.forward(z); G.backward(dy)
+    # torch restatement with the same parameters
+    P = [torch.tensor(p.copy(), requires_grad=True) for p, _ in G.parameters()]
+    it = iter(P)
+    h = F.linear(torch.tensor(z), next(it), next(it)); h = F.prelu(h, next(it)).view(-1, 512, 4, 4)
+    for pad in (1, 1, 2):
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+        h = F.conv2d(h, next(it), next(it), padding=pad)
+        C = h.shape[1]
+        h = F.batch_norm(h, torch.zeros(C), torch.ones(C), next(it), next(it), training=True, momentum=0.1, eps=1e-5)
+        h = F.prelu(h, next(it))
+    h = torch.sigmoid(F.conv2d(h, next(it), next(it), padding=1))
+    h.backward(torch.tensor(dy))
+    close(y, h.detach().numpy(), atol=3e-5)
+    gref = np.concatenate([p.grad.numpy().reshape(-1) for p in P])
+    # Two fp32 implementations disagree on the sign of a handful of BN outputs with |x| < 1e-5, which flips
+    # the PReLU derivative there (0.25 <-> 1): a few-element O(1%) effect on individual sums.  So: tight on
+    # the bulk (mean error), loose on the max.
+    off = 0
+    for p_, _ in G.parameters():
+        a, b = gG[off:off + p_.size], gref[off:off + p_.size]
+        off += p_.size
+        scale = np.abs(b).max() + 1e-6
+        assert np.abs(a - b).max() <= 3e-2 * scale
+        assert np.abs(a - b).mean() <= 2e-3 * scale
