@@ -1,0 +1,220 @@
+"""adversarial.lua's training iteration on the engine (the hot path; adversarial.lua:27-292).
+
+`State` carries what train.lua keeps in Lua globals (OPT, MODEL_G/D, CRITERION, PARAMETERS_*, OPTSTATE,
+CONFUSION, ...; train.lua:51-220).  `train()` is adversarial.train(); `iteration()` is the body of its for-loop
+(one D update + one G update, :51-275).  Batches, targets, noise and gradients-w.r.t.-images stay in HBM; the
+reference's per-image host loops (:225-238) become one gather kernel + one device copy.
+
+Differences from the reference, all inert on results:
+  * fevalG_on_D calls MODEL_D:updateGradInput instead of :backward — the D weight gradients the reference
+    accumulates there (:192) are zeroed by the next fevalD (:81) before anyone reads them
+    (OPT.exact_reference_backward=True restores the wasted work);
+  * penalty + clamp + Adam run as one fused kernel (OPT.fused_update=False restores the separate passes);
+  * the rolling-accuracy gate (:144-166) only reads the confusion counts back when D_maxAcc <= 1 can trigger.
+Under data parallelism the flat gradient is all-reduced (mean) right after backward, i.e. before penalty and
+clamp — the order adversarial.lua:89-112 fixes.
+"""
+import math
+import time
+
+import numpy as np
+import torch
+
+from . import nn, nn_utils, optim, parallel
+from .tensor import Tensor, lib, stream
+
+DEFAULT_OPT = dict(  # train.lua:15-49
+    batchSize=32, N_epoch=1000, G_L1=0.0, G_L2=0.0, D_L1=0.0, D_L2=1e-4, D_iterations=1, G_iterations=1,
+    D_maxAcc=1.01, D_clamp=1.0, G_clamp=5.0, D_optmethod="adam", G_optmethod="adam", noiseDim=100, scale=32,
+    seed=1, colorSpace="rgb", fused_update=True, exact_reference_backward=False,
+)
+
+
+class TrainData:
+    """A pool of real images resident in HBM ([P,C,H,W], NHWC) with the bits of the dataset table API the loop
+    uses: size() and random row access (adversarial.lua:226-227)."""
+
+    def __init__(self, pool):
+        self.pool = nn.as_nhwc(nn.to_device(pool))
+
+    def size(self):
+        return self.pool.shape[0]
+
+
+class State:
+    Y_GENERATOR = 0
+    Y_NOT_GENERATOR = 1
+    CLASSES = ("0", "1")
+
+    def __init__(self, OPT, MODEL_G, MODEL_D):
+        self.OPT = dict(DEFAULT_OPT)
+        self.OPT.update(OPT)
+        self.MODEL_G, self.MODEL_D = MODEL_G, MODEL_D
+        self.CRITERION = nn.BCECriterion()                                   # train.lua:181
+        self.PARAMETERS_D, self.GRAD_PARAMETERS_D = MODEL_D.getParameters()   # train.lua:184
+        self.PARAMETERS_G, self.GRAD_PARAMETERS_G = MODEL_G.getParameters()   # train.lua:185
+        self.CONFUSION = optim.ConfusionMatrix(self.CLASSES)                  # train.lua:188
+        self.OPTSTATE = {"adam": {"D": {}, "G": {}}}                          # train.lua:191-207
+        self.EPOCH = 1
+        self.random = np.random.RandomState(self.OPT["seed"])  # math.randomseed(OPT.seed), train.lua:61
+        self.accs = []
+        self._cache = {}
+
+
+def mean(t):
+    """adversarial.mean (adversarial.lua:12-24)."""
+    v = [x for x in t if isinstance(x, (int, float))]
+    return sum(v) / len(v)
+
+
+def _buffers(S, thisBatchSize, dims):
+    key = (thisBatchSize, tuple(dims))
+    b = S._cache.get(key)
+    if b is None:
+        half = thisBatchSize // 2
+        b = dict(
+            inputs=Tensor.zeros((thisBatchSize,) + tuple(dims), "nhwc"),
+            targets_D=Tensor.from_numpy(np.concatenate([np.full(half, S.Y_NOT_GENERATOR, np.float32),
+                                                        np.full(half, S.Y_GENERATOR, np.float32)])),
+            targets_G=Tensor.from_numpy(np.full(thisBatchSize, S.Y_NOT_GENERATOR, np.float32)),
+            idx=torch.zeros(half, dtype=torch.int32, device=S.PARAMETERS_D.t.device),
+        )
+        S._cache[key] = b
+    return b
+
+
+def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=20, real_idx=None, noise_D=None,
+              noise_G=None):
+    """One pass of the loop body adversarial.lua:51-275.  real_idx / noise_D / noise_G inject the random draws
+    (parity tests); by default they come from the seeded host RNG / the device counter stream."""
+    OPT = S.OPT
+    N = thisBatchSize or OPT["batchSize"]
+    assert N >= 4 and N % 2 == 0  # adversarial.lua:65-68
+    dims = trainData.pool.shape[1:]
+    buf = _buffers(S, N, dims)
+    inputs, half = buf["inputs"], N // 2
+    rowlen = int(np.prod(dims))
+    st = {"doTrainD": True}
+
+    # ------------------------------------------------------------------ fevalD (adversarial.lua:72-167)
+    def fevalD(x):
+        if x is not S.PARAMETERS_D:
+            S.PARAMETERS_D.copy(x)
+        S.GRAD_PARAMETERS_D.zero()
+        targets = buf["targets_D"]
+        outputs = S.MODEL_D.forward(inputs)
+        f = S.CRITERION.forward(outputs, targets)
+        df_do = S.CRITERION.backward(outputs, targets)
+        S.MODEL_D.backward(inputs, df_do)
+        parallel.allreduce_mean_(S.GRAD_PARAMETERS_D.t)
+        if not OPT["fused_update"]:
+            if OPT["D_L1"] != 0 or OPT["D_L2"] != 0:
+                f = float(f) + OPT["D_L1"] * S.PARAMETERS_D.norm(1) + OPT["D_L2"] * S.PARAMETERS_D.norm(2) ** 2 / 2
+                if OPT["D_L1"] != 0:
+                    lib().axpy_sign(stream(), OPT["D_L1"], S.PARAMETERS_D.ptr, S.GRAD_PARAMETERS_D.ptr,
+                                    S.PARAMETERS_D.nElement())
+                S.GRAD_PARAMETERS_D.add(OPT["D_L2"], S.PARAMETERS_D)
+        S.CONFUSION.batchAdd(nn.as_plain(outputs), targets)
+        if not OPT["fused_update"] and OPT["D_clamp"] != 0:
+            S.GRAD_PARAMETERS_D.clamp(-OPT["D_clamp"], OPT["D_clamp"])
+        S._last = dict(outputs_D=outputs, f_D=f)
+        if maxAccuracyD <= 1.0:  # the gate can trigger: read this batch's accuracy back (:115-166)
+            o = nn.as_plain(outputs).numpy().reshape(-1)
+            t = targets.numpy().reshape(-1)
+            tV = float(np.mean((o > 0.5) == (t > 0.5)))
+            S.accs.append(tV)
+            if len(S.accs) > accsInterval:
+                S.accs.pop(0)
+            st["doTrainD"] = mean(S.accs) < maxAccuracyD
+            if not st["doTrainD"]:
+                return False, False
+        return f, S.GRAD_PARAMETERS_D
+
+    # --------------------------------------------------------- fevalG_on_D (adversarial.lua:171-215)
+    def fevalG_on_D(x):
+        if x is not S.PARAMETERS_G:
+            S.PARAMETERS_G.copy(x)
+        S.GRAD_PARAMETERS_G.zero()
+        targets = buf["targets_G"]
+        samples = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
+        outputs = S.MODEL_D.forward(samples)
+        f = S.CRITERION.forward(outputs, targets)
+        df_samples = S.CRITERION.backward(outputs, targets)
+        if OPT["exact_reference_backward"]:
+            S.MODEL_D.backward(samples, df_samples)
+        else:
+            S.MODEL_D.updateGradInput(samples, df_samples)
+        df_do = S.MODEL_D.modules[0].gradInput
+        S.MODEL_G.backward(st["noiseInputs"], df_do)
+        parallel.allreduce_mean_(S.GRAD_PARAMETERS_G.t)
+        if not OPT["fused_update"]:
+            if OPT["G_L1"] != 0 or OPT["G_L2"] != 0:
+                f = float(f) + OPT["G_L1"] * S.PARAMETERS_G.norm(1) + OPT["G_L2"] * S.PARAMETERS_G.norm(2) ** 2 / 2
+                # adversarial.lua:206 scales the sign term by G_L2 (upstream slip, inert at the defaults)
+                lib().axpy_sign(stream(), OPT["G_L2"], S.PARAMETERS_G.ptr, S.GRAD_PARAMETERS_G.ptr,
+                                S.PARAMETERS_G.nElement())
+                S.GRAD_PARAMETERS_G.add(OPT["G_L2"], S.PARAMETERS_G)
+            if OPT["G_clamp"] != 0:
+                S.GRAD_PARAMETERS_G.clamp(-OPT["G_clamp"], OPT["G_clamp"])
+        S._last.update(outputs_G=outputs, f_G=f, samples=samples)
+        return f, S.GRAD_PARAMETERS_G
+
+    # ----------------------------------------------------------------- (1) update D (:221-249)
+    for _ in range(OPT["D_iterations"]):
+        # (1.1) real data: N/2 random rows of the pool (math.random(trainData:size()), :226)
+        idx = real_idx if real_idx is not None else S.random.randint(0, trainData.size(), size=half)
+        buf["idx"].copy_(torch.from_numpy(np.asarray(idx, dtype=np.int32)), non_blocking=True)
+        lib().gather_rows(stream(), trainData.pool.ptr, buf["idx"].data_ptr(), inputs.ptr, half, rowlen)
+        # (1.2) sampled data
+        noise = nn.to_device(noise_D) if noise_D is not None else nn_utils.createNoiseInputs(S, half)
+        samples = nn.as_nhwc(nn_utils.createImagesFromNoise(S, noise, False))
+        lib().memcpy_d2d(stream(), inputs.ptr + half * rowlen * 4, samples.ptr, half * rowlen * 4)
+        S._last_fake = samples
+        fused = dict(l1=OPT["D_L1"], l2=OPT["D_L2"], clamp=OPT["D_clamp"]) if OPT["fused_update"] else None
+        assert OPT["D_optmethod"] == "adam", "only adam (the default) is implemented"
+        optim.adam(fevalD, S.PARAMETERS_D, S.OPTSTATE["adam"]["D"], fused=fused)
+
+    # ----------------------------------------------------------------- (2) update G (:253-266)
+    for _ in range(OPT["G_iterations"]):
+        st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.createNoiseInputs(S, N)
+        # upstream multiplies the L1 sign term by G_L2 (:206): keep that in the fused form too
+        fused = dict(l1=OPT["G_L2"] if OPT["G_L1"] != 0 or OPT["G_L2"] != 0 else 0.0, l2=OPT["G_L2"],
+                     clamp=OPT["G_clamp"]) if OPT["fused_update"] else None
+        assert OPT["G_optmethod"] == "adam", "only adam (the default) is implemented"
+        optim.adam(fevalG_on_D, S.PARAMETERS_G, S.OPTSTATE["adam"]["G"], fused=fused)
+    return st["doTrainD"]
+
+
+def train(S, trainData, maxAccuracyD=1.01, accsInterval=20, verbose=True):
+    """adversarial.train (adversarial.lua:27-292): one epoch."""
+    OPT = S.OPT
+    N_epoch = OPT["N_epoch"] if OPT["N_epoch"] > 0 else trainData.size()
+    dataBatchSize = OPT["batchSize"] // 2
+    t0 = time.time()
+    countTrainedD = countNotTrainedD = 0
+    if verbose:
+        print(f"<trainer> Epoch #{S.EPOCH} [batchSize = {OPT['batchSize']}]")
+    for t in range(1, N_epoch + 1, dataBatchSize):
+        thisBatchSize = min(OPT["batchSize"], N_epoch - t + 1)
+        if thisBatchSize < 4:
+            if verbose:
+                print(f"[INFO] skipping batch at t={t}, because its size is less than 4")
+            break
+        thisBatchSize -= thisBatchSize % 2
+        if iteration(S, trainData, thisBatchSize, maxAccuracyD, accsInterval):
+            countTrainedD += 1
+        else:
+            countNotTrainedD += 1
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    dt = time.time() - t0
+    tV = S.CONFUSION.updateValids()
+    if verbose:
+        print(f"<trainer> time required for this epoch = {dt:.0f} s")
+        print(f"<trainer> time to learn 1 sample = {1000 * dt / N_epoch:f} ms")
+        print(f"<trainer> trained D {countTrainedD} of {countTrainedD + countNotTrainedD} times.")
+        print("Confusion of D:")
+        print(S.CONFUSION)
+    S.CONFUSION.zero()
+    S.EPOCH += 1
+    return tV

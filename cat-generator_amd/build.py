@@ -1,0 +1,40 @@
+"""Builds the gfx950 HIP extension (libcatgan_hip.so) in-tree with hipcc.
+
+No torch / pybind in the link: the library is a plain C-ABI shared object
+(include/catgan.h) so that LuaJIT's FFI, ctypes or a C++ driver can bind it.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libcatgan_hip.so")
+SOURCES = ["gemm.hip", "ops.hip"]
+ARCH = "gfx950"
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "catgan.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

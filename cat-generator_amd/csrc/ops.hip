@@ -340,6 +340,12 @@ __global__ void gather_rows_k(const float* src, const int32_t* idx, float* dst, 
 __global__ void fill_k(float* x, float v, long n) { GRID_STRIDE(i, n) x[i] = v; }
 __global__ void add_k(const float* a, const float* b, float* o, long n) { GRID_STRIDE(i, n) o[i] = a[i] + b[i]; }
 __global__ void axpy_k(float al, const float* x, float* y, long n) { GRID_STRIDE(i, n) y[i] += al * x[i]; }
+__global__ void axpy_sign_k(float al, const float* x, float* y, long n) {
+    GRID_STRIDE(i, n) {
+        const float v = x[i];
+        y[i] += al * (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f));
+    }
+}
 __global__ void scale_k(float* x, float al, long n) { GRID_STRIDE(i, n) x[i] *= al; }
 __global__ void clamp_k(float* x, float lo, float hi, long n) {
     GRID_STRIDE(i, n) { x[i] = fminf(fmaxf(x[i], lo), hi); }
@@ -745,6 +751,10 @@ int cg_add(void* stream, const float* a, const float* b, float* out, long n) {
 int cg_axpy(void* stream, float alpha, const float* x, float* y, long n) {
     CG_REQUIRE(x && y, "cg_axpy: null pointer");
     EW_LAUNCH(axpy_k, n, alpha, x, y, n); return 0;
+}
+int cg_axpy_sign(void* stream, float alpha, const float* x, float* y, long n) {
+    CG_REQUIRE(x && y, "cg_axpy_sign: null pointer");
+    EW_LAUNCH(axpy_sign_k, n, alpha, x, y, n); return 0;
 }
 int cg_scale(void* stream, float* x, float alpha, long n) {
     CG_REQUIRE(x, "cg_scale: null pointer");

@@ -183,6 +183,7 @@ int cg_gather_rows(void* stream, const float* src, const int32_t* idx, float* ds
 int cg_fill(void* stream, float* x, float value, long n);
 int cg_add(void* stream, const float* a, const float* b, float* out, long n); /* out = a+b */
 int cg_axpy(void* stream, float alpha, const float* x, float* y, long n);    /* y += alpha*x */
+int cg_axpy_sign(void* stream, float alpha, const float* x, float* y, long n); /* y += alpha*sign(x) (adversarial.lua:97) */
 int cg_scale(void* stream, float* x, float alpha, long n);
 int cg_clamp(void* stream, float* x, float lo, float hi, long n);
 /* *out (double) = sum x^2 / sum |x| : torch.norm(p,2)^2, torch.norm(p,1)
