@@ -1,0 +1,360 @@
+"""GPU parity tests: the HIP path (through the C ABI / the nn module layer) against the CPU oracle on the same
+seeded inputs, plus size-independent properties at BASELINE.json's full sizes.
+
+Tolerance (fp32, stated per north_star): both sides are fp32 with different summation orders, so
+|d| <= tol * sqrt(K/1024) * max(1, max|ref|) with tol = 2e-5 for single operators (K = reduction length);
+whole-network gradients additionally see PReLU-kink sign flips of |x| < 1e-5 activations (see
+tests/test_oracle_vs_torch.py) and are checked tight-on-the-bulk / loose-on-the-max.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def cg():
+    mod = importlib.import_module("cat-generator_amd")
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    mod.lib()  # fails loudly if the HIP extension is missing
+    return mod
+
+
+def close(a, b, K=1024, tol=2e-5, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    s = max(1.0, np.sqrt(K / 1024.0)) * max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * s, f"{what}: max|d|={err:.3e} > {tol * s:.3e} (K={K})"
+
+
+def bulk_close(a, b, max_rel=3e-2, mean_rel=2e-3, what=""):
+    a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+    scale = max(float(np.abs(b).max()), 1e-12)
+    d = np.abs(a - b)
+    assert d.max() <= max_rel * scale, f"{what}: max|d|={d.max():.3e} vs scale {scale:.3e}"
+    if a.size > 1:
+        assert d.mean() <= mean_rel * scale, f"{what}: mean|d|={d.mean():.3e} vs scale {scale:.3e}"
+
+
+# ------------------------------------------------------------------------------ convolution
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, ups
+    (2, 3, 8, 8, 5, 3, 0),       # scalar A and B paths, ragged tiles
+    (3, 8, 5, 7, 12, 3, 0),      # M = 105: ragged M, non-square
+    (4, 16, 16, 16, 16, 3, 0),   # localisation-net conv: K tile straddles taps, (128,32) tile
+    (4, 3, 32, 32, 64, 3, 0),    # D conv1 (models.lua:646)
+    (2, 64, 16, 16, 64, 3, 0),   # D branch conv
+    (2, 64, 16, 16, 128, 5, 0),  # D branch-4 5x5 (models.lua:681)
+    (2, 128, 8, 8, 128, 7, 0),   # D branch-4 7x7 (models.lua:685)
+    (2, 512, 4, 4, 512, 3, 1),   # G conv1 with folded upsampling (models.lua:205-206), split-K
+    (1, 256, 16, 16, 128, 5, 1), # G conv3 (models.lua:217-218)
+    (2, 128, 32, 32, 3, 3, 0),   # G conv4, Cout = 3 (models.lua:222)
+    (2, 64, 8, 8, 1, 3, 0),      # Cout = 1
+]
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,k,ups", CONV_CASES)
+def test_spatial_convolution_fwd_bwd(cg, N, Cin, H, W, Cout, k, ups):
+    rs = np.random.RandomState(hash((N, Cin, H, Cout, k)) % 2**31)
+    pad = (k - 1) // 2
+    m = cg.nn.SpatialConvolution(Cin, Cout, k, k, 1, 1, pad)
+    w = (rs.randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)).astype(f32)
+    b = rs.randn(Cout).astype(f32)
+    m.weight.copy(w); m.bias.copy(b)
+    x = rs.randn(N, Cin, H, W).astype(f32)
+    xin = cg.Tensor.from_numpy(x)
+    xl = x
+    if ups:
+        up = cg.nn.SpatialUpSamplingNearest(2)
+        xin = up.forward(xin)
+        xl = np.repeat(np.repeat(x, 2, axis=2), 2, axis=3)
+    Kf = Cin * k * k
+    y = m.forward(xin).numpy()
+    close(y, O.conv2d_forward(xl, w, b, pad), K=Kf, what="updateOutput")
+    dy = rs.randn(*y.shape).astype(f32)
+    m.gradWeight.fill(1.0); m.gradBias.fill(1.0)  # accGradParameters must ACCUMULATE
+    gi = m.backward(xin, cg.Tensor.from_numpy(dy)).numpy()
+    close(gi, O.conv2d_backward_data(dy, w, xl.shape, pad), K=Cout * k * k, what="updateGradInput")
+    gw, gb = np.ones_like(w), np.ones_like(b)
+    O.conv2d_backward_weight(xl, dy, gw, gb, pad)
+    P = y.shape[0] * y.shape[2] * y.shape[3]
+    close(m.gradWeight.numpy(), gw, K=P, tol=4e-5, what="gradWeight")
+    close(m.gradBias.numpy(), gb, K=P, tol=4e-5, what="gradBias")
+    if ups:  # the upsampling module's own backward: 2x2 block sum
+        g_lo = up.updateGradInput(None, m.gradInput).numpy()
+        ref = O.UpSample2().backward(O.conv2d_backward_data(dy, w, xl.shape, pad))
+        close(g_lo, ref, K=4 * Cout * k * k, what="upsample backward")
+
+
+@pytest.mark.parametrize("N,i,o", [(128, 100, 8192), (6, 20480, 256), (5, 64, 4), (3, 256, 1), (64, 1024, 64)])
+def test_linear_fwd_bwd(cg, N, i, o):
+    rs = np.random.RandomState(N + i + o)
+    m = cg.nn.Linear(i, o)
+    w = (rs.randn(o, i) / np.sqrt(i)).astype(f32); b = rs.randn(o).astype(f32)
+    m.weight.copy(w); m.bias.copy(b)
+    x = rs.randn(N, i).astype(f32); dy = rs.randn(N, o).astype(f32)
+    close(m.forward(cg.Tensor.from_numpy(x)).numpy(), O.linear_forward(x, w, b), K=i, what="forward")
+    m.gradWeight.zero(); m.gradBias.zero()
+    gi = m.backward(cg.Tensor.from_numpy(x), cg.Tensor.from_numpy(dy)).numpy()
+    close(gi, O.linear_backward_data(dy, w), K=o, what="gradInput")
+    gw, gb = np.zeros_like(w), np.zeros_like(b)
+    O.linear_backward_weight(x, dy, gw, gb)
+    close(m.gradWeight.numpy(), gw, K=N, what="gradWeight"); close(m.gradBias.numpy(), gb, K=N, what="gradBias")
+
+
+def test_conv_upsample_layer_is_a_view(cg):
+    """layers/SpatialConvolutionUpsample.lua:16-24: NCHW buffer [N,nOut*f^2,h,w] reinterpreted, not pixel-shuffled."""
+    rs = np.random.RandomState(0)
+    m = cg.nn.SpatialConvolutionUpsample(4, 3, 3, 3, 2)
+    w, b = m.weight.numpy(), m.bias.numpy()
+    x = rs.randn(2, 4, 5, 5).astype(f32)
+    y = m.forward(cg.Tensor.from_numpy(x)).numpy()
+    ref = O.conv2d_forward(x, w, b, 1).reshape(2, 3, 10, 10)
+    close(y, ref, K=36)
+    dy = rs.randn(2, 3, 10, 10).astype(f32)
+    gi = m.backward(cg.Tensor.from_numpy(x), cg.Tensor.from_numpy(dy, fmt="plain")).numpy()
+    close(gi, O.conv2d_backward_data(dy.reshape(2, 12, 5, 5), w, x.shape, 1), K=108)
+
+
+# ------------------------------------------------------------------------ memory-bound operators
+def test_activations_and_bce(cg):
+    rs = np.random.RandomState(1)
+    x = rs.randn(3, 8, 6, 6).astype(f32); dy = rs.randn(3, 8, 6, 6).astype(f32)
+    x[0, 0, 0, 0] = 0.0
+    for P, Oc in ((cg.nn.PReLU(), O.PReLU()), (cg.nn.LeakyReLU(), O.LeakyReLU()), (cg.nn.Sigmoid(), O.Sigmoid())):
+        yo = Oc.forward(x); go = Oc.backward(dy)
+        xin = cg.Tensor.from_numpy(x)
+        close(P.forward(xin).numpy(), yo, tol=1e-6, what=type(Oc).__name__)
+        close(P.backward(xin, cg.Tensor.from_numpy(dy)).numpy(), go, tol=1e-6, what=type(Oc).__name__ + " bwd")
+        if isinstance(Oc, O.PReLU):
+            close(P.gradWeight.numpy(), Oc.grad_weight, K=x.size, what="dalpha")
+    p = rs.rand(16, 1).astype(f32) * 0.98 + 0.01; t = (rs.rand(16) > 0.5).astype(f32)
+    crit = cg.nn.BCECriterion()
+    f = float(crit.forward(cg.Tensor.from_numpy(p), cg.Tensor.from_numpy(t)))
+    assert abs(f - O.bce_forward(p, t)) < 1e-6
+    close(crit.backward(cg.Tensor.from_numpy(p), cg.Tensor.from_numpy(t)).numpy(), O.bce_backward(p, t.reshape(16, 1)), tol=1e-6)
+
+
+@pytest.mark.parametrize("N,C,H", [(4, 16, 8), (8, 128, 16), (3, 70, 5)])
+def test_batchnorm_train(cg, N, C, H):
+    rs = np.random.RandomState(C)
+    x = (rs.randn(N, C, H, H) * 1.5 + 0.7).astype(f32); dy = rs.randn(N, C, H, H).astype(f32)
+    P, Oc = cg.nn.SpatialBatchNormalization(C), O.SBN(C, O.RNG(3))
+    Oc.weight[...] = P.weight.numpy(); Oc.bias[...] = rs.randn(C).astype(f32); P.bias.copy(Oc.bias)
+    xin = cg.Tensor.from_numpy(x)
+    close(P.forward(xin).numpy(), Oc.forward(x), tol=2e-5, what="bn fwd")
+    close(P.running_mean.numpy(), Oc.running_mean, tol=1e-6); close(P.running_var.numpy(), Oc.running_var, tol=1e-5)
+    gi = P.backward(xin, cg.Tensor.from_numpy(dy)).numpy()
+    close(gi, Oc.backward(dy), tol=5e-5, what="bn bwd")
+    close(P.gradWeight.numpy(), Oc.grad_weight, K=N * H * H, what="dgamma")
+    close(P.gradBias.numpy(), Oc.grad_bias, K=N * H * H, what="dbeta")
+    P.evaluate(); Oc.train = False
+    close(P.forward(xin).numpy(), Oc.forward(x), tol=2e-5, what="bn eval")
+
+
+def test_pooling_upsample_layout(cg):
+    rs = np.random.RandomState(2)
+    x = rs.randn(3, 10, 8, 12).astype(f32)
+    for P, Oc in ((cg.nn.SpatialAveragePooling(2, 2, 2, 2), O.AvgPool2()), (cg.nn.SpatialMaxPooling(2, 2), O.MaxPool2())):
+        xin = cg.Tensor.from_numpy(x)
+        yo = Oc.forward(x); g = rs.randn(*yo.shape).astype(f32)
+        close(P.forward(xin).numpy(), yo, tol=1e-6)
+        close(P.backward(xin, cg.Tensor.from_numpy(g)).numpy(), Oc.backward(g), tol=1e-6)
+    up = cg.nn.SpatialUpSamplingNearest(2)
+    close(cg.nn.materialise(up.forward(cg.Tensor.from_numpy(x))).numpy(), O.UpSample2().forward(x), tol=0)
+    # View: the NCHW reinterpretation must survive NHWC storage (models.lua:202, :696)
+    v = cg.nn.View(10, 8, 12); flat = x.reshape(3, -1)
+    t = v.forward(cg.Tensor.from_numpy(flat))
+    assert t.fmt == "nhwc"; close(t.numpy(), x, tol=0)
+    close(v.backward(None, t).numpy(), flat, tol=0)
+    v2 = cg.nn.View(10 * 8 * 12)
+    close(v2.forward(cg.Tensor.from_numpy(x)).numpy(), flat, tol=0)
+
+
+def test_dropout_masks_share_the_counter_stream(cg):
+    cg.manual_seed(11); rng = O.RNG(11)
+    x = np.random.RandomState(3).randn(6, 20, 4, 4).astype(f32)
+    for P, Oc in ((cg.nn.SpatialDropout(0.2), O.SpatialDropout(0.2, rng)), (cg.nn.Dropout(), O.Dropout(0.5, rng)),
+                  (cg.nn.SpatialDropout(), O.SpatialDropout(0.5, rng))):
+        xin = cg.Tensor.from_numpy(x)
+        close(P.forward(xin).numpy(), Oc.forward(x), tol=0, what="mask")
+        close(P.backward(xin, xin).numpy(), Oc.backward(x), tol=0)
+    P.evaluate(); Oc.train = False
+    close(P.forward(cg.Tensor.from_numpy(x)).numpy(), Oc.forward(x), tol=1e-7)
+
+
+def test_spatial_transformer_module(cg):
+    """createSpatialTransformer (models.lua:814-906) end to end, with a non-identity classifier."""
+    cg.manual_seed(5); rng = O.RNG(5)
+    P = cg.models.createSpatialTransformer(True, True, True, 16, 8, False)
+    Oc = O.SpatialTransformer(True, True, True, 16, 8, rng)
+    rs = np.random.RandomState(4)
+    wcls = (rs.randn(4, 64) * 0.05).astype(f32)
+    P.modules[0].modules[1].modules[0].modules[-1].weight.copy(wcls)
+    Oc.loc.mods[-1].weight[...] = wcls
+    for (pp, _), po in zip(Oc.parameters(), P.parameters()[0]):
+        np.testing.assert_array_equal(pp, po.numpy())
+    x = rs.rand(5, 8, 16, 16).astype(f32); dy = rs.randn(5, 8, 16, 16).astype(f32)
+    xin = cg.Tensor.from_numpy(x)
+    close(P.forward(xin).numpy(), Oc.forward(x), tol=3e-5, what="st fwd")
+    P.zeroGradParameters()
+    gi = P.backward(xin, cg.Tensor.from_numpy(dy)).numpy()
+    go = Oc.backward(dy)
+    close(gi, go, K=4096, tol=5e-5, what="st gradInput")
+    for (_, go_), gp in zip(Oc.parameters(), P.parameters()[1]):
+        bulk_close(gp.numpy(), go_, max_rel=2e-3, mean_rel=2e-4, what="st param grad")
+    # identity initialisation reproduces the input exactly (models.lua:859-860)
+    P2 = cg.models.createSpatialTransformer(True, False, False, 32, 3, False)
+    x2 = rs.rand(2, 3, 32, 32).astype(f32)
+    close(P2.forward(cg.Tensor.from_numpy(x2)).numpy(), x2, tol=1e-6)
+
+
+def test_adam_and_fused_penalty_clamp(cg):
+    rs = np.random.RandomState(6)
+    n = 100003
+    p0 = rs.randn(n).astype(f32); st_o = {}
+    x = cg.Tensor.from_numpy(p0.copy()); st_p = {}
+    po = p0.copy()
+    for it in range(3):
+        g = (rs.randn(n) * 3).astype(f32)
+        go = g + f32(1e-4) * po
+        np.clip(go, -1, 1, out=go)
+        O.adam(po, go.astype(f32), st_o)
+        gt = cg.Tensor.from_numpy(g)
+        cg.optim.adam(lambda _: (0.0, gt), x, st_p, fused=dict(l1=0.0, l2=1e-4, clamp=1.0))
+        close(gt.numpy(), go, tol=1e-6, what="clamped grad written back")
+    close(x.numpy(), po, tol=2e-6, what="adam params")
+    close(st_p["m"].numpy(), st_o["m"], tol=1e-6); close(st_p["v"].numpy(), st_o["v"], tol=1e-6)
+
+
+# ------------------------------------------------------------------------------ whole networks
+def _pair(cg, seed, which, size=32, ch=3):
+    cg.manual_seed(seed); rng = O.RNG(seed)
+    if which == "G":
+        return cg.models.create_G((ch, size, size), 100), O.create_G32up_c(ch, 100, rng), rng
+    if which == "G32up":
+        return cg.models.create_G_decoder_upsampling32((ch, size, size), 100), O.create_G32up(ch, 100, rng), rng
+    return cg.models.create_D((ch, size, size)), O.create_D32_st3(ch, size, rng), rng
+
+
+@pytest.mark.parametrize("which,ch", [("G", 3), ("G32up", 1)])
+def test_generator_forward_backward(cg, which, ch):
+    P, Oc, _ = _pair(cg, 21, which, ch=ch)
+    pP, gP = P.getParameters(); pO, gO = O.get_parameters(Oc)
+    np.testing.assert_array_equal(pP.numpy(), pO)
+    rs = np.random.RandomState(7)
+    z = (rs.rand(6, 100) * 2 - 1).astype(f32); dy = (rs.randn(6, ch, 32, 32) * 0.1).astype(f32)
+    zin = cg.Tensor.from_numpy(z)
+    close(P.forward(zin).numpy(), Oc.forward(z), tol=5e-5, what="G forward")
+    P.backward(zin, cg.Tensor.from_numpy(dy)); Oc.backward(dy)
+    off = 0
+    for p_, _ in Oc.parameters():
+        a, b = gP.numpy()[off:off + p_.size], gO[off:off + p_.size]
+        off += p_.size
+        scale = max(np.abs(b).max(), 1e-4 * np.abs(gO).max())
+        d = np.abs(a - b)
+        assert d.max() <= 3e-2 * scale and (a.size == 1 or d.mean() <= 2e-3 * scale), (p_.shape, d.max(), scale)
+
+
+def test_discriminator_forward_backward(cg):
+    P, Oc, rng = _pair(cg, 22, "D")
+    pP, gP = P.getParameters(); pO, gO = O.get_parameters(Oc)
+    np.testing.assert_array_equal(pP.numpy(), pO)
+    # make the spatial transformers do something: perturb their (zero-initialised) classifiers identically
+    rs = np.random.RandomState(8)
+    bump = (rs.randn(pO.size) * 0.01).astype(f32)
+    pO += bump; pP.copy(pO)
+    x = rs.rand(6, 3, 32, 32).astype(f32); t = np.array([1, 1, 1, 0, 0, 0], f32)
+    xin = cg.Tensor.from_numpy(x)
+    out_p = P.forward(xin).numpy(); out_o = Oc.forward(x)
+    close(out_p, out_o, tol=5e-5, what="D forward")
+    g = O.bce_backward(out_o, t.reshape(out_o.shape))
+    gi_p = P.backward(xin, cg.Tensor.from_numpy(g)).numpy(); gi_o = Oc.backward(g)
+    bulk_close(gi_p, gi_o, what="D gradInput")
+    bulk_close(gP.numpy(), gO, what="D flat gradient")
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_three_training_steps(cg, fused):
+    """adversarial.lua:51-275 x3 against the oracle Trainer on identical real batches / noise / masks."""
+    seed, N = 31, 8
+    cg.manual_seed(seed); rng = O.RNG(seed)
+    G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
+    Go, Do = O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng)
+    S = cg.adversarial.State(dict(batchSize=N, fused_update=fused), G, D)
+    T = O.Trainer(Go, Do)
+    np.testing.assert_array_equal(S.PARAMETERS_D.numpy(), T.pD)
+    rs = np.random.RandomState(9)
+    pool = rs.rand(32, 3, 32, 32).astype(f32)
+    data = cg.adversarial.TrainData(pool)
+    for step in range(3):
+        idx = rs.randint(0, 32, size=N // 2)
+        nd = (rs.rand(N // 2, 100) * 2 - 1).astype(f32); ng = (rs.rand(N, 100) * 2 - 1).astype(f32)
+        cg.adversarial.iteration(S, data, N, real_idx=idx, noise_D=nd, noise_G=ng)
+        r = T.step(pool[idx], nd, ng)
+        close(S._last_fake.numpy(), r["fake"], tol=2e-4, what=f"step {step} fake images")
+        close(cg.nn.as_plain(S._last["outputs_D"]).numpy(), r["outD"], tol=5e-4, what=f"step {step} D outputs")
+        assert abs(float(S._last["f_G"]) - r["fG"] + (0 if fused else 0)) < 5e-3 or not fused
+        lr = 1e-3
+        for name, a, b in (("pD", S.PARAMETERS_D.numpy(), T.pD), ("pG", S.PARAMETERS_G.numpy(), T.pG)):
+            d = np.abs(a - b)
+            assert d.max() <= 2.5 * lr * (step + 1), f"{name} step {step}: max drift {d.max():.2e}"
+            assert d.mean() <= 2e-5 * (step + 1), f"{name} step {step}: mean drift {d.mean():.2e}"
+            assert np.mean(d > 1e-4) < 2e-3 * (step + 1), f"{name} step {step}: {np.mean(d > 1e-4):.2e} outliers"
+
+
+# ------------------------------------------------- size-independent properties at BASELINE sizes
+def test_conv_adjoint_identity_at_full_size(cg):
+    """<conv(x;w), dy> = <x_up, dgrad(dy;w)> = <w, wgrad(x,dy)> for the dominant layer at config #2's size
+    (conv 5x5 256->128 on 128 x 16x16 upsampled to 32x32; models.lua:217-218)."""
+    N = 128
+    m = cg.nn.SpatialConvolution(256, 128, 5, 5, 1, 1, 2)
+    m.bias.zero()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = cg.Tensor(torch.randn(N * 16 * 16 * 256, device="cuda", generator=g), (N, 256, 16, 16), "nhwc")
+    dy = cg.Tensor(torch.randn(N * 32 * 32 * 128, device="cuda", generator=g), (N, 128, 32, 32), "nhwc")
+    up = cg.nn.SpatialUpSamplingNearest(2)
+    xin = up.forward(x)
+    y = m.forward(xin)
+    m.gradWeight.zero(); m.gradBias.zero()
+    gi_hi = m.backward(xin, dy)
+    gi_lo = up.updateGradInput(x, gi_hi)
+    a = torch.dot(y.t.double(), dy.t.double()).item()
+    b = torch.dot(x.t.double(), gi_lo.t.double()).item()
+    c = torch.dot(m.weight.t.reshape(-1).double(), m.gradWeight.t.reshape(-1).double()).item()
+    assert abs(a - b) <= 1e-5 * abs(a) + 1e-2, (a, b)
+    assert abs(a - c) <= 1e-5 * abs(a) + 1e-2, (a, c)
+    # linearity: conv(2x) = 2 conv(x) exactly (power-of-two scaling commutes with fp32 rounding)
+    y1 = y.t.clone()
+    x.t.mul_(2.0)
+    y2 = m.forward(up.forward(x))
+    assert torch.equal(y2.t, 2 * y1)
+
+
+def test_full_batch_step_runs_and_stays_finite(cg):
+    """Config #2 (batch 128) for two iterations: finite parameters, D output in (0,1), Adam state advanced."""
+    cg.manual_seed(1)
+    G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
+    S = cg.adversarial.State(dict(batchSize=128), G, D)
+    pool = np.random.RandomState(0).rand(256, 3, 32, 32).astype(f32)
+    data = cg.adversarial.TrainData(pool)
+    p0 = S.PARAMETERS_G.numpy().copy()
+    for _ in range(2):
+        cg.adversarial.iteration(S, data)
+    torch.cuda.synchronize()
+    pg, pd = S.PARAMETERS_G.numpy(), S.PARAMETERS_D.numpy()
+    assert np.isfinite(pg).all() and np.isfinite(pd).all()
+    assert S.OPTSTATE["adam"]["G"]["t"] == 2 and S.OPTSTATE["adam"]["D"]["t"] == 2
+    d = np.abs(pg - p0)
+    assert 0 < d.max() <= 2.1e-3  # |step| <= lr per Adam update at t<=2 (bias-corrected), two updates
+    out = cg.nn.as_plain(S._last["outputs_D"]).numpy()
+    assert out.shape == (128, 1) and (out > 0).all() and (out < 1).all()
+    S.CONFUSION.updateValids()
+    assert S.CONFUSION.counts.sum().item() == 256
