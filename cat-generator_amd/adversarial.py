@@ -59,6 +59,7 @@ class State:
         self.random = np.random.RandomState(self.OPT["seed"])  # math.randomseed(OPT.seed), train.lua:61
         self.accs = []
         self._cache = {}
+        self.keep_outputs = False  # tests: snapshot D's output before the G-step reuses the buffer
 
 
 def mean(t):
@@ -117,7 +118,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         S.CONFUSION.batchAdd(nn.as_plain(outputs), targets)
         if not OPT["fused_update"] and OPT["D_clamp"] != 0:
             S.GRAD_PARAMETERS_D.clamp(-OPT["D_clamp"], OPT["D_clamp"])
-        S._last = dict(outputs_D=outputs, f_D=f)
+        S._last = dict(outputs_D=outputs.clone() if S.keep_outputs else outputs, f_D=f)
         if maxAccuracyD <= 1.0:  # the gate can trigger: read this batch's accuracy back (:115-166)
             o = nn.as_plain(outputs).numpy().reshape(-1)
             t = targets.numpy().reshape(-1)
@@ -169,7 +170,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         noise = nn.to_device(noise_D) if noise_D is not None else nn_utils.createNoiseInputs(S, half)
         samples = nn.as_nhwc(nn_utils.createImagesFromNoise(S, noise, False))
         lib().memcpy_d2d(stream(), inputs.ptr + half * rowlen * 4, samples.ptr, half * rowlen * 4)
-        S._last_fake = samples
+        S._last_fake = samples.clone() if S.keep_outputs else samples
         fused = dict(l1=OPT["D_L1"], l2=OPT["D_L2"], clamp=OPT["D_clamp"]) if OPT["fused_update"] else None
         assert OPT["D_optmethod"] == "adam", "only adam (the default) is implemented"
         optim.adam(fevalD, S.PARAMETERS_D, S.OPTSTATE["adam"]["D"], fused=fused)

@@ -1,0 +1,108 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/catgan.h declares, argument
+validation fails loudly with a message, and the host-side module layer reproduces the reference's graph structure
+(parameter counts, getParameters() ordering and aliasing, weight-init scoping) bit-for-bit against the oracle."""
+import ctypes
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cg():
+    return importlib.import_module("cat-generator_amd")
+
+
+def test_library_exports_every_declared_symbol(cg):
+    abi = importlib.import_module("cat-generator_amd._abi")
+    protos = abi.parse_header()
+    assert len(protos) >= 60
+    dll = ctypes.CDLL(abi.LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), f"{name} declared in include/catgan.h but not exported"
+    L = cg.lib()
+    assert L.abi_version() == 1
+    # nothing but extern "C" cg_* entry points with plain C types
+    for name, (ret, args) in protos.items():
+        assert ret in ("int", "size_t", "const char*")
+        for typ, _ in args:
+            assert typ in abi._CTYPES, f"{name}: non-C-ABI type {typ}"
+
+
+def test_argument_validation_fails_loudly(cg):
+    L = cg.lib()
+    with pytest.raises(cg.CatganError, match="null pointer"):
+        L.conv2d_forward(None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, None, 0)
+    with pytest.raises(cg.CatganError, match="bad geometry"):
+        L.conv2d_forward(None, 16, 16, None, 16, 0, 1, 1, 1, 1, 1, 1, 0, 0, 0, None, 0)
+    with pytest.raises(cg.CatganError, match="out of range"):
+        L.copy_channels(None, 16, 16, 4, 8, 6, 8, 0, 4)
+    assert L.conv2d_workspace_bytes(128, 1, 1, 20480, 256, 1, 1, 0, 0, 0) > 0          # split-K linear head
+    assert L.conv2d_workspace_bytes(128, 16, 16, 256, 128, 5, 5, 2, 2, 1) == 0           # big conv: no split
+
+
+def test_missing_library_has_no_fallback(cg, monkeypatch):
+    abi = importlib.import_module("cat-generator_amd._abi")
+    monkeypatch.setattr(abi, "LIB_PATH", "/nonexistent/libcatgan_hip.so")
+    with pytest.raises(abi.CatganError, match="no CPU fallback"):
+        abi.Lib()
+
+
+def test_models_match_oracle_structure_bit_for_bit(cg):
+    cg.manual_seed(1); rng = O.RNG(1)
+    G = cg.models.create_G((3, 32, 32), 100); D = cg.models.create_D((3, 32, 32))
+    Go = O.create_G32up_c(3, 100, rng); Do = O.create_D32_st3(3, 32, rng)
+    assert cg.nn_utils.getNumberOfParameters(G) == 5191687
+    assert cg.nn_utils.getNumberOfParameters(D) == 6664777
+    pG, gG = G.getParameters(); pD, gD = D.getParameters()
+    a, _ = O.get_parameters(Go); b, _ = O.get_parameters(Do)
+    np.testing.assert_array_equal(pG.numpy(), a)
+    np.testing.assert_array_equal(pD.numpy(), b)
+    assert cg.tensor.rng().offset == rng.offset  # both consumed the same number of draws
+    # getParameters(): module tensors alias the flat vector (train.lua:184-185)
+    conv = G.modules[4]
+    assert conv.typename == "cudnn.SpatialConvolution" and conv.weight.t.data_ptr() >= pG.t.data_ptr()
+    pG.t[conv.weight.t.data_ptr() // 4 - pG.t.data_ptr() // 4] = 42.0
+    assert conv.weight.numpy().reshape(-1)[0] == 42.0
+    # weight-init scoping (weight-init.lua:52): G conv bias zeroed; D Concat children keep default bias
+    assert np.all(conv.bias.numpy() == 0)
+    assert np.any(D.modules[7].modules[0].modules[1].bias.numpy() != 0)
+    # spatial transformer initialised to the identity (models.lua:859-860)
+    cls = D.modules[0].modules[0].modules[1].modules[0].modules[-1]
+    assert np.all(cls.weight.numpy() == 0) and np.all(cls.bias.numpy() == [0.0])
+
+
+def test_g32up_and_64px_variants(cg):
+    cg.manual_seed(2)
+    G1 = cg.models.create_G_decoder_upsampling32((1, 32, 32), 100)
+    assert cg.nn_utils.getNumberOfParameters(G1) == 2468100
+    G64 = cg.models.create_G((3, 64, 64), 100)
+    D64 = cg.models.create_D((3, 64, 64))
+    assert cg.nn_utils.getNumberOfParameters(D64) == 22737481        # SURVEY.md Appendix A.3 (S=64)
+    assert G64.modules[0].weight.size(1) == 512 * 8 * 8
+
+
+def test_transpose_is_a_relabeling_of_nhwc_storage(cg):
+    x = np.arange(2 * 3 * 4 * 5, dtype=np.float32).reshape(2, 3, 4, 5)
+    t = cg.Tensor.from_numpy(x)
+    tr = cg.nn.Transpose((3, 4), (2, 4))
+    y = tr.updateOutput(t)
+    assert y.shape == (2, 4, 5, 3) and y.fmt == "plain" and y.t.data_ptr() == t.t.data_ptr()
+    np.testing.assert_array_equal(y.numpy(), x.transpose(0, 2, 3, 1))
+    back = cg.nn.Transpose((2, 4), (3, 4)).updateOutput(y)
+    assert back.fmt == "nhwc" and back.shape == (2, 3, 4, 5)
+    np.testing.assert_array_equal(back.numpy(), x)
+    up = cg.nn.SpatialUpSamplingNearest(2).updateOutput(t)
+    assert up.ups == 1 and up.shape == (2, 3, 8, 10) and up.t.data_ptr() == t.t.data_ptr()  # never materialised
+    np.testing.assert_array_equal(up.numpy(), np.repeat(np.repeat(x, 2, 2), 2, 3))
+
+
+def test_host_rng_is_the_oracle_stream(cg):
+    r = cg.tensor.SplitMix(77); ro = O.RNG(77)
+    np.testing.assert_array_equal(r.uniform((1000,), -0.3, 0.7), ro.uniform((1000,), -0.3, 0.7))
+    np.testing.assert_array_equal(r.u01(17), O.u01(17, 77, 1000))
