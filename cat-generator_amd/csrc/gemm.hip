@@ -6,66 +6,135 @@
 // (models.lua:646-685,844-846) and nn.Linear (models.lua:199,697,700,850,853):
 //   igemm_nn : updateOutput and updateGradInput  (Y[m][n] = sum_k A(m,k) W[k][n])
 //   igemm_tn : accGradParameters                 (dW[k][n] = sum_m A(m,k) dY[m][n])
-// A(m,k) is never materialised: m -> output pixel (n,oy,ox), k -> (tap,ci),
-// gathered from the NHWC activation with zero padding and, if ups==1, through
-// a virtual nearest-neighbour 2x upsampling (models.lua:205,211,217).
+// A(m,k) is never materialised: m -> grid pixel (n,oy,ox), k -> (tap,ci), gathered from the NHWC tensor.
 //
-// Tiling (wave64, 4 waves / workgroup): block tile BM x BN, K step 16, each
-// wave owns (BM/WM) x (BN/WN) as MI x NI MFMA 32x32 accumulators.  Both
-// operands sit K-major in LDS ([k][m] / [k][n]) so a fragment read is one
-// conflict-free ds_read_b32 per operand per MFMA; global->register->LDS
-// staging is double buffered (one barrier per K tile) with the next tile's
-// global loads issued before the MFMA block of the current one.
+// nn.SpatialUpSamplingNearest(2) -> conv (models.lua:205-206,211-212,217-218) is executed as FOUR PHASE
+// CONVOLUTIONS on the low-resolution input: output pixel (2i+a, 2j+b) only ever sees ceil((k+1)/2)^2 distinct
+// low-res taps, so the k x k weights are pre-summed per phase (a,b) into k' x k' kernels (k'=2 for k=3, 3 for
+// k=5): 2.25x / 2.78x fewer MACs than convolving the materialised upsampled map, identical up to fp32
+// re-association of the weight sums.  The data gradient w.r.t. the low-res input (upsampling's 2x2 block sum
+// folded in) is ONE GEMM over the 4 phases' taps; the weight gradient is taken per phase and mapped back onto
+// the canonical taps by the reduce kernel.
+//
+// fp32 MFMA issues at exactly the fp32 VALU rate, so every VALU instruction in the main loop costs MFMA
+// throughput (measured: 4.9 VALU per MFMA = 73 % pipe utilisation).  The FAST path therefore keeps the gather
+// lean: tap bookkeeping lives in SGPRs, per-row validity is a precomputed 64-bit tap mask, and loads are
+// buffer_load_dwordx4 whose out-of-range offset returns 0 (no branches, no zero-fills).
+//
+// Tiling (wave64, 4 waves / workgroup): block tile BM x BN, K step 16, each wave owns MI x NI MFMA 32x32
+// accumulators.  Both operands sit K-major in LDS ([k][m] XOR-swizzled, [k][n]) so a fragment read is one
+// conflict-free ds_read_b32 per operand per MFMA; global->register->LDS staging is double buffered (one
+// barrier per K tile) with the next tile's loads issued before the current tile's MFMAs.  32 KiB LDS and
+// <= 128 registers per workgroup -> 4 workgroups per CU.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;
+constexpr unsigned OOB = 0x80000000u;  // >= num_records of every descriptor below: the load returns 0
 
-struct ConvGeom {
-    int M;            // N*Ho*Wo output pixels
-    int HoWo, Wo;     // output spatial
-    int Hl, Wl;       // logical input spatial (physical << ups)
-    int Hp, Wp;       // physical input spatial
-    int Cin, Cout;
-    int kW;           // tap -> (ky = tap / kW, kx = tap % kW)
-    int padH, padW, ups;
-    int Ktot;         // kH*kW*Cin
+// tap t of a launch -> (ty, tx, element offset):  group = t / kk, (ry,rx) = (t % kk) / kw, % kw
+//   phase bits (a,b) = launch phase (nphase == 4)  or  group bits (ngroups == 4)  or  0
+//   ty = sgn*(r0y(a)+ry), tx = sgn*(r0x(b)+rx);  source pixel = ((oy+ty)*ss + a*(ss==2), (ox+tx)*ss + b*(ss==2))
+struct TapDesc {
+    int kw, kk, ngroups, sgn, ss;
+    int r0y0, r0y1, r0x0, r0x1;   // tap origin per phase bit (no arrays: runtime indexing would go to scratch)
+};
+
+struct Geom {
+    int M;                 // grid pixels per phase: N*Hg*Wg
+    int Hg, Wg;            // grid per image
+    int lgW, lgHW;         // log2(Wg), log2(Hg*Wg) when both are powers of two, else -1
+    int Hv, Wv;            // (oy+ty, ox+tx) must lie in [0,Hv) x [0,Wv)
+    int Hs, Ws;            // source tensor spatial dims
+    int Cin, Cout;         // GEMM K-channels / N
+    int so, Hout, Wout;    // grid pixel -> (n, oy*so+a, ox*so+b) of an [N,Hout,Wout] tensor (NN: y; TN: dy)
+    int nphase;            // 1 or 4 (blockIdx.z)
+    int ntaps, Ktot;       // per phase; Ktot = ntaps*Cin
+    TapDesc td;
 };
 
 struct NNArgs {
     const float* x;
-    const float* w;     // [Ktot][Cout]
+    const float* w;     // [nphase][Ktot][Cout]
     const float* bias;  // [Cout] or null
-    float* y;           // [M][Cout] or split partials [S][M][Cout]
-    ConvGeom g;
+    float* y;           // output tensor, or split partials [S][nphase][M][Cout]
+    Geom g;
     int kchunk;         // K range per split (multiple of BK)
-    long split_stride;  // M*Cout
+    int nsplit;
 };
 
 struct TNArgs {
     const float* x;
-    const float* dy;    // [M][Cout]
-    float* part;        // [S][Ktot][Cout]
-    ConvGeom g;
+    const float* dy;
+    float* part;        // [S][nphase][Ktot][Cout]
+    Geom g;
     int pchunk;         // pixels per split (multiple of BK)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// NOTE: cast the WHOLE vector.  Extracting the four dwords one by one (bit_cast(float, v.x) ...) makes LLVM's
+// InstCombine (ROCm 7.2, -O3) narrow the v4i32 buffer load to a single i32 and splat it - a silent miscompile.
+__device__ __forceinline__ float4 bufld4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const f32x4 f = __builtin_bit_cast(f32x4, v);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+
+__device__ __forceinline__ void tap_decode(const Geom& g, int t, int pa, int pb, int& ty, int& tx, int& off) {
+    const TapDesc& d = g.td;
+    const int grp = t / d.kk;
+    const int tt = t - grp * d.kk;
+    const int ry = tt / d.kw, rx = tt - (tt / d.kw) * d.kw;
+    int a = pa, b = pb;
+    if (d.ngroups > 1) { a = grp >> 1; b = grp & 1; }
+    ty = d.sgn * ((a ? d.r0y1 : d.r0y0) + ry);
+    tx = d.sgn * ((b ? d.r0x1 : d.r0x0) + rx);
+    const int ay = d.ss == 2 ? a : 0, ax = d.ss == 2 ? b : 0;
+    off = ((ty * d.ss + ay) * g.Ws + (tx * d.ss + ax)) * g.Cin;
+}
+
+__device__ __forceinline__ void pix_decode(const Geom& g, int m, int& n, int& oy, int& ox) {
+    if (g.lgW >= 0) {
+        n = m >> g.lgHW;
+        oy = (m >> g.lgW) & (g.Hg - 1);
+        ox = m & (g.Wg - 1);
+    } else {
+        const int hw = g.Hg * g.Wg;
+        n = m / hw;
+        const int r = m - n * hw;
+        oy = r / g.Wg;
+        ox = r - oy * g.Wg;
+    }
+}
+
+// element offset of grid pixel m (phase bits pa,pb) in the [N,Hout,Wout,Cout] tensor
+__device__ __forceinline__ long out_row(const Geom& g, int m, int pa, int pb) {
+    if (g.so == 1 && g.nphase == 1) return (long)m * g.Cout;
+    int n, oy, ox;
+    pix_decode(g, m, n, oy, ox);
+    return ((long)(n * g.Hout + oy * g.so + pa) * g.Wout + ox * g.so + pb) * g.Cout;
+}
+
 // ---------------------------------------------------------------------------
 // NN: Y[m][n] = sum_k A(m,k) * W[k][n]
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool VECA, bool VECB>
-__global__ __launch_bounds__(256) void igemm_nn_kernel(NNArgs a) {
+template <int BM, int BN, int WM, int WN, bool FAST, bool VECB>
+__global__ __launch_bounds__(256, 4) void igemm_nn_kernel(NNArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int MI = BM / WM / 32;
     constexpr int NI = BN / WN / 32;
     static_assert(MI >= 1 && NI >= 1, "wave tile >= 32x32");
-    constexpr int LDA = BM + 2;  // 4*LDA % 32 == 8: transposed ds_write_b32 conflict-free
-    constexpr int LDB = BN + 4;  // rows stay 16-B aligned for ds_write_b128
+    // A tile [k][m], column XOR-swizzled by ((k>>2)&3)<<3: the transposed ds_write_b32 of a float4 (4
+    // consecutive k of one pixel) hits 32 distinct banks per half-wave, and a fragment read (32 consecutive m
+    // at fixed k) stays a permutation of the 32 banks.  No padding.
+    constexpr int LDA = BM, LDB = BN;
     constexpr int A_TILE = BK * LDA, B_TILE = BK * LDB;
     constexpr int AROWS = BM / 64;  // float4 per thread per tile (A)
     static_assert(BM % 64 == 0, "BM multiple of 64");
@@ -77,7 +146,7 @@ __global__ __launch_bounds__(256) void igemm_nn_kernel(NNArgs a) {
     float* As = smem;
     float* Bs = smem + 2 * A_TILE;
 
-    const ConvGeom& g = a.g;
+    const Geom& g = a.g;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -88,97 +157,151 @@ __global__ __launch_bounds__(256) void igemm_nn_kernel(NNArgs a) {
     const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
+    const int phase = blockIdx.z, pa = phase >> 1, pb = phase & 1;
     const int ks = split * a.kchunk;
     const int kend = min(g.Ktot, ks + a.kchunk);
     const int T = (kend - ks + BK - 1) / BK;
+    const float* wph = a.w + (long)phase * g.Ktot * g.Cout;
 
     // ---- A staging: thread owns k-vector a_kv (4 consecutive k) of rows a_r + 64p
     const int a_kv = tid & 3, a_r = tid >> 2;
-    int a_pix[AROWS], a_oy[AROWS], a_ox[AROWS];
-    bool a_ok[AROWS];
+    int rowb[AROWS], r_oy[AROWS], r_ox[AROWS];
+    bool r_ok[AROWS];
 #pragma unroll
     for (int p = 0; p < AROWS; ++p) {
         const int m = m0 + a_r + 64 * p;
-        a_ok[p] = m < g.M;
-        const int mm = a_ok[p] ? m : 0;
-        const int n = mm / g.HoWo;
-        const int rem = mm - n * g.HoWo;
-        a_oy[p] = rem / g.Wo;
-        a_ox[p] = rem - a_oy[p] * g.Wo;
-        a_pix[p] = n * g.Hp * g.Wp;
+        r_ok[p] = m < g.M;
+        int n, oy, ox;
+        pix_decode(g, r_ok[p] ? m : 0, n, oy, ox);
+        r_oy[p] = oy; r_ox[p] = ox;
+        rowb[p] = ((n * g.Hs + oy * g.td.ss) * g.Ws + ox * g.td.ss) * g.Cin;
     }
-    // ---- B staging
     const int b_nv = tid % NVEC, b_kr = tid / NVEC;
 
     float4 areg[AROWS];
     float4 breg[BPASS];
 
+    // ---- FAST-path state -------------------------------------------------------------------------------
+    unsigned long long cur[AROWS];     // tap-validity mask of each row, shifted so bit 0 = next tile's tap
+    unsigned rowbytes[AROWS];
+    unsigned bvoff[BPASS];
+    int tapi = 0, ci0 = 0, toff = 0, minoff = 0;
+    __amdgpu_buffer_rsrc_t rsx, rsw;
+    if (FAST) {
+        const TapDesc& d = g.td;
+        const int kh = d.kk / d.kw;
+#pragma unroll
+        for (int p = 0; p < AROWS; ++p) cur[p] = 0ull;
+        for (int grp = 0; grp < d.ngroups; ++grp) {
+            int ga = pa, gb = pb;
+            if (d.ngroups > 1) { ga = grp >> 1; gb = grp & 1; }
+            unsigned xb[AROWS];
+#pragma unroll
+            for (int p = 0; p < AROWS; ++p) xb[p] = 0u;
+            for (int rx = 0; rx < d.kw; ++rx) {
+                const int tx = d.sgn * ((gb ? d.r0x1 : d.r0x0) + rx);
+#pragma unroll
+                for (int p = 0; p < AROWS; ++p)
+                    xb[p] |= ((unsigned)(r_ox[p] + tx) < (unsigned)g.Wv ? 1u : 0u) << rx;
+            }
+            for (int ry = 0; ry < kh; ++ry) {
+                const int ty = d.sgn * ((ga ? d.r0y1 : d.r0y0) + ry);
+                const int sh = grp * d.kk + ry * d.kw;
+#pragma unroll
+                for (int p = 0; p < AROWS; ++p)
+                    if (r_ok[p] && (unsigned)(r_oy[p] + ty) < (unsigned)g.Hv) cur[p] |= (unsigned long long)xb[p] << sh;
+            }
+        }
+        for (int t = 0; t < g.ntaps; ++t) {
+            int ty, tx, off;
+            tap_decode(g, t, pa, pb, ty, tx, off);
+            minoff = min(minoff, off);
+        }
+        tapi = ks / g.Cin;
+        ci0 = ks - tapi * g.Cin;
+        { int ty, tx; tap_decode(g, tapi, pa, pb, ty, tx, toff); }
+#pragma unroll
+        for (int p = 0; p < AROWS; ++p) {
+            cur[p] >>= tapi;
+            rowbytes[p] = (unsigned)(rowb[p] + 4 * a_kv) * 4u;
+        }
+        // base shifted down by the most negative tap offset so that the SGPR offset stays non-negative
+        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + minoff), 0, 0x7fffffff, 0x00020000);
+        rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wph, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < BPASS; ++q) {
+            const int kr = b_kr + q * BRPP;
+            const int n = n0 + 4 * b_nv;
+            bvoff[q] = (kr < BK && n < g.Cout) ? (unsigned)(kr * g.Cout + n) * 4u : OOB;
+        }
+    }
+
     auto load_tile = [&](int k0) {
-        const int k = k0 + 4 * a_kv;
-        if (VECA) {
-            const bool kok = k < kend;
-            const int tap = k / g.Cin;
-            const int ci = k - tap * g.Cin;
-            const int ky = tap / g.kW;
-            const int kx = tap - ky * g.kW;
+        if (FAST) {
+            // (tapi, ci0, toff) describe this tile; all SGPR arithmetic
+            const int soff = (toff - minoff + ci0) * 4;
 #pragma unroll
             for (int p = 0; p < AROWS; ++p) {
-                const int iy = a_oy[p] + ky - g.padH;
-                const int ix = a_ox[p] + kx - g.padW;
-                const bool ok = a_ok[p] && kok && (unsigned)iy < (unsigned)g.Hl && (unsigned)ix < (unsigned)g.Wl;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) {
-                    const long off = ((long)(a_pix[p] + (iy >> g.ups) * g.Wp + (ix >> g.ups))) * g.Cin + ci;
-                    v = ld4(a.x + off);
-                }
-                areg[p] = v;
+                const unsigned voff = ((unsigned)cur[p] & 1u) ? rowbytes[p] : OOB;
+                areg[p] = bufld4(rsx, voff, soff);
+            }
+            if (VECB) {
+                const int sb = k0 * g.Cout * 4;
+#pragma unroll
+                for (int q = 0; q < BPASS; ++q) breg[q] = bufld4(rsw, bvoff[q], sb);
+            }
+            ci0 += BK;
+            if (ci0 >= g.Cin) {
+                ci0 = 0;
+                ++tapi;
+#pragma unroll
+                for (int p = 0; p < AROWS; ++p) cur[p] >>= 1;
+                if (tapi < g.ntaps) { int ty, tx; tap_decode(g, tapi, pa, pb, ty, tx, toff); }
             }
         } else {
             float tmp[AROWS][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int kj = k + j;
+                const int kj = k0 + 4 * a_kv + j;
                 const bool kok = kj < kend;
-                const int tap = kj / g.Cin;
+                const int tap = kok ? kj / g.Cin : 0;
                 const int ci = kj - tap * g.Cin;
-                const int ky = tap / g.kW;
-                const int kx = tap - ky * g.kW;
+                int ty, tx, off;
+                tap_decode(g, tap, pa, pb, ty, tx, off);
 #pragma unroll
                 for (int p = 0; p < AROWS; ++p) {
-                    const int iy = a_oy[p] + ky - g.padH;
-                    const int ix = a_ox[p] + kx - g.padW;
-                    const bool ok = a_ok[p] && kok && (unsigned)iy < (unsigned)g.Hl && (unsigned)ix < (unsigned)g.Wl;
+                    const bool ok = r_ok[p] && kok && (unsigned)(r_oy[p] + ty) < (unsigned)g.Hv &&
+                                    (unsigned)(r_ox[p] + tx) < (unsigned)g.Wv;
                     float v = 0.f;
-                    if (ok) {
-                        const long off = ((long)(a_pix[p] + (iy >> g.ups) * g.Wp + (ix >> g.ups))) * g.Cin + ci;
-                        v = a.x[off];
-                    }
+                    if (ok) v = a.x[(long)rowb[p] + off + ci];
                     tmp[p][j] = v;
                 }
             }
 #pragma unroll
             for (int p = 0; p < AROWS; ++p) areg[p] = make_float4(tmp[p][0], tmp[p][1], tmp[p][2], tmp[p][3]);
         }
+        if (!(FAST && VECB)) {
 #pragma unroll
-        for (int q = 0; q < BPASS; ++q) {
-            const int kr = b_kr + q * BRPP;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kr < BK) {
-                const int kk = k0 + kr;
-                const int n = n0 + 4 * b_nv;
-                if (kk < kend) {
-                    const float* wp = a.w + (long)kk * g.Cout + n;
-                    if (VECB) {
-                        if (n < g.Cout) v = ld4(wp);
-                    } else {
-                        if (n + 0 < g.Cout) v.x = wp[0];
-                        if (n + 1 < g.Cout) v.y = wp[1];
-                        if (n + 2 < g.Cout) v.z = wp[2];
-                        if (n + 3 < g.Cout) v.w = wp[3];
+            for (int q = 0; q < BPASS; ++q) {
+                const int kr = b_kr + q * BRPP;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kr < BK) {
+                    const int kk = k0 + kr;
+                    const int n = n0 + 4 * b_nv;
+                    if (kk < kend) {
+                        const float* wp = wph + (long)kk * g.Cout + n;
+                        if (VECB) {
+                            if (n < g.Cout) v = ld4(wp);
+                        } else {
+                            if (n + 0 < g.Cout) v.x = wp[0];
+                            if (n + 1 < g.Cout) v.y = wp[1];
+                            if (n + 2 < g.Cout) v.z = wp[2];
+                            if (n + 3 < g.Cout) v.w = wp[3];
+                        }
                     }
                 }
+                breg[q] = v;
             }
-            breg[q] = v;
         }
     };
 
@@ -187,11 +310,11 @@ __global__ __launch_bounds__(256) void igemm_nn_kernel(NNArgs a) {
         float* B = Bs + buf * B_TILE;
 #pragma unroll
         for (int p = 0; p < AROWS; ++p) {
-            const int r = a_r + 64 * p;
-            A[(4 * a_kv + 0) * LDA + r] = areg[p].x;
-            A[(4 * a_kv + 1) * LDA + r] = areg[p].y;
-            A[(4 * a_kv + 2) * LDA + r] = areg[p].z;
-            A[(4 * a_kv + 3) * LDA + r] = areg[p].w;
+            const int rs = (a_r + 64 * p) ^ ((a_kv & 3) << 3);
+            A[(4 * a_kv + 0) * LDA + rs] = areg[p].x;
+            A[(4 * a_kv + 1) * LDA + rs] = areg[p].y;
+            A[(4 * a_kv + 2) * LDA + rs] = areg[p].z;
+            A[(4 * a_kv + 3) * LDA + rs] = areg[p].w;
         }
 #pragma unroll
         for (int q = 0; q < BPASS; ++q) {
@@ -217,13 +340,13 @@ __global__ __launch_bounds__(256) void igemm_nn_kernel(NNArgs a) {
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
         if (t + 1 < T) load_tile(ks + (t + 1) * BK);
-        const float* A = As + buf * A_TILE + wm0 + l31;
+        const float* A = As + buf * A_TILE + wm0;
         const float* B = Bs + buf * B_TILE + wn0 + l31;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float av[MI], bv[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) av[i] = A[(kk + h) * LDA + i * 32];
+            for (int i = 0; i < MI; ++i) av[i] = A[(kk + h) * LDA + i * 32 + (l31 ^ (((kk >> 2) & 3) << 3))];
 #pragma unroll
             for (int j = 0; j < NI; ++j) bv[j] = B[(kk + h) * LDB + j * 32];
 #pragma unroll
@@ -237,53 +360,58 @@ __global__ __launch_bounds__(256) void igemm_nn_kernel(NNArgs a) {
     }
 
     // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*h (pixel), j = l31 (channel)
-    float* yout = a.y + (long)split * a.split_stride;
-    const bool add_bias = (a.bias != nullptr) && (gridDim.y == 1);
+    const bool partial = a.nsplit > 1;
+    const bool add_bias = (a.bias != nullptr) && !partial;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn0 + j * 32 + l31;
-        if (n >= g.Cout) continue;
-        const float bv = add_bias ? a.bias[n] : 0.f;
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= g.M) continue;
+            const long ro = partial ? ((long)(split * g.nphase + phase) * g.M + m) * g.Cout : out_row(g, m, pa, pb);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < g.M) yout[(long)m * g.Cout + n] = acc[i][j][r] + bv;
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn0 + j * 32 + l31;
+                if (n < g.Cout) a.y[ro + n] = acc[i][j][r] + (add_bias ? a.bias[n] : 0.f);
             }
         }
     }
 }
 
-// split-K reduce for NN: y[m][n] = bias[n] + sum_s part[s][m][n]
-__global__ void nn_splitk_reduce_kernel(const float* part, const float* bias, float* y, long MN, int Cout, int S) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < MN; i += (long)gridDim.x * blockDim.x) {
+// split-K reduce for NN: y[out_row(m)][n] = bias[n] + sum_s part[s][phase][m][n]
+__global__ void nn_splitk_reduce_kernel(const float* part, const float* bias, float* y, Geom g, int S) {
+    const long PMN = (long)g.nphase * g.M * g.Cout;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < PMN; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < S; ++k) s += part[(long)k * MN + i];
-        if (bias) s += bias[i % Cout];
-        y[i] = s;
+        for (int k = 0; k < S; ++k) s += part[(long)k * PMN + i];
+        const int n = (int)(i % g.Cout);
+        const long pm = i / g.Cout;
+        const int m = (int)(pm % g.M);
+        const int phase = (int)(pm / g.M);
+        if (bias) s += bias[n];
+        y[out_row(g, m, phase >> 1, phase & 1) + n] = s;
     }
 }
 
 // ---------------------------------------------------------------------------
-// TN: dW[k][n] = sum_m A(m,k) * dY[m][n]   (k = (tap,ci) rows, m = pixels reduced)
+// TN: dW[k][n] = sum_m A(m,k) * dY[m][n]   (k = (tap,ci) rows, m = grid pixels reduced)
 // ---------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool VECA, bool VECB>
-__global__ __launch_bounds__(256) void igemm_tn_kernel(TNArgs a) {
+__global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int MI = BM / WM / 32;
     constexpr int NI = BN / WN / 32;
-    constexpr int LDA = BM + 4;
-    constexpr int LDB = BN + 4;
+    constexpr int LDA = BM, LDB = BN;
     constexpr int A_TILE = BK * LDA, B_TILE = BK * LDB;
     constexpr int AVEC = BM / 4, ARPP = 256 / AVEC, APASS = (BK + ARPP - 1) / ARPP;
     constexpr int BVEC = BN / 4, BRPP = 256 / BVEC, BPASS = (BK + BRPP - 1) / BRPP;
+    constexpr int NJ = VECA ? 1 : 4;
 
     __shared__ __attribute__((aligned(16))) float smem[2 * A_TILE + 2 * B_TILE];
     float* As = smem;
     float* Bs = smem + 2 * A_TILE;
 
-    const ConvGeom& g = a.g;
+    const Geom& g = a.g;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -294,26 +422,29 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TNArgs a) {
     const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
     const int m0 = tm * BM, n0 = tn * BN;  // m0: row of dW (tap,ci)
     const int split = blockIdx.y;
+    const int phase = blockIdx.z, pa = phase >> 1, pb = phase & 1;
     const int ps = split * a.pchunk;
     const int pend = min(g.M, ps + a.pchunk);
     const int T = (pend - ps + BK - 1) / BK;
 
     // A staging: fixed (tap,ci) columns per thread, pixel rows vary per tile
     const int a_mv = tid % AVEC, a_kr = tid / AVEC;
-    int a_ci[VECA ? 1 : 4], a_dy[VECA ? 1 : 4], a_dx[VECA ? 1 : 4];
-    bool a_cok[VECA ? 1 : 4];
+    int c_off[NJ], c_ty[NJ], c_tx[NJ];
+    bool c_ok[NJ];
 #pragma unroll
-    for (int j = 0; j < (VECA ? 1 : 4); ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int mm = m0 + 4 * a_mv + j;
-        a_cok[j] = mm < g.Ktot;
-        const int mc = a_cok[j] ? mm : 0;
+        c_ok[j] = mm < g.Ktot;
+        const int mc = c_ok[j] ? mm : 0;
         const int tap = mc / g.Cin;
-        a_ci[j] = mc - tap * g.Cin;
-        const int ky = tap / g.kW;
-        a_dy[j] = ky - g.padH;
-        a_dx[j] = (tap - ky * g.kW) - g.padW;
+        int off;
+        tap_decode(g, tap, pa, pb, c_ty[j], c_tx[j], off);
+        c_off[j] = off + (mc - tap * g.Cin);
     }
     const int b_nv = tid % BVEC, b_kr = tid / BVEC;
+    const bool b_nok = n0 + 4 * b_nv < g.Cout;
+    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, 0x7fffffff, 0x00020000);
 
     float4 areg[APASS];
     float4 breg[BPASS];
@@ -325,33 +456,25 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TNArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kr < BK) {
                 const int pix = p0 + kr;
-                if (pix < pend) {
-                    const int n = pix / g.HoWo;
-                    const int rem = pix - n * g.HoWo;
-                    const int oy = rem / g.Wo;
-                    const int ox = rem - oy * g.Wo;
-                    const int base = n * g.Hp * g.Wp;
-                    if (VECA) {
-                        const int iy = oy + a_dy[0], ix = ox + a_dx[0];
-                        if (a_cok[0] && (unsigned)iy < (unsigned)g.Hl && (unsigned)ix < (unsigned)g.Wl) {
-                            const long off = ((long)(base + (iy >> g.ups) * g.Wp + (ix >> g.ups))) * g.Cin + a_ci[0];
-                            v = ld4(a.x + off);
-                        }
-                    } else {
-                        float t4[4];
+                int n, oy, ox;
+                pix_decode(g, pix < pend ? pix : 0, n, oy, ox);
+                const int base = ((n * g.Hs + oy * g.td.ss) * g.Ws + ox * g.td.ss) * g.Cin;
+                if (VECA) {
+                    const bool ok = pix < pend && c_ok[0] && (unsigned)(oy + c_ty[0]) < (unsigned)g.Hv &&
+                                    (unsigned)(ox + c_tx[0]) < (unsigned)g.Wv;
+                    v = bufld4(rsx, ok ? (unsigned)(base + c_off[0]) * 4u : OOB, 0);
+                } else {
+                    float t4[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int jj = VECA ? 0 : j;
-                            const int iy = oy + a_dy[jj], ix = ox + a_dx[jj];
-                            float e = 0.f;
-                            if (a_cok[jj] && (unsigned)iy < (unsigned)g.Hl && (unsigned)ix < (unsigned)g.Wl) {
-                                const long off = ((long)(base + (iy >> g.ups) * g.Wp + (ix >> g.ups))) * g.Cin + a_ci[jj];
-                                e = a.x[off];
-                            }
-                            t4[j] = e;
-                        }
-                        v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                    for (int j = 0; j < 4; ++j) {
+                        const int jj = VECA ? 0 : j;
+                        const bool ok = pix < pend && c_ok[jj] && (unsigned)(oy + c_ty[jj]) < (unsigned)g.Hv &&
+                                        (unsigned)(ox + c_tx[jj]) < (unsigned)g.Wv;
+                        float e = 0.f;
+                        if (ok) e = a.x[(long)base + c_off[jj]];
+                        t4[j] = e;
                     }
+                    v = make_float4(t4[0], t4[1], t4[2], t4[3]);
                 }
             }
             areg[q] = v;
@@ -363,16 +486,15 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TNArgs a) {
             if (kr < BK) {
                 const int pix = p0 + kr;
                 const int n = n0 + 4 * b_nv;
-                if (pix < pend) {
-                    const float* dp = a.dy + (long)pix * g.Cout + n;
-                    if (VECB) {
-                        if (n < g.Cout) v = ld4(dp);
-                    } else {
-                        if (n + 0 < g.Cout) v.x = dp[0];
-                        if (n + 1 < g.Cout) v.y = dp[1];
-                        if (n + 2 < g.Cout) v.z = dp[2];
-                        if (n + 3 < g.Cout) v.w = dp[3];
-                    }
+                const long ro = out_row(g, pix < pend ? pix : 0, pa, pb);
+                if (VECB) {
+                    v = bufld4(rsd, (pix < pend && b_nok) ? (unsigned)(ro + n) * 4u : OOB, 0);
+                } else if (pix < pend) {
+                    const float* dp = a.dy + ro + n;
+                    if (n + 0 < g.Cout) v.x = dp[0];
+                    if (n + 1 < g.Cout) v.y = dp[1];
+                    if (n + 2 < g.Cout) v.z = dp[2];
+                    if (n + 3 < g.Cout) v.w = dp[3];
                 }
             }
             breg[q] = v;
@@ -430,7 +552,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(TNArgs a) {
         __syncthreads();
     }
 
-    float* pout = a.part + (long)split * g.Ktot * g.Cout;
+    float* pout = a.part + (long)(split * g.nphase + phase) * g.Ktot * g.Cout;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn0 + j * 32 + l31;
@@ -461,11 +583,36 @@ __global__ void wgrad_reduce_kernel(const float* part, float* gw, int Ktot, int 
     }
 }
 
+// canonical tap d of a k-tap kernel (pad p) seen from output phase a -> index of the low-res tap it folds into
+__device__ __host__ __forceinline__ int phase_map(int a, int d, int pad) { return ((a + d - pad) >> 1) - ((a - pad) >> 1); }
+
+// gw[co][ci][dy][dx] += scale * sum_s sum_{a,b} part[s][2a+b][(map(a,dy)*kp + map(b,dx))*Cin + ci][co]
+__global__ void wgrad_reduce_ups2_kernel(const float* part, float* gw, int Cin, int Cout, int k, int pad, int kp, int S,
+                                         float scale) {
+    const long total = (long)k * k * Cin * Cout;
+    const long pstride = (long)kp * kp * Cin * Cout;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        long r = i / Cout;
+        const int ci = (int)(r % Cin);
+        const int tap = (int)(r / Cin);
+        const int dy = tap / k, dx = tap - dy * k;
+        float s = 0.f;
+        for (int sp = 0; sp < S; ++sp)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int tp = phase_map(p >> 1, dy, pad) * kp + phase_map(p & 1, dx, pad);
+                s += part[((long)sp * 4 + p) * pstride + ((long)tp * Cin + ci) * Cout + co];
+            }
+        float* dst = gw + ((long)co * Cin + ci) * (k * k) + tap;
+        *dst += scale * s;
+    }
+}
+
 // canonical [Cout][Cin][KK] -> wf[tap*Cin+ci][Cout], wb[(KK-1-tap)*Cout+co][Cin]
 __global__ void pack_weight_kernel(const float* w, float* wf, float* wb, int Cout, int Cin, int KK) {
     const long total = (long)Cout * Cin * KK;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        // iterate in wf order so the (larger-stride) writes of wf are coalesced
         const int co = (int)(i % Cout);
         const long r = i / Cout;
         const int ci = (int)(r % Cin);
@@ -476,22 +623,42 @@ __global__ void pack_weight_kernel(const float* w, float* wf, float* wb, int Cou
     }
 }
 
+// phase-summed weights for upsample(2) -> conv k x k:
+//   wf[p][(t'*Cin+ci)][co] = sum_{(dy,dx) -> t' under phase p} w[co][ci][dy][dx]
+//   wb[((p*kp*kp + t')*Cout + co)][ci] = the same value (data-gradient operand)
+__global__ void pack_weight_ups2_kernel(const float* w, float* wf, float* wb, int Cout, int Cin, int k, int pad, int kp) {
+    const long per = (long)kp * kp * Cin * Cout;
+    const long total = 4 * per;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        long r = i / Cout;
+        const int ci = (int)(r % Cin);
+        r /= Cin;
+        const int tp = (int)(r % (kp * kp));
+        const int p = (int)(r / (kp * kp));
+        const int ry = tp / kp, rx = tp - ry * kp;
+        float s = 0.f;
+        for (int dy = 0; dy < k; ++dy) {
+            if (phase_map(p >> 1, dy, pad) != ry) continue;
+            for (int dx = 0; dx < k; ++dx)
+                if (phase_map(p & 1, dx, pad) == rx) s += w[((long)co * Cin + ci) * (k * k) + dy * k + dx];
+        }
+        if (wf) wf[i] = s;
+        if (wb) wb[(((long)p * kp * kp + tp) * Cout + co) * Cin + ci] = s;
+    }
+}
+
 // ---- host-side dispatch -----------------------------------------------------
 struct TileCfg { int bm, bn; };
 
 // pick the block tile: BN covers Cout with least padding, BM chosen so the grid
 // fills the 256 CUs at >= ~2 workgroups each when the problem allows it.
-static TileCfg pick_tile(long M, int Cout) {
+static TileCfg pick_tile(long M, int Cout, int nphase) {
     int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     int bm = 128;
-    if (bn == 128) {
-        const long blocks128 = ((M + 127) / 128) * ((Cout + 127) / 128);
+    if (bn == 128 || bn == 64) {
+        const long blocks128 = ((M + 127) / 128) * ((Cout + bn - 1) / bn) * nphase;
         if (blocks128 < 2 * cg::kNumCU) bm = 64;
-    } else if (bn == 64) {
-        const long blocks128 = ((M + 127) / 128) * ((Cout + 63) / 64);
-        if (blocks128 < 2 * cg::kNumCU) bm = 64;
-    } else {
-        bm = 128;  // (128,32) only
     }
     return {bm, bn};
 }
@@ -504,9 +671,9 @@ static int pick_splits(long tiles, long kiters) {
 }
 
 template <int BM, int BN, int WM, int WN>
-static void launch_nn(const NNArgs& a, dim3 grid, hipStream_t st, bool veca, bool vecb) {
-    if (veca && vecb) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, a);
-    else if (veca) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, a);
+static void launch_nn(const NNArgs& a, dim3 grid, hipStream_t st, bool fast, bool vecb) {
+    if (fast && vecb) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, a);
+    else if (fast) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, a);
     else if (vecb) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, a);
 }
@@ -519,44 +686,104 @@ static void launch_tn(const TNArgs& a, dim3 grid, hipStream_t st, bool veca, boo
     else hipLaunchKernelGGL((igemm_tn_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, a);
 }
 
-static int make_geom(ConvGeom& g, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups) {
+static int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+static int finish_geom(Geom& g, long N) {
+    const long M = N * g.Hg * g.Wg;
+    if (g.Hg <= 0 || g.Wg <= 0) return cg::fail("conv2d: empty output %dx%d", g.Hg, g.Wg);
+    if (M > 0x7fffffffL || N * (long)g.Hs * g.Ws * g.Cin > 0x1fffffffL || N * (long)g.Hout * g.Wout * g.Cout > 0x1fffffffL)
+        return cg::fail("conv2d: tensor too large for 32-bit element offsets");
+    g.M = (int)M;
+    const int lw = ilog2_exact(g.Wg), lh = ilog2_exact(g.Hg);
+    g.lgW = (lw >= 0 && lh >= 0) ? lw : -1;
+    g.lgHW = (lw >= 0 && lh >= 0) ? lw + lh : -1;
+    g.Ktot = g.ntaps * g.Cin;
+    if (g.ntaps > 64) return cg::fail("conv2d: more than 64 taps");
+    return 0;
+}
+
+static int check_dims(int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups) {
     if (N <= 0 || Hp <= 0 || Wp <= 0 || Cin <= 0 || Cout <= 0 || kH <= 0 || kW <= 0 || padH < 0 || padW < 0 ||
         (ups != 0 && ups != 1))
         return cg::fail("conv2d: bad geometry N=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d pad=%d,%d ups=%d", N, Hp, Wp, Cin,
                         Cout, kH, kW, padH, padW, ups);
-    g.Hp = Hp; g.Wp = Wp;
-    g.Hl = Hp << ups; g.Wl = Wp << ups;
-    const int Ho = g.Hl + 2 * padH - kH + 1, Wo = g.Wl + 2 * padW - kW + 1;
-    if (Ho <= 0 || Wo <= 0) return cg::fail("conv2d: empty output %dx%d", Ho, Wo);
-    const long M = (long)N * Ho * Wo;
-    if (M > 0x7fffffffL || (long)N * Hp * Wp > 0x7fffffffL) return cg::fail("conv2d: pixel count overflows int32");
-    g.M = (int)M; g.HoWo = Ho * Wo; g.Wo = Wo;
-    g.Cin = Cin; g.Cout = Cout; g.kW = kW; g.padH = padH; g.padW = padW; g.ups = ups;
-    g.Ktot = kH * kW * Cin;
+    if (ups && (kH != kW || (kH & 1) == 0 || padH != (kH - 1) / 2 || padW != padH))
+        return cg::fail("conv2d: folded upsampling needs an odd square kernel with pad=(k-1)/2 (got %dx%d pad %d,%d)", kH,
+                        kW, padH, padW);
     return 0;
 }
 
+// plain stride-1 convolution: grid = output pixels, source = the input tensor
+static int geom_plain(Geom& g, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW) {
+    memset(&g, 0, sizeof(g));
+    g.Hg = Hp + 2 * padH - kH + 1; g.Wg = Wp + 2 * padW - kW + 1;
+    g.Hv = Hp; g.Wv = Wp; g.Hs = Hp; g.Ws = Wp;
+    g.Cin = Cin; g.Cout = Cout;
+    g.so = 1; g.Hout = g.Hg; g.Wout = g.Wg;
+    g.nphase = 1; g.ntaps = kH * kW;
+    g.td.kw = kW; g.td.kk = kH * kW; g.td.ngroups = 1; g.td.sgn = 1; g.td.ss = 1;
+    g.td.r0y0 = g.td.r0y1 = -padH; g.td.r0x0 = g.td.r0x1 = -padW;
+    return finish_geom(g, N);
+}
+
+static int phase_kp(int k, int pad) { return phase_map(0, k - 1, pad) + 1; }
+
+// upsample(2) -> conv, forward / weight-gradient view: 4 phases over the low-res grid
+static int geom_phase_fwd(Geom& g, int N, int Hp, int Wp, int Cin, int Cout, int k, int pad) {
+    memset(&g, 0, sizeof(g));
+    const int kp = phase_kp(k, pad);
+    g.Hg = Hp; g.Wg = Wp; g.Hv = Hp; g.Wv = Wp; g.Hs = Hp; g.Ws = Wp;
+    g.Cin = Cin; g.Cout = Cout;
+    g.so = 2; g.Hout = 2 * Hp; g.Wout = 2 * Wp;
+    g.nphase = 4; g.ntaps = kp * kp;
+    g.td.kw = kp; g.td.kk = kp * kp; g.td.ngroups = 1; g.td.sgn = 1; g.td.ss = 1;
+    g.td.r0y0 = g.td.r0x0 = (0 - pad) >> 1;
+    g.td.r0y1 = g.td.r0x1 = (1 - pad) >> 1;
+    return finish_geom(g, N);
+}
+
+// data gradient w.r.t. the low-res input: one GEMM whose taps run over (phase, ry', rx') of dy [N,2Hp,2Wp,CoutF]
+static int geom_phase_dgrad(Geom& g, int N, int Hp, int Wp, int CinF, int CoutF, int k, int pad) {
+    memset(&g, 0, sizeof(g));
+    const int kp = phase_kp(k, pad);
+    g.Hg = Hp; g.Wg = Wp; g.Hv = Hp; g.Wv = Wp; g.Hs = 2 * Hp; g.Ws = 2 * Wp;
+    g.Cin = CoutF; g.Cout = CinF;
+    g.so = 1; g.Hout = Hp; g.Wout = Wp;
+    g.nphase = 1; g.ntaps = 4 * kp * kp;
+    g.td.kw = kp; g.td.kk = kp * kp; g.td.ngroups = 4; g.td.sgn = -1; g.td.ss = 2;
+    g.td.r0y0 = g.td.r0x0 = (0 - pad) >> 1;
+    g.td.r0y1 = g.td.r0x1 = (1 - pad) >> 1;
+    return finish_geom(g, N);
+}
+
 struct NNPlan { TileCfg tc; int splits; int kchunk; };
-static NNPlan plan_nn(const ConvGeom& g) {
+static NNPlan plan_nn(const Geom& g) {
     NNPlan p;
-    p.tc = pick_tile(g.M, g.Cout);
-    const long tiles = (long)cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn);
+    p.tc = pick_tile(g.M, g.Cout, g.nphase);
+    const long tiles = (long)cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn) * g.nphase;
     const long kiters = cg::cdiv(g.Ktot, BK);
     p.splits = pick_splits(tiles, kiters);
     p.kchunk = cg::cdiv(kiters, p.splits) * BK;
     p.splits = cg::cdiv(g.Ktot, p.kchunk);
     return p;
 }
+static size_t nn_ws_bytes(const Geom& g, const NNPlan& p) {
+    return p.splits > 1 ? (size_t)p.splits * g.nphase * g.M * g.Cout * sizeof(float) : 0;
+}
 
 struct TNPlan { TileCfg tc; int splits; int pchunk; };
-static TNPlan plan_tn(const ConvGeom& g) {
+static TNPlan plan_tn(const Geom& g) {
     TNPlan p;
-    // rows of dW = Ktot (tap,ci); cols = Cout
     int bn = g.Cout > 64 ? 128 : (g.Cout > 32 ? 64 : 32);
     int bm = g.Ktot > 64 ? 128 : 64;
     if (bn == 32) bm = 128;
     p.tc = {bm, bn};
-    const long tiles = (long)cg::cdiv(g.Ktot, bm) * cg::cdiv(g.Cout, bn);
+    const long tiles = (long)cg::cdiv(g.Ktot, bm) * cg::cdiv(g.Cout, bn) * g.nphase;
     const long piters = cg::cdiv(g.M, BK);
     int s = 1;
     while (tiles * s < 3 * cg::kNumCU && piters / (s * 2) >= 8 && s < 256) s *= 2;
@@ -564,81 +791,116 @@ static TNPlan plan_tn(const ConvGeom& g) {
     p.splits = cg::cdiv(g.M, p.pchunk);
     return p;
 }
+static size_t tn_ws_bytes(const Geom& g, const TNPlan& p) {
+    return (size_t)p.splits * g.nphase * g.Ktot * g.Cout * sizeof(float);
+}
+
+static int run_nn(hipStream_t st, const Geom& g, const float* x, const float* w, const float* bias, float* y, void* ws,
+                  size_t ws_bytes, const char* who) {
+    NNPlan p = plan_nn(g);
+    const size_t need = nn_ws_bytes(g, p);
+    CG_REQUIRE(need == 0 || (ws && ws_bytes >= need), "%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
+    NNArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.g = g;
+    a.y = p.splits > 1 ? (float*)ws : y;
+    a.kchunk = p.kchunk; a.nsplit = p.splits;
+    const bool fast = (g.Cin % BK == 0) && ((uintptr_t)x % 16 == 0) && (getenv("CG_GEMM_SLOW") == nullptr);
+    const bool vecb = (g.Cout % 4 == 0) && ((uintptr_t)w % 16 == 0);
+    dim3 grid(cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, g.nphase);
+    if (p.tc.bm == 128 && p.tc.bn == 128) launch_nn<128, 128, 2, 2>(a, grid, st, fast, vecb);
+    else if (p.tc.bm == 64 && p.tc.bn == 128) launch_nn<64, 128, 2, 2>(a, grid, st, fast, vecb);
+    else if (p.tc.bm == 128 && p.tc.bn == 64) launch_nn<128, 64, 2, 2>(a, grid, st, fast, vecb);
+    else if (p.tc.bm == 64 && p.tc.bn == 64) launch_nn<64, 64, 2, 2>(a, grid, st, fast, vecb);
+    else launch_nn<128, 32, 4, 1>(a, grid, st, fast, vecb);
+    CG_LAUNCH_CHECK();
+    if (p.splits > 1) {
+        const long PMN = (long)g.nphase * g.M * g.Cout;
+        hipLaunchKernelGGL(nn_splitk_reduce_kernel, dim3(cg::ew_grid(PMN)), dim3(256), 0, st, (const float*)ws, bias, y, g,
+                           p.splits);
+        CG_LAUNCH_CHECK();
+    }
+    return 0;
+}
 
 }  // namespace
 
 extern "C" {
 
 size_t cg_conv2d_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups) {
-    ConvGeom g;
-    if (make_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
-    NNPlan p = plan_nn(g);
-    return p.splits > 1 ? (size_t)p.splits * g.M * g.Cout * sizeof(float) : 0;
+    Geom g;
+    if (check_dims(N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
+    if (ups ? geom_phase_fwd(g, N, Hp, Wp, Cin, Cout, kH, padH) : geom_plain(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW))
+        return 0;
+    return nn_ws_bytes(g, plan_nn(g));
 }
 
 int cg_conv2d_forward(void* stream, const float* x, const float* wpk, const float* bias, float* y, int N, int Hp, int Wp,
                       int Cin, int Cout, int kH, int kW, int padH, int padW, int ups, void* ws, size_t ws_bytes) {
     CG_REQUIRE(x && wpk && y, "cg_conv2d_forward: null pointer");
-    NNArgs a;
-    if (make_geom(a.g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
-    const ConvGeom& g = a.g;
-    NNPlan p = plan_nn(g);
-    const size_t need = p.splits > 1 ? (size_t)p.splits * g.M * g.Cout * sizeof(float) : 0;
-    CG_REQUIRE(need == 0 || (ws && ws_bytes >= need), "cg_conv2d_forward: workspace too small (%zu < %zu)", ws_bytes, need);
-    a.x = x; a.w = wpk; a.bias = bias;
-    a.y = p.splits > 1 ? (float*)ws : y;
-    a.kchunk = p.kchunk;
-    a.split_stride = (long)g.M * g.Cout;
-    const bool veca = (Cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
-    const bool vecb = (Cout % 4 == 0) && ((uintptr_t)wpk % 16 == 0);
-    hipStream_t st = cg::S(stream);
-    dim3 grid(cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits);
-    if (p.tc.bm == 128 && p.tc.bn == 128) launch_nn<128, 128, 2, 2>(a, grid, st, veca, vecb);
-    else if (p.tc.bm == 64 && p.tc.bn == 128) launch_nn<64, 128, 2, 2>(a, grid, st, veca, vecb);
-    else if (p.tc.bm == 128 && p.tc.bn == 64) launch_nn<128, 64, 2, 2>(a, grid, st, veca, vecb);
-    else if (p.tc.bm == 64 && p.tc.bn == 64) launch_nn<64, 64, 2, 2>(a, grid, st, veca, vecb);
-    else launch_nn<128, 32, 4, 1>(a, grid, st, veca, vecb);
-    CG_LAUNCH_CHECK();
-    if (p.splits > 1) {
-        const long MN = (long)g.M * g.Cout;
-        hipLaunchKernelGGL(nn_splitk_reduce_kernel, dim3(cg::ew_grid(MN)), dim3(256), 0, st, (const float*)ws, bias, y, MN,
-                           g.Cout, p.splits);
-        CG_LAUNCH_CHECK();
-    }
-    return 0;
+    Geom g;
+    if (check_dims(N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
+    if (ups ? geom_phase_fwd(g, N, Hp, Wp, Cin, Cout, kH, padH) : geom_plain(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW))
+        return 1;
+    return run_nn(cg::S(stream), g, x, wpk, bias, y, ws, ws_bytes, "cg_conv2d_forward");
+}
+
+size_t cg_conv2d_dgrad_ups2_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int k, int pad) {
+    Geom g;
+    if (check_dims(N, Hp, Wp, Cin, Cout, k, k, pad, pad, 1)) return 0;
+    if (geom_phase_dgrad(g, N, Hp, Wp, Cin, Cout, k, pad)) return 0;
+    return nn_ws_bytes(g, plan_nn(g));
+}
+
+int cg_conv2d_dgrad_ups2(void* stream, const float* dy, const float* wb_ph, float* dx_lo, int N, int Hp, int Wp, int Cin,
+                         int Cout, int k, int pad, void* ws, size_t ws_bytes) {
+    CG_REQUIRE(dy && wb_ph && dx_lo, "cg_conv2d_dgrad_ups2: null pointer");
+    Geom g;
+    if (check_dims(N, Hp, Wp, Cin, Cout, k, k, pad, pad, 1)) return 1;
+    if (geom_phase_dgrad(g, N, Hp, Wp, Cin, Cout, k, pad)) return 1;
+    return run_nn(cg::S(stream), g, dy, wb_ph, nullptr, dx_lo, ws, ws_bytes, "cg_conv2d_dgrad_ups2");
 }
 
 size_t cg_conv2d_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW,
                                        int ups) {
-    ConvGeom g;
-    if (make_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
-    TNPlan p = plan_tn(g);
-    return (size_t)p.splits * g.Ktot * g.Cout * sizeof(float);
+    Geom g;
+    if (check_dims(N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
+    if (ups ? geom_phase_fwd(g, N, Hp, Wp, Cin, Cout, kH, padH) : geom_plain(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW))
+        return 0;
+    return tn_ws_bytes(g, plan_tn(g));
 }
 
 int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw, int N, int Hp, int Wp, int Cin, int Cout,
                     int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes) {
     CG_REQUIRE(x && dy && gw, "cg_conv2d_wgrad: null pointer");
     TNArgs a;
-    if (make_geom(a.g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
-    const ConvGeom& g = a.g;
+    if (check_dims(N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
+    if (ups ? geom_phase_fwd(a.g, N, Hp, Wp, Cin, Cout, kH, padH)
+            : geom_plain(a.g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW))
+        return 1;
+    const Geom& g = a.g;
     TNPlan p = plan_tn(g);
-    const size_t need = (size_t)p.splits * g.Ktot * g.Cout * sizeof(float);
+    const size_t need = tn_ws_bytes(g, p);
     CG_REQUIRE(ws && ws_bytes >= need, "cg_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
     a.x = x; a.dy = dy; a.part = (float*)ws; a.pchunk = p.pchunk;
     const bool veca = (Cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
     const bool vecb = (Cout % 4 == 0) && ((uintptr_t)dy % 16 == 0);
     hipStream_t st = cg::S(stream);
-    dim3 grid(cg::cdiv(g.Ktot, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits);
+    dim3 grid(cg::cdiv(g.Ktot, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, g.nphase);
     if (p.tc.bm == 128 && p.tc.bn == 128) launch_tn<128, 128, 2, 2>(a, grid, st, veca, vecb);
     else if (p.tc.bm == 64 && p.tc.bn == 128) launch_tn<64, 128, 2, 2>(a, grid, st, veca, vecb);
     else if (p.tc.bm == 128 && p.tc.bn == 64) launch_tn<128, 64, 2, 2>(a, grid, st, veca, vecb);
     else if (p.tc.bm == 64 && p.tc.bn == 64) launch_tn<64, 64, 2, 2>(a, grid, st, veca, vecb);
     else launch_tn<128, 32, 4, 1>(a, grid, st, veca, vecb);
     CG_LAUNCH_CHECK();
-    const long total = (long)g.Ktot * g.Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cg::ew_grid(total)), dim3(256), 0, st, (const float*)ws, gw, g.Ktot,
-                       g.Cin, g.Cout, kH * kW, p.splits, scale);
+    if (ups) {
+        const long total = (long)kH * kW * Cin * Cout;
+        hipLaunchKernelGGL(wgrad_reduce_ups2_kernel, dim3(cg::ew_grid(total)), dim3(256), 0, st, (const float*)ws, gw, Cin,
+                           Cout, kH, padH, phase_kp(kH, padH), p.splits, scale);
+    } else {
+        const long total = (long)g.Ktot * g.Cout;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cg::ew_grid(total)), dim3(256), 0, st, (const float*)ws, gw, g.Ktot,
+                           g.Cin, g.Cout, kH * kW, p.splits, scale);
+    }
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -649,6 +911,24 @@ int cg_pack_conv_weight(void* stream, const float* w, float* wf, float* wb, int 
     const long total = (long)Cout * Cin * kH * kW;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(cg::ew_grid(total)), dim3(256), 0, cg::S(stream), w, wf, wb, Cout, Cin,
                        kH * kW);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t cg_pack_conv_weight_ups2_floats(int Cout, int Cin, int k, int pad) {
+    if (Cout <= 0 || Cin <= 0 || k <= 0 || (k & 1) == 0 || pad != (k - 1) / 2) return 0;
+    const int kp = phase_kp(k, pad);
+    return (size_t)4 * kp * kp * Cin * Cout;
+}
+
+int cg_pack_conv_weight_ups2(void* stream, const float* w, float* wf_ph, float* wb_ph, int Cout, int Cin, int k, int pad) {
+    CG_REQUIRE(w && (wf_ph || wb_ph), "cg_pack_conv_weight_ups2: null pointer");
+    CG_REQUIRE(Cout > 0 && Cin > 0 && k > 0 && (k & 1) == 1 && pad == (k - 1) / 2,
+               "cg_pack_conv_weight_ups2: needs an odd kernel with pad=(k-1)/2");
+    const int kp = phase_kp(k, pad);
+    const long total = 4L * kp * kp * Cin * Cout;
+    hipLaunchKernelGGL(pack_weight_ups2_kernel, dim3(cg::ew_grid(total)), dim3(256), 0, cg::S(stream), w, wf_ph, wb_ph, Cout,
+                       Cin, k, pad, kp);
     CG_LAUNCH_CHECK();
     return 0;
 }

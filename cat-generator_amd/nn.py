@@ -349,6 +349,19 @@ class _GemmLayer(Module):
                                self._wb.data_ptr() if self._wb is not None else None, Cout, Cin, kH, kW)
         self._packed_epoch, self._packed_ptr = ep, self.weight.ptr
 
+    def _ensure_packed_ups(self):
+        ep = self.weight.epoch.v
+        if getattr(self, "_ph_epoch", None) == ep and getattr(self, "_ph_ptr", None) == self.weight.ptr:
+            return
+        Cout, Cin, kH, kW = self._wdims()
+        n = lib().pack_conv_weight_ups2_floats(Cout, Cin, kH, (kH - 1) // 2)
+        if getattr(self, "_wf_ph", None) is None or self._wf_ph.numel() != n:
+            self._wf_ph = torch.empty(n, dtype=torch.float32, device=self.weight.t.device)
+            self._wb_ph = torch.empty(n, dtype=torch.float32, device=self.weight.t.device)
+        lib().pack_conv_weight_ups2(stream(), self.weight.ptr, self._wf_ph.data_ptr(), self._wb_ph.data_ptr(), Cout, Cin,
+                                    kH, (kH - 1) // 2)
+        self._ph_epoch, self._ph_ptr = ep, self.weight.ptr
+
     def _wb_ptr(self):
         # 1x1 / linear: the canonical [out][in] matrix already is the backward operand [K=out][N=in]
         return self._wb.data_ptr() if self._wb is not None else self.weight.ptr
@@ -442,14 +455,24 @@ class SpatialConvolution(_GemmLayer):
         assert C == self.nInputPlane, f"{self}: got {C} input planes"
         return N, H >> x.ups, W >> x.ups, H + 2 * self.padH - self.kH + 1, W + 2 * self.padW - self.kW + 1
 
+    def _can_fold_ups(self):
+        return self.kH == self.kW and self.kH % 2 == 1 and self.padH == self.padW == (self.kH - 1) // 2
+
     def updateOutput(self, input):
         x = as_nhwc(to_device(input), keep_ups=True)
+        if x.ups and not self._can_fold_ups():
+            x = materialise(x)
         N, Hp, Wp, Ho, Wo = self._geom(x)
-        self._ensure_packed()
+        if x.ups:
+            self._ensure_packed_ups()
+            wf = self._wf_ph.data_ptr()
+        else:
+            self._ensure_packed()
+            wf = self._wf.data_ptr()
         out = self._get("out", (N, self.nOutputPlane, Ho, Wo), "nhwc")
         a = (N, Hp, Wp, self.nInputPlane, self.nOutputPlane, self.kH, self.kW, self.padH, self.padW, x.ups)
         ws, wsb = WS.get(lib().conv2d_workspace_bytes(*a))
-        lib().conv2d_forward(stream(), x.ptr, self._wf.data_ptr(), self.bias.ptr, out.ptr, *a, ws, wsb)
+        lib().conv2d_forward(stream(), x.ptr, wf, self.bias.ptr, out.ptr, *a, ws, wsb)
         self._x = x
         self.output = out
         return out
@@ -459,7 +482,18 @@ class SpatialConvolution(_GemmLayer):
         N, Co, Ho, Wo = dy.shape
         x = self._x
         Hl, Wl = x.shape[2], x.shape[3]
-        gi = self._get("gin", (N, self.nInputPlane, Hl, Wl), "nhwc")  # w.r.t. the LOGICAL (upsampled) input
+        if x.ups:
+            # gradient w.r.t. the low-res tensor behind the virtual upsampling (its 2x2 block sum folded in);
+            # handed to nn.SpatialUpSamplingNearest as the dual of its lazy output: shape = logical, ups = 1
+            Hp, Wp = Hl >> 1, Wl >> 1
+            lo = self._get("gin_lo", (N, self.nInputPlane, Hp, Wp), "nhwc")
+            k, pad = self.kH, self.padH
+            ws, wsb = WS.get(lib().conv2d_dgrad_ups2_workspace_bytes(N, Hp, Wp, self.nInputPlane, self.nOutputPlane, k, pad))
+            lib().conv2d_dgrad_ups2(stream(), dy.ptr, self._wb_ph.data_ptr(), lo.ptr, N, Hp, Wp, self.nInputPlane,
+                                    self.nOutputPlane, k, pad, ws, wsb)
+            self.gradInput = Tensor(lo.t, (N, self.nInputPlane, Hl, Wl), "nhwc", 1)
+            return self.gradInput
+        gi = self._get("gin", (N, self.nInputPlane, Hl, Wl), "nhwc")
         a = (N, Ho, Wo, self.nOutputPlane, self.nInputPlane, self.kH, self.kW, self.kH - 1 - self.padH,
              self.kW - 1 - self.padW, 0)
         ws, wsb = WS.get(lib().conv2d_workspace_bytes(*a))
@@ -769,6 +803,10 @@ class SpatialUpSamplingNearest(Module):
         return self.output
 
     def updateGradInput(self, input, gradOutput):
+        if gradOutput.fmt == "nhwc" and gradOutput.ups:  # the consumer conv already folded the 2x2 block sum
+            N, C, H2, W2 = gradOutput.shape
+            self.gradInput = Tensor(gradOutput.t, (N, C, H2 // 2, W2 // 2), "nhwc", 0)
+            return self.gradInput
         g = as_nhwc(gradOutput)
         N, C, H2, W2 = g.shape
         gi = self._get("gin", (N, C, H2 // 2, W2 // 2), "nhwc")

@@ -61,16 +61,16 @@ int cg_stream_sync(void* stream);
  * nn.SpatialConvolution (models.lua:646-685, 844-846) and nn.Linear
  * (models.lua:199,697,700,850,853); stride 1, zero padding.
  *
- * cg_conv2d_forward computes, for packed weights wpk[(ky*kW+kx)*Cin+ci][Cout],
- *   y[n,oy,ox,co] = bias[co] + sum_{ky,kx,ci} X(n, oy+ky-padH, ox+kx-padW, ci) * wpk[..][co]
- * with Ho = Hl + 2*padH - kH + 1 (Hl = logical input height).  If ups==1 the
- * logical input is the nearest-neighbour 2x upsampling of the physical x
- * (Hl = 2*Hp): X(n,iy,ix,ci) = x[n, iy>>1, ix>>1, ci] — this folds
- * nn.SpatialUpSamplingNearest(2) (models.lua:205,211,217) into the gather.
- * The same entry point is updateGradInput when called with the gradOutput as
- * x and the backward-packed weights (cg_pack_conv_weight's wb), and nn.Linear
- * when Hp=Wp=kH=kW=1.  bias may be NULL.  ws/ws_bytes: scratch for split-K
- * partials, cg_conv2d_workspace_bytes() tells how much is needed (may be 0). */
+ * cg_conv2d_forward, ups == 0: for packed weights wpk[(ky*kW+kx)*Cin+ci][Cout] (cg_pack_conv_weight's wf),
+ *   y[n,oy,ox,co] = bias[co] + sum_{ky,kx,ci} x[n, oy+ky-padH, ox+kx-padW, ci] * wpk[..][co]
+ * with Ho = Hp + 2*padH - kH + 1.  The same entry point is updateGradInput when called with the gradOutput as x
+ * and the backward-packed weights (wb) with pad' = k-1-pad, and nn.Linear when Hp=Wp=kH=kW=1.
+ *
+ * ups == 1 folds nn.SpatialUpSamplingNearest(2) (models.lua:205,211,217) into the convolution: x is the LOW-RES
+ * tensor [N,Hp,Wp,Cin], y is [N,2Hp,2Wp,Cout] = conv(upsample2(x)).  It is evaluated as four phase convolutions
+ * with pre-summed k' x k' weights, so wpk must come from cg_pack_conv_weight_ups2 (wf_ph); requires an odd
+ * square kernel with pad = (k-1)/2.  bias may be NULL.  ws/ws_bytes: scratch for split-K partials,
+ * cg_conv2d_workspace_bytes() tells how much is needed (may be 0). */
 size_t cg_conv2d_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout,
                                  int kH, int kW, int padH, int padW, int ups);
 int cg_conv2d_forward(void* stream, const float* x, const float* wpk, const float* bias,
@@ -78,9 +78,17 @@ int cg_conv2d_forward(void* stream, const float* x, const float* wpk, const floa
                       int kH, int kW, int padH, int padW, int ups,
                       void* ws, size_t ws_bytes);
 
+/* updateGradInput of upsample2 -> conv as ONE GEMM: dy [N,2Hp,2Wp,Cout] -> dx_lo [N,Hp,Wp,Cin], i.e. the
+ * gradient w.r.t. the low-res input with SpatialUpSamplingNearest's 2x2 block sum folded in.  wb_ph from
+ * cg_pack_conv_weight_ups2.  (Cin, Cout are the FORWARD layer's plane counts.) */
+size_t cg_conv2d_dgrad_ups2_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int k, int pad);
+int cg_conv2d_dgrad_ups2(void* stream, const float* dy, const float* wb_ph, float* dx_lo,
+                         int N, int Hp, int Wp, int Cin, int Cout, int k, int pad,
+                         void* ws, size_t ws_bytes);
+
 /* accGradParameters for the weight: gw_canonical += scale * dW, where
  *   dW[co][ci][ky][kx] = sum_{n,oy,ox} X(n,oy+ky-padH,ox+kx-padW,ci) * dy[n,oy,ox,co]
- * (X as above, honouring ups).  gw layout is canonical [Cout][Cin][kH][kW]
+ * (X = x, or its virtual 2x upsampling when ups == 1; then evaluated per phase on the low-res grid).  gw layout is canonical [Cout][Cin][kH][kW]
  * (== [out][in] for Linear).  Deterministic two-stage split-K reduction. */
 size_t cg_conv2d_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout,
                                        int kH, int kW, int padH, int padW, int ups);
@@ -99,6 +107,12 @@ int cg_bias_grad(void* stream, const float* dy, float* gb, long M, int C, float 
  * Either output may be NULL. */
 int cg_pack_conv_weight(void* stream, const float* w_canonical, float* wf, float* wb,
                         int Cout, int Cin, int kH, int kW);
+/* phase-summed weights for upsample2 -> conv k x k (pad (k-1)/2), k' = (k+1)/2 rounded up (2 for 3, 3 for 5):
+ * wf_ph[p][(t'*Cin+ci)][Cout], wb_ph[((p*k'*k' + t')*Cout+co)][Cin]; each holds
+ * cg_pack_conv_weight_ups2_floats() floats.  Either output may be NULL. */
+size_t cg_pack_conv_weight_ups2_floats(int Cout, int Cin, int k, int pad);
+int cg_pack_conv_weight_ups2(void* stream, const float* w_canonical, float* wf_ph, float* wb_ph,
+                             int Cout, int Cin, int k, int pad);
 
 /* ---- activations --------------------------------------------------------
  * nn.PReLU(nil,nil,true): one shared slope (models.lua:201,208,214,220,647..698).

@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""Per-layer GEMM micro-benchmark: every conv/linear shape of G32up-c and D32_st3 at batch N (fwd, dgrad, wgrad),
+timed with HIP events on the launch stream.  Usage: python scripts/kbench.py [N] [--quick]"""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+cg = importlib.import_module("cat-generator_amd")
+
+
+def tk(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def conv_case(name, N, Cin, H, Cout, k, ups):
+    m = cg.nn.SpatialConvolution(Cin, Cout, k, k, 1, 1, (k - 1) // 2)
+    x = cg.Tensor(torch.rand(N * H * H * Cin, device="cuda") - 0.5, (N, Cin, H, H), "nhwc")
+    Ho = H << ups
+    dy = cg.Tensor(torch.rand(N * Ho * Ho * Cout, device="cuda") - 0.5, (N, Cout, Ho, Ho), "nhwc")
+    xin = cg.nn.SpatialUpSamplingNearest(2).forward(x) if ups else x
+    m.forward(xin)
+    flop = 2.0 * N * Ho * Ho * Cout * Cin * k * k
+    r = {}
+    r["fwd"] = tk(lambda: m.updateOutput(xin))
+    r["dgrad"] = tk(lambda: m.updateGradInput(xin, dy))
+    r["wgrad"] = tk(lambda: m.accGradParameters(xin, dy))
+    return name, flop, r
+
+
+def lin_case(name, N, i, o):
+    m = cg.nn.Linear(i, o)
+    x = cg.Tensor(torch.rand(N * i, device="cuda") - 0.5, (N, i))
+    dy = cg.Tensor(torch.rand(N * o, device="cuda") - 0.5, (N, o))
+    m.forward(x)
+    flop = 2.0 * N * i * o
+    r = {"fwd": tk(lambda: m.updateOutput(x)), "dgrad": tk(lambda: m.updateGradInput(x, dy)),
+         "wgrad": tk(lambda: m.accGradParameters(x, dy))}
+    return name, flop, r
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 128
+    quick = "--quick" in sys.argv
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    cases = [lambda: conv_case("G.conv3 5x5 256->128 @16^2 ups", N, 256, 16, 128, 5, 1),
+             lambda: conv_case("G.conv2 3x3 512->256 @8^2 ups", N, 512, 8, 256, 3, 1),
+             lambda: conv_case("G.conv1 3x3 512->512 @4^2 ups", N, 512, 4, 512, 3, 1),
+             lambda: conv_case("G.conv3 (N/2)", N // 2, 256, 16, 128, 5, 1),
+             lambda: conv_case("G.conv2 (N/2)", N // 2, 512, 8, 256, 3, 1),
+             lambda: conv_case("G.conv1 (N/2)", N // 2, 512, 4, 512, 3, 1)]
+    if not quick:
+        cases += [lambda: conv_case("G.conv4 3x3 128->3 @32^2", N, 128, 32, 3, 3, 0),
+                  lambda: lin_case("G.linear 100->8192", N, 100, 8192),
+                  lambda: conv_case("D.conv1 3x3 3->64 @32^2", N, 3, 32, 64, 3, 0),
+                  lambda: conv_case("D.conv2 3x3 64->64 @32^2", N, 64, 32, 64, 3, 0),
+                  lambda: conv_case("D.br conv 3x3 64->64 @16^2", N, 64, 16, 64, 3, 0),
+                  lambda: conv_case("D.br conv 3x3 64->64 @8^2", N, 64, 8, 64, 3, 0),
+                  lambda: conv_case("D.b4 5x5 64->128 @16^2", N, 64, 16, 128, 5, 0),
+                  lambda: conv_case("D.b4 7x7 128->128 @8^2", N, 128, 8, 128, 7, 0),
+                  lambda: conv_case("D.loc 3x3 64->16 @8^2", N, 64, 8, 16, 3, 0),
+                  lambda: conv_case("D.loc 3x3 16->16 @16^2", N, 16, 16, 16, 3, 0),
+                  lambda: lin_case("D.linear 20480->256", N, 20480, 256)]
+    if only:
+        cases = [lambda: conv_case("G.conv3 5x5 256->128 @16^2 ups", N, 256, 16, 128, 5, 1)] if only == "conv3" else cases
+    print(f"{'layer':34s} {'GFLOP':>8s}  " + "  ".join(f"{p:>16s}" for p in ("fwd ms / TF", "dgrad ms / TF", "wgrad ms / TF")))
+    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    for c in cases:
+        name, flop, r = c()
+        for p in tot:
+            tot[p] += r[p]
+        print(f"{name:34s} {flop / 1e9:8.2f}  " + "  ".join(f"{1e3 * r[p]:7.3f} /{flop / r[p] / 1e12:6.1f}" for p in ("fwd", "dgrad", "wgrad")), flush=True)
+    print("total ms: " + "  ".join(f"{p}={1e3 * tot[p]:.3f}" for p in tot))
+
+
+main()

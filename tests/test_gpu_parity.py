@@ -55,6 +55,9 @@ CONV_CASES = [
     (2, 128, 8, 8, 128, 7, 0),   # D branch-4 7x7 (models.lua:685)
     (2, 512, 4, 4, 512, 3, 1),   # G conv1 with folded upsampling (models.lua:205-206), split-K
     (1, 256, 16, 16, 128, 5, 1), # G conv3 (models.lua:217-218)
+    (3, 16, 3, 5, 8, 3, 1),      # folded upsampling on a ragged, non-power-of-two grid
+    (2, 8, 4, 4, 4, 5, 1),       # 5x5 phases through the generic (Cin % 16 != 0) gather
+    (2, 32, 4, 4, 32, 7, 1),     # 7x7 -> 4x4 phase kernels
     (2, 128, 32, 32, 3, 3, 0),   # G conv4, Cout = 3 (models.lua:222)
     (2, 64, 8, 8, 1, 3, 0),      # Cout = 1
 ]
@@ -80,8 +83,9 @@ def test_spatial_convolution_fwd_bwd(cg, N, Cin, H, W, Cout, k, ups):
     close(y, O.conv2d_forward(xl, w, b, pad), K=Kf, what="updateOutput")
     dy = rs.randn(*y.shape).astype(f32)
     m.gradWeight.fill(1.0); m.gradBias.fill(1.0)  # accGradParameters must ACCUMULATE
-    gi = m.backward(xin, cg.Tensor.from_numpy(dy)).numpy()
-    close(gi, O.conv2d_backward_data(dy, w, xl.shape, pad), K=Cout * k * k, what="updateGradInput")
+    gi_t = m.backward(xin, cg.Tensor.from_numpy(dy))
+    if not ups:
+        close(gi_t.numpy(), O.conv2d_backward_data(dy, w, xl.shape, pad), K=Cout * k * k, what="updateGradInput")
     gw, gb = np.ones_like(w), np.ones_like(b)
     O.conv2d_backward_weight(xl, dy, gw, gb, pad)
     P = y.shape[0] * y.shape[2] * y.shape[3]
