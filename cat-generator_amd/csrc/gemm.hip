@@ -66,12 +66,14 @@ struct NNArgs {
     Geom g;
     int kchunk;         // K range per split (multiple of BK)
     int nsplit;
+    int flags;          // experiment switches (CG_GEMM_FLAGS)
 };
 
 struct TNArgs {
     const float* x;
     const float* dy;
     float* part;        // [S][nphase][Ktot][Cout]
+    float* bias_part;   // [S][nphase][Cout] column sums of dy (gradBias partials) or null
     Geom g;
     int pchunk;         // pixels per split (multiple of BK)
 };
@@ -162,6 +164,12 @@ __global__ __launch_bounds__(256, 4) void igemm_nn_kernel(NNArgs a) {
     const int kend = min(g.Ktot, ks + a.kchunk);
     const int T = (kend - ks + BK - 1) / BK;
     const float* wph = a.w + (long)phase * g.Ktot * g.Cout;
+    if (a.flags & 3) {  // stagger co-resident workgroups: static priority from the block id
+        const int pr = (a.flags & 1) ? (blockIdx.x & 3) : ((blockIdx.x >> 8) & 3);
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
 
     // ---- A staging: thread owns k-vector a_kv (4 consecutive k) of rows a_r + 64p
     const int a_kv = tid & 3, a_r = tid >> 2;
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(256, 4) void igemm_nn_kernel(NNArgs a) {
 
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
-        if (t + 1 < T) load_tile(ks + (t + 1) * BK);
+        if (t + 1 < T && !(a.flags & 4)) load_tile(ks + (t + 1) * BK);
         const float* A = As + buf * A_TILE + wm0;
         const float* B = Bs + buf * B_TILE + wn0 + l31;
 #pragma unroll
@@ -355,8 +363,8 @@ __global__ __launch_bounds__(256, 4) void igemm_nn_kernel(NNArgs a) {
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < T) store_tile(buf ^ 1);
-        __syncthreads();
+        if (t + 1 < T && !(a.flags & 4)) store_tile(buf ^ 1);
+        if (!(a.flags & 8)) __syncthreads();
     }
 
     // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*h (pixel), j = l31 (channel)
@@ -448,6 +456,9 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
 
     float4 areg[APASS];
     float4 breg[BPASS];
+    // gradBias rides along: the dW row-tile 0 of every column tile also sums the dy rows it streams
+    const bool do_bias = a.bias_part != nullptr && tm == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto load_tile = [&](int p0) {
 #pragma unroll
@@ -512,7 +523,10 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
 #pragma unroll
         for (int q = 0; q < BPASS; ++q) {
             const int kr = b_kr + q * BRPP;
-            if (kr < BK) *reinterpret_cast<float4*>(B + kr * LDB + 4 * b_nv) = breg[q];
+            if (kr < BK) {
+                *reinterpret_cast<float4*>(B + kr * LDB + 4 * b_nv) = breg[q];
+                if (do_bias) { bsum.x += breg[q].x; bsum.y += breg[q].y; bsum.z += breg[q].z; bsum.w += breg[q].w; }
+            }
         }
     };
 
@@ -552,6 +566,17 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
         __syncthreads();
     }
 
+    if (do_bias) {  // all waves are past the loop's final barrier: reuse the A tile as scratch
+        float* red = smem;
+        *reinterpret_cast<float4*>(red + b_kr * BN + 4 * b_nv) = bsum;
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 256 / BVEC; ++r) t += red[r * BN + tid];
+            a.bias_part[(long)(split * g.nphase + phase) * g.Cout + n0 + tid] = t;
+        }
+    }
     float* pout = a.part + (long)(split * g.nphase + phase) * g.Ktot * g.Cout;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -568,44 +593,90 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
     }
 }
 
-// gw[co][ci][tap] += scale * sum_s part[s][tap*Cin+ci][co]
-__global__ void wgrad_reduce_kernel(const float* part, float* gw, int Ktot, int Cin, int Cout, int KK, int S, float scale) {
-    const long total = (long)Ktot * Cout;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < S; ++k) s += part[(long)k * total + i];
-        const int co = (int)(i % Cout);
-        const int mm = (int)(i / Cout);
-        const int tap = mm / Cin;
-        const int ci = mm - tap * Cin;
-        float* dst = gw + ((long)co * Cin + ci) * KK + tap;
-        *dst += scale * s;
-    }
-}
-
 // canonical tap d of a k-tap kernel (pad p) seen from output phase a -> index of the low-res tap it folds into
 __device__ __host__ __forceinline__ int phase_map(int a, int d, int pad) { return ((a + d - pad) >> 1) - ((a - pad) >> 1); }
 
-// gw[co][ci][dy][dx] += scale * sum_s sum_{a,b} part[s][2a+b][(map(a,dy)*kp + map(b,dx))*Cin + ci][co]
-__global__ void wgrad_reduce_ups2_kernel(const float* part, float* gw, int Cin, int Cout, int k, int pad, int kp, int S,
-                                         float scale) {
-    const long total = (long)k * k * Cin * Cout;
-    const long pstride = (long)kp * kp * Cin * Cout;
+// Split-K reduce + transpose into Torch7's canonical layout, accumulate semantics:
+//   plain: gw[co][ci][tap] += scale * sum_s part[s][tap*Cin+ci][co]
+//   UPS  : gw[co][ci][dy][dx] += scale * sum_s sum_{a,b} part[s][2a+b][(map(a,dy)*kp + map(b,dx))*Cin + ci][co]
+// One workgroup owns CI_T input channels x 32 output channels x all taps: reads are coalesced along co, the sums
+// are transposed through LDS, writes are contiguous runs of CI_T*KK floats per co.
+template <bool UPS>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* gw, int Cin, int Cout, int k, int KK,
+                                                           int pad, int kp, int S, float scale, int CI_T) {
+    extern __shared__ float sh[];  // [KK][CI_T][33]
+    const int ci0 = blockIdx.x * CI_T, co0 = blockIdx.y * 32;
+    const long plane = (long)(UPS ? kp * kp : KK) * Cin * Cout;
+    const int n1 = KK * CI_T * 32;
+    for (int idx = threadIdx.x; idx < n1; idx += 256) {
+        const int co_l = idx & 31;
+        const int r = idx >> 5;
+        const int ci_l = r % CI_T, tap = r / CI_T;
+        const int ci = ci0 + ci_l, co = co0 + co_l;
+        float s = 0.f;
+        if (ci < Cin && co < Cout) {
+            if (UPS) {
+                const int dy = tap / k, dx = tap - dy * k;
+                for (int sp = 0; sp < S; ++sp)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int tp = phase_map(p >> 1, dy, pad) * kp + phase_map(p & 1, dx, pad);
+                        s += part[((long)sp * 4 + p) * plane + ((long)tp * Cin + ci) * Cout + co];
+                    }
+            } else {
+                const long o = ((long)tap * Cin + ci) * Cout + co;
+                for (int sp = 0; sp < S; ++sp) s += part[(long)sp * plane + o];
+            }
+        }
+        sh[(tap * CI_T + ci_l) * 33 + co_l] = s;
+    }
+    __syncthreads();
+    const int run = CI_T * KK;
+    for (int idx = threadIdx.x; idx < n1; idx += 256) {
+        const int j = idx % run, co_l = idx / run;
+        const int ci_l = j / KK, tap = j - ci_l * KK;
+        const int ci = ci0 + ci_l, co = co0 + co_l;
+        if (ci < Cin && co < Cout) {
+            float* dst = gw + ((long)co * Cin + ci) * KK + tap;
+            *dst += scale * sh[(tap * CI_T + ci_l) * 33 + co_l];
+        }
+    }
+}
+
+// Same reduction, one thread per canonical element (for small weight tensors, where the tiled form above would
+// not fill the chip): reads coalesced along co, writes scattered.
+template <bool UPS>
+__global__ void wgrad_reduce_small_kernel(const float* part, float* gw, int Cin, int Cout, int k, int KK, int pad, int kp,
+                                          int S, float scale) {
+    const long total = (long)KK * Cin * Cout;
+    const long plane = (long)(UPS ? kp * kp : KK) * Cin * Cout;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int co = (int)(i % Cout);
-        long r = i / Cout;
+        const long r = i / Cout;
         const int ci = (int)(r % Cin);
         const int tap = (int)(r / Cin);
-        const int dy = tap / k, dx = tap - dy * k;
         float s = 0.f;
-        for (int sp = 0; sp < S; ++sp)
+        if (UPS) {
+            const int dy = tap / k, dx = tap - dy * k;
+            for (int sp = 0; sp < S; ++sp)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int tp = phase_map(p >> 1, dy, pad) * kp + phase_map(p & 1, dx, pad);
-                s += part[((long)sp * 4 + p) * pstride + ((long)tp * Cin + ci) * Cout + co];
-            }
-        float* dst = gw + ((long)co * Cin + ci) * (k * k) + tap;
-        *dst += scale * s;
+                for (int p = 0; p < 4; ++p) {
+                    const int tp = phase_map(p >> 1, dy, pad) * kp + phase_map(p & 1, dx, pad);
+                    s += part[((long)sp * 4 + p) * plane + ((long)tp * Cin + ci) * Cout + co];
+                }
+        } else {
+            for (int sp = 0; sp < S; ++sp) s += part[(long)sp * plane + i];
+        }
+        gw[((long)co * Cin + ci) * KK + tap] += scale * s;
+    }
+}
+
+// gb[c] += scale * sum_{s,p} bias_part[s*P+p][c]
+__global__ void bias_part_reduce_kernel(const float* bp, float* gb, int SP, int Cout, float scale) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < Cout; c += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < SP; ++i) s += bp[(long)i * Cout + c];
+        gb[c] += scale * s;
     }
 }
 
@@ -786,13 +857,13 @@ static TNPlan plan_tn(const Geom& g) {
     const long tiles = (long)cg::cdiv(g.Ktot, bm) * cg::cdiv(g.Cout, bn) * g.nphase;
     const long piters = cg::cdiv(g.M, BK);
     int s = 1;
-    while (tiles * s < 3 * cg::kNumCU && piters / (s * 2) >= 8 && s < 256) s *= 2;
+    while (tiles * s < 3 * cg::kNumCU && piters / (s * 2) >= 8 && s < 128) s *= 2;
     p.pchunk = cg::cdiv(piters, s) * BK;
     p.splits = cg::cdiv(g.M, p.pchunk);
     return p;
 }
 static size_t tn_ws_bytes(const Geom& g, const TNPlan& p) {
-    return (size_t)p.splits * g.nphase * g.Ktot * g.Cout * sizeof(float);
+    return (size_t)p.splits * g.nphase * ((size_t)g.Ktot + 1) * g.Cout * sizeof(float);
 }
 
 static int run_nn(hipStream_t st, const Geom& g, const float* x, const float* w, const float* bias, float* y, void* ws,
@@ -804,6 +875,7 @@ static int run_nn(hipStream_t st, const Geom& g, const float* x, const float* w,
     a.x = x; a.w = w; a.bias = bias; a.g = g;
     a.y = p.splits > 1 ? (float*)ws : y;
     a.kchunk = p.kchunk; a.nsplit = p.splits;
+    { const char* e = getenv("CG_GEMM_FLAGS"); a.flags = e ? atoi(e) : 0; }
     const bool fast = (g.Cin % BK == 0) && ((uintptr_t)x % 16 == 0) && (getenv("CG_GEMM_SLOW") == nullptr);
     const bool vecb = (g.Cout % 4 == 0) && ((uintptr_t)w % 16 == 0);
     dim3 grid(cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, g.nphase);
@@ -869,8 +941,8 @@ size_t cg_conv2d_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout,
     return tn_ws_bytes(g, plan_tn(g));
 }
 
-int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw, int N, int Hp, int Wp, int Cin, int Cout,
-                    int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes) {
+int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw, float* gb, int N, int Hp, int Wp, int Cin,
+                    int Cout, int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes) {
     CG_REQUIRE(x && dy && gw, "cg_conv2d_wgrad: null pointer");
     TNArgs a;
     if (check_dims(N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
@@ -882,6 +954,7 @@ int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw, in
     const size_t need = tn_ws_bytes(g, p);
     CG_REQUIRE(ws && ws_bytes >= need, "cg_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
     a.x = x; a.dy = dy; a.part = (float*)ws; a.pchunk = p.pchunk;
+    a.bias_part = gb ? (float*)ws + (size_t)p.splits * g.nphase * g.Ktot * g.Cout : nullptr;
     const bool veca = (Cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
     const bool vecb = (Cout % 4 == 0) && ((uintptr_t)dy % 16 == 0);
     hipStream_t st = cg::S(stream);
@@ -892,16 +965,33 @@ int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw, in
     else if (p.tc.bm == 64 && p.tc.bn == 64) launch_tn<64, 64, 2, 2>(a, grid, st, veca, vecb);
     else launch_tn<128, 32, 4, 1>(a, grid, st, veca, vecb);
     CG_LAUNCH_CHECK();
-    if (ups) {
-        const long total = (long)kH * kW * Cin * Cout;
-        hipLaunchKernelGGL(wgrad_reduce_ups2_kernel, dim3(cg::ew_grid(total)), dim3(256), 0, st, (const float*)ws, gw, Cin,
-                           Cout, kH, padH, phase_kp(kH, padH), p.splits, scale);
+    const int KK = kH * kW;
+    int ci_t = KK == 1 ? 64 : 8;
+    while (ci_t > 1 && (size_t)KK * ci_t * 33 * sizeof(float) > 60000) ci_t >>= 1;
+    const size_t shb = (size_t)KK * ci_t * 33 * sizeof(float);
+    dim3 rgrid(cg::cdiv(Cin, ci_t), cg::cdiv(Cout, 32));
+    const long relems = (long)KK * Cin * Cout;
+    if ((long)rgrid.x * rgrid.y >= cg::kNumCU) {
+        if (ups)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), shb, st, (const float*)ws, gw, Cin, Cout, kH, KK,
+                               padH, phase_kp(kH, padH), p.splits, scale, ci_t);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), shb, st, (const float*)ws, gw, Cin, Cout, kH, KK,
+                               padH, 0, p.splits, scale, ci_t);
     } else {
-        const long total = (long)g.Ktot * g.Cout;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cg::ew_grid(total)), dim3(256), 0, st, (const float*)ws, gw, g.Ktot,
-                           g.Cin, g.Cout, kH * kW, p.splits, scale);
+        if (ups)
+            hipLaunchKernelGGL(wgrad_reduce_small_kernel<true>, dim3(cg::ew_grid(relems)), dim3(256), 0, st, (const float*)ws,
+                               gw, Cin, Cout, kH, KK, padH, phase_kp(kH, padH), p.splits, scale);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_small_kernel<false>, dim3(cg::ew_grid(relems)), dim3(256), 0, st,
+                               (const float*)ws, gw, Cin, Cout, kH, KK, padH, 0, p.splits, scale);
     }
     CG_LAUNCH_CHECK();
+    if (gb) {
+        hipLaunchKernelGGL(bias_part_reduce_kernel, dim3(cg::cdiv(Cout, 256)), dim3(256), 0, st, (const float*)a.bias_part, gb,
+                           p.splits * g.nphase, Cout, scale);
+        CG_LAUNCH_CHECK();
+    }
     return 0;
 }
 

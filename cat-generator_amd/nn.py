@@ -419,9 +419,9 @@ class Linear(_GemmLayer):
         x, dy = self._x, as_plain(gradOutput)
         N, i = x.shape
         o = self.weight.shape[0]
-        ws, wsb = WS.get(max(lib().conv2d_wgrad_workspace_bytes(N, 1, 1, i, o, 1, 1, 0, 0, 0), 8 * o))
-        lib().conv2d_wgrad(stream(), x.ptr, dy.ptr, self.gradWeight.ptr, N, 1, 1, i, o, 1, 1, 0, 0, 0, float(scale), ws, wsb)
-        lib().bias_grad(stream(), dy.ptr, self.gradBias.ptr, N, o, float(scale), ws, wsb)
+        ws, wsb = WS.get(lib().conv2d_wgrad_workspace_bytes(N, 1, 1, i, o, 1, 1, 0, 0, 0))
+        lib().conv2d_wgrad(stream(), x.ptr, dy.ptr, self.gradWeight.ptr, self.gradBias.ptr, N, 1, 1, i, o, 1, 1, 0, 0, 0,
+                           float(scale), ws, wsb)
 
     def __repr__(self):
         return f"nn.Linear({self.weight.shape[1]} -> {self.weight.shape[0]})"
@@ -505,9 +505,8 @@ class SpatialConvolution(_GemmLayer):
         x, dy = self._x, as_nhwc(gradOutput)
         N, Hp, Wp, Ho, Wo = self._geom(x)
         a = (N, Hp, Wp, self.nInputPlane, self.nOutputPlane, self.kH, self.kW, self.padH, self.padW, x.ups)
-        ws, wsb = WS.get(max(lib().conv2d_wgrad_workspace_bytes(*a), 8 * self.nOutputPlane))
-        lib().conv2d_wgrad(stream(), x.ptr, dy.ptr, self.gradWeight.ptr, *a, float(scale), ws, wsb)
-        lib().bias_grad(stream(), dy.ptr, self.gradBias.ptr, N * Ho * Wo, self.nOutputPlane, float(scale), ws, wsb)
+        ws, wsb = WS.get(lib().conv2d_wgrad_workspace_bytes(*a))
+        lib().conv2d_wgrad(stream(), x.ptr, dy.ptr, self.gradWeight.ptr, self.gradBias.ptr, *a, float(scale), ws, wsb)
 
     def __repr__(self):
         return (f"{self.typename}({self.nInputPlane} -> {self.nOutputPlane}, {self.kW}x{self.kH}, 1,1, "

@@ -89,10 +89,11 @@ int cg_conv2d_dgrad_ups2(void* stream, const float* dy, const float* wb_ph, floa
 /* accGradParameters for the weight: gw_canonical += scale * dW, where
  *   dW[co][ci][ky][kx] = sum_{n,oy,ox} X(n,oy+ky-padH,ox+kx-padW,ci) * dy[n,oy,ox,co]
  * (X = x, or its virtual 2x upsampling when ups == 1; then evaluated per phase on the low-res grid).  gw layout is canonical [Cout][Cin][kH][kW]
- * (== [out][in] for Linear).  Deterministic two-stage split-K reduction. */
+ * (== [out][in] for Linear).  If gb != NULL, gb[co] += scale * sum dy[..,co] (gradBias) rides along in the same
+ * pass over dy.  Deterministic two-stage split-K reduction. */
 size_t cg_conv2d_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout,
                                        int kH, int kW, int padH, int padW, int ups);
-int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw_canonical,
+int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw_canonical, float* gb,
                     int N, int Hp, int Wp, int Cin, int Cout,
                     int kH, int kW, int padH, int padW, int ups, float scale,
                     void* ws, size_t ws_bytes);

@@ -113,9 +113,8 @@ function Conv:accGradParameters(x, dy, scale)
    local N, H, W = x.shape[1], x.shape[3], x.shape[4]
    local Hp, Wp = bit.rshift(H, x.ups), bit.rshift(W, x.ups)
    local ws, wsb = workspace(C.cg_conv2d_wgrad_workspace_bytes(N, Hp, Wp, self.nInputPlane, self.nOutputPlane, self.kH, self.kW, self.padH, self.padW, x.ups))
-   check(C.cg_conv2d_wgrad(stream, x.ptr, dy.ptr, self.gradWeight.ptr, N, Hp, Wp, self.nInputPlane, self.nOutputPlane,
-                           self.kH, self.kW, self.padH, self.padW, x.ups, scale or 1, ws, wsb))
-   check(C.cg_bias_grad(stream, dy.ptr, self.gradBias.ptr, N * dy.shape[3] * dy.shape[4], self.nOutputPlane, scale or 1, ws, wsb))
+   check(C.cg_conv2d_wgrad(stream, x.ptr, dy.ptr, self.gradWeight.ptr, self.gradBias.ptr, N, Hp, Wp, self.nInputPlane,
+                           self.nOutputPlane, self.kH, self.kW, self.padH, self.padW, x.ups, scale or 1, ws, wsb))
 end
 function Conv:reset(stdv)  -- host-side init exactly as nn.SpatialConvolution:reset [upstream]
    stdv = stdv and stdv * math.sqrt(3) or 1 / math.sqrt(self.kW * self.kH * self.nInputPlane)

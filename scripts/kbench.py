@@ -73,8 +73,11 @@ def main():
                   lambda: conv_case("D.loc 3x3 64->16 @8^2", N, 64, 8, 16, 3, 0),
                   lambda: conv_case("D.loc 3x3 16->16 @16^2", N, 16, 16, 16, 3, 0),
                   lambda: lin_case("D.linear 20480->256", N, 20480, 256)]
+    named = {"conv3": lambda: conv_case("G.conv3 5x5 256->128 @16^2 ups", N, 256, 16, 128, 5, 1),
+             "b4": lambda: conv_case("D.b4 7x7 128->128 @8^2", N, 128, 8, 128, 7, 0),
+             "conv1": lambda: conv_case("G.conv1 3x3 512->512 @4^2 ups", N, 512, 4, 512, 3, 1)}
     if only:
-        cases = [lambda: conv_case("G.conv3 5x5 256->128 @16^2 ups", N, 256, 16, 128, 5, 1)] if only == "conv3" else cases
+        cases = [named[o] for o in only.split(",")]
     print(f"{'layer':34s} {'GFLOP':>8s}  " + "  ".join(f"{p:>16s}" for p in ("fwd ms / TF", "dgrad ms / TF", "wgrad ms / TF")))
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     for c in cases:
