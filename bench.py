@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="force hipGraph replay also for N > 1")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -107,15 +109,25 @@ def main():
     pool = np.random.RandomState(100 + rank).rand(1024, 3, 32, 32).astype(np.float32)
     data = cg.adversarial.TrainData(pool)
 
+    use_graph = (world == 1 and not args.no_graph) or args.graph
+    launch = "eager"
+    step = lambda: cg.adversarial.iteration(S, data)
+    if use_graph:
+        try:
+            step = cg.adversarial.GraphedIteration(S, data, N)
+            launch = "hipGraph replay"
+        except Exception as e:  # capture is an optimisation, not a requirement
+            launch = f"eager (graph capture failed: {type(e).__name__})"
+            step = lambda: cg.adversarial.iteration(S, data)
     for _ in range(args.warmup):
-        cg.adversarial.iteration(S, data)
+        step()
     cg.parallel.barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
     for _ in range(args.steps):
-        cg.adversarial.iteration(S, data)
+        step()
     e1.record()
     torch.cuda.synchronize()
     cg.parallel.barrier()
@@ -137,7 +149,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: G32up-c + D32_st3, 32x32 RGB, batch 128 per GPU, one "
                                    "adversarial.lua D+G update (Adam, D_L2=1e-4, clamps 1/5)",
-                       "global_batch": N * world, "parallelism": f"dp{world}",
+                       "global_batch": N * world, "parallelism": f"dp{world}", "launch": launch,
                        "ms_per_sample_reference_unit": 1e3 * dt / args.steps / (N * world / 2)},
             "step_roofline": {"bound": "mfma", "work_gflop_per_image": W_STEP / 1e9,
                               "achieved": per_gpu * W_STEP / 1e12, "peak": PEAK_FP32_MFMA / 1e12,

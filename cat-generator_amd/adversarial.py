@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import nn, nn_utils, optim, parallel
-from .tensor import Tensor, lib, stream
+from .tensor import Tensor, lib, rng, stream
 
 DEFAULT_OPT = dict(  # train.lua:15-49
     batchSize=32, N_epoch=1000, G_L1=0.0, G_L2=0.0, D_L1=0.0, D_L2=1e-4, D_iterations=1, G_iterations=1,
@@ -60,6 +60,7 @@ class State:
         self.accs = []
         self._cache = {}
         self.keep_outputs = False  # tests: snapshot D's output before the G-step reuses the buffer
+        self.device_rng = False    # draw the real-batch indices on the device (required under hipGraph replay)
 
 
 def mean(t):
@@ -163,8 +164,12 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
     # ----------------------------------------------------------------- (1) update D (:221-249)
     for _ in range(OPT["D_iterations"]):
         # (1.1) real data: N/2 random rows of the pool (math.random(trainData:size()), :226)
-        idx = real_idx if real_idx is not None else S.random.randint(0, trainData.size(), size=half)
-        buf["idx"].copy_(torch.from_numpy(np.asarray(idx, dtype=np.int32)), non_blocking=True)
+        if real_idx is None and S.device_rng:
+            r = rng()
+            lib().rng_randint_dev(stream(), buf["idx"].data_ptr(), half, trainData.size(), r.seed, r.take(half), r.base_ptr())
+        else:
+            idx = real_idx if real_idx is not None else S.random.randint(0, trainData.size(), size=half)
+            buf["idx"].copy_(torch.from_numpy(np.asarray(idx, dtype=np.int32)), non_blocking=True)
         lib().gather_rows(stream(), trainData.pool.ptr, buf["idx"].data_ptr(), inputs.ptr, half, rowlen)
         # (1.2) sampled data
         noise = nn.to_device(noise_D) if noise_D is not None else nn_utils.createNoiseInputs(S, half)
@@ -184,6 +189,48 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         assert OPT["G_optmethod"] == "adam", "only adam (the default) is implemented"
         optim.adam(fevalG_on_D, S.PARAMETERS_G, S.OPTSTATE["adam"]["G"], fused=fused)
     return st["doTrainD"]
+
+
+class GraphedIteration:
+    """The whole D+G iteration captured once in a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm) and replayed:
+    ~730 launches per step stop costing host time and inter-kernel gaps.  Everything that varies per step lives in
+    device memory: the counter-stream position of every mask / noise / index draw (SplitMix.dev_base, advanced by
+    `stride` draws per replay) and Adam's step counts (optim.adam device_step).  Only the inert-by-default accuracy
+    gate (D_maxAcc <= 1) needs the host, so it is not available here."""
+
+    def __init__(self, S, trainData, thisBatchSize=None, warmup=2):
+        assert torch.cuda.is_available()
+        self.S, self.data, self.N = S, trainData, thisBatchSize or S.OPT["batchSize"]
+        S.device_rng = True
+        for k in ("D", "G"):
+            S.OPTSTATE["adam"][k]["device_step"] = True
+        r = rng()
+        self.base = r.enable_device_base()
+        self.off0 = r.offset
+        self.stride = None
+        for _ in range(max(1, warmup)):  # eager passes: allocate every buffer, pack weights, learn the stride
+            self._eager()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        self.replays = 0
+
+    def _body(self):
+        r = rng()
+        r.offset = self.off0
+        iteration(self.S, self.data, self.N)
+        self.stride = r.offset - self.off0
+        lib().counter_add(stream(), self.base.data_ptr(), self.stride)
+
+    def _eager(self):
+        self._body()
+
+    def __call__(self):
+        self.graph.replay()
+        self.replays += 1
+        for k in ("D", "G"):
+            self.S.OPTSTATE["adam"][k]["t"] += 1
 
 
 def train(S, trainData, maxAccuracyD=1.01, accsInterval=20, verbose=True):

@@ -292,12 +292,24 @@ __device__ __forceinline__ float u01(uint64_t seed, uint64_t ctr) {
     z = z ^ (z >> 31);
     return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
-__global__ void rng_bernoulli_k(float* out, long n, float keep, float value, uint64_t seed, uint64_t offset) {
+__global__ void rng_bernoulli_k(float* out, long n, float keep, float value, uint64_t seed, uint64_t offset,
+                                const uint64_t* base) {
+    if (base) offset += *base;
     GRID_STRIDE(i, n) { out[i] = u01(seed, offset + (uint64_t)i) < keep ? value : 0.f; }
 }
-__global__ void rng_uniform_k(float* out, long n, float lo, float hi, uint64_t seed, uint64_t offset) {
+__global__ void rng_uniform_k(float* out, long n, float lo, float hi, uint64_t seed, uint64_t offset,
+                              const uint64_t* base) {
+    if (base) offset += *base;
     GRID_STRIDE(i, n) { out[i] = lo + (hi - lo) * u01(seed, offset + (uint64_t)i); }
 }
+__global__ void rng_randint_k(int32_t* out, long n, int32_t range, uint64_t seed, uint64_t offset, const uint64_t* base) {
+    if (base) offset += *base;
+    GRID_STRIDE(i, n) {
+        int32_t v = (int32_t)(u01(seed, offset + (uint64_t)i) * (float)range);
+        out[i] = v < range ? v : range - 1;
+    }
+}
+__global__ void counter_add_k(uint64_t* c, uint64_t d) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += d; }
 
 // --------------------------------------------------------------------- layout
 __global__ void nchw_to_nhwc_k(const float* in, float* out, int N, int C, int H, int W) {
@@ -510,7 +522,11 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const float* img, const fl
 
 // ------------------------------------------------------------------ optimiser
 __global__ void adam_k(float* p, float* g, float* m, float* v, long n, float step, float b1, float b2, float eps,
-                       float l1, float l2, float clampv, int write_back) {
+                       float l1, float l2, float clampv, int write_back, float lr, const uint64_t* t_dev) {
+    if (t_dev) {  // replay-safe: bias correction from the device-side step counter
+        const double t = (double)*t_dev;
+        step = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    }
     GRID_STRIDE(i, n) {
         const float pi = p[i];
         float gi = g[i];
@@ -709,13 +725,34 @@ int cg_mask_mul(void* stream, const float* x, const float* mask, float* y, int N
     const long total = (long)N * HW * C;
     EW_LAUNCH(mask_mul_k, total, x, mask, y, total, HW * C, C, spatial); return 0;
 }
-int cg_rng_bernoulli(void* stream, float* out, long n, float keep_prob, float value, uint64_t seed, uint64_t offset) {
+int cg_rng_bernoulli_dev(void* stream, float* out, long n, float keep_prob, float value, uint64_t seed, uint64_t offset,
+                         const uint64_t* base) {
     CG_REQUIRE(out, "cg_rng_bernoulli: null pointer");
-    EW_LAUNCH(rng_bernoulli_k, n, out, n, keep_prob, value, seed, offset); return 0;
+    EW_LAUNCH(rng_bernoulli_k, n, out, n, keep_prob, value, seed, offset, base); return 0;
+}
+int cg_rng_uniform_dev(void* stream, float* out, long n, float lo, float hi, uint64_t seed, uint64_t offset,
+                       const uint64_t* base) {
+    CG_REQUIRE(out, "cg_rng_uniform: null pointer");
+    EW_LAUNCH(rng_uniform_k, n, out, n, lo, hi, seed, offset, base); return 0;
+}
+int cg_rng_randint_dev(void* stream, int32_t* out, long n, int32_t range, uint64_t seed, uint64_t offset,
+                       const uint64_t* base) {
+    CG_REQUIRE(out && range > 0, "cg_rng_randint: bad args");
+    EW_LAUNCH(rng_randint_k, n, out, n, range, seed, offset, base); return 0;
+}
+int cg_rng_bernoulli(void* stream, float* out, long n, float keep_prob, float value, uint64_t seed, uint64_t offset) {
+    return cg_rng_bernoulli_dev(stream, out, n, keep_prob, value, seed, offset, nullptr);
 }
 int cg_rng_uniform(void* stream, float* out, long n, float lo, float hi, uint64_t seed, uint64_t offset) {
-    CG_REQUIRE(out, "cg_rng_uniform: null pointer");
-    EW_LAUNCH(rng_uniform_k, n, out, n, lo, hi, seed, offset); return 0;
+    return cg_rng_uniform_dev(stream, out, n, lo, hi, seed, offset, nullptr);
+}
+int cg_rng_randint(void* stream, int32_t* out, long n, int32_t range, uint64_t seed, uint64_t offset) {
+    return cg_rng_randint_dev(stream, out, n, range, seed, offset, nullptr);
+}
+int cg_counter_add(void* stream, uint64_t* counter, uint64_t delta) {
+    CG_REQUIRE(counter, "cg_counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_k, dim3(1), dim3(64), 0, cg::S(stream), counter, delta);
+    CG_LAUNCH_CHECK(); return 0;
 }
 int cg_nchw_to_nhwc(void* stream, const float* in, float* out, int N, int C, int H, int W) {
     CG_REQUIRE(in && out, "cg_nchw_to_nhwc: null pointer");
@@ -823,7 +860,13 @@ int cg_adam_step(void* stream, float* p, float* g, float* m, float* v, long n, f
     const double bc1 = 1.0 - pow((double)beta1, (double)t);
     const double bc2 = 1.0 - pow((double)beta2, (double)t);
     const float step = (float)((double)lr * sqrt(bc2) / bc1);
-    EW_LAUNCH(adam_k, n, p, g, m, v, n, step, beta1, beta2, eps, l1, l2, clamp, write_back_grad);
+    EW_LAUNCH(adam_k, n, p, g, m, v, n, step, beta1, beta2, eps, l1, l2, clamp, write_back_grad, lr, (const uint64_t*)nullptr);
+    return 0;
+}
+int cg_adam_step_dev(void* stream, float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                     float eps, const uint64_t* t_dev, float l1, float l2, float clamp, int write_back_grad) {
+    CG_REQUIRE(p && g && m && v && t_dev, "cg_adam_step_dev: bad args");
+    EW_LAUNCH(adam_k, n, p, g, m, v, n, 0.f, beta1, beta2, eps, l1, l2, clamp, write_back_grad, lr, t_dev);
     return 0;
 }
 int cg_confusion_update(void* stream, const float* outputs, const float* targets, int32_t* counts, long n) {

@@ -879,7 +879,7 @@ class SpatialDropout(Module):
             else:
                 self.noise = self._get("noise", (N, C))
                 r = rng()
-                lib().rng_bernoulli(stream(), self.noise.ptr, N * C, 1.0 - self.p, 1.0, r.seed, r.take(N * C))
+                lib().rng_bernoulli_dev(stream(), self.noise.ptr, N * C, 1.0 - self.p, 1.0, r.seed, r.take(N * C), r.base_ptr())
             lib().mask_mul(stream(), x.ptr, self.noise.ptr, out.ptr, N, H * W, C, 1)
         else:
             out.copy(x).mul(1.0 - self.p)
@@ -919,7 +919,8 @@ class Dropout(Module):
         else:
             self.noise = self._get("noise", x.shape, x.fmt)
             r = rng()
-            lib().rng_bernoulli(stream(), self.noise.ptr, n, 1.0 - self.p, 1.0 / (1.0 - self.p), r.seed, r.take(n))
+            lib().rng_bernoulli_dev(stream(), self.noise.ptr, n, 1.0 - self.p, 1.0 / (1.0 - self.p), r.seed, r.take(n),
+                                    r.base_ptr())
         out = self._get("out", x.shape, x.fmt)
         lib().mask_mul(stream(), x.ptr, self.noise.ptr, out.ptr, 1, n, 1, 0)
         self.output = out

@@ -9,7 +9,7 @@ def createNoiseInputs(S, N):
     """U(-1,1) noise [N, noiseDim], generated on the device from the engine's counter stream."""
     t = Tensor.empty((N, S.OPT["noiseDim"]))
     r = rng()
-    lib().rng_uniform(stream(), t.ptr, t.nElement(), -1.0, 1.0, r.seed, r.take(t.nElement()))
+    lib().rng_uniform_dev(stream(), t.ptr, t.nElement(), -1.0, 1.0, r.seed, r.take(t.nElement()), r.base_ptr())
     return t
 
 

@@ -28,8 +28,17 @@ def adam(opfunc, x, config=None, state=None, fused=None):
         state["v"] = Tensor(torch.zeros_like(x.t), x.shape)
     state["t"] += 1
     l1, l2, clamp = (fused.get("l1", 0.0), fused.get("l2", 0.0), fused.get("clamp", 0.0)) if fused else (0.0, 0.0, 0.0)
-    lib().adam_step(stream(), x.ptr, dfdx.ptr, state["m"].ptr, state["v"].ptr, x.nElement(), lr, beta1, beta2,
-                    epsilon, state["t"], l1, l2, clamp, 1 if fused and fused.get("write_back", True) else 0)
+    wb = 1 if fused and fused.get("write_back", True) else 0
+    if config.get("device_step"):
+        # hipGraph replay mode: the step count lives in device memory (kernel arguments are frozen under replay)
+        if "t_dev" not in state:
+            state["t_dev"] = torch.full((1,), state["t"] - 1, dtype=torch.int64, device=x.t.device)
+        lib().counter_add(stream(), state["t_dev"].data_ptr(), 1)
+        lib().adam_step_dev(stream(), x.ptr, dfdx.ptr, state["m"].ptr, state["v"].ptr, x.nElement(), lr, beta1, beta2,
+                            epsilon, state["t_dev"].data_ptr(), l1, l2, clamp, wb)
+    else:
+        lib().adam_step(stream(), x.ptr, dfdx.ptr, state["m"].ptr, state["v"].ptr, x.nElement(), lr, beta1, beta2,
+                        epsilon, state["t"], l1, l2, clamp, wb)
     x.epoch.bump()
     return x, [fx]
 

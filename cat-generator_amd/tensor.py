@@ -52,6 +52,15 @@ class SplitMix:
     def __init__(self, seed=1):
         self.seed = int(seed)
         self.offset = 0
+        self.dev_base = None  # int64 device scalar added to every kernel-side offset (hipGraph replay mode)
+
+    def base_ptr(self):
+        return self.dev_base.data_ptr() if self.dev_base is not None else None
+
+    def enable_device_base(self):
+        if self.dev_base is None:
+            self.dev_base = torch.zeros(1, dtype=torch.int64, device=device())
+        return self.dev_base
 
     def take(self, n):
         o = self.offset

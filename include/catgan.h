@@ -183,6 +183,17 @@ int cg_rng_bernoulli(void* stream, float* out, long n, float keep_prob, float va
                      uint64_t seed, uint64_t offset);
 int cg_rng_uniform(void* stream, float* out, long n, float lo, float hi,
                    uint64_t seed, uint64_t offset);
+/* out[i] = floor(u * range) as int32: math.random(trainData:size()) - 1 (adversarial.lua:226). */
+int cg_rng_randint(void* stream, int32_t* out, long n, int32_t range, uint64_t seed, uint64_t offset);
+/* Replay-safe variants for hipGraph capture: the stream position is offset + *base, where *base is a device-side
+ * counter the host advances once per step with cg_counter_add (kernel arguments are frozen under graph replay). */
+int cg_rng_bernoulli_dev(void* stream, float* out, long n, float keep_prob, float value,
+                         uint64_t seed, uint64_t offset, const uint64_t* base);
+int cg_rng_uniform_dev(void* stream, float* out, long n, float lo, float hi,
+                       uint64_t seed, uint64_t offset, const uint64_t* base);
+int cg_rng_randint_dev(void* stream, int32_t* out, long n, int32_t range, uint64_t seed, uint64_t offset,
+                       const uint64_t* base);
+int cg_counter_add(void* stream, uint64_t* counter, uint64_t delta);
 
 /* ---- layout / data movement --------------------------------------------- */
 int cg_nchw_to_nhwc(void* stream, const float* in, float* out, int N, int C, int H, int W);
@@ -237,6 +248,11 @@ int cg_bilinear_sampler_backward(void* stream, const float* img, const float* gr
 int cg_adam_step(void* stream, float* p, float* g, float* m, float* v, long n,
                  float lr, float beta1, float beta2, float eps, int t,
                  float l1, float l2, float clamp, int write_back_grad);
+/* Same update with the step count read from device memory (t = (int)*t_dev, a counter the host advances with
+ * cg_counter_add before the call), so the launch can be replayed from a hipGraph. */
+int cg_adam_step_dev(void* stream, float* p, float* g, float* m, float* v, long n,
+                     float lr, float beta1, float beta2, float eps, const uint64_t* t_dev,
+                     float l1, float l2, float clamp, int write_back_grad);
 
 /* counts[pred*2 + target] += 1 with pred = out>0.5 (adversarial.lua:101-106). */
 int cg_confusion_update(void* stream, const float* outputs, const float* targets,

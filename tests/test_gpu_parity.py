@@ -368,3 +368,37 @@ def test_full_batch_step_runs_and_stays_finite(cg):
     assert out.shape == (128, 1) and (out > 0).all() and (out < 1).all()
     S.CONFUSION.updateValids()
     assert S.CONFUSION.counts.sum().item() == 256
+
+
+def test_graph_replay_matches_eager(cg):
+    """hipGraph replay of the iteration vs eager launches: same parameters (to drift tolerance) after 3 steps (device-side RNG/Adam
+    counters make the replay advance its mask / noise / index streams and step counts exactly like eager mode)."""
+    def run(graph):
+        cg.manual_seed(41)
+        G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
+        S = cg.adversarial.State(dict(batchSize=16), G, D)
+        pool = np.random.RandomState(5).rand(64, 3, 32, 32).astype(f32)
+        data = cg.adversarial.TrainData(pool)
+        if graph:
+            it = cg.adversarial.GraphedIteration(S, data, 16, warmup=2)   # 2 eager steps
+            it()                                                          # + 1 replayed
+        else:
+            S.device_rng = True
+            for k in ("D", "G"):
+                S.OPTSTATE["adam"][k]["device_step"] = True
+            r = cg.tensor.rng(); r.enable_device_base()
+            for _ in range(3):
+                off0 = r.offset
+                cg.adversarial.iteration(S, data, 16)
+                cg.lib().counter_add(cg.tensor.stream(), r.dev_base.data_ptr(), r.offset - off0)
+                r.offset = off0
+        torch.cuda.synchronize()
+        return S.PARAMETERS_G.numpy(), S.PARAMETERS_D.numpy(), int(S.OPTSTATE["adam"]["G"]["t_dev"].item())
+    gG, gD, tg = run(True)
+    eG, eD, te = run(False)
+    assert tg == te == 3
+    # same streams and step counts; a few kernels accumulate with float atomics (PReLU dalpha, sampler scatter),
+    # so two runs agree to rounding, which Adam turns into +-lr flips on ~0 gradients: the usual drift bound
+    for a, b in ((gG, eG), (gD, eD)):
+        d = np.abs(a - b)
+        assert d.max() <= 3 * 2.5e-3 and d.mean() <= 1e-5, (d.max(), d.mean())
