@@ -671,12 +671,21 @@ __global__ void wgrad_reduce_small_kernel(const float* part, float* gw, int Cin,
     }
 }
 
-// gb[c] += scale * sum_{s,p} bias_part[s*P+p][c]
-__global__ void bias_part_reduce_kernel(const float* bp, float* gb, int SP, int Cout, float scale) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < Cout; c += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int i = 0; i < SP; ++i) s += bp[(long)i * Cout + c];
-        gb[c] += scale * s;
+// gb[c] += scale * sum_{s,p} bias_part[s*P+p][c]; 32 channels x 8 partial-sum lanes per workgroup
+__global__ __launch_bounds__(256) void bias_part_reduce_kernel(const float* bp, float* gb, int SP, int Cout, float scale) {
+    __shared__ float sh[8][33];
+    const int cl = threadIdx.x & 31, ln = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s = 0.f;
+    if (c < Cout)
+        for (int i = ln; i < SP; i += 8) s += bp[(long)i * Cout + c];
+    sh[ln][cl] = s;
+    __syncthreads();
+    if (ln == 0 && c < Cout) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += sh[r][cl];
+        gb[c] += scale * t;
     }
 }
 
@@ -988,7 +997,7 @@ int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw, fl
     }
     CG_LAUNCH_CHECK();
     if (gb) {
-        hipLaunchKernelGGL(bias_part_reduce_kernel, dim3(cg::cdiv(Cout, 256)), dim3(256), 0, st, (const float*)a.bias_part, gb,
+        hipLaunchKernelGGL(bias_part_reduce_kernel, dim3(cg::cdiv(Cout, 32)), dim3(256), 0, st, (const float*)a.bias_part, gb,
                            p.splits * g.nphase, Cout, scale);
         CG_LAUNCH_CHECK();
     }

@@ -27,6 +27,122 @@ using cg::wave_sum;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
 // ---------------------------------------------------------------- activations
+// Memory-bound elementwise kernels move 16 B per lane (float4) when the buffers are 16-B aligned; `n4` counts
+// whole float4s, the (<4)-element tail is handled by the last lanes with scalar accesses.
+#define V4_LOOP(i, n4) \
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n4); i += (long)gridDim.x * blockDim.x)
+__device__ __forceinline__ float4 ldv(const float* p, long i) { return reinterpret_cast<const float4*>(p)[i]; }
+__device__ __forceinline__ void stv(float* p, long i, float4 v) { reinterpret_cast<float4*>(p)[i] = v; }
+// per-channel parameters are views into the flat vector (any 4-B alignment): four scalar loads
+__device__ __forceinline__ float4 ldc(const float* p, int c4) { return make_float4(p[4 * c4], p[4 * c4 + 1], p[4 * c4 + 2], p[4 * c4 + 3]); }
+
+__global__ void prelu_fwd_v4k(const float* x, const float* alpha, float* y, long n4) {
+    const float a = *alpha;
+    V4_LOOP(i, n4) {
+        float4 v = ldv(x, i);
+        v.x = v.x > 0.f ? v.x : a * v.x; v.y = v.y > 0.f ? v.y : a * v.y;
+        v.z = v.z > 0.f ? v.z : a * v.z; v.w = v.w > 0.f ? v.w : a * v.w;
+        stv(y, i, v);
+    }
+}
+__global__ void prelu_bwd_v4k(const float* x, const float* dy, const float* alpha, float* dx, float* galpha, float scale,
+                              long n4) {
+    __shared__ double sh[4];
+    const float a = *alpha;
+    float s = 0.f;
+    V4_LOOP(i, n4) {
+        const float4 v = ldv(x, i), g = ldv(dy, i);
+        float4 o;
+        o.x = v.x > 0.f ? g.x : a * g.x; o.y = v.y > 0.f ? g.y : a * g.y;
+        o.z = v.z > 0.f ? g.z : a * g.z; o.w = v.w > 0.f ? g.w : a * g.w;
+        stv(dx, i, o);
+        s += (v.x <= 0.f ? v.x * g.x : 0.f) + (v.y <= 0.f ? v.y * g.y : 0.f) + (v.z <= 0.f ? v.z * g.z : 0.f) +
+             (v.w <= 0.f ? v.w * g.w : 0.f);
+    }
+    const double t = block_sum_256((double)s, sh);
+    if (threadIdx.x == 0 && galpha) atomicAdd(galpha, (float)(t * scale));
+}
+__global__ void lrelu_fwd_v4k(const float* x, float* y, float s, long n4) {
+    V4_LOOP(i, n4) {
+        float4 v = ldv(x, i);
+        v.x = v.x >= 0.f ? v.x : s * v.x; v.y = v.y >= 0.f ? v.y : s * v.y;
+        v.z = v.z >= 0.f ? v.z : s * v.z; v.w = v.w >= 0.f ? v.w : s * v.w;
+        stv(y, i, v);
+    }
+}
+__global__ void lrelu_bwd_v4k(const float* x, const float* dy, float* dx, float s, long n4) {
+    V4_LOOP(i, n4) {
+        const float4 v = ldv(x, i);
+        float4 g = ldv(dy, i);
+        g.x = v.x >= 0.f ? g.x : s * g.x; g.y = v.y >= 0.f ? g.y : s * g.y;
+        g.z = v.z >= 0.f ? g.z : s * g.z; g.w = v.w >= 0.f ? g.w : s * g.w;
+        stv(dx, i, g);
+    }
+}
+__global__ void add_v4k(const float* a, const float* b, float* o, long n4) {
+    V4_LOOP(i, n4) {
+        const float4 u = ldv(a, i), v = ldv(b, i);
+        stv(o, i, make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w));
+    }
+}
+__global__ void axpy_v4k(float al, const float* x, float* y, long n4) {
+    V4_LOOP(i, n4) {
+        const float4 u = ldv(x, i);
+        float4 v = ldv(y, i);
+        v.x += al * u.x; v.y += al * u.y; v.z += al * u.z; v.w += al * u.w;
+        stv(y, i, v);
+    }
+}
+// spatial dropout with C % 4 == 0: mask[n][c..c+3] is one float4
+__global__ void mask_mul_sp_v4k(const float* x, const float* mask, float* y, long n4, long HWC4, int C4) {
+    V4_LOOP(i, n4) {
+        const long n = i / HWC4;
+        const float4 m = ldc(mask, (int)(n * C4 + (i % C4)));
+        float4 v = ldv(x, i);
+        v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+        stv(y, i, v);
+    }
+}
+__global__ void mask_mul_v4k(const float* x, const float* mask, float* y, long n4) {
+    V4_LOOP(i, n4) {
+        const float4 m = ldv(mask, i);
+        float4 v = ldv(x, i);
+        v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+        stv(y, i, v);
+    }
+}
+// batch-norm apply / backward with C % 4 == 0
+__global__ void bn_apply_v4k(const float* x, float* y, const float* gamma, const float* beta, const float* mean,
+                             const float* invstd, long n4, int C4) {
+    V4_LOOP(i, n4) {
+        const int c = (int)(i % C4);
+        const float4 g = ldc(gamma, c), b = ldc(beta, c), m = ldc(mean, c), s = ldc(invstd, c);
+        float4 v = ldv(x, i);
+        v.x = (v.x - m.x) * s.x * g.x + b.x; v.y = (v.y - m.y) * s.y * g.y + b.y;
+        v.z = (v.z - m.z) * s.z * g.z + b.z; v.w = (v.w - m.w) * s.w * g.w + b.w;
+        stv(y, i, v);
+    }
+}
+__global__ void bn_bwd_v4k(const float* x, const float* dy, const float* gamma, const float* mean, const float* invstd,
+                           const double* sums, double count, long n4, int C4, float* dx) {
+    V4_LOOP(i, n4) {
+        const int c = (int)(i % C4);
+        const float4 g = ldc(gamma, c), m = ldc(mean, c), s = ldc(invstd, c);
+        const float4 v = ldv(x, i), d = ldv(dy, i);
+        const int C = C4 * 4;
+        float4 o;
+#define BNB(f, k)                                                                      \
+        {                                                                              \
+            const float xh = (v.f - m.f) * s.f;                                        \
+            const float m1 = (float)(sums[4 * c + k] / count), m2 = (float)(sums[C + 4 * c + k] / count); \
+            o.f = g.f * s.f * (d.f - m1 - xh * m2);                                    \
+        }
+        BNB(x, 0) BNB(y, 1) BNB(z, 2) BNB(w, 3)
+#undef BNB
+        stv(dx, i, o);
+    }
+}
+
 __global__ void prelu_fwd_k(const float* x, const float* alpha, float* y, long n) {
     const float a = *alpha;
     GRID_STRIDE(i, n) {
@@ -552,6 +668,7 @@ __global__ void confusion_k(const float* out, const float* tgt, int32_t* counts,
 
 }  // namespace
 
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 #define EW_LAUNCH(kern, n, ...)                                                                  \
     do {                                                                                         \
         if ((n) > 0) {                                                                           \
@@ -591,19 +708,25 @@ int cg_stream_sync(void* stream) { CG_HIP(hipStreamSynchronize(cg::S(stream))); 
 
 int cg_prelu_forward(void* stream, const float* x, const float* alpha, float* y, long n) {
     CG_REQUIRE(x && alpha && y, "cg_prelu_forward: null pointer");
+    if (n % 4 == 0 && al16(x) && al16(y)) { EW_LAUNCH(prelu_fwd_v4k, n / 4, x, alpha, y, n / 4); return 0; }
     EW_LAUNCH(prelu_fwd_k, n, x, alpha, y, n); return 0;
 }
 int cg_prelu_backward(void* stream, const float* x, const float* dy, const float* alpha, float* dx, float* galpha,
                       float scale, long n) {
     CG_REQUIRE(x && dy && alpha && dx, "cg_prelu_backward: null pointer");
+    if (n % 4 == 0 && al16(x) && al16(dy) && al16(dx)) {
+        EW_LAUNCH(prelu_bwd_v4k, n / 4, x, dy, alpha, dx, galpha, scale, n / 4); return 0;
+    }
     EW_LAUNCH(prelu_bwd_k, n, x, dy, alpha, dx, galpha, scale, n); return 0;
 }
 int cg_leakyrelu_forward(void* stream, const float* x, float* y, float slope, long n) {
     CG_REQUIRE(x && y, "cg_leakyrelu_forward: null pointer");
+    if (n % 4 == 0 && al16(x) && al16(y)) { EW_LAUNCH(lrelu_fwd_v4k, n / 4, x, y, slope, n / 4); return 0; }
     EW_LAUNCH(lrelu_fwd_k, n, x, y, slope, n); return 0;
 }
 int cg_leakyrelu_backward(void* stream, const float* x, const float* dy, float* dx, float slope, long n) {
     CG_REQUIRE(x && dy && dx, "cg_leakyrelu_backward: null pointer");
+    if (n % 4 == 0 && al16(x) && al16(dy) && al16(dx)) { EW_LAUNCH(lrelu_bwd_v4k, n / 4, x, dy, dx, slope, n / 4); return 0; }
     EW_LAUNCH(lrelu_bwd_k, n, x, dy, dx, slope, n); return 0;
 }
 int cg_sigmoid_forward(void* stream, const float* x, float* y, long n) {
@@ -663,6 +786,11 @@ int cg_bn_forward(void* stream, const float* x, float* y, const float* gamma, co
     CG_REQUIRE(x && y && gamma && beta && sums && save_mean && save_invstd && C > 0 && count > 0, "cg_bn_forward: bad args");
     EW_LAUNCH(bn_prepare_k, (long)C, sums, count, C, eps, momentum, running_mean, running_var, save_mean, save_invstd);
     const long total = M * C;
+    if (C % 4 == 0 && al16(x) && al16(y)) {
+        EW_LAUNCH(bn_apply_v4k, total / 4, x, y, gamma, beta, (const float*)save_mean, (const float*)save_invstd, total / 4,
+                  C / 4);
+        return 0;
+    }
     EW_LAUNCH(bn_apply_k, total, x, y, gamma, beta, (const float*)save_mean, (const float*)save_invstd, total, C);
     return 0;
 }
@@ -684,7 +812,11 @@ int cg_bn_backward(void* stream, const float* x, const float* dy, const float* g
     CG_REQUIRE(x && dy && gamma && save_mean && save_invstd && sums && local_sums && dx && C > 0 && count > 0,
                "cg_bn_backward: bad args");
     const long total = M * C;
-    EW_LAUNCH(bn_bwd_k, total, x, dy, gamma, save_mean, save_invstd, sums, count, total, C, dx);
+    if (C % 4 == 0 && al16(x) && al16(dy) && al16(dx)) {
+        EW_LAUNCH(bn_bwd_v4k, total / 4, x, dy, gamma, save_mean, save_invstd, sums, count, total / 4, C / 4, dx);
+    } else {
+        EW_LAUNCH(bn_bwd_k, total, x, dy, gamma, save_mean, save_invstd, sums, count, total, C, dx);
+    }
     EW_LAUNCH(bn_bwd_param_k, (long)C, local_sums, C, ggamma, gbeta, scale);
     return 0;
 }
@@ -723,6 +855,12 @@ int cg_maxpool2_backward(void* stream, const float* x, const float* dy, float* d
 int cg_mask_mul(void* stream, const float* x, const float* mask, float* y, int N, long HW, int C, int spatial) {
     CG_REQUIRE(x && mask && y, "cg_mask_mul: null pointer");
     const long total = (long)N * HW * C;
+    if (al16(x) && al16(y)) {
+        if (spatial && C % 4 == 0) {
+            EW_LAUNCH(mask_mul_sp_v4k, total / 4, x, mask, y, total / 4, HW * C / 4, C / 4); return 0;
+        }
+        if (!spatial && total % 4 == 0 && al16(mask)) { EW_LAUNCH(mask_mul_v4k, total / 4, x, mask, y, total / 4); return 0; }
+    }
     EW_LAUNCH(mask_mul_k, total, x, mask, y, total, HW * C, C, spatial); return 0;
 }
 int cg_rng_bernoulli_dev(void* stream, float* out, long n, float keep_prob, float value, uint64_t seed, uint64_t offset,
@@ -783,10 +921,12 @@ int cg_fill(void* stream, float* x, float value, long n) {
 }
 int cg_add(void* stream, const float* a, const float* b, float* out, long n) {
     CG_REQUIRE(a && b && out, "cg_add: null pointer");
+    if (n % 4 == 0 && al16(a) && al16(b) && al16(out)) { EW_LAUNCH(add_v4k, n / 4, a, b, out, n / 4); return 0; }
     EW_LAUNCH(add_k, n, a, b, out, n); return 0;
 }
 int cg_axpy(void* stream, float alpha, const float* x, float* y, long n) {
     CG_REQUIRE(x && y, "cg_axpy: null pointer");
+    if (n % 4 == 0 && al16(x) && al16(y)) { EW_LAUNCH(axpy_v4k, n / 4, alpha, x, y, n / 4); return 0; }
     EW_LAUNCH(axpy_k, n, alpha, x, y, n); return 0;
 }
 int cg_axpy_sign(void* stream, float alpha, const float* x, float* y, long n) {
