@@ -152,19 +152,36 @@ def main():
                        "global_batch": N * world, "parallelism": f"dp{world}", "launch": launch,
                        "ms_per_sample_reference_unit": 1e3 * dt / args.steps / (N * world / 2)},
             "step_roofline": {"bound": "mfma", "work_gflop_per_image": W_STEP / 1e9,
+                              "note": "direct-count necessary work W = 3.5 F_G + 5 F_D (SURVEY.md 8d); the engine "
+                                      "executes ~5.42 GFLOP/image after folding the upsamplings",
                               "achieved": per_gpu * W_STEP / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
                               "unit": "TFLOP/s", "frac": per_gpu * W_STEP / PEAK_FP32_MFMA},
             "event_ms_per_step": e0.elapsed_time(e1) / args.steps, "finite": finite,
         }
         if not args.no_kernel_roofline:
             flop, t = dominant_kernel_roofline(cg, N)
-            ach = flop / t["igemm_nn_fwd"] / 1e12
-            res["roofline"] = {"bound": "mfma", "kernel": "igemm_nn_kernel<128,128,2,2> (conv5x5 256->128 @32x32, "
-                               "upsample folded, batch %d)" % N, "achieved": ach, "peak": PEAK_FP32_MFMA / 1e12,
-                               "unit": "TFLOP/s", "frac": ach * 1e12 / PEAK_FP32_MFMA, "traffic": None,
-                               "flop_per_launch": flop,
+            # HBM traffic of that launch from the PMC pass committed under profiles/ (2*FETCH_SIZE + WRITE_SIZE,
+            # the gfx950 correction of MI355X_MICROARCH.md); bench.py cannot run rocprofv3 on itself
+            traffic, util = None, None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_dominant_conv.json")))
+                k = [v for name, v in pmc.items() if "igemm_nn" in name and "grid=262144" in name][0]
+                traffic, util = k["hbm_bytes_per_launch_corrected"], k["mfma_pipe_util"]
+            except Exception:
+                pass
+            # executed FLOPs: the 4-phase form of upsample2 -> conv5x5 runs 4 x 3x3 taps per low-res pixel
+            flop_exec = flop * 36.0 / 100.0
+            res["roofline"] = {"bound": "mfma", "kernel": "igemm_nn_kernel<128,128,2,2,FAST> (G conv5x5 256->128 @32x32 "
+                               "with the 2x nearest upsampling folded in as 4 phase convs, batch %d)" % N,
+                               "achieved": flop_exec / t["igemm_nn_fwd"] / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
+                               "unit": "TFLOP/s", "frac": flop_exec / t["igemm_nn_fwd"] / PEAK_FP32_MFMA,
+                               "traffic": traffic, "mfma_pipe_util_pmc": util,
+                               "note": "achieved/frac count EXECUTED MFMA FLOPs (2.78x fewer than the direct-count "
+                                       "algorithmic FLOPs of the layer); direct-count rate in `tflops_direct`",
+                               "flop_per_launch": flop_exec, "flop_per_launch_direct": flop,
                                "launch_ms": {k: 1e3 * v for k, v in t.items()},
-                               "tflops": {k: flop / v / 1e12 for k, v in t.items()}}
+                               "tflops_direct": {k: flop / v / 1e12 for k, v in t.items()},
+                               "tflops_executed": {k: flop_exec / v / 1e12 for k, v in t.items()}}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -460,18 +460,27 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
     const bool do_bias = a.bias_part != nullptr && tm == 0;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // Lean per-tile address math (every VALU op here costs MFMA issue slots): 32-bit offsets, the pixel decoded
+    // once per row and shared by both operands when their row mappings coincide, source base = pix*Cin when the
+    // grid and the source tensor have the same geometry (always true for "same"-padded layers).
+    const bool lin_src = g.td.ss == 1 && g.Hs == g.Hg && g.Ws == g.Wg;
+    const bool lin_out = g.so == 1 && g.nphase == 1;
+    constexpr bool SAME_ROWS = (AVEC == BVEC);
     auto load_tile = [&](int p0) {
+        int rn[APASS], roy[APASS], rox[APASS];
 #pragma unroll
         for (int q = 0; q < APASS; ++q) {
             const int kr = a_kr + q * ARPP;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kr < BK) {
+            if (APASS * ARPP == BK || kr < BK) {
                 const int pix = p0 + kr;
+                const bool pok = pix < pend;
                 int n, oy, ox;
-                pix_decode(g, pix < pend ? pix : 0, n, oy, ox);
-                const int base = ((n * g.Hs + oy * g.td.ss) * g.Ws + ox * g.td.ss) * g.Cin;
+                pix_decode(g, pok ? pix : 0, n, oy, ox);
+                rn[q] = n; roy[q] = oy; rox[q] = ox;
+                const int base = lin_src ? pix * g.Cin : ((n * g.Hs + oy * g.td.ss) * g.Ws + ox * g.td.ss) * g.Cin;
                 if (VECA) {
-                    const bool ok = pix < pend && c_ok[0] && (unsigned)(oy + c_ty[0]) < (unsigned)g.Hv &&
+                    const bool ok = pok && c_ok[0] && (unsigned)(oy + c_ty[0]) < (unsigned)g.Hv &&
                                     (unsigned)(ox + c_tx[0]) < (unsigned)g.Wv;
                     v = bufld4(rsx, ok ? (unsigned)(base + c_off[0]) * 4u : OOB, 0);
                 } else {
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int jj = VECA ? 0 : j;
-                        const bool ok = pix < pend && c_ok[jj] && (unsigned)(oy + c_ty[jj]) < (unsigned)g.Hv &&
+                        const bool ok = pok && c_ok[jj] && (unsigned)(oy + c_ty[jj]) < (unsigned)g.Hv &&
                                         (unsigned)(ox + c_tx[jj]) < (unsigned)g.Wv;
                         float e = 0.f;
                         if (ok) e = a.x[(long)base + c_off[jj]];
@@ -494,14 +503,23 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
         for (int q = 0; q < BPASS; ++q) {
             const int kr = b_kr + q * BRPP;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kr < BK) {
+            if (BPASS * BRPP == BK || kr < BK) {
                 const int pix = p0 + kr;
+                const bool pok = pix < pend;
                 const int n = n0 + 4 * b_nv;
-                const long ro = out_row(g, pix < pend ? pix : 0, pa, pb);
+                int ro;
+                if (lin_out) {
+                    ro = pix * g.Cout;
+                } else {
+                    int pn, poy, pox;
+                    if (SAME_ROWS) { pn = rn[q < APASS ? q : 0]; poy = roy[q < APASS ? q : 0]; pox = rox[q < APASS ? q : 0]; }
+                    else pix_decode(g, pok ? pix : 0, pn, poy, pox);
+                    ro = ((pn * g.Hout + poy * g.so + pa) * g.Wout + pox * g.so + pb) * g.Cout;
+                }
                 if (VECB) {
-                    v = bufld4(rsd, (pix < pend && b_nok) ? (unsigned)(ro + n) * 4u : OOB, 0);
-                } else if (pix < pend) {
-                    const float* dp = a.dy + ro + n;
+                    v = bufld4(rsd, (pok && b_nok) ? (unsigned)(ro + n) * 4u : OOB, 0);
+                } else if (pok) {
+                    const float* dp = a.dy + (long)ro + n;
                     if (n + 0 < g.Cout) v.x = dp[0];
                     if (n + 1 < g.Cout) v.y = dp[1];
                     if (n + 2 < g.Cout) v.z = dp[2];
@@ -518,12 +536,12 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
 #pragma unroll
         for (int q = 0; q < APASS; ++q) {
             const int kr = a_kr + q * ARPP;
-            if (kr < BK) *reinterpret_cast<float4*>(A + kr * LDA + 4 * a_mv) = areg[q];
+            if (APASS * ARPP == BK || kr < BK) *reinterpret_cast<float4*>(A + kr * LDA + 4 * a_mv) = areg[q];
         }
 #pragma unroll
         for (int q = 0; q < BPASS; ++q) {
             const int kr = b_kr + q * BRPP;
-            if (kr < BK) {
+            if (BPASS * BRPP == BK || kr < BK) {
                 *reinterpret_cast<float4*>(B + kr * LDB + 4 * b_nv) = breg[q];
                 if (do_bias) { bsum.x += breg[q].x; bsum.y += breg[q].y; bsum.z += breg[q].z; bsum.w += breg[q].w; }
             }
