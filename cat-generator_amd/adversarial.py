@@ -26,7 +26,7 @@ from .tensor import Tensor, lib, rng, stream
 DEFAULT_OPT = dict(  # train.lua:15-49
     batchSize=32, N_epoch=1000, G_L1=0.0, G_L2=0.0, D_L1=0.0, D_L2=1e-4, D_iterations=1, G_iterations=1,
     D_maxAcc=1.01, D_clamp=1.0, G_clamp=5.0, D_optmethod="adam", G_optmethod="adam", noiseDim=100, scale=32,
-    seed=1, colorSpace="rgb", fused_update=True, exact_reference_backward=False,
+    seed=1, colorSpace="rgb", fused_update=True, exact_reference_backward=False, overlap_comm=True,
 )
 
 
@@ -54,7 +54,11 @@ class State:
         self.PARAMETERS_D, self.GRAD_PARAMETERS_D = MODEL_D.getParameters()   # train.lua:184
         self.PARAMETERS_G, self.GRAD_PARAMETERS_G = MODEL_G.getParameters()   # train.lua:185
         self.CONFUSION = optim.ConfusionMatrix(self.CLASSES)                  # train.lua:188
-        self.OPTSTATE = {"adam": {"D": {}, "G": {}}}                          # train.lua:191-207
+        o = self.OPT                                                          # train.lua:191-207
+        self.OPTSTATE = {"adagrad": {"D": {"learningRate": 1e-3}, "G": {"learningRate": 1e-3 * 3}},
+                         "adam": {"D": {}, "G": {}},
+                         "sgd": {"D": {"learningRate": o.get("D_sgd_lr", 0.02), "momentum": o.get("D_sgd_momentum", 0)},
+                                 "G": {"learningRate": o.get("G_sgd_lr", 0.02), "momentum": o.get("G_sgd_momentum", 0)}}}
         self.EPOCH = 1
         self.random = np.random.RandomState(self.OPT["seed"])  # math.randomseed(OPT.seed), train.lua:61
         self.accs = []
@@ -108,7 +112,10 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         f = S.CRITERION.forward(outputs, targets)
         df_do = S.CRITERION.backward(outputs, targets)
         S.MODEL_D.backward(inputs, df_do)
-        parallel.allreduce_mean_(S.GRAD_PARAMETERS_D.t)
+        if st.get("overlap"):  # start the xGMI all-reduce now, finish it after the G-step's generator forward
+            st["pendingD"] = parallel.allreduce_mean_async(S.GRAD_PARAMETERS_D.t)
+        else:
+            parallel.allreduce_mean_(S.GRAD_PARAMETERS_D.t)
         if not OPT["fused_update"]:
             if OPT["D_L1"] != 0 or OPT["D_L2"] != 0:
                 f = float(f) + OPT["D_L1"] * S.PARAMETERS_D.norm(1) + OPT["D_L2"] * S.PARAMETERS_D.norm(2) ** 2 / 2
@@ -138,7 +145,9 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
             S.PARAMETERS_G.copy(x)
         S.GRAD_PARAMETERS_G.zero()
         targets = buf["targets_G"]
-        samples = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
+        samples = st.pop("samples_pre", None)
+        if samples is None:
+            samples = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
         outputs = S.MODEL_D.forward(samples)
         f = S.CRITERION.forward(outputs, targets)
         df_samples = S.CRITERION.backward(outputs, targets)
@@ -177,17 +186,31 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         lib().memcpy_d2d(stream(), inputs.ptr + half * rowlen * 4, samples.ptr, half * rowlen * 4)
         S._last_fake = samples.clone() if S.keep_outputs else samples
         fused = dict(l1=OPT["D_L1"], l2=OPT["D_L2"], clamp=OPT["D_clamp"]) if OPT["fused_update"] else None
-        assert OPT["D_optmethod"] == "adam", "only adam (the default) is implemented"
-        optim.adam(fevalD, S.PARAMETERS_D, S.OPTSTATE["adam"]["D"], fused=fused)
+        m = OPT["D_optmethod"]  # adversarial.lua:240-248
+        assert m in ("sgd", "adagrad", "adam"), "[Warning] Unknown optimizer method chosen for D."
+        # Data-parallel overlap: D's gradient all-reduce travels over xGMI while the G-step's generator forward
+        # (which reads no D parameter) runs; D's update is applied after the wait, before D sees those samples.
+        st["overlap"] = (parallel.world_size() > 1 and OPT.get("overlap_comm", True) and OPT["fused_update"]
+                         and OPT["D_iterations"] == 1 and OPT["G_iterations"] == 1 and noise_G is None)
+        if st["overlap"]:
+            fD, gD = fevalD(S.PARAMETERS_D)
+            st["noiseInputs"] = nn_utils.createNoiseInputs(S, N)
+            st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
+            st.pop("pendingD").finish()
+            getattr(optim, m)(lambda _x: (fD, gD), S.PARAMETERS_D, S.OPTSTATE[m]["D"], fused=fused)
+        else:
+            getattr(optim, m)(fevalD, S.PARAMETERS_D, S.OPTSTATE[m]["D"], fused=fused)
 
     # ----------------------------------------------------------------- (2) update G (:253-266)
     for _ in range(OPT["G_iterations"]):
-        st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.createNoiseInputs(S, N)
+        if "samples_pre" not in st:
+            st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.createNoiseInputs(S, N)
         # upstream multiplies the L1 sign term by G_L2 (:206): keep that in the fused form too
         fused = dict(l1=OPT["G_L2"] if OPT["G_L1"] != 0 or OPT["G_L2"] != 0 else 0.0, l2=OPT["G_L2"],
                      clamp=OPT["G_clamp"]) if OPT["fused_update"] else None
-        assert OPT["G_optmethod"] == "adam", "only adam (the default) is implemented"
-        optim.adam(fevalG_on_D, S.PARAMETERS_G, S.OPTSTATE["adam"]["G"], fused=fused)
+        m = OPT["G_optmethod"]  # adversarial.lua:257-265
+        assert m in ("sgd", "adagrad", "adam"), "[Warning] Unknown optimizer method chosen for G."
+        getattr(optim, m)(fevalG_on_D, S.PARAMETERS_G, S.OPTSTATE[m]["G"], fused=fused)
     return st["doTrainD"]
 
 

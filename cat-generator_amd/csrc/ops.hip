@@ -658,6 +658,36 @@ __global__ void adam_k(float* p, float* g, float* m, float* v, long n, float ste
         if (write_back) g[i] = gi;
     }
 }
+__device__ __forceinline__ float pen_clamp(float pi, float gi, float l1, float l2, float clampv) {
+    if (l1 != 0.f || l2 != 0.f) {
+        const float sg = pi > 0.f ? 1.f : (pi < 0.f ? -1.f : 0.f);
+        gi += sg * l1 + pi * l2;
+    }
+    if (clampv > 0.f) gi = fminf(fmaxf(gi, -clampv), clampv);
+    return gi;
+}
+__global__ void sgd_k(float* p, float* g, float* v, long n, float lr, float mom, float damp, float l1, float l2,
+                      float clampv, int write_back) {
+    GRID_STRIDE(i, n) {
+        const float pi = p[i];
+        const float gi = pen_clamp(pi, g[i], l1, l2, clampv);
+        float d = gi;
+        if (mom != 0.f) { d = mom * v[i] + (1.f - damp) * gi; v[i] = d; }
+        p[i] = pi - lr * d;
+        if (write_back) g[i] = gi;
+    }
+}
+__global__ void adagrad_k(float* p, float* g, float* var, long n, float lr, float l1, float l2, float clampv,
+                          int write_back) {
+    GRID_STRIDE(i, n) {
+        const float pi = p[i];
+        const float gi = pen_clamp(pi, g[i], l1, l2, clampv);
+        const float vi = var[i] + gi * gi;
+        var[i] = vi;
+        p[i] = pi - lr * gi / (sqrtf(vi) + 1e-10f);
+        if (write_back) g[i] = gi;
+    }
+}
 __global__ void confusion_k(const float* out, const float* tgt, int32_t* counts, long n) {
     GRID_STRIDE(i, n) {
         const int pred = out[i] > 0.5f ? 1 : 0;
@@ -1007,6 +1037,18 @@ int cg_adam_step_dev(void* stream, float* p, float* g, float* m, float* v, long 
                      float eps, const uint64_t* t_dev, float l1, float l2, float clamp, int write_back_grad) {
     CG_REQUIRE(p && g && m && v && t_dev, "cg_adam_step_dev: bad args");
     EW_LAUNCH(adam_k, n, p, g, m, v, n, 0.f, beta1, beta2, eps, l1, l2, clamp, write_back_grad, lr, t_dev);
+    return 0;
+}
+int cg_sgd_step(void* stream, float* p, float* g, float* v, long n, float lr, float momentum, float dampening, float l1,
+                float l2, float clamp, int write_back_grad) {
+    CG_REQUIRE(p && g && (v || momentum == 0.f), "cg_sgd_step: bad args");
+    EW_LAUNCH(sgd_k, n, p, g, v, n, lr, momentum, dampening, l1, l2, clamp, write_back_grad);
+    return 0;
+}
+int cg_adagrad_step(void* stream, float* p, float* g, float* var, long n, float lr, float l1, float l2, float clamp,
+                    int write_back_grad) {
+    CG_REQUIRE(p && g && var, "cg_adagrad_step: bad args");
+    EW_LAUNCH(adagrad_k, n, p, g, var, n, lr, l1, l2, clamp, write_back_grad);
     return 0;
 }
 int cg_confusion_update(void* stream, const float* outputs, const float* targets, int32_t* counts, long n) {

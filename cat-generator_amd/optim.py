@@ -43,6 +43,50 @@ def adam(opfunc, x, config=None, state=None, fused=None):
     return x, [fx]
 
 
+def _fused(fused):
+    return ((fused.get("l1", 0.0), fused.get("l2", 0.0), fused.get("clamp", 0.0), 1 if fused.get("write_back", True) else 0)
+            if fused else (0.0, 0.0, 0.0, 0))
+
+
+def sgd(opfunc, x, config=None, state=None, fused=None):
+    """optim.sgd as train.lua:201-204 configures it (learningRate, momentum; Torch7 defaults: dampening = momentum,
+    no Nesterov, no weight decay, no lr decay).  First step with momentum: v = g [upstream: dfdx:clone()]."""
+    config = config if config is not None else {}
+    state = state if state is not None else config
+    lr = config.get("learningRate", 1e-3)
+    mom = config.get("momentum", 0.0)
+    damp = config.get("dampening", mom)
+    fx, dfdx = opfunc(x)
+    if fx is False:
+        return x, [fx]
+    l1, l2, clamp, wb = _fused(fused)
+    first = "dfdx" not in state
+    if mom != 0 and first:
+        state["dfdx"] = Tensor(torch.zeros_like(x.t), x.shape)
+    state["evalCounter"] = state.get("evalCounter", 0) + 1
+    lib().sgd_step(stream(), x.ptr, dfdx.ptr, state["dfdx"].ptr if mom != 0 else None, x.nElement(), lr, mom,
+                   0.0 if (mom != 0 and first) else damp, l1, l2, clamp, wb)
+    x.epoch.bump()
+    return x, [fx]
+
+
+def adagrad(opfunc, x, config=None, state=None, fused=None):
+    """optim.adagrad (train.lua:193-196): paramVariance += g^2; x -= lr * g / (sqrt(paramVariance) + 1e-10)."""
+    config = config if config is not None else {}
+    state = state if state is not None else config
+    lr = config.get("learningRate", 1e-3)
+    fx, dfdx = opfunc(x)
+    if fx is False:
+        return x, [fx]
+    l1, l2, clamp, wb = _fused(fused)
+    if "paramVariance" not in state:
+        state["paramVariance"] = Tensor(torch.zeros_like(x.t), x.shape)
+    state["evalCounter"] = state.get("evalCounter", 0) + 1
+    lib().adagrad_step(stream(), x.ptr, dfdx.ptr, state["paramVariance"].ptr, x.nElement(), lr, l1, l2, clamp, wb)
+    x.epoch.bump()
+    return x, [fx]
+
+
 class ConfusionMatrix:
     """optim.ConfusionMatrix(CLASSES) for the binary case of adversarial.lua:74,101-106,285-289, kept on the
     device: counts[pred][target] are only copied back when read."""

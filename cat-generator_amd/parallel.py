@@ -22,7 +22,7 @@ def init_from_env(backend=None):
     if world > 1 and not _S["init"]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("CATGAN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         _S["init"] = True
     _S["world"], _S["rank"] = world, rank
@@ -74,6 +74,32 @@ def allreduce_mean_(t):
         else:
             t.mul_(1.0 / _S["world"])
     return t
+
+
+class _Pending:
+    """An all-reduce(mean) in flight on RCCL's stream; finish() makes the compute stream wait for it and applies
+    the 1/world scale."""
+
+    def __init__(self, t, work):
+        self.t, self.work = t, work
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()
+            if self.t.is_cuda:
+                from .tensor import lib, stream
+                lib().scale(stream(), self.t.data_ptr(), 1.0 / _S["world"], self.t.numel())
+            else:
+                self.t.mul_(1.0 / _S["world"])
+        return self.t
+
+
+def allreduce_mean_async(t):
+    """Start the gradient all-reduce without blocking the compute stream (xGMI transfer overlaps the kernels
+    launched until finish())."""
+    if _S["world"] > 1:
+        return _Pending(t, dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+    return _Pending(t, None)
 
 
 def barrier():

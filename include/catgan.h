@@ -254,6 +254,15 @@ int cg_adam_step_dev(void* stream, float* p, float* g, float* m, float* v, long 
                      float lr, float beta1, float beta2, float eps, const uint64_t* t_dev,
                      float l1, float l2, float clamp, int write_back_grad);
 
+/* optim.sgd (adversarial.lua:240,257; train.lua:201-204: learningRate, momentum; Torch7 form, no Nesterov, no
+ * dampening change: v = mom*v + (1-damp)*g with damp = mom on the first call semantics folded by the host):
+ *   g' = penalty/clamp as in cg_adam_step;  v = momentum*v + (1-dampening)*g' (momentum != 0);  p -= lr * (v or g').
+ * optim.adagrad (train.lua:193-196):  var += g'^2 ;  p -= lr * g' / (sqrt(var) + 1e-10). */
+int cg_sgd_step(void* stream, float* p, float* g, float* v, long n, float lr, float momentum, float dampening,
+                float l1, float l2, float clamp, int write_back_grad);
+int cg_adagrad_step(void* stream, float* p, float* g, float* var, long n, float lr,
+                    float l1, float l2, float clamp, int write_back_grad);
+
 /* counts[pred*2 + target] += 1 with pred = out>0.5 (adversarial.lua:101-106). */
 int cg_confusion_update(void* stream, const float* outputs, const float* targets,
                         int32_t* counts, long n);

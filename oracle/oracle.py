@@ -728,6 +728,26 @@ def adam(x, g, state, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
     x -= step * m / denom
 
 
+def sgd(x, g, state, lr=0.02, momentum=0.0):
+    """Torch7 optim.sgd (train.lua:201-204): dampening defaults to momentum; first step v = g [upstream]."""
+    if momentum != 0:
+        if "v" not in state:
+            state["v"] = g.copy()
+        else:
+            state["v"] *= f32(momentum); state["v"] += f32(1 - momentum) * g
+        x -= f32(lr) * state["v"]
+    else:
+        x -= f32(lr) * g
+
+
+def adagrad(x, g, state, lr=1e-3):
+    """Torch7 optim.adagrad: var += g^2; x -= lr * g / (sqrt(var) + 1e-10) [upstream]."""
+    if "var" not in state:
+        state["var"] = np.zeros_like(x)
+    state["var"] += g * g
+    x -= f32(lr) * g / (np.sqrt(state["var"]) + f32(1e-10))
+
+
 # --------------------------------------------------------------------- the hot path
 class Trainer:
     """One iteration of adversarial.lua:51-275 with D_iterations=G_iterations=1, Adam, defaults of

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, backend, q):
+def _worker(rank, world, port, backend, overlap, q):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -27,7 +27,7 @@ def _worker(rank, world, port, backend, q):
         cg.parallel.attach(world, rank)
         cg.manual_seed(7)
         G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
-        S = cg.adversarial.State(dict(batchSize=8, seed=1 + rank), G, D)
+        S = cg.adversarial.State(dict(batchSize=8, seed=1 + rank, overlap_comm=overlap), G, D)
         cg.tensor.rng().offset += rank << 40
         pool = np.random.RandomState(100 + rank).rand(32, 3, 32, 32).astype(np.float32)
         data = cg.adversarial.TrainData(pool)
@@ -42,12 +42,12 @@ def _worker(rank, world, port, backend, q):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("backend", ["gloo"])
-def test_two_ranks_stay_replicas(backend):
+@pytest.mark.parametrize("backend,overlap", [("gloo", True), ("gloo", False)])
+def test_two_ranks_stay_replicas(backend, overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + os.getpid() % 200
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+    port = 29700 + os.getpid() % 200 + (50 if overlap else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, backend, overlap, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=400) for _ in procs], key=lambda r: r[0])

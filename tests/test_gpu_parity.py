@@ -240,6 +240,24 @@ def test_adam_and_fused_penalty_clamp(cg):
     close(st_p["m"].numpy(), st_o["m"], tol=1e-6); close(st_p["v"].numpy(), st_o["v"], tol=1e-6)
 
 
+def test_sgd_and_adagrad(cg):
+    rs = np.random.RandomState(8)
+    n = 50001
+    for name in ("sgd", "sgd_mom", "adagrad"):
+        p0 = rs.randn(n).astype(f32); po = p0.copy(); st_o, st_p = {}, {}
+        x = cg.Tensor.from_numpy(p0.copy())
+        for it in range(3):
+            g = rs.randn(n).astype(f32)
+            gt = cg.Tensor.from_numpy(g)
+            if name == "adagrad":
+                O.adagrad(po, g, st_o, lr=1e-3); cg.optim.adagrad(lambda _: (0.0, gt), x, {"learningRate": 1e-3}, st_p)
+            else:
+                mom = 0.9 if name == "sgd_mom" else 0.0
+                O.sgd(po, g, st_o, lr=0.02, momentum=mom)
+                cg.optim.sgd(lambda _: (0.0, gt), x, {"learningRate": 0.02, "momentum": mom}, st_p)
+        close(x.numpy(), po, tol=2e-6, what=name)
+
+
 # ------------------------------------------------------------------------------ whole networks
 def _pair(cg, seed, which, size=32, ch=3):
     cg.manual_seed(seed); rng = O.RNG(seed)
