@@ -629,11 +629,11 @@ def weight_init_heuristic(net, rng):
 
 
 # ------------------------------------------------------------------ model factories
-def create_G32up_c(channels, noise_dim, rng):
-    """models.lua:196-228 create_G_decoder_upsampling32c."""
+def create_G32up_c(channels, noise_dim, rng, base=4):
+    """models.lua:196-228 create_G_decoder_upsampling32c (base=8: the 64x64 extension of BASELINE config #5)."""
     cd = "cudnn.SpatialConvolution"  # does not match weight-init's typename test (weight-init.lua:54)
     m = Sequential(
-        Linear(noise_dim, 512 * 4 * 4, rng), PReLU(), View(512, 4, 4),
+        Linear(noise_dim, 512 * base * base, rng), PReLU(), View(512, base, base),
         UpSample2(), Conv(512, 512, 3, 1, rng, cd), SBN(512, rng), PReLU(),
         UpSample2(), Conv(512, 256, 3, 1, rng, cd), SBN(256, rng), PReLU(),
         UpSample2(), Conv(256, 128, 5, 2, rng, cd), SBN(128, rng), PReLU(),

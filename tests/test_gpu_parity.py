@@ -338,6 +338,36 @@ def test_three_training_steps(cg, fused):
             assert np.mean(d > 1e-4) < 2e-3 * (step + 1), f"{name} step {step}: {np.mean(d > 1e-4):.2e} outliers"
 
 
+@pytest.mark.parametrize("cfg", ["G32up-y-32", "G32up-c-64"])
+def test_other_baseline_configs_one_step(cg, cfg):
+    """BASELINE.json configs[2] (G32up, grayscale) and configs[4] (G32up-c scaled to 64x64, D32_st3 at 64x64):
+    one full D+G update against the oracle at a small batch."""
+    seed, N = 51, 4
+    cg.manual_seed(seed); rng = O.RNG(seed)
+    if cfg == "G32up-y-32":
+        ch, size = 1, 32
+        G = cg.models.create_G_decoder_upsampling32((ch, size, size), 100); Go = O.create_G32up(ch, 100, rng)
+    else:
+        ch, size = 3, 64
+        G = cg.models.create_G((ch, size, size), 100); Go = O.create_G32up_c(ch, 100, rng, base=8)
+    D = cg.models.create_D((ch, size, size)); Do = O.create_D32_st3(ch, size, rng)
+    S = cg.adversarial.State(dict(batchSize=N), G, D); S.keep_outputs = True
+    T = O.Trainer(Go, Do)
+    np.testing.assert_array_equal(S.PARAMETERS_G.numpy(), T.pG)
+    np.testing.assert_array_equal(S.PARAMETERS_D.numpy(), T.pD)
+    rs = np.random.RandomState(3)
+    pool = rs.rand(8, ch, size, size).astype(f32)
+    idx = rs.randint(0, 8, size=N // 2)
+    nd = (rs.rand(N // 2, 100) * 2 - 1).astype(f32); ng = (rs.rand(N, 100) * 2 - 1).astype(f32)
+    cg.adversarial.iteration(S, cg.adversarial.TrainData(pool), N, real_idx=idx, noise_D=nd, noise_G=ng)
+    r = T.step(pool[idx], nd, ng)
+    close(S._last_fake.numpy(), r["fake"], tol=2e-4, what="fake images")
+    close(cg.nn.as_plain(S._last["outputs_D"]).numpy(), r["outD"], tol=5e-4, what="D outputs")
+    for name, a, b in (("pD", S.PARAMETERS_D.numpy(), T.pD), ("pG", S.PARAMETERS_G.numpy(), T.pG)):
+        d = np.abs(a - b)
+        assert d.max() <= 2.5e-3 and d.mean() <= 2e-5, (name, d.max(), d.mean())
+
+
 # ------------------------------------------------- size-independent properties at BASELINE sizes
 def test_conv_adjoint_identity_at_full_size(cg):
     """<conv(x;w), dy> = <x_up, dgrad(dy;w)> = <w, wgrad(x,dy)> for the dominant layer at config #2's size
