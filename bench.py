@@ -58,10 +58,12 @@ def dominant_kernel_roofline(cg, N):
     return flop, out
 
 
-def cpu_baseline(steps=4, N=16):
+def cpu_baseline(steps=16, N=16):
     """The oracle (a port: im2col + blocked SGEMM + OpenMP, the algorithm class of THNN SpatialConvolutionMM)
     timed on this box's host cores on a bounded sample: `steps` iterations at batch 16 (BASELINE configs[0])."""
     from oracle import oracle as O
+    # the port parallelises its convolutions over the N samples of the batch: more threads than that only spin
+    O.set_num_threads(min(os.cpu_count() or 1, N))
     rng = O.RNG(1)
     T = O.Trainer(O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng))
     rs = np.random.RandomState(0)

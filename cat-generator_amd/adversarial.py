@@ -167,7 +167,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
                 S.GRAD_PARAMETERS_G.add(OPT["G_L2"], S.PARAMETERS_G)
             if OPT["G_clamp"] != 0:
                 S.GRAD_PARAMETERS_G.clamp(-OPT["G_clamp"], OPT["G_clamp"])
-        S._last.update(outputs_G=outputs, f_G=f, samples=samples)
+        S._last.update(outputs_G=outputs.clone() if S.keep_outputs else outputs, f_G=f, samples=samples)
         return f, S.GRAD_PARAMETERS_G
 
     # ----------------------------------------------------------------- (1) update D (:221-249)
