@@ -27,6 +27,7 @@ DEFAULT_OPT = dict(  # train.lua:15-49
     batchSize=32, N_epoch=1000, G_L1=0.0, G_L2=0.0, D_L1=0.0, D_L2=1e-4, D_iterations=1, G_iterations=1,
     D_maxAcc=1.01, D_clamp=1.0, G_clamp=5.0, D_optmethod="adam", G_optmethod="adam", noiseDim=100, scale=32,
     seed=1, colorSpace="rgb", fused_update=True, exact_reference_backward=False, overlap_comm=True,
+    concurrent_g_forward=False,  # measured: no gain at N=1 (the chip is already busy); kept as an option
 )
 
 
@@ -65,6 +66,7 @@ class State:
         self._cache = {}
         self.keep_outputs = False  # tests: snapshot D's output before the G-step reuses the buffer
         self.device_rng = False    # draw the real-batch indices on the device (required under hipGraph replay)
+        self._side = None          # side HIP stream + fork/join events for the concurrent G-step forward
 
 
 def mean(t):
@@ -146,6 +148,8 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         S.GRAD_PARAMETERS_G.zero()
         targets = buf["targets_G"]
         samples = st.pop("samples_pre", None)
+        if "join" in st:  # the forward ran on the side stream: join before anything consumes it
+            torch.cuda.current_stream().wait_event(st.pop("join"))
         if samples is None:
             samples = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
         outputs = S.MODEL_D.forward(samples)
@@ -185,6 +189,21 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         samples = nn.as_nhwc(nn_utils.createImagesFromNoise(S, noise, False))
         lib().memcpy_d2d(stream(), inputs.ptr + half * rowlen * 4, samples.ptr, half * rowlen * 4)
         S._last_fake = samples.clone() if S.keep_outputs else samples
+        # Fork: the G-step's generator forward (fresh noise) depends only on G's parameters, not on anything the
+        # D update does, and D's many small kernels leave CUs idle -> run it on a side HIP stream concurrently
+        # with fevalD / D's Adam.  It must follow the fake-generation forward (shared BN statistics buffers).
+        if (OPT.get("concurrent_g_forward", False) and torch.cuda.is_available() and OPT["D_iterations"] == 1
+                and OPT["G_iterations"] == 1):
+            if S._side is None:
+                S._side = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
+            side, ev_fork, ev_join = S._side
+            ev_fork.record()
+            side.wait_event(ev_fork)
+            with torch.cuda.stream(side):
+                st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.createNoiseInputs(S, N)
+                st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
+                ev_join.record()
+            st["join"] = ev_join
         fused = dict(l1=OPT["D_L1"], l2=OPT["D_L2"], clamp=OPT["D_clamp"]) if OPT["fused_update"] else None
         m = OPT["D_optmethod"]  # adversarial.lua:240-248
         assert m in ("sgd", "adagrad", "adam"), "[Warning] Unknown optimizer method chosen for D."
@@ -194,8 +213,9 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
                          and OPT["D_iterations"] == 1 and OPT["G_iterations"] == 1 and noise_G is None)
         if st["overlap"]:
             fD, gD = fevalD(S.PARAMETERS_D)
-            st["noiseInputs"] = nn_utils.createNoiseInputs(S, N)
-            st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
+            if "samples_pre" not in st:
+                st["noiseInputs"] = nn_utils.createNoiseInputs(S, N)
+                st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
             st.pop("pendingD").finish()
             getattr(optim, m)(lambda _x: (fD, gD), S.PARAMETERS_D, S.OPTSTATE[m]["D"], fused=fused)
         else:

@@ -762,9 +762,15 @@ static TileCfg pick_tile(long M, int Cout, int nphase) {
 }
 
 static int pick_splits(long tiles, long kiters) {
-    // aim for >= 2 workgroups per CU, keep >= 8 K-iterations per split
+    // Small grids are latency-bound (one global-load round trip per K tile, nothing to overlap it with), so
+    // split K until there are CG_SPLIT_TARGET workgroups per CU, keeping >= CG_SPLIT_MINK K-iterations per split.
+    static int target = -1, mink = -1;
+    if (target < 0) {
+        const char* e = getenv("CG_SPLIT_TARGET"); target = e ? atoi(e) : 2;
+        const char* f = getenv("CG_SPLIT_MINK"); mink = f ? atoi(f) : 8;
+    }
     int s = 1;
-    while (tiles * s < 2 * cg::kNumCU && kiters / (s * 2) >= 8 && s < 64) s *= 2;
+    while (tiles * s < (long)target * cg::kNumCU && kiters / (s * 2) >= mink && s < 64) s *= 2;
     return s;
 }
 
@@ -883,8 +889,10 @@ static TNPlan plan_tn(const Geom& g) {
     p.tc = {bm, bn};
     const long tiles = (long)cg::cdiv(g.Ktot, bm) * cg::cdiv(g.Cout, bn) * g.nphase;
     const long piters = cg::cdiv(g.M, BK);
+    static int smax = -1, tgt = -1;
+    if (smax < 0) { const char* e = getenv("CG_TN_SMAX"); smax = e ? atoi(e) : 128; const char* f = getenv("CG_TN_TARGET"); tgt = f ? atoi(f) : 3; }
     int s = 1;
-    while (tiles * s < 3 * cg::kNumCU && piters / (s * 2) >= 8 && s < 128) s *= 2;
+    while (tiles * s < (long)tgt * cg::kNumCU && piters / (s * 2) >= 8 && s < smax) s *= 2;
     p.pchunk = cg::cdiv(piters, s) * BK;
     p.splits = cg::cdiv(g.M, p.pchunk);
     return p;

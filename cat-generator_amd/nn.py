@@ -85,10 +85,13 @@ class Module:
         return getattr(self, "_typename", "nn." + type(self).__name__)
 
     def _get(self, key, shape, fmt="plain"):
+        # one persistent buffer per (role, size): the half-batch (fake generation) and full-batch passes of the
+        # same module keep separate storage, nothing is freed while another stream may still read it
         shape = tuple(int(s) for s in shape)
         n = int(np.prod(shape))
+        key = (key, n)
         b = self._bufs.get(key)
-        if b is None or b.t.numel() != n:
+        if b is None:
             b = Tensor.empty(shape, fmt)
             self._bufs[key] = b
             return b
@@ -280,13 +283,36 @@ class ConcatTable(Sequential):
 class Concat(Sequential):
     """nn.Concat(2) (models.lua:688-692): branch outputs joined on channels."""
 
+    concurrent = False  # option: branches on separate HIP streams (measured: no gain under graph replay, slower eager)
+
     def __init__(self, dimension):
         super().__init__()
         assert dimension == 2, "only channel concatenation is on the path"
         self.dimension = dimension
+        self._streams = None
+
+    def _fork_join(self, fns):
+        """Run the thunks concurrently, one side stream per branch; results in order.  The branches of D32_st3 are
+        dozens of tiny kernels each (localisation nets), so their fixed per-kernel costs overlap."""
+        if not (self.concurrent and torch.cuda.is_available() and len(fns) > 1):
+            return [f() for f in fns]
+        if self._streams is None:
+            self._streams = [(torch.cuda.Stream(), torch.cuda.Event()) for _ in fns]
+            self._fork_ev = torch.cuda.Event()
+        main = torch.cuda.current_stream()
+        self._fork_ev.record(main)
+        out = []
+        for (s, ev), f in zip(self._streams, fns):
+            s.wait_event(self._fork_ev)
+            with torch.cuda.stream(s):
+                out.append(f())
+                ev.record(s)
+        for s, ev in self._streams:
+            main.wait_event(ev)
+        return out
 
     def updateOutput(self, input):
-        outs = [as_nhwc(m.updateOutput(input)) for m in self.modules]
+        outs = self._fork_join([(lambda m=m: as_nhwc(m.updateOutput(input))) for m in self.modules])
         N, _, H, W = outs[0].shape
         self._sizes = [o.shape[1] for o in outs]
         Ct = sum(self._sizes)
@@ -321,14 +347,16 @@ class Concat(Sequential):
         return acc
 
     def updateGradInput(self, input, gradOutput):
-        return self._accumulate([m.updateGradInput(input, s) for m, s in self._slices(gradOutput)])
+        sl = list(self._slices(gradOutput))
+        return self._accumulate(self._fork_join([(lambda m=m, s=s: as_nhwc(m.updateGradInput(input, s))) for m, s in sl]))
 
     def accGradParameters(self, input, gradOutput, scale=1.0):
         for m, s in self._slices(gradOutput):
             m.accGradParameters(input, s, scale)
 
     def backward(self, input, gradOutput, scale=1.0):
-        return self._accumulate([m.backward(input, s, scale) for m, s in self._slices(gradOutput)])
+        sl = list(self._slices(gradOutput))
+        return self._accumulate(self._fork_join([(lambda m=m, s=s: as_nhwc(m.backward(input, s, scale))) for m, s in sl]))
 
 
 # ------------------------------------------------------------- parameterised layers

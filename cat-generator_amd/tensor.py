@@ -242,16 +242,20 @@ class Tensor:
 
 
 class Workspace:
-    """Grow-only device scratch shared by the GEMM entry points (split-K partials)."""
+    """Grow-only device scratch for the GEMM entry points (split-K partials), one per HIP stream so that work
+    forked onto a side stream never shares partials with the main stream."""
 
     def __init__(self):
-        self.t = None
+        self.per_stream = {}
 
     def get(self, nbytes):
         nbytes = max(int(nbytes), 4096)
-        if self.t is None or self.t.numel() < nbytes:
-            self.t = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=device())
-        return self.t.data_ptr(), self.t.numel()
+        key = stream()
+        t = self.per_stream.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=device())
+            self.per_stream[key] = t
+        return t.data_ptr(), t.numel()
 
 
 WS = Workspace()

@@ -450,3 +450,47 @@ def test_graph_replay_matches_eager(cg):
     for a, b in ((gG, eG), (gD, eD)):
         d = np.abs(a - b)
         assert d.max() <= 3 * 2.5e-3 and d.mean() <= 1e-5, (d.max(), d.mean())
+
+
+def test_copy_wrapped_nets_take_and_return_host_tensors(cg):
+    """GPU-mode construction of the reference: D built with nn.Copy layers at head and tail (models.lua:642-644,
+    703-706) and G wrapped by NN_UTILS.activateCuda (nn_utils.lua:620-680) consume / produce host FloatTensors."""
+    cg.manual_seed(61)
+    D_plain = cg.models.create_D((3, 32, 32), False)
+    cg.manual_seed(61)
+    D_copy = cg.models.create_D((3, 32, 32), True)
+    assert D_copy.modules[0].typename == "nn.Copy" and D_copy.modules[-1].typename == "nn.Copy"
+    for m in D_plain.listModules() + D_copy.listModules():
+        if isinstance(m, (cg.nn.SpatialDropout, cg.nn.Dropout)):
+            m.train = False  # deterministic comparison
+    x = np.random.RandomState(1).rand(4, 3, 32, 32).astype(f32)
+    out_h = D_copy.forward(x)
+    assert isinstance(out_h, np.ndarray) and out_h.shape == (4, 1)
+    close(out_h, D_plain.forward(cg.Tensor.from_numpy(x)).numpy(), tol=1e-6)
+    g = np.ones((4, 1), f32)
+    gi_h = D_copy.backward(x, g)
+    assert isinstance(gi_h, np.ndarray) and gi_h.shape == x.shape
+    close(gi_h, D_plain.backward(cg.Tensor.from_numpy(x), cg.Tensor.from_numpy(g)).numpy(), tol=1e-5)
+    G = cg.nn_utils.activateCuda(cg.models.create_G((3, 32, 32), 100))
+    img = G.forward((np.random.RandomState(2).rand(4, 100) * 2 - 1).astype(f32))
+    assert isinstance(img, np.ndarray) and img.shape == (4, 3, 32, 32) and (img > 0).all() and (img < 1).all()
+    assert cg.nn_utils.activateCuda(G) is G  # already contains Copy layers
+
+
+def test_adversarial_train_epoch_loop(cg, capsys):
+    """adversarial.train (adversarial.lua:27-292): one epoch = ceil(N_epoch / (batchSize/2)) iterations, confusion
+    matrix over every D batch, accuracy gate inert at the default D_maxAcc."""
+    cg.manual_seed(62)
+    G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
+    S = cg.adversarial.State(dict(batchSize=16, N_epoch=40), G, D)
+    data = cg.adversarial.TrainData(np.random.RandomState(3).rand(64, 3, 32, 32).astype(f32))
+    tV = cg.adversarial.train(S, data, maxAccuracyD=1.01, accsInterval=20)
+    out = capsys.readouterr().out
+    assert "<trainer> Epoch #1 [batchSize = 16]" in out and "time to learn 1 sample" in out and "trained D 5 of 5" in out
+    assert 0.0 <= tV <= 1.0 and S.EPOCH == 2
+    assert S.OPTSTATE["adam"]["D"]["t"] == 5 and S.OPTSTATE["adam"]["G"]["t"] == 5
+    # the gate (adversarial.lua:144-166): with maxAccuracyD = 0 D is never trained, G still is
+    pD = S.PARAMETERS_D.numpy().copy()
+    cg.adversarial.train(S, data, maxAccuracyD=0.0, accsInterval=20, verbose=False)
+    np.testing.assert_array_equal(S.PARAMETERS_D.numpy(), pD)
+    assert S.OPTSTATE["adam"]["G"]["t"] == 10 and S.OPTSTATE["adam"]["D"]["t"] == 5
