@@ -66,7 +66,6 @@ struct NNArgs {
     Geom g;
     int kchunk;         // K range per split (multiple of BK)
     int nsplit;
-    int flags;          // experiment switches (CG_GEMM_FLAGS)
 };
 
 struct TNArgs {
@@ -164,12 +163,6 @@ __global__ __launch_bounds__(256, 4) void igemm_nn_kernel(NNArgs a) {
     const int kend = min(g.Ktot, ks + a.kchunk);
     const int T = (kend - ks + BK - 1) / BK;
     const float* wph = a.w + (long)phase * g.Ktot * g.Cout;
-    if (a.flags & 3) {  // stagger co-resident workgroups: static priority from the block id
-        const int pr = (a.flags & 1) ? (blockIdx.x & 3) : ((blockIdx.x >> 8) & 3);
-        if (pr == 1) __builtin_amdgcn_s_setprio(1);
-        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-    }
 
     // ---- A staging: thread owns k-vector a_kv (4 consecutive k) of rows a_r + 64p
     const int a_kv = tid & 3, a_r = tid >> 2;
@@ -347,7 +340,7 @@ __global__ __launch_bounds__(256, 4) void igemm_nn_kernel(NNArgs a) {
 
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
-        if (t + 1 < T && !(a.flags & 4)) load_tile(ks + (t + 1) * BK);
+        if (t + 1 < T) load_tile(ks + (t + 1) * BK);
         const float* A = As + buf * A_TILE + wm0;
         const float* B = Bs + buf * B_TILE + wn0 + l31;
 #pragma unroll
@@ -363,8 +356,8 @@ __global__ __launch_bounds__(256, 4) void igemm_nn_kernel(NNArgs a) {
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < T && !(a.flags & 4)) store_tile(buf ^ 1);
-        if (!(a.flags & 8)) __syncthreads();
+        if (t + 1 < T) store_tile(buf ^ 1);
+        __syncthreads();
     }
 
     // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*h (pixel), j = l31 (channel)
@@ -910,7 +903,6 @@ static int run_nn(hipStream_t st, const Geom& g, const float* x, const float* w,
     a.x = x; a.w = w; a.bias = bias; a.g = g;
     a.y = p.splits > 1 ? (float*)ws : y;
     a.kchunk = p.kchunk; a.nsplit = p.splits;
-    { const char* e = getenv("CG_GEMM_FLAGS"); a.flags = e ? atoi(e) : 0; }
     const bool fast = (g.Cin % BK == 0) && ((uintptr_t)x % 16 == 0) && (getenv("CG_GEMM_SLOW") == nullptr);
     const bool vecb = (g.Cout % 4 == 0) && ((uintptr_t)w % 16 == 0);
     dim3 grid(cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, g.nphase);

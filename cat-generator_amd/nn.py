@@ -72,8 +72,6 @@ class LazyScalar:
 
 # ---------------------------------------------------------------------- base class
 class Module:
-    __typename = "nn.Module"
-
     def __init__(self):
         self.output = None
         self.gradInput = None

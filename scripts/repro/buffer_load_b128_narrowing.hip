@@ -1,3 +1,7 @@
+// Reproducer for a ROCm 7.2 (-O3) miscompile: extracting the four dwords of a
+// __builtin_amdgcn_raw_buffer_load_b128 result one by one makes InstCombine narrow the v4i32 buffer load to a single
+// i32 and splat it (output "0 0 0 0 4 4 4 4 ..." instead of "0 1 2 3 4 5 6 7 ...").  Casting the whole vector
+// (csrc/gemm.hip bufld4) keeps buffer_load_dwordx4.  Build: hipcc --offload-arch=gfx950 -O3 this.hip -o t && ./t
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
