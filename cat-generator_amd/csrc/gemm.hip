@@ -126,8 +126,8 @@ __device__ __forceinline__ long out_row(const Geom& g, int m, int pa, int pb) {
 // ---------------------------------------------------------------------------
 // NN: Y[m][n] = sum_k A(m,k) * W[k][n]
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool FAST, bool VECB>
-__global__ __launch_bounds__(256, 4) void igemm_nn_kernel(NNArgs a) {
+template <int BM, int BN, int WM, int WN, bool FAST, bool VECB, int BK>
+__global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int MI = BM / WM / 32;
     constexpr int NI = BN / WN / 32;
@@ -137,8 +137,10 @@ __global__ __launch_bounds__(256, 4) void igemm_nn_kernel(NNArgs a) {
     // at fixed k) stays a permutation of the 32 banks.  No padding.
     constexpr int LDA = BM, LDB = BN;
     constexpr int A_TILE = BK * LDA, B_TILE = BK * LDB;
-    constexpr int AROWS = BM / 64;  // float4 per thread per tile (A)
-    static_assert(BM % 64 == 0, "BM multiple of 64");
+    constexpr int KV = BK / 4;        // float4 per A row
+    constexpr int ARPP = 256 / KV;    // A rows per pass
+    constexpr int AROWS = BM / ARPP;  // float4 per thread per tile (A)
+    static_assert(BM % ARPP == 0 && AROWS >= 1, "BM multiple of rows-per-pass");
     constexpr int NVEC = BN / 4;
     constexpr int BRPP = 256 / NVEC;  // B rows per pass
     constexpr int BPASS = (BK + BRPP - 1) / BRPP;
@@ -165,12 +167,12 @@ __global__ __launch_bounds__(256, 4) void igemm_nn_kernel(NNArgs a) {
     const float* wph = a.w + (long)phase * g.Ktot * g.Cout;
 
     // ---- A staging: thread owns k-vector a_kv (4 consecutive k) of rows a_r + 64p
-    const int a_kv = tid & 3, a_r = tid >> 2;
+    const int a_kv = tid % KV, a_r = tid / KV;
     int rowb[AROWS], r_oy[AROWS], r_ox[AROWS];
     bool r_ok[AROWS];
 #pragma unroll
     for (int p = 0; p < AROWS; ++p) {
-        const int m = m0 + a_r + 64 * p;
+        const int m = m0 + a_r + ARPP * p;
         r_ok[p] = m < g.M;
         int n, oy, ox;
         pix_decode(g, r_ok[p] ? m : 0, n, oy, ox);
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256, 4) void igemm_nn_kernel(NNArgs a) {
         float* B = Bs + buf * B_TILE;
 #pragma unroll
         for (int p = 0; p < AROWS; ++p) {
-            const int rs = (a_r + 64 * p) ^ ((a_kv & 3) << 3);
+            const int rs = (a_r + ARPP * p) ^ ((a_kv & 3) << 3);
             A[(4 * a_kv + 0) * LDA + rs] = areg[p].x;
             A[(4 * a_kv + 1) * LDA + rs] = areg[p].y;
             A[(4 * a_kv + 2) * LDA + rs] = areg[p].z;
@@ -768,11 +770,16 @@ static int pick_splits(long tiles, long kiters) {
 }
 
 template <int BM, int BN, int WM, int WN>
-static void launch_nn(const NNArgs& a, dim3 grid, hipStream_t st, bool fast, bool vecb) {
-    if (fast && vecb) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, a);
-    else if (fast) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, a);
-    else if (vecb) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, a);
+static void launch_nn(const NNArgs& a, dim3 grid, hipStream_t st, bool fast, bool vecb, bool bk32) {
+    if (fast && vecb) {
+        // 64-row tiles do only 8-16 MFMAs per wave per K step of 16: give them 32 so the per-tile work
+        // (address VALU, LDS stores, barrier) is amortised like in the 128x128 tile
+        if (BM == 64 && bk32) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, (BM == 64 ? 32 : 16)>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, 16>), grid, dim3(256), 0, st, a);
+    }
+    else if (fast) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, false, 16>), grid, dim3(256), 0, st, a);
+    else if (vecb) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, false, true, 16>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, false, false, 16>), grid, dim3(256), 0, st, a);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -865,7 +872,7 @@ static NNPlan plan_nn(const Geom& g) {
     const long tiles = (long)cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn) * g.nphase;
     const long kiters = cg::cdiv(g.Ktot, BK);
     p.splits = pick_splits(tiles, kiters);
-    p.kchunk = cg::cdiv(kiters, p.splits) * BK;
+    p.kchunk = cg::cdiv(cg::cdiv(kiters, p.splits) * BK, 32) * 32;
     p.splits = cg::cdiv(g.Ktot, p.kchunk);
     return p;
 }
@@ -905,12 +912,15 @@ static int run_nn(hipStream_t st, const Geom& g, const float* x, const float* w,
     a.kchunk = p.kchunk; a.nsplit = p.splits;
     const bool fast = (g.Cin % BK == 0) && ((uintptr_t)x % 16 == 0) && (getenv("CG_GEMM_SLOW") == nullptr);
     const bool vecb = (g.Cout % 4 == 0) && ((uintptr_t)w % 16 == 0);
+    static int use32 = -1;
+    if (use32 < 0) { const char* e = getenv("CG_GEMM_BK32"); use32 = e ? atoi(e) : 1; }
+    const bool bk32 = use32 && (g.Cin % 32 == 0) && (p.kchunk % 32 == 0);
     dim3 grid(cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, g.nphase);
-    if (p.tc.bm == 128 && p.tc.bn == 128) launch_nn<128, 128, 2, 2>(a, grid, st, fast, vecb);
-    else if (p.tc.bm == 64 && p.tc.bn == 128) launch_nn<64, 128, 2, 2>(a, grid, st, fast, vecb);
-    else if (p.tc.bm == 128 && p.tc.bn == 64) launch_nn<128, 64, 2, 2>(a, grid, st, fast, vecb);
-    else if (p.tc.bm == 64 && p.tc.bn == 64) launch_nn<64, 64, 2, 2>(a, grid, st, fast, vecb);
-    else launch_nn<128, 32, 4, 1>(a, grid, st, fast, vecb);
+    if (p.tc.bm == 128 && p.tc.bn == 128) launch_nn<128, 128, 2, 2>(a, grid, st, fast, vecb, bk32);
+    else if (p.tc.bm == 64 && p.tc.bn == 128) launch_nn<64, 128, 2, 2>(a, grid, st, fast, vecb, bk32);
+    else if (p.tc.bm == 128 && p.tc.bn == 64) launch_nn<128, 64, 2, 2>(a, grid, st, fast, vecb, bk32);
+    else if (p.tc.bm == 64 && p.tc.bn == 64) launch_nn<64, 64, 2, 2>(a, grid, st, fast, vecb, bk32);
+    else launch_nn<128, 32, 4, 1>(a, grid, st, fast, vecb, bk32);
     CG_LAUNCH_CHECK();
     if (p.splits > 1) {
         const long PMN = (long)g.nphase * g.M * g.Cout;
