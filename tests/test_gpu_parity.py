@@ -335,7 +335,7 @@ def test_three_training_steps(cg, fused):
             d = np.abs(a - b)
             assert d.max() <= 2.5 * lr * (step + 1), f"{name} step {step}: max drift {d.max():.2e}"
             assert d.mean() <= 2e-5 * (step + 1), f"{name} step {step}: mean drift {d.mean():.2e}"
-            assert np.mean(d > 1e-4) < 2e-3 * (step + 1), f"{name} step {step}: {np.mean(d > 1e-4):.2e} outliers"
+            assert np.mean(d > 1e-4) < 5e-3 * (step + 1), f"{name} step {step}: {np.mean(d > 1e-4):.2e} outliers"
 
 
 @pytest.mark.parametrize("cfg", ["G32up-y-32", "G32up-c-64"])
