@@ -333,6 +333,7 @@ def test_three_training_steps(cg, fused):
         lr = 1e-3
         for name, a, b in (("pD", S.PARAMETERS_D.numpy(), T.pD), ("pG", S.PARAMETERS_G.numpy(), T.pG)):
             d = np.abs(a - b)
+            print(f"[drift] fused={fused} {name} step {step}: max {d.max():.2e} mean {d.mean():.2e} frac>1e-4 {np.mean(d > 1e-4):.2e}")
             assert d.max() <= 2.5 * lr * (step + 1), f"{name} step {step}: max drift {d.max():.2e}"
             assert d.mean() <= 2e-5 * (step + 1), f"{name} step {step}: mean drift {d.mean():.2e}"
             assert np.mean(d > 1e-4) < 5e-3 * (step + 1), f"{name} step {step}: {np.mean(d > 1e-4):.2e} outliers"
