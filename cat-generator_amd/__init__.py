@@ -8,7 +8,7 @@
 The arithmetic lives in lib/libcatgan_hip.so (csrc/*.hip, C ABI in include/catgan.h).  There is no CPU or
 PyTorch fallback for it: a missing library or a failing HIP call raises.
 """
-from . import _abi, adversarial, cudnn, models, nn, nn_utils, optim, parallel, tensor, weight_init  # noqa: F401
+from . import _abi, adversarial, checkpoint, cudnn, models, nn, nn_utils, optim, parallel, tensor, weight_init  # noqa: F401
 from ._abi import CatganError, lib  # noqa: F401
 from .tensor import Tensor, manual_seed  # noqa: F401
 

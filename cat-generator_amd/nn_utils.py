@@ -1,6 +1,8 @@
 """utils/nn_utils.lua — the subset the training step uses:
 createNoiseInputs :35-39, createImagesFromNoise :45-69, createImages :75-77, getNumberOfParameters :453-462,
 activateCuda :620-680.  Visualisation / checkpoint helpers are outside the hot path (row 5b)."""
+import numpy as np
+
 from . import nn
 from .tensor import Tensor, lib, rng, stream
 
@@ -39,6 +41,37 @@ def createImagesFromNoise(S, noiseInputs, outputAsList=False, *_):
 
 def createImages(S, N, outputAsList=False):
     return createImagesFromNoise(S, createNoiseInputs(S, N), outputAsList)
+
+
+def switchToEvaluationMode(S):
+    """nn_utils.lua:334-340: dropout off, batch-norm on running statistics."""
+    S.MODEL_G.evaluate()
+    S.MODEL_D.evaluate()
+
+
+def switchToTrainingMode(S):
+    """nn_utils.lua:343-349."""
+    S.MODEL_G.training()
+    S.MODEL_D.training()
+
+
+def sortImagesByPrediction(S, images, ascending=False, nbMaxOut=None):
+    """nn_utils.lua:89-117: rate images with D (in chunks of OPT.batchSize) and sort them by D's certainty that they
+    are real; returns (images as a host array [n,C,H,W], predictions [n]).  Used by sample.lua:104-105 and the
+    epoch visualisation (nn_utils.lua:138-147)."""
+    imgs = nn.as_nhwc(nn.to_device(images))
+    N, bs = imgs.shape[0], S.OPT["batchSize"]
+    preds = []
+    for a in range(1, N + 1, bs):
+        b = min(a + bs - 1, N)
+        preds.append(nn.as_plain(S.MODEL_D.forward(imgs.rows(a, b))).numpy().reshape(-1))
+    preds = np.concatenate(preds)
+    order = np.argsort(preds, kind="stable")
+    if not ascending:
+        order = order[::-1]
+    if nbMaxOut is not None:
+        order = order[:nbMaxOut]
+    return imgs.numpy()[order], preds[order]
 
 
 def getNumberOfParameters(net):

@@ -495,3 +495,52 @@ def test_adversarial_train_epoch_loop(cg, capsys):
     cg.adversarial.train(S, data, maxAccuracyD=0.0, accsInterval=20, verbose=False)
     np.testing.assert_array_equal(S.PARAMETERS_D.numpy(), pD)
     assert S.OPTSTATE["adam"]["G"]["t"] == 10 and S.OPTSTATE["adam"]["D"]["t"] == 5
+
+
+def test_checkpoint_resume_continues_the_run(cg, tmp_path):
+    """save after 2 iterations, resume in a fresh State, and the 3rd iteration equals the
+    uninterrupted run (parameters, Adam moments, step counts, BN running statistics, RNG position)."""
+    def fresh():
+        cg.manual_seed(71)
+        G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
+        return cg.adversarial.State(dict(batchSize=8), G, D)
+    pool = np.random.RandomState(9).rand(32, 3, 32, 32).astype(f32)
+    data = cg.adversarial.TrainData(pool)
+    idx = [np.random.RandomState(i).randint(0, 32, size=4) for i in range(3)]
+    A = fresh()
+    for k in range(2):
+        cg.adversarial.iteration(A, data, 8, real_idx=idx[k])
+    ck = cg.checkpoint.save(str(tmp_path / "adversarial.npz"), A)
+    cg.adversarial.iteration(A, data, 8, real_idx=idx[2])
+    pG_ref, pD_ref = A.PARAMETERS_G.numpy(), A.PARAMETERS_D.numpy()
+    B = fresh()
+    cg.checkpoint.load(ck, B)
+    assert B.OPTSTATE["adam"]["G"]["t"] == 2 and B.OPTSTATE["adam"]["D"]["t"] == 2
+    cg.adversarial.iteration(B, data, 8, real_idx=idx[2])
+    for a, b in ((B.PARAMETERS_G.numpy(), pG_ref), (B.PARAMETERS_D.numpy(), pD_ref)):
+        d = np.abs(a - b)
+        assert d.max() <= 2.5e-3 and d.mean() <= 1e-6, (d.max(), d.mean())  # atomics-order noise only
+
+
+def test_sampling_in_evaluate_mode_and_ranking(cg):
+    """SURVEY.md §8 f4 (sample.lua:89-105, nn_utils.lua:89-117,334-349): G in evaluate() mode normalises with the
+    BN running statistics, D ranks the images; against the oracle in the same mode."""
+    seed = 81
+    cg.manual_seed(seed); rng = O.RNG(seed)
+    G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
+    Go, Do = O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng)
+    S = cg.adversarial.State(dict(batchSize=8), G, D)
+    rs = np.random.RandomState(2)
+    z0 = (rs.rand(8, 100) * 2 - 1).astype(f32)
+    G.forward(cg.Tensor.from_numpy(z0)); Go.forward(z0)       # one training-mode pass moves the running stats
+    cg.nn_utils.switchToEvaluationMode(S); Go.training(False); Do.training(False)
+    z = (rs.rand(20, 100) * 2 - 1).astype(f32)
+    imgs = cg.nn_utils.createImagesFromNoise(S, z)
+    ref = np.concatenate([Go.forward(z[i:i + 8]) for i in range(0, 20, 8)])
+    close(imgs.numpy(), ref, tol=1e-4, what="evaluate-mode images")
+    sorted_imgs, preds = cg.nn_utils.sortImagesByPrediction(S, imgs)
+    ref_preds = np.concatenate([Do.forward(ref[i:i + 8]) for i in range(0, 20, 8)]).reshape(-1)
+    close(np.sort(preds)[::-1], np.sort(ref_preds)[::-1], tol=2e-4, what="D ratings")
+    assert np.all(np.diff(preds) <= 0) and sorted_imgs.shape == (20, 3, 32, 32)
+    cg.nn_utils.switchToTrainingMode(S)
+    assert all(m.train for m in G.listModules())
