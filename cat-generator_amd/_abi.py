@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libcatgan_hip.so")
 _CTYPES = {
     "void*": C.c_void_p, "const void*": C.c_void_p, "void**": C.POINTER(C.c_void_p),
     "float*": C.c_void_p, "const float*": C.c_void_p,
+    "const float* const*": C.c_void_p, "float* const*": C.c_void_p,
     "double*": C.c_void_p, "const double*": C.c_void_p,
     "int32_t*": C.c_void_p, "const int32_t*": C.c_void_p, "uint64_t*": C.c_void_p, "const uint64_t*": C.c_void_p,
     "int32_t": C.c_int32, "int*": C.POINTER(C.c_int),

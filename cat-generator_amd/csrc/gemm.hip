@@ -58,24 +58,32 @@ struct Geom {
     TapDesc td;
 };
 
+constexpr int MAXG = 4;  // groups per launch: same geometry, separate tensors (D32_st3's identical branches)
+
 struct NNArgs {
-    const float* x;
-    const float* w;     // [nphase][Ktot][Cout]
-    const float* bias;  // [Cout] or null
-    float* y;           // output tensor, or split partials [S][nphase][M][Cout]
+    const float* x0; const float* x1; const float* x2; const float* x3;   // per group (no arrays: see TapDesc)
+    const float* w0; const float* w1; const float* w2; const float* w3;   // [nphase][Ktot][Cout]
+    const float* b0; const float* b1; const float* b2; const float* b3;   // [Cout] or null
+    float* y0; float* y1; float* y2; float* y3;                           // output tensors
+    float* part;        // split partials [S][ngroups*nphase][M][Cout] (nsplit > 1)
+    int ngroups;
     Geom g;
     int kchunk;         // K range per split (multiple of BK)
     int nsplit;
 };
 
 struct TNArgs {
-    const float* x;
-    const float* dy;
-    float* part;        // [S][nphase][Ktot][Cout]
-    float* bias_part;   // [S][nphase][Cout] column sums of dy (gradBias partials) or null
+    const float* x0; const float* x1; const float* x2; const float* x3;
+    const float* d0; const float* d1; const float* d2; const float* d3;   // dy per group
+    int ngroups;
+    float* part;        // [S][ngroups*nphase][Ktot][Cout]
+    float* bias_part;   // [S][ngroups*nphase][Cout] column sums of dy (gradBias partials) or null
     Geom g;
     int pchunk;         // pixels per split (multiple of BK)
 };
+
+template <typename T>
+__device__ __forceinline__ T sel4(int i, T a, T b, T c, T d) { return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d)); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -160,11 +168,16 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
     const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
-    const int phase = blockIdx.z, pa = phase >> 1, pb = phase & 1;
+    const int zz = blockIdx.z;
+    const int group = zz / g.nphase;
+    const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
+    const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
+    const float* gbias = sel4(group, a.b0, a.b1, a.b2, a.b3);
+    float* gy = sel4(group, a.y0, a.y1, a.y2, a.y3);
     const int ks = split * a.kchunk;
     const int kend = min(g.Ktot, ks + a.kchunk);
     const int T = (kend - ks + BK - 1) / BK;
-    const float* wph = a.w + (long)phase * g.Ktot * g.Cout;
+    const float* wph = sel4(group, a.w0, a.w1, a.w2, a.w3) + (long)phase * g.Ktot * g.Cout;
 
     // ---- A staging: thread owns k-vector a_kv (4 consecutive k) of rows a_r + 64p
     const int a_kv = tid % KV, a_r = tid / KV;
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
             rowbytes[p] = (unsigned)(rowb[p] + 4 * a_kv) * 4u;
         }
         // base shifted down by the most negative tap offset so that the SGPR offset stays non-negative
-        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + minoff), 0, 0x7fffffff, 0x00020000);
+        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(gx + minoff), 0, 0x7fffffff, 0x00020000);
         rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wph, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int q = 0; q < BPASS; ++q) {
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
                     const bool ok = r_ok[p] && kok && (unsigned)(r_oy[p] + ty) < (unsigned)g.Hv &&
                                     (unsigned)(r_ox[p] + tx) < (unsigned)g.Wv;
                     float v = 0.f;
-                    if (ok) v = a.x[(long)rowb[p] + off + ci];
+                    if (ok) v = gx[(long)rowb[p] + off + ci];
                     tmp[p][j] = v;
                 }
             }
@@ -364,35 +377,40 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
 
     // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*h (pixel), j = l31 (channel)
     const bool partial = a.nsplit > 1;
-    const bool add_bias = (a.bias != nullptr) && !partial;
+    const bool add_bias = (gbias != nullptr) && !partial;
+    float* yout = partial ? a.part : gy;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m >= g.M) continue;
-            const long ro = partial ? ((long)(split * g.nphase + phase) * g.M + m) * g.Cout : out_row(g, m, pa, pb);
+            const long ro = partial ? ((long)(split * (a.ngroups * g.nphase) + zz) * g.M + m) * g.Cout : out_row(g, m, pa, pb);
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int n = n0 + wn0 + j * 32 + l31;
-                if (n < g.Cout) a.y[ro + n] = acc[i][j][r] + (add_bias ? a.bias[n] : 0.f);
+                if (n < g.Cout) yout[ro + n] = acc[i][j][r] + (add_bias ? gbias[n] : 0.f);
             }
         }
     }
 }
 
-// split-K reduce for NN: y[out_row(m)][n] = bias[n] + sum_s part[s][phase][m][n]
-__global__ void nn_splitk_reduce_kernel(const float* part, const float* bias, float* y, Geom g, int S) {
-    const long PMN = (long)g.nphase * g.M * g.Cout;
+// split-K reduce for NN: y_group[out_row(m)][n] = bias_group[n] + sum_s part[s][group*nphase+phase][m][n]
+__global__ void nn_splitk_reduce_kernel(NNArgs a, int S) {
+    const Geom& g = a.g;
+    const long PMN = (long)a.ngroups * g.nphase * g.M * g.Cout;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < PMN; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < S; ++k) s += part[(long)k * PMN + i];
+        for (int k = 0; k < S; ++k) s += a.part[(long)k * PMN + i];
         const int n = (int)(i % g.Cout);
         const long pm = i / g.Cout;
         const int m = (int)(pm % g.M);
-        const int phase = (int)(pm / g.M);
-        if (bias) s += bias[n];
-        y[out_row(g, m, phase >> 1, phase & 1) + n] = s;
+        const int zz = (int)(pm / g.M);
+        const int group = zz / g.nphase, phase = zz - group * g.nphase;
+        const float* gbias = sel4(group, a.b0, a.b1, a.b2, a.b3);
+        float* gy = sel4(group, a.y0, a.y1, a.y2, a.y3);
+        if (gbias) s += gbias[n];
+        gy[out_row(g, m, phase >> 1, phase & 1) + n] = s;
     }
 }
 
@@ -425,7 +443,11 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
     const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
     const int m0 = tm * BM, n0 = tn * BN;  // m0: row of dW (tap,ci)
     const int split = blockIdx.y;
-    const int phase = blockIdx.z, pa = phase >> 1, pb = phase & 1;
+    const int zz = blockIdx.z;
+    const int group = zz / g.nphase;
+    const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
+    const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
+    const float* gdy = sel4(group, a.d0, a.d1, a.d2, a.d3);
     const int ps = split * a.pchunk;
     const int pend = min(g.M, ps + a.pchunk);
     const int T = (pend - ps + BK - 1) / BK;
@@ -446,8 +468,8 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
     }
     const int b_nv = tid % BVEC, b_kr = tid / BVEC;
     const bool b_nok = n0 + 4 * b_nv < g.Cout;
-    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0x7fffffff, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)gx, 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)gdy, 0, 0x7fffffff, 0x00020000);
 
     float4 areg[APASS];
     float4 breg[BPASS];
@@ -486,7 +508,7 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
                         const bool ok = pok && c_ok[jj] && (unsigned)(oy + c_ty[jj]) < (unsigned)g.Hv &&
                                         (unsigned)(ox + c_tx[jj]) < (unsigned)g.Wv;
                         float e = 0.f;
-                        if (ok) e = a.x[(long)base + c_off[jj]];
+                        if (ok) e = gx[(long)base + c_off[jj]];
                         t4[j] = e;
                     }
                     v = make_float4(t4[0], t4[1], t4[2], t4[3]);
@@ -514,7 +536,7 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
                 if (VECB) {
                     v = bufld4(rsd, (pok && b_nok) ? (unsigned)(ro + n) * 4u : OOB, 0);
                 } else if (pok) {
-                    const float* dp = a.dy + (long)ro + n;
+                    const float* dp = gdy + (long)ro + n;
                     if (n + 0 < g.Cout) v.x = dp[0];
                     if (n + 1 < g.Cout) v.y = dp[1];
                     if (n + 2 < g.Cout) v.z = dp[2];
@@ -587,10 +609,10 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 256 / BVEC; ++r) t += red[r * BN + tid];
-            a.bias_part[(long)(split * g.nphase + phase) * g.Cout + n0 + tid] = t;
+            a.bias_part[(long)(split * (a.ngroups * g.nphase) + zz) * g.Cout + n0 + tid] = t;
         }
     }
-    float* pout = a.part + (long)(split * g.nphase + phase) * g.Ktot * g.Cout;
+    float* pout = a.part + (long)(split * (a.ngroups * g.nphase) + zz) * g.Ktot * g.Cout;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn0 + j * 32 + l31;
@@ -616,7 +638,7 @@ __device__ __host__ __forceinline__ int phase_map(int a, int d, int pad) { retur
 // are transposed through LDS, writes are contiguous runs of CI_T*KK floats per co.
 template <bool UPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* gw, int Cin, int Cout, int k, int KK,
-                                                           int pad, int kp, int S, float scale, int CI_T) {
+                                                           int pad, int kp, int S, float scale, int CI_T, long sstride) {
     extern __shared__ float sh[];  // [KK][CI_T][33]
     const int ci0 = blockIdx.x * CI_T, co0 = blockIdx.y * 32;
     const long plane = (long)(UPS ? kp * kp : KK) * Cin * Cout;
@@ -634,11 +656,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const int tp = phase_map(p >> 1, dy, pad) * kp + phase_map(p & 1, dx, pad);
-                        s += part[((long)sp * 4 + p) * plane + ((long)tp * Cin + ci) * Cout + co];
+                        s += part[(long)sp * sstride + (long)p * plane + ((long)tp * Cin + ci) * Cout + co];
                     }
             } else {
                 const long o = ((long)tap * Cin + ci) * Cout + co;
-                for (int sp = 0; sp < S; ++sp) s += part[(long)sp * plane + o];
+                for (int sp = 0; sp < S; ++sp) s += part[(long)sp * sstride + o];
             }
         }
         sh[(tap * CI_T + ci_l) * 33 + co_l] = s;
@@ -660,7 +682,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
 // not fill the chip): reads coalesced along co, writes scattered.
 template <bool UPS>
 __global__ void wgrad_reduce_small_kernel(const float* part, float* gw, int Cin, int Cout, int k, int KK, int pad, int kp,
-                                          int S, float scale) {
+                                          int S, float scale, long sstride) {
     const long total = (long)KK * Cin * Cout;
     const long plane = (long)(UPS ? kp * kp : KK) * Cin * Cout;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -675,23 +697,25 @@ __global__ void wgrad_reduce_small_kernel(const float* part, float* gw, int Cin,
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int tp = phase_map(p >> 1, dy, pad) * kp + phase_map(p & 1, dx, pad);
-                    s += part[((long)sp * 4 + p) * plane + ((long)tp * Cin + ci) * Cout + co];
+                    s += part[(long)sp * sstride + (long)p * plane + ((long)tp * Cin + ci) * Cout + co];
                 }
         } else {
-            for (int sp = 0; sp < S; ++sp) s += part[(long)sp * plane + i];
+            for (int sp = 0; sp < S; ++sp) s += part[(long)sp * sstride + i];
         }
         gw[((long)co * Cin + ci) * KK + tap] += scale * s;
     }
 }
 
 // gb[c] += scale * sum_{s,p} bias_part[s*P+p][c]; 32 channels x 8 partial-sum lanes per workgroup
-__global__ __launch_bounds__(256) void bias_part_reduce_kernel(const float* bp, float* gb, int SP, int Cout, float scale) {
+// (S splits x P phases of one group; consecutive splits are `sstride` floats apart)
+__global__ __launch_bounds__(256) void bias_part_reduce_kernel(const float* bp, float* gb, int S, int P, long sstride,
+                                                               int Cout, float scale) {
     __shared__ float sh[8][33];
     const int cl = threadIdx.x & 31, ln = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
     if (c < Cout)
-        for (int i = ln; i < SP; i += 8) s += bp[(long)i * Cout + c];
+        for (int i = ln; i < S * P; i += 8) s += bp[(long)(i / P) * sstride + (long)(i % P) * Cout + c];
     sh[ln][cl] = s;
     __syncthreads();
     if (ln == 0 && c < Cout) {
@@ -866,28 +890,29 @@ static int geom_phase_dgrad(Geom& g, int N, int Hp, int Wp, int CinF, int CoutF,
 }
 
 struct NNPlan { TileCfg tc; int splits; int kchunk; };
-static NNPlan plan_nn(const Geom& g) {
+static NNPlan plan_nn(const Geom& g, int ngroups) {
     NNPlan p;
-    p.tc = pick_tile(g.M, g.Cout, g.nphase);
-    const long tiles = (long)cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn) * g.nphase;
+    const int zdim = g.nphase * ngroups;
+    p.tc = pick_tile(g.M, g.Cout, zdim);
+    const long tiles = (long)cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn) * zdim;
     const long kiters = cg::cdiv(g.Ktot, BK);
     p.splits = pick_splits(tiles, kiters);
     p.kchunk = cg::cdiv(cg::cdiv(kiters, p.splits) * BK, 32) * 32;
     p.splits = cg::cdiv(g.Ktot, p.kchunk);
     return p;
 }
-static size_t nn_ws_bytes(const Geom& g, const NNPlan& p) {
-    return p.splits > 1 ? (size_t)p.splits * g.nphase * g.M * g.Cout * sizeof(float) : 0;
+static size_t nn_ws_bytes(const Geom& g, const NNPlan& p, int ngroups) {
+    return p.splits > 1 ? (size_t)p.splits * ngroups * g.nphase * g.M * g.Cout * sizeof(float) : 0;
 }
 
 struct TNPlan { TileCfg tc; int splits; int pchunk; };
-static TNPlan plan_tn(const Geom& g) {
+static TNPlan plan_tn(const Geom& g, int ngroups) {
     TNPlan p;
     int bn = g.Cout > 64 ? 128 : (g.Cout > 32 ? 64 : 32);
     int bm = g.Ktot > 64 ? 128 : 64;
     if (bn == 32) bm = 128;
     p.tc = {bm, bn};
-    const long tiles = (long)cg::cdiv(g.Ktot, bm) * cg::cdiv(g.Cout, bn) * g.nphase;
+    const long tiles = (long)cg::cdiv(g.Ktot, bm) * cg::cdiv(g.Cout, bn) * g.nphase * ngroups;
     const long piters = cg::cdiv(g.M, BK);
     static int smax = -1, tgt = -1;
     if (smax < 0) { const char* e = getenv("CG_TN_SMAX"); smax = e ? atoi(e) : 128; const char* f = getenv("CG_TN_TARGET"); tgt = f ? atoi(f) : 3; }
@@ -897,25 +922,41 @@ static TNPlan plan_tn(const Geom& g) {
     p.splits = cg::cdiv(g.M, p.pchunk);
     return p;
 }
-static size_t tn_ws_bytes(const Geom& g, const TNPlan& p) {
-    return (size_t)p.splits * g.nphase * ((size_t)g.Ktot + 1) * g.Cout * sizeof(float);
+static size_t tn_ws_bytes(const Geom& g, const TNPlan& p, int ngroups) {
+    return (size_t)p.splits * ngroups * g.nphase * ((size_t)g.Ktot + 1) * g.Cout * sizeof(float);
 }
 
-static int run_nn(hipStream_t st, const Geom& g, const float* x, const float* w, const float* bias, float* y, void* ws,
-                  size_t ws_bytes, const char* who) {
-    NNPlan p = plan_nn(g);
-    const size_t need = nn_ws_bytes(g, p);
+static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const* x, const float* const* w,
+                  const float* const* bias, float* const* y, void* ws, size_t ws_bytes, const char* who) {
+    CG_REQUIRE(ngroups >= 1 && ngroups <= MAXG, "%s: 1..%d groups per launch", who, MAXG);
+    NNPlan p = plan_nn(g, ngroups);
+    const size_t need = nn_ws_bytes(g, p, ngroups);
     CG_REQUIRE(need == 0 || (ws && ws_bytes >= need), "%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
     NNArgs a;
-    a.x = x; a.w = w; a.bias = bias; a.g = g;
-    a.y = p.splits > 1 ? (float*)ws : y;
+    memset(&a, 0, sizeof(a));
+    const float* xs[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+    const float* wsv[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+    const float* bs[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+    float* ys[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+    bool al = true, alw = true;
+    for (int i = 0; i < ngroups; ++i) {
+        CG_REQUIRE(x[i] && w[i] && y[i], "%s: null pointer (group %d)", who, i);
+        xs[i] = x[i]; wsv[i] = w[i]; bs[i] = bias ? bias[i] : nullptr; ys[i] = y[i];
+        al = al && ((uintptr_t)x[i] % 16 == 0);
+        alw = alw && ((uintptr_t)w[i] % 16 == 0);
+    }
+    a.x0 = xs[0]; a.x1 = xs[1]; a.x2 = xs[2]; a.x3 = xs[3];
+    a.w0 = wsv[0]; a.w1 = wsv[1]; a.w2 = wsv[2]; a.w3 = wsv[3];
+    a.b0 = bs[0]; a.b1 = bs[1]; a.b2 = bs[2]; a.b3 = bs[3];
+    a.y0 = ys[0]; a.y1 = ys[1]; a.y2 = ys[2]; a.y3 = ys[3];
+    a.part = (float*)ws; a.ngroups = ngroups; a.g = g;
     a.kchunk = p.kchunk; a.nsplit = p.splits;
-    const bool fast = (g.Cin % BK == 0) && ((uintptr_t)x % 16 == 0) && (getenv("CG_GEMM_SLOW") == nullptr);
-    const bool vecb = (g.Cout % 4 == 0) && ((uintptr_t)w % 16 == 0);
+    const bool fast = (g.Cin % BK == 0) && al && (getenv("CG_GEMM_SLOW") == nullptr);
+    const bool vecb = (g.Cout % 4 == 0) && alw;
     static int use32 = -1;
     if (use32 < 0) { const char* e = getenv("CG_GEMM_BK32"); use32 = e ? atoi(e) : 1; }
     const bool bk32 = use32 && (g.Cin % 32 == 0) && (p.kchunk % 32 == 0);
-    dim3 grid(cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, g.nphase);
+    dim3 grid(cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, g.nphase * ngroups);
     if (p.tc.bm == 128 && p.tc.bn == 128) launch_nn<128, 128, 2, 2>(a, grid, st, fast, vecb, bk32);
     else if (p.tc.bm == 64 && p.tc.bn == 128) launch_nn<64, 128, 2, 2>(a, grid, st, fast, vecb, bk32);
     else if (p.tc.bm == 128 && p.tc.bn == 64) launch_nn<128, 64, 2, 2>(a, grid, st, fast, vecb, bk32);
@@ -923,41 +964,54 @@ static int run_nn(hipStream_t st, const Geom& g, const float* x, const float* w,
     else launch_nn<128, 32, 4, 1>(a, grid, st, fast, vecb, bk32);
     CG_LAUNCH_CHECK();
     if (p.splits > 1) {
-        const long PMN = (long)g.nphase * g.M * g.Cout;
-        hipLaunchKernelGGL(nn_splitk_reduce_kernel, dim3(cg::ew_grid(PMN)), dim3(256), 0, st, (const float*)ws, bias, y, g,
-                           p.splits);
+        const long PMN = (long)ngroups * g.nphase * g.M * g.Cout;
+        hipLaunchKernelGGL(nn_splitk_reduce_kernel, dim3(cg::ew_grid(PMN)), dim3(256), 0, st, a, p.splits);
         CG_LAUNCH_CHECK();
     }
     return 0;
+}
+
+static int conv_geom(Geom& g, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups) {
+    if (check_dims(N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
+    return ups ? geom_phase_fwd(g, N, Hp, Wp, Cin, Cout, kH, padH) : geom_plain(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW);
 }
 
 }  // namespace
 
 extern "C" {
 
-size_t cg_conv2d_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups) {
+size_t cg_conv2d_workspace_bytes_grouped(int ngroups, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH,
+                                         int padW, int ups) {
     Geom g;
-    if (check_dims(N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
-    if (ups ? geom_phase_fwd(g, N, Hp, Wp, Cin, Cout, kH, padH) : geom_plain(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW))
-        return 0;
-    return nn_ws_bytes(g, plan_nn(g));
+    if (ngroups < 1 || ngroups > MAXG || conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
+    return nn_ws_bytes(g, plan_nn(g, ngroups), ngroups);
+}
+size_t cg_conv2d_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups) {
+    return cg_conv2d_workspace_bytes_grouped(1, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups);
+}
+
+int cg_conv2d_forward_grouped(void* stream, int ngroups, const float* const* x, const float* const* wpk,
+                              const float* const* bias, float* const* y, int N, int Hp, int Wp, int Cin, int Cout, int kH,
+                              int kW, int padH, int padW, int ups, void* ws, size_t ws_bytes) {
+    CG_REQUIRE(x && wpk && y, "cg_conv2d_forward_grouped: null pointer");
+    Geom g;
+    if (conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
+    return run_nn(cg::S(stream), g, ngroups, x, wpk, bias, y, ws, ws_bytes, "cg_conv2d_forward_grouped");
 }
 
 int cg_conv2d_forward(void* stream, const float* x, const float* wpk, const float* bias, float* y, int N, int Hp, int Wp,
                       int Cin, int Cout, int kH, int kW, int padH, int padW, int ups, void* ws, size_t ws_bytes) {
     CG_REQUIRE(x && wpk && y, "cg_conv2d_forward: null pointer");
     Geom g;
-    if (check_dims(N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
-    if (ups ? geom_phase_fwd(g, N, Hp, Wp, Cin, Cout, kH, padH) : geom_plain(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW))
-        return 1;
-    return run_nn(cg::S(stream), g, x, wpk, bias, y, ws, ws_bytes, "cg_conv2d_forward");
+    if (conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
+    return run_nn(cg::S(stream), g, 1, &x, &wpk, bias ? &bias : nullptr, &y, ws, ws_bytes, "cg_conv2d_forward");
 }
 
 size_t cg_conv2d_dgrad_ups2_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int k, int pad) {
     Geom g;
     if (check_dims(N, Hp, Wp, Cin, Cout, k, k, pad, pad, 1)) return 0;
     if (geom_phase_dgrad(g, N, Hp, Wp, Cin, Cout, k, pad)) return 0;
-    return nn_ws_bytes(g, plan_nn(g));
+    return nn_ws_bytes(g, plan_nn(g, 1), 1);
 }
 
 int cg_conv2d_dgrad_ups2(void* stream, const float* dy, const float* wb_ph, float* dx_lo, int N, int Hp, int Wp, int Cin,
@@ -966,36 +1020,50 @@ int cg_conv2d_dgrad_ups2(void* stream, const float* dy, const float* wb_ph, floa
     Geom g;
     if (check_dims(N, Hp, Wp, Cin, Cout, k, k, pad, pad, 1)) return 1;
     if (geom_phase_dgrad(g, N, Hp, Wp, Cin, Cout, k, pad)) return 1;
-    return run_nn(cg::S(stream), g, dy, wb_ph, nullptr, dx_lo, ws, ws_bytes, "cg_conv2d_dgrad_ups2");
+    return run_nn(cg::S(stream), g, 1, &dy, &wb_ph, nullptr, &dx_lo, ws, ws_bytes, "cg_conv2d_dgrad_ups2");
 }
 
+size_t cg_conv2d_wgrad_workspace_bytes_grouped(int ngroups, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW,
+                                               int padH, int padW, int ups) {
+    Geom g;
+    if (ngroups < 1 || ngroups > MAXG || conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
+    return tn_ws_bytes(g, plan_tn(g, ngroups), ngroups);
+}
 size_t cg_conv2d_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW,
                                        int ups) {
-    Geom g;
-    if (check_dims(N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
-    if (ups ? geom_phase_fwd(g, N, Hp, Wp, Cin, Cout, kH, padH) : geom_plain(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW))
-        return 0;
-    return tn_ws_bytes(g, plan_tn(g));
+    return cg_conv2d_wgrad_workspace_bytes_grouped(1, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups);
 }
 
-int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw, float* gb, int N, int Hp, int Wp, int Cin,
-                    int Cout, int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes) {
+int cg_conv2d_wgrad_grouped(void* stream, int ngroups, const float* const* x, const float* const* dy, float* const* gw,
+                            float* const* gb, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW,
+                            int ups, float scale, void* ws, size_t ws_bytes) {
     CG_REQUIRE(x && dy && gw, "cg_conv2d_wgrad: null pointer");
+    CG_REQUIRE(ngroups >= 1 && ngroups <= MAXG, "cg_conv2d_wgrad: 1..%d groups per launch", MAXG);
     TNArgs a;
-    if (check_dims(N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
-    if (ups ? geom_phase_fwd(a.g, N, Hp, Wp, Cin, Cout, kH, padH)
-            : geom_plain(a.g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW))
-        return 1;
+    memset(&a, 0, sizeof(a));
+    if (conv_geom(a.g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
     const Geom& g = a.g;
-    TNPlan p = plan_tn(g);
-    const size_t need = tn_ws_bytes(g, p);
+    TNPlan p = plan_tn(g, ngroups);
+    const size_t need = tn_ws_bytes(g, p, ngroups);
     CG_REQUIRE(ws && ws_bytes >= need, "cg_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
-    a.x = x; a.dy = dy; a.part = (float*)ws; a.pchunk = p.pchunk;
-    a.bias_part = gb ? (float*)ws + (size_t)p.splits * g.nphase * g.Ktot * g.Cout : nullptr;
-    const bool veca = (Cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
-    const bool vecb = (Cout % 4 == 0) && ((uintptr_t)dy % 16 == 0);
+    const float* xs[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+    const float* ds[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+    bool veca = Cin % 4 == 0, vecb = Cout % 4 == 0, any_gb = false;
+    for (int i = 0; i < ngroups; ++i) {
+        CG_REQUIRE(x[i] && dy[i] && gw[i], "cg_conv2d_wgrad: null pointer (group %d)", i);
+        xs[i] = x[i]; ds[i] = dy[i];
+        veca = veca && ((uintptr_t)x[i] % 16 == 0);
+        vecb = vecb && ((uintptr_t)dy[i] % 16 == 0);
+        any_gb = any_gb || (gb && gb[i]);
+    }
+    a.x0 = xs[0]; a.x1 = xs[1]; a.x2 = xs[2]; a.x3 = xs[3];
+    a.d0 = ds[0]; a.d1 = ds[1]; a.d2 = ds[2]; a.d3 = ds[3];
+    a.ngroups = ngroups; a.part = (float*)ws; a.pchunk = p.pchunk;
+    const int ZP = ngroups * g.nphase;
+    const long wplane = (long)g.Ktot * g.Cout;              // one (group, phase) slab of weight partials
+    a.bias_part = any_gb ? (float*)ws + (size_t)p.splits * ZP * wplane : nullptr;
     hipStream_t st = cg::S(stream);
-    dim3 grid(cg::cdiv(g.Ktot, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, g.nphase);
+    dim3 grid(cg::cdiv(g.Ktot, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, ZP);
     if (p.tc.bm == 128 && p.tc.bn == 128) launch_tn<128, 128, 2, 2>(a, grid, st, veca, vecb);
     else if (p.tc.bm == 64 && p.tc.bn == 128) launch_tn<64, 128, 2, 2>(a, grid, st, veca, vecb);
     else if (p.tc.bm == 128 && p.tc.bn == 64) launch_tn<128, 64, 2, 2>(a, grid, st, veca, vecb);
@@ -1008,28 +1076,41 @@ int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw, fl
     const size_t shb = (size_t)KK * ci_t * 33 * sizeof(float);
     dim3 rgrid(cg::cdiv(Cin, ci_t), cg::cdiv(Cout, 32));
     const long relems = (long)KK * Cin * Cout;
-    if ((long)rgrid.x * rgrid.y >= cg::kNumCU) {
-        if (ups)
-            hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), shb, st, (const float*)ws, gw, Cin, Cout, kH, KK,
-                               padH, phase_kp(kH, padH), p.splits, scale, ci_t);
-        else
-            hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), shb, st, (const float*)ws, gw, Cin, Cout, kH, KK,
-                               padH, 0, p.splits, scale, ci_t);
-    } else {
-        if (ups)
-            hipLaunchKernelGGL(wgrad_reduce_small_kernel<true>, dim3(cg::ew_grid(relems)), dim3(256), 0, st, (const float*)ws,
-                               gw, Cin, Cout, kH, KK, padH, phase_kp(kH, padH), p.splits, scale);
-        else
-            hipLaunchKernelGGL(wgrad_reduce_small_kernel<false>, dim3(cg::ew_grid(relems)), dim3(256), 0, st,
-                               (const float*)ws, gw, Cin, Cout, kH, KK, padH, 0, p.splits, scale);
-    }
-    CG_LAUNCH_CHECK();
-    if (gb) {
-        hipLaunchKernelGGL(bias_part_reduce_kernel, dim3(cg::cdiv(Cout, 32)), dim3(256), 0, st, (const float*)a.bias_part, gb,
-                           p.splits * g.nphase, Cout, scale);
+    const long sstride = (long)ZP * wplane;                 // floats between consecutive splits
+    const int kp = ups ? phase_kp(kH, padH) : 0;
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const float* pg = (const float*)ws + (long)gi * g.nphase * wplane;
+        if ((long)rgrid.x * rgrid.y >= cg::kNumCU) {
+            if (ups)
+                hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), shb, st, pg, gw[gi], Cin, Cout, kH, KK, padH, kp,
+                                   p.splits, scale, ci_t, sstride);
+            else
+                hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), shb, st, pg, gw[gi], Cin, Cout, kH, KK, padH,
+                                   0, p.splits, scale, ci_t, sstride);
+        } else {
+            if (ups)
+                hipLaunchKernelGGL(wgrad_reduce_small_kernel<true>, dim3(cg::ew_grid(relems)), dim3(256), 0, st, pg, gw[gi], Cin,
+                                   Cout, kH, KK, padH, kp, p.splits, scale, sstride);
+            else
+                hipLaunchKernelGGL(wgrad_reduce_small_kernel<false>, dim3(cg::ew_grid(relems)), dim3(256), 0, st, pg, gw[gi],
+                                   Cin, Cout, kH, KK, padH, 0, p.splits, scale, sstride);
+        }
         CG_LAUNCH_CHECK();
+        if (gb && gb[gi]) {
+            hipLaunchKernelGGL(bias_part_reduce_kernel, dim3(cg::cdiv(Cout, 32)), dim3(256), 0, st,
+                               (const float*)a.bias_part + (long)gi * g.nphase * Cout, gb[gi], p.splits, g.nphase,
+                               (long)ZP * Cout, Cout, scale);
+            CG_LAUNCH_CHECK();
+        }
     }
     return 0;
+}
+
+int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw, float* gb, int N, int Hp, int Wp, int Cin,
+                    int Cout, int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes) {
+    CG_REQUIRE(x && dy && gw, "cg_conv2d_wgrad: null pointer");
+    return cg_conv2d_wgrad_grouped(stream, 1, &x, &dy, &gw, &gb, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups, scale, ws,
+                                   ws_bytes);
 }
 
 int cg_pack_conv_weight(void* stream, const float* w, float* wf, float* wb, int Cout, int Cin, int kH, int kW) {

@@ -70,6 +70,49 @@ class LazyScalar:
         return f"{float(self):.6f}"
 
 
+# ------------------------------------------------------- lockstep execution of identical branches
+class _GroupCtx:
+    """Per-branch positions in the counter stream, so that walking several branches layer by layer draws exactly
+    the masks a branch-after-branch walk would (and the oracle does)."""
+
+    def __init__(self, cursors):
+        self.cur = list(cursors)
+
+
+def _ptr_array(ptrs):
+    import ctypes
+    return (ctypes.c_void_p * len(ptrs))(*[int(p) if p else None for p in ptrs])
+
+
+def group_forward(mods, inputs, ctx):
+    return type(mods[0])._group_forward(mods, inputs, ctx)
+
+
+def group_backward(mods, inputs, gouts, scale, acc, ctx):
+    """acc=True: Module:backward (gradInput + accGradParameters); acc=False: updateGradInput only."""
+    return type(mods[0])._group_backward(mods, inputs, gouts, scale, acc, ctx)
+
+
+def _freeze(v):
+    if isinstance(v, (list, tuple)):
+        return tuple(_freeze(e) for e in v)
+    if isinstance(v, dict):
+        return tuple(sorted((k, _freeze(e)) for k, e in v.items()))
+    return v
+
+
+def structure_signature(m):
+    """Two modules with equal signatures run the same launches with the same geometry."""
+    sig = []
+    for mod in m.listModules():
+        shapes = tuple(getattr(mod, n).shape for n in mod._param_names if getattr(mod, n, None) is not None)
+        extra = tuple(getattr(mod, k, None) for k in ("kW", "kH", "padW", "padH", "p", "sizes", "negative_scale", "height",
+                                                      "width", "useRotation", "useScale", "useTranslation", "permutations",
+                                                      "dimension", "scale_factor", "train"))
+        sig.append((type(mod).__name__, shapes, _freeze(extra)))
+    return tuple(sig)
+
+
 # ---------------------------------------------------------------------- base class
 class Module:
     def __init__(self):
@@ -115,6 +158,23 @@ class Module:
         self.updateGradInput(input, gradOutput)
         self.accGradParameters(input, gradOutput, scale)
         return self.gradInput
+
+    # --- lockstep defaults: one call per branch, each at its own position in the counter stream
+    @staticmethod
+    def _group_forward(mods, inputs, ctx):
+        outs = []
+        r = rng()
+        for b, (m, x) in enumerate(zip(mods, inputs)):
+            saved, r.offset = r.offset, ctx.cur[b]
+            outs.append(m.updateOutput(x))
+            ctx.cur[b], r.offset = r.offset, saved
+        return outs
+
+    @staticmethod
+    def _group_backward(mods, inputs, gouts, scale, acc, ctx):
+        if acc:
+            return [m.backward(x, g, scale) for m, x, g in zip(mods, inputs, gouts)]
+        return [m.updateGradInput(x, g) for m, x, g in zip(mods, inputs, gouts)]
 
     # --- parameters
     _param_names = ()
@@ -241,6 +301,25 @@ class Sequential(Module):
     def backward(self, input, gradOutput, scale=1.0):
         return self._walk_back(input, gradOutput, lambda m, i, g: m.backward(i, g, scale))
 
+    @staticmethod
+    def _group_forward(mods, inputs, ctx):
+        cur = list(inputs)
+        for i in range(len(mods[0].modules)):
+            cur = group_forward([m.modules[i] for m in mods], cur, ctx)
+        for m, c in zip(mods, cur):
+            m.output = c
+        return cur
+
+    @staticmethod
+    def _group_backward(mods, inputs, gouts, scale, acc, ctx):
+        cur = list(gouts)
+        for i in range(len(mods[0].modules) - 1, 0, -1):
+            cur = group_backward([m.modules[i] for m in mods], [m.modules[i - 1].output for m in mods], cur, scale, acc, ctx)
+        cur = group_backward([m.modules[0] for m in mods], list(inputs), cur, scale, acc, ctx)
+        for m, c in zip(mods, cur):
+            m.gradInput = c
+        return cur
+
     def __repr__(self):
         return "nn.Sequential {\n  " + "\n  ".join(repr(m).replace("\n", "\n  ") for m in self.modules) + "\n}"
 
@@ -277,6 +356,20 @@ class ConcatTable(Sequential):
     def backward(self, input, gradOutput, scale=1.0):
         return self._sum([m.backward(input, g, scale) for m, g in zip(self.modules, gradOutput)])
 
+    @staticmethod
+    def _group_forward(mods, inputs, ctx):
+        per_child = [group_forward([m.modules[j] for m in mods], list(inputs), ctx) for j in range(len(mods[0].modules))]
+        outs = [[per_child[j][b] for j in range(len(per_child))] for b in range(len(mods))]
+        for m, o in zip(mods, outs):
+            m.output = o
+        return outs
+
+    @staticmethod
+    def _group_backward(mods, inputs, gouts, scale, acc, ctx):
+        per_child = [group_backward([m.modules[j] for m in mods], list(inputs), [g[j] for g in gouts], scale, acc, ctx)
+                     for j in range(len(mods[0].modules))]
+        return [m._sum([per_child[j][b] for j in range(len(per_child))]) for b, m in enumerate(mods)]
+
 
 class Concat(Sequential):
     """nn.Concat(2) (models.lua:688-692): branch outputs joined on channels."""
@@ -309,8 +402,71 @@ class Concat(Sequential):
             main.wait_event(ev)
         return out
 
+    grouped = True  # identical branches run in lockstep with grouped GEMM launches
+
+    def _branch_groups(self):
+        if getattr(self, "_groups", None) is None:
+            by_sig = {}
+            for i, m in enumerate(self.modules):
+                by_sig.setdefault(structure_signature(m), []).append(i)
+            self._groups = [g[k:k + 4] for g in by_sig.values() for k in range(0, len(g), 4)]
+            self._groups.sort(key=lambda g: g[0])
+            self._draws = {}
+        return self._groups
+
+    def _forward_branches(self, input):
+        """Branch outputs in order.  Groups of identical branches run layer by layer (GEMMs as one grouped launch);
+        the first pass at a given input shape runs branch after branch and records how many counter-stream draws each
+        branch consumes, so that lockstep passes can place every branch at exactly the same stream position."""
+        if not (self.grouped and torch.cuda.is_available()):
+            return self._fork_join([(lambda m=m: as_nhwc(m.updateOutput(input))) for m in self.modules])
+        groups = self._branch_groups()
+        key = (tuple(input.shape), self.modules[0].train)
+        r = rng()
+        outs = [None] * len(self.modules)
+        if key not in self._draws:
+            draws = []
+            for i, m in enumerate(self.modules):
+                o0 = r.offset
+                outs[i] = as_nhwc(m.updateOutput(input))
+                draws.append(r.offset - o0)
+            self._draws[key] = draws
+            return outs
+        draws = self._draws[key]
+        base = [r.offset + sum(draws[:i]) for i in range(len(self.modules))]
+        end = r.offset + sum(draws)
+        for idxs in groups:
+            mods = [self.modules[i] for i in idxs]
+            if len(idxs) > 1:
+                ctx = _GroupCtx([base[i] for i in idxs])
+                res = group_forward(mods, [input] * len(idxs), ctx)
+            else:
+                r.offset = base[idxs[0]]
+                res = [mods[0].updateOutput(input)]
+            for i, o in zip(idxs, res):
+                outs[i] = as_nhwc(o)
+        r.offset = end
+        return outs
+
+    def _backward_branches(self, input, slices, scale, acc):
+        if not (self.grouped and torch.cuda.is_available()):
+            if acc:
+                return self._fork_join([(lambda m=m, s=s: as_nhwc(m.backward(input, s, scale))) for m, s in slices])
+            return self._fork_join([(lambda m=m, s=s: as_nhwc(m.updateGradInput(input, s))) for m, s in slices])
+        grads = [None] * len(self.modules)
+        for idxs in self._branch_groups():
+            mods = [self.modules[i] for i in idxs]
+            gs = [slices[i][1] for i in idxs]
+            if len(idxs) > 1:
+                res = group_backward(mods, [input] * len(idxs), gs, scale, acc, _GroupCtx([0] * len(idxs)))
+            else:
+                res = [mods[0].backward(input, gs[0], scale) if acc else mods[0].updateGradInput(input, gs[0])]
+            for i, g in zip(idxs, res):
+                grads[i] = as_nhwc(g)
+        return grads
+
     def updateOutput(self, input):
-        outs = self._fork_join([(lambda m=m: as_nhwc(m.updateOutput(input))) for m in self.modules])
+        outs = self._forward_branches(input)
         N, _, H, W = outs[0].shape
         self._sizes = [o.shape[1] for o in outs]
         Ct = sum(self._sizes)
@@ -345,16 +501,14 @@ class Concat(Sequential):
         return acc
 
     def updateGradInput(self, input, gradOutput):
-        sl = list(self._slices(gradOutput))
-        return self._accumulate(self._fork_join([(lambda m=m, s=s: as_nhwc(m.updateGradInput(input, s))) for m, s in sl]))
+        return self._accumulate(self._backward_branches(input, list(self._slices(gradOutput)), 1.0, False))
 
     def accGradParameters(self, input, gradOutput, scale=1.0):
         for m, s in self._slices(gradOutput):
             m.accGradParameters(input, s, scale)
 
     def backward(self, input, gradOutput, scale=1.0):
-        sl = list(self._slices(gradOutput))
-        return self._accumulate(self._fork_join([(lambda m=m, s=s: as_nhwc(m.backward(input, s, scale))) for m, s in sl]))
+        return self._accumulate(self._backward_branches(input, list(self._slices(gradOutput)), scale, True))
 
 
 # ------------------------------------------------------------- parameterised layers
@@ -392,6 +546,54 @@ class _GemmLayer(Module):
         # 1x1 / linear: the canonical [out][in] matrix already is the backward operand [K=out][N=in]
         return self._wb.data_ptr() if self._wb is not None else self.weight.ptr
 
+    # Subclasses provide _prep_fwd(input) -> (x, wf_ptr, out, geom), _prep_gin(gradOutput) -> (dy, wb_ptr, gi, geom) or
+    # None (not groupable), _prep_acc(gradOutput) -> (x, dy, geom); geom is the 10-tuple the C ABI takes.
+    def updateOutput(self, input):
+        x, wf, out, a = self._prep_fwd(input)
+        ws, wsb = WS.get(lib().conv2d_workspace_bytes(*a))
+        lib().conv2d_forward(stream(), x.ptr, wf, self.bias.ptr, out.ptr, *a, ws, wsb)
+        self._x, self.output = x, out
+        return out
+
+    def accGradParameters(self, input, gradOutput, scale=1.0):
+        x, dy, a = self._prep_acc(gradOutput)
+        ws, wsb = WS.get(lib().conv2d_wgrad_workspace_bytes(*a))
+        lib().conv2d_wgrad(stream(), x.ptr, dy.ptr, self.gradWeight.ptr, self.gradBias.ptr, *a, float(scale), ws, wsb)
+
+    @staticmethod
+    def _group_forward(mods, inputs, ctx):
+        preps = [m._prep_fwd(x) for m, x in zip(mods, inputs)]
+        if len({p[3] for p in preps}) != 1:
+            return Module._group_forward(mods, inputs, ctx)
+        a, G = preps[0][3], len(mods)
+        ws, wsb = WS.get(lib().conv2d_workspace_bytes_grouped(G, *a))
+        lib().conv2d_forward_grouped(stream(), G, _ptr_array([p[0].ptr for p in preps]), _ptr_array([p[1] for p in preps]),
+                                     _ptr_array([m.bias.ptr for m in mods]), _ptr_array([p[2].ptr for p in preps]), *a, ws, wsb)
+        for m, p_ in zip(mods, preps):
+            m._x, m.output = p_[0], p_[2]
+        return [p_[2] for p_ in preps]
+
+    @staticmethod
+    def _group_backward(mods, inputs, gouts, scale, acc, ctx):
+        G = len(mods)
+        gin = [m._prep_gin(g) for m, g in zip(mods, gouts)]
+        if any(p_ is None for p_ in gin) or len({p_[3] for p_ in gin}) != 1:
+            return Module._group_backward(mods, inputs, gouts, scale, acc, ctx)
+        a = gin[0][3]
+        ws, wsb = WS.get(lib().conv2d_workspace_bytes_grouped(G, *a))
+        lib().conv2d_forward_grouped(stream(), G, _ptr_array([p_[0].ptr for p_ in gin]), _ptr_array([p_[1] for p_ in gin]),
+                                     None, _ptr_array([p_[2].ptr for p_ in gin]), *a, ws, wsb)
+        for m, p_ in zip(mods, gin):
+            m.gradInput = p_[2]
+        if acc:
+            accp = [m._prep_acc(g) for m, g in zip(mods, gouts)]
+            aa = accp[0][2]
+            ws, wsb = WS.get(lib().conv2d_wgrad_workspace_bytes_grouped(G, *aa))
+            lib().conv2d_wgrad_grouped(stream(), G, _ptr_array([p_[0].ptr for p_ in accp]), _ptr_array([p_[1].ptr for p_ in accp]),
+                                       _ptr_array([m.gradWeight.ptr for m in mods]), _ptr_array([m.gradBias.ptr for m in mods]),
+                                       *aa, float(scale), ws, wsb)
+        return [p_[2] for p_ in gin]
+
     def reset(self, stdv=None):
         """nn.Linear:reset / nn.SpatialConvolution:reset [upstream]: U(+-stdv*sqrt(3)) if stdv given, else
         U(+-1/sqrt(fan_in)), for weight and bias."""
@@ -419,35 +621,30 @@ class Linear(_GemmLayer):
     def _fan_in(self):
         return self.weight.shape[1]
 
-    def updateOutput(self, input):
+    def _prep_fwd(self, input):
         x = as_plain(to_device(input))
         N, i = x.shape
         o = self.weight.shape[0]
         self._ensure_packed()
-        out = self._get("out", (N, o))
-        ws, wsb = WS.get(lib().conv2d_workspace_bytes(N, 1, 1, i, o, 1, 1, 0, 0, 0))
-        lib().conv2d_forward(stream(), x.ptr, self._wf.data_ptr(), self.bias.ptr, out.ptr, N, 1, 1, i, o, 1, 1, 0, 0, 0, ws, wsb)
-        self._x = x
-        self.output = out
-        return out
+        return x, self._wf.data_ptr(), self._get("out", (N, o)), (N, 1, 1, i, o, 1, 1, 0, 0, 0)
 
-    def updateGradInput(self, input, gradOutput):
+    def _prep_gin(self, gradOutput):
         dy = as_plain(gradOutput)
         N, o = dy.shape
         i = self.weight.shape[1]
-        gi = self._get("gin", (N, i))
-        ws, wsb = WS.get(lib().conv2d_workspace_bytes(N, 1, 1, o, i, 1, 1, 0, 0, 0))
-        lib().conv2d_forward(stream(), dy.ptr, self.weight.ptr, None, gi.ptr, N, 1, 1, o, i, 1, 1, 0, 0, 0, ws, wsb)
-        self.gradInput = gi
-        return gi
+        return dy, self.weight.ptr, self._get("gin", (N, i)), (N, 1, 1, o, i, 1, 1, 0, 0, 0)
 
-    def accGradParameters(self, input, gradOutput, scale=1.0):
+    def _prep_acc(self, gradOutput):
         x, dy = self._x, as_plain(gradOutput)
         N, i = x.shape
-        o = self.weight.shape[0]
-        ws, wsb = WS.get(lib().conv2d_wgrad_workspace_bytes(N, 1, 1, i, o, 1, 1, 0, 0, 0))
-        lib().conv2d_wgrad(stream(), x.ptr, dy.ptr, self.gradWeight.ptr, self.gradBias.ptr, N, 1, 1, i, o, 1, 1, 0, 0, 0,
-                           float(scale), ws, wsb)
+        return x, dy, (N, 1, 1, i, self.weight.shape[0], 1, 1, 0, 0, 0)
+
+    def updateGradInput(self, input, gradOutput):
+        dy, wb, gi, a = self._prep_gin(gradOutput)
+        ws, wsb = WS.get(lib().conv2d_workspace_bytes(*a))
+        lib().conv2d_forward(stream(), dy.ptr, wb, None, gi.ptr, *a, ws, wsb)
+        self.gradInput = gi
+        return gi
 
     def __repr__(self):
         return f"nn.Linear({self.weight.shape[1]} -> {self.weight.shape[0]})"
@@ -484,7 +681,7 @@ class SpatialConvolution(_GemmLayer):
     def _can_fold_ups(self):
         return self.kH == self.kW and self.kH % 2 == 1 and self.padH == self.padW == (self.kH - 1) // 2
 
-    def updateOutput(self, input):
+    def _prep_fwd(self, input):
         x = as_nhwc(to_device(input), keep_ups=True)
         if x.ups and not self._can_fold_ups():
             x = materialise(x)
@@ -496,21 +693,30 @@ class SpatialConvolution(_GemmLayer):
             self._ensure_packed()
             wf = self._wf.data_ptr()
         out = self._get("out", (N, self.nOutputPlane, Ho, Wo), "nhwc")
-        a = (N, Hp, Wp, self.nInputPlane, self.nOutputPlane, self.kH, self.kW, self.padH, self.padW, x.ups)
-        ws, wsb = WS.get(lib().conv2d_workspace_bytes(*a))
-        lib().conv2d_forward(stream(), x.ptr, wf, self.bias.ptr, out.ptr, *a, ws, wsb)
-        self._x = x
-        self.output = out
-        return out
+        return x, wf, out, (N, Hp, Wp, self.nInputPlane, self.nOutputPlane, self.kH, self.kW, self.padH, self.padW, x.ups)
 
-    def updateGradInput(self, input, gradOutput):
+    def _prep_gin(self, gradOutput):
+        x = self._x
+        if x.ups:
+            return None  # folded-upsampling data gradient: its own entry point, not grouped
         dy = as_nhwc(gradOutput)
         N, Co, Ho, Wo = dy.shape
+        gi = self._get("gin", (N, self.nInputPlane, x.shape[2], x.shape[3]), "nhwc")
+        return dy, self._wb_ptr(), gi, (N, Ho, Wo, self.nOutputPlane, self.nInputPlane, self.kH, self.kW,
+                                        self.kH - 1 - self.padH, self.kW - 1 - self.padW, 0)
+
+    def _prep_acc(self, gradOutput):
+        x, dy = self._x, as_nhwc(gradOutput)
+        N, Hp, Wp, Ho, Wo = self._geom(x)
+        return x, dy, (N, Hp, Wp, self.nInputPlane, self.nOutputPlane, self.kH, self.kW, self.padH, self.padW, x.ups)
+
+    def updateGradInput(self, input, gradOutput):
         x = self._x
-        Hl, Wl = x.shape[2], x.shape[3]
         if x.ups:
             # gradient w.r.t. the low-res tensor behind the virtual upsampling (its 2x2 block sum folded in);
             # handed to nn.SpatialUpSamplingNearest as the dual of its lazy output: shape = logical, ups = 1
+            dy = as_nhwc(gradOutput)
+            N, Hl, Wl = dy.shape[0], x.shape[2], x.shape[3]
             Hp, Wp = Hl >> 1, Wl >> 1
             lo = self._get("gin_lo", (N, self.nInputPlane, Hp, Wp), "nhwc")
             k, pad = self.kH, self.padH
@@ -519,20 +725,11 @@ class SpatialConvolution(_GemmLayer):
                                     self.nOutputPlane, k, pad, ws, wsb)
             self.gradInput = Tensor(lo.t, (N, self.nInputPlane, Hl, Wl), "nhwc", 1)
             return self.gradInput
-        gi = self._get("gin", (N, self.nInputPlane, Hl, Wl), "nhwc")
-        a = (N, Ho, Wo, self.nOutputPlane, self.nInputPlane, self.kH, self.kW, self.kH - 1 - self.padH,
-             self.kW - 1 - self.padW, 0)
+        dy, wb, gi, a = self._prep_gin(gradOutput)
         ws, wsb = WS.get(lib().conv2d_workspace_bytes(*a))
-        lib().conv2d_forward(stream(), dy.ptr, self._wb_ptr(), None, gi.ptr, *a, ws, wsb)
+        lib().conv2d_forward(stream(), dy.ptr, wb, None, gi.ptr, *a, ws, wsb)
         self.gradInput = gi
         return gi
-
-    def accGradParameters(self, input, gradOutput, scale=1.0):
-        x, dy = self._x, as_nhwc(gradOutput)
-        N, Hp, Wp, Ho, Wo = self._geom(x)
-        a = (N, Hp, Wp, self.nInputPlane, self.nOutputPlane, self.kH, self.kW, self.padH, self.padW, x.ups)
-        ws, wsb = WS.get(lib().conv2d_wgrad_workspace_bytes(*a))
-        lib().conv2d_wgrad(stream(), x.ptr, dy.ptr, self.gradWeight.ptr, self.gradBias.ptr, *a, float(scale), ws, wsb)
 
     def __repr__(self):
         return (f"{self.typename}({self.nInputPlane} -> {self.nOutputPlane}, {self.kW}x{self.kH}, 1,1, "
@@ -543,6 +740,8 @@ class SpatialConvolutionUpsample(SpatialConvolution):
     """layers/SpatialConvolutionUpsample.lua:1-56: conv to nOut*f^2 planes, then the NCHW buffer
     [N, nOut*f^2, h, w] is *reinterpreted* (a plain view, not a pixel shuffle) as [N, nOut, h*f, w*f]."""
     _typename = "nn.SpatialConvolutionUpsample"
+    _group_forward = staticmethod(Module._group_forward)
+    _group_backward = staticmethod(Module._group_backward)
 
     def __init__(self, nInputPlane, nOutputPlane, kW, kH, factor=2):
         assert kW and kH and nInputPlane and nOutputPlane

@@ -78,6 +78,15 @@ int cg_conv2d_forward(void* stream, const float* x, const float* wpk, const floa
                       int kH, int kW, int padH, int padW, int ups,
                       void* ws, size_t ws_bytes);
 
+/* Grouped form: `ngroups` (<= 4) independent convolutions of IDENTICAL geometry in one launch (blockIdx.z = group);
+ * x/wpk/bias/y are arrays of ngroups device pointers (bias may be NULL, or hold NULL entries).  Used for the
+ * structurally identical branches of D32_st3 (models.lua:653-678): same shapes, separate tensors and parameters. */
+size_t cg_conv2d_workspace_bytes_grouped(int ngroups, int N, int Hp, int Wp, int Cin, int Cout,
+                                         int kH, int kW, int padH, int padW, int ups);
+int cg_conv2d_forward_grouped(void* stream, int ngroups, const float* const* x, const float* const* wpk,
+                              const float* const* bias, float* const* y, int N, int Hp, int Wp, int Cin, int Cout,
+                              int kH, int kW, int padH, int padW, int ups, void* ws, size_t ws_bytes);
+
 /* updateGradInput of upsample2 -> conv as ONE GEMM: dy [N,2Hp,2Wp,Cout] -> dx_lo [N,Hp,Wp,Cin], i.e. the
  * gradient w.r.t. the low-res input with SpatialUpSamplingNearest's 2x2 block sum folded in.  wb_ph from
  * cg_pack_conv_weight_ups2.  (Cin, Cout are the FORWARD layer's plane counts.) */
@@ -97,6 +106,12 @@ int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw_can
                     int N, int Hp, int Wp, int Cin, int Cout,
                     int kH, int kW, int padH, int padW, int ups, float scale,
                     void* ws, size_t ws_bytes);
+
+size_t cg_conv2d_wgrad_workspace_bytes_grouped(int ngroups, int N, int Hp, int Wp, int Cin, int Cout,
+                                               int kH, int kW, int padH, int padW, int ups);
+int cg_conv2d_wgrad_grouped(void* stream, int ngroups, const float* const* x, const float* const* dy,
+                            float* const* gw_canonical, float* const* gb, int N, int Hp, int Wp, int Cin, int Cout,
+                            int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes);
 
 /* gb[c] += scale * sum_m dy[m][c]   (gradBias of conv / linear).
  * ws: scratch of at least 8*C bytes (fp64 column sums). */
