@@ -396,12 +396,30 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
 }
 
 // split-K reduce for NN: y_group[out_row(m)][n] = bias_group[n] + sum_s part[s][group*nphase+phase][m][n]
-__global__ void nn_splitk_reduce_kernel(NNArgs a, int S) {
+// LANES > 1: 256/LANES outputs per workgroup, the S partials of one output shared by LANES threads (small outputs
+// with many splits would otherwise be one long serial load chain per thread).
+template <int LANES>
+__global__ __launch_bounds__(256) void nn_splitk_reduce_kernel(NNArgs a, int S) {
+    constexpr int OUTS = 256 / LANES;
+    __shared__ float sh[LANES > 1 ? LANES : 1][OUTS + 1];
     const Geom& g = a.g;
     const long PMN = (long)a.ngroups * g.nphase * g.M * g.Cout;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < PMN; i += (long)gridDim.x * blockDim.x) {
+    const int ol = threadIdx.x % OUTS, ln = threadIdx.x / OUTS;
+    for (long i0 = blockIdx.x * (long)OUTS; i0 < PMN; i0 += (long)gridDim.x * OUTS) {
+        const long i = i0 + ol;
         float s = 0.f;
-        for (int k = 0; k < S; ++k) s += a.part[(long)k * PMN + i];
+        if (i < PMN)
+            for (int k = ln; k < S; k += LANES) s += a.part[(long)k * PMN + i];
+        if (LANES > 1) {
+            __syncthreads();
+            sh[ln][ol] = s;
+            __syncthreads();
+            if (ln != 0) continue;
+            s = 0.f;
+#pragma unroll
+            for (int r = 0; r < LANES; ++r) s += sh[r][ol];
+        }
+        if (i >= PMN) continue;
         const int n = (int)(i % g.Cout);
         const long pm = i / g.Cout;
         const int m = (int)(pm % g.M);
@@ -678,31 +696,68 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
     }
 }
 
-// Same reduction, one thread per canonical element (for small weight tensors, where the tiled form above would
-// not fill the chip): reads coalesced along co, writes scattered.
+// Same reduction for small weight tensors (where the tiled form above would not fill the chip), all groups of a
+// grouped launch and their bias gradients in ONE launch: grid (weight blocks + bias blocks, ngroups); a workgroup
+// owns 32 consecutive partial elements (or 32 bias channels) and splits the S partials over 8 lanes.
+struct RedPtrs { float* gw0; float* gw1; float* gw2; float* gw3; float* gb0; float* gb1; float* gb2; float* gb3; };
+
 template <bool UPS>
-__global__ void wgrad_reduce_small_kernel(const float* part, float* gw, int Cin, int Cout, int k, int KK, int pad, int kp,
-                                          int S, float scale, long sstride) {
-    const long total = (long)KK * Cin * Cout;
-    const long plane = (long)(UPS ? kp * kp : KK) * Cin * Cout;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % Cout);
-        const long r = i / Cout;
-        const int ci = (int)(r % Cin);
-        const int tap = (int)(r / Cin);
-        float s = 0.f;
-        if (UPS) {
-            const int dy = tap / k, dx = tap - dy * k;
-            for (int sp = 0; sp < S; ++sp)
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* part, const float* bias_part, RedPtrs rp, int Cin,
+                                                                 int Cout, int k, int KK, int pad, int kp, int S, int P,
+                                                                 float scale, long sstride, long gstride, long bsstride,
+                                                                 int wblocks) {
+    __shared__ float sh[8][33];
+    const int ol = threadIdx.x & 31, ln = threadIdx.x >> 5;
+    const int group = blockIdx.y;
+    float s = 0.f;
+    if ((int)blockIdx.x < wblocks) {
+        const long total = (long)KK * Cin * Cout;
+        const long plane = (long)(UPS ? kp * kp : KK) * Cin * Cout;
+        const long i = blockIdx.x * 32L + ol;
+        const float* pg = part + (long)group * gstride;
+        int co = 0, ci = 0, tap = 0;
+        if (i < total) {
+            co = (int)(i % Cout);
+            const long r = i / Cout;
+            ci = (int)(r % Cin);
+            tap = (int)(r / Cin);
+            if (UPS) {
+                const int dy = tap / k, dx = tap - dy * k;
+                for (int sp = ln; sp < S; sp += 8)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int tp = phase_map(p >> 1, dy, pad) * kp + phase_map(p & 1, dx, pad);
-                    s += part[(long)sp * sstride + (long)p * plane + ((long)tp * Cin + ci) * Cout + co];
-                }
-        } else {
-            for (int sp = 0; sp < S; ++sp) s += part[(long)sp * sstride + i];
+                    for (int p = 0; p < 4; ++p) {
+                        const int tp = phase_map(p >> 1, dy, pad) * kp + phase_map(p & 1, dx, pad);
+                        s += pg[(long)sp * sstride + (long)p * plane + ((long)tp * Cin + ci) * Cout + co];
+                    }
+            } else {
+#pragma unroll 4
+                for (int sp = ln; sp < S; sp += 8) s += pg[(long)sp * sstride + i];
+            }
         }
-        gw[((long)co * Cin + ci) * KK + tap] += scale * s;
+        sh[ln][ol] = s;
+        __syncthreads();
+        if (ln == 0 && i < total) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += sh[r][ol];
+            float* gw = sel4(group, rp.gw0, rp.gw1, rp.gw2, rp.gw3);
+            gw[((long)co * Cin + ci) * KK + tap] += scale * t;
+        }
+    } else {
+        float* gb = sel4(group, rp.gb0, rp.gb1, rp.gb2, rp.gb3);
+        if (!gb) return;
+        const int c = ((int)blockIdx.x - wblocks) * 32 + ol;
+        const float* bp = bias_part + (long)group * P * Cout;
+        if (c < Cout)
+            for (int i = ln; i < S * P; i += 8) s += bp[(long)(i / P) * bsstride + (long)(i % P) * Cout + c];
+        sh[ln][ol] = s;
+        __syncthreads();
+        if (ln == 0 && c < Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += sh[r][ol];
+            gb[c] += scale * t;
+        }
     }
 }
 
@@ -727,41 +782,122 @@ __global__ __launch_bounds__(256) void bias_part_reduce_kernel(const float* bp, 
 }
 
 // canonical [Cout][Cin][KK] -> wf[tap*Cin+ci][Cout], wb[(KK-1-tap)*Cout+co][Cin]
-__global__ void pack_weight_kernel(const float* w, float* wf, float* wb, int Cout, int Cin, int KK) {
-    const long total = (long)Cout * Cin * KK;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % Cout);
-        const long r = i / Cout;
-        const int ci = (int)(r % Cin);
-        const int tap = (int)(r / Cin);
-        const float v = w[((long)co * Cin + ci) * KK + tap];
-        if (wf) wf[i] = v;
-        if (wb) wb[((long)(KK - 1 - tap) * Cout + co) * Cin + ci] = v;
+// (the parameters change every step, so this runs every step).  One workgroup owns a 32 ci x 32 co block: thread
+// (ci_l, co_l + 8j) reads its canonical tap run, writes wb directly (ci-fastest, coalesced) and transposes the
+// 32x32 plane of each tap through LDS for wf (co-fastest).
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float* wf, float* wb, int Cout, int Cin, int KK) {
+    __shared__ float sh[32][33];
+    const int lo = threadIdx.x & 31, hi = threadIdx.x >> 5;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    for (int tap = 0; tap < KK; ++tap) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ci = ci0 + lo, co_l = hi + 8 * j, co = co0 + co_l;
+            float v = 0.f;
+            if (ci < Cin && co < Cout) {
+                v = w[((long)co * Cin + ci) * KK + tap];
+                if (wb) wb[((long)(KK - 1 - tap) * Cout + co) * Cin + ci] = v;
+            }
+            sh[lo][co_l] = v;
+        }
+        if (wf) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + lo, ci_l = hi + 8 * j, ci = ci0 + ci_l;
+                if (ci < Cin && co < Cout) wf[((long)tap * Cin + ci) * Cout + co] = sh[ci_l][lo];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// phase-summed weights, k in {3, 5} (the generator's layers): same 32x32 blocking as pack_weight_kernel, the tap
+// sums fully unrolled so every accumulator index is a compile-time constant.
+template <int K>
+__global__ __launch_bounds__(256) void pack_weight_ups2_fast_kernel(const float* w, float* wf, float* wb, int Cout, int Cin) {
+    constexpr int KK = K * K, PAD = (K - 1) / 2, KPD = K == 3 ? 2 : 3, KP = KPD * KPD;
+    __shared__ float sh[KP][32][33];
+    const int lo = threadIdx.x & 31, hi = threadIdx.x >> 5;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    float v[4][KK];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + lo, co = co0 + hi + 8 * j;
+        const bool ok = ci < Cin && co < Cout;
+        const float* src = w + ((long)co * Cin + ci) * KK;
+#pragma unroll
+        for (int t = 0; t < KK; ++t) v[j][t] = ok ? src[t] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc[KP];
+#pragma unroll
+            for (int t = 0; t < KP; ++t) acc[t] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx)
+                    acc[phase_map(p >> 1, dy, PAD) * KPD + phase_map(p & 1, dx, PAD)] += v[j][dy * K + dx];
+            const int ci = ci0 + lo, co_l = hi + 8 * j, co = co0 + co_l;
+#pragma unroll
+            for (int t = 0; t < KP; ++t) {
+                if (wb && ci < Cin && co < Cout) wb[(((long)p * KP + t) * Cout + co) * Cin + ci] = acc[t];
+                sh[t][lo][co_l] = acc[t];
+            }
+        }
+        if (wf) {
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < KP; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int co = co0 + lo, ci_l = hi + 8 * j, ci = ci0 + ci_l;
+                    if (ci < Cin && co < Cout) wf[(((long)p * KP + t) * Cin + ci) * Cout + co] = sh[t][ci_l][lo];
+                }
+            __syncthreads();
+        }
     }
 }
 
 // phase-summed weights for upsample(2) -> conv k x k:
 //   wf[p][(t'*Cin+ci)][co] = sum_{(dy,dx) -> t' under phase p} w[co][ci][dy][dx]
 //   wb[((p*kp*kp + t')*Cout + co)][ci] = the same value (data-gradient operand)
-__global__ void pack_weight_ups2_kernel(const float* w, float* wf, float* wb, int Cout, int Cin, int k, int pad, int kp) {
-    const long per = (long)kp * kp * Cin * Cout;
-    const long total = 4 * per;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % Cout);
-        long r = i / Cout;
-        const int ci = (int)(r % Cin);
-        r /= Cin;
-        const int tp = (int)(r % (kp * kp));
-        const int p = (int)(r / (kp * kp));
-        const int ry = tp / kp, rx = tp - ry * kp;
-        float s = 0.f;
-        for (int dy = 0; dy < k; ++dy) {
-            if (phase_map(p >> 1, dy, pad) != ry) continue;
-            for (int dx = 0; dx < k; ++dx)
-                if (phase_map(p & 1, dx, pad) == rx) s += w[((long)co * Cin + ci) * (k * k) + dy * k + dx];
+// Same LDS staging as pack_weight_kernel.
+__global__ __launch_bounds__(256) void pack_weight_ups2_kernel(const float* w, float* wf, float* wb, int Cout, int Cin, int k,
+                                                               int pad, int kp, int CI_T) {
+    extern __shared__ float sh[];  // [32][CI_T*KK + 1]
+    const int KK = k * k, KP = kp * kp;
+    const int run = CI_T * KK, ld = run + 1;
+    const int ci0 = blockIdx.x * CI_T, co0 = blockIdx.y * 32;
+    const int cis = min(CI_T, Cin - ci0);
+    for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+        const int j = idx % run, co_l = idx / run;
+        if (co0 + co_l < Cout && j < cis * KK) sh[co_l * ld + j] = w[((long)(co0 + co_l) * Cin + ci0) * KK + j];
+    }
+    __syncthreads();
+    const int n = 4 * KP * CI_T * 32;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 0 ? wf == nullptr : wb == nullptr) continue;
+        for (int idx = threadIdx.x; idx < n; idx += 256) {
+            int co_l, ci_l, q;
+            if (pass == 0) { co_l = idx & 31; const int r = idx >> 5; ci_l = r % CI_T; q = r / CI_T; }
+            else { ci_l = idx % CI_T; const int r = idx / CI_T; co_l = r & 31; q = r >> 5; }
+            if (co0 + co_l >= Cout || ci_l >= cis) continue;
+            const int tp = q % KP, p = q / KP;
+            const int ry = tp / kp, rx = tp - ry * kp;
+            const float* src = sh + co_l * ld + ci_l * KK;
+            float s = 0.f;
+            for (int dy = 0; dy < k; ++dy) {
+                if (phase_map(p >> 1, dy, pad) != ry) continue;
+                for (int dx = 0; dx < k; ++dx)
+                    if (phase_map(p & 1, dx, pad) == rx) s += src[dy * k + dx];
+            }
+            if (pass == 0) wf[(((long)p * KP + tp) * Cin + ci0 + ci_l) * Cout + co0 + co_l] = s;
+            else wb[(((long)p * KP + tp) * Cout + co0 + co_l) * Cin + ci0 + ci_l] = s;
         }
-        if (wf) wf[i] = s;
-        if (wb) wb[(((long)p * kp * kp + tp) * Cout + co) * Cin + ci] = s;
     }
 }
 
@@ -965,7 +1101,10 @@ static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const
     CG_LAUNCH_CHECK();
     if (p.splits > 1) {
         const long PMN = (long)ngroups * g.nphase * g.M * g.Cout;
-        hipLaunchKernelGGL(nn_splitk_reduce_kernel, dim3(cg::ew_grid(PMN)), dim3(256), 0, st, a, p.splits);
+        if (PMN >= 256L * 1024 || p.splits < 8)
+            hipLaunchKernelGGL(nn_splitk_reduce_kernel<1>, dim3(cg::ew_grid(PMN)), dim3(256), 0, st, a, p.splits);
+        else
+            hipLaunchKernelGGL(nn_splitk_reduce_kernel<8>, dim3((unsigned)cg::cdiv(PMN, 32)), dim3(256), 0, st, a, p.splits);
         CG_LAUNCH_CHECK();
     }
     return 0;
@@ -1078,23 +1217,34 @@ int cg_conv2d_wgrad_grouped(void* stream, int ngroups, const float* const* x, co
     const long relems = (long)KK * Cin * Cout;
     const long sstride = (long)ZP * wplane;                 // floats between consecutive splits
     const int kp = ups ? phase_kp(kH, padH) : 0;
+    if ((long)rgrid.x * rgrid.y < cg::kNumCU) {
+        RedPtrs rp;
+        float* gws[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+        float* gbs[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+        for (int gi = 0; gi < ngroups; ++gi) { gws[gi] = gw[gi]; gbs[gi] = gb ? gb[gi] : nullptr; }
+        rp.gw0 = gws[0]; rp.gw1 = gws[1]; rp.gw2 = gws[2]; rp.gw3 = gws[3];
+        rp.gb0 = gbs[0]; rp.gb1 = gbs[1]; rp.gb2 = gbs[2]; rp.gb3 = gbs[3];
+        const int wblocks = cg::cdiv(relems, 32), bblocks = any_gb ? cg::cdiv(Cout, 32) : 0;
+        dim3 sgrid(wblocks + bblocks, ngroups);
+        if (ups)
+            hipLaunchKernelGGL(wgrad_reduce_small_kernel<true>, sgrid, dim3(256), 0, st, (const float*)ws,
+                               (const float*)a.bias_part, rp, Cin, Cout, kH, KK, padH, kp, p.splits, g.nphase, scale, sstride,
+                               (long)g.nphase * wplane, (long)ZP * Cout, wblocks);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_small_kernel<false>, sgrid, dim3(256), 0, st, (const float*)ws,
+                               (const float*)a.bias_part, rp, Cin, Cout, kH, KK, padH, 0, p.splits, g.nphase, scale, sstride,
+                               (long)g.nphase * wplane, (long)ZP * Cout, wblocks);
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
     for (int gi = 0; gi < ngroups; ++gi) {
         const float* pg = (const float*)ws + (long)gi * g.nphase * wplane;
-        if ((long)rgrid.x * rgrid.y >= cg::kNumCU) {
-            if (ups)
-                hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), shb, st, pg, gw[gi], Cin, Cout, kH, KK, padH, kp,
-                                   p.splits, scale, ci_t, sstride);
-            else
-                hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), shb, st, pg, gw[gi], Cin, Cout, kH, KK, padH,
-                                   0, p.splits, scale, ci_t, sstride);
-        } else {
-            if (ups)
-                hipLaunchKernelGGL(wgrad_reduce_small_kernel<true>, dim3(cg::ew_grid(relems)), dim3(256), 0, st, pg, gw[gi], Cin,
-                                   Cout, kH, KK, padH, kp, p.splits, scale, sstride);
-            else
-                hipLaunchKernelGGL(wgrad_reduce_small_kernel<false>, dim3(cg::ew_grid(relems)), dim3(256), 0, st, pg, gw[gi],
-                                   Cin, Cout, kH, KK, padH, 0, p.splits, scale, sstride);
-        }
+        if (ups)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), shb, st, pg, gw[gi], Cin, Cout, kH, KK, padH, kp,
+                               p.splits, scale, ci_t, sstride);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), shb, st, pg, gw[gi], Cin, Cout, kH, KK, padH,
+                               0, p.splits, scale, ci_t, sstride);
         CG_LAUNCH_CHECK();
         if (gb && gb[gi]) {
             hipLaunchKernelGGL(bias_part_reduce_kernel, dim3(cg::cdiv(Cout, 32)), dim3(256), 0, st,
@@ -1113,12 +1263,19 @@ int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw, fl
                                    ws_bytes);
 }
 
+// input channels per pack workgroup: the largest power of two with ci_t*KK <= 448 floats per output channel (57 KB of LDS)
+static int pack_ci_tile(int Cin, int KK) {
+    int t = 1;
+    while (t * 2 * KK <= 448 && t < Cin) t *= 2;
+    return t;
+}
+
 int cg_pack_conv_weight(void* stream, const float* w, float* wf, float* wb, int Cout, int Cin, int kH, int kW) {
     CG_REQUIRE(w && (wf || wb), "cg_pack_conv_weight: null pointer");
     CG_REQUIRE(Cout > 0 && Cin > 0 && kH > 0 && kW > 0, "cg_pack_conv_weight: bad dims");
-    const long total = (long)Cout * Cin * kH * kW;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(cg::ew_grid(total)), dim3(256), 0, cg::S(stream), w, wf, wb, Cout, Cin,
-                       kH * kW);
+    const int KK = kH * kW;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(cg::cdiv(Cin, 32), cg::cdiv(Cout, 32)), dim3(256), 0, cg::S(stream), w, wf,
+                       wb, Cout, Cin, KK);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -1134,9 +1291,20 @@ int cg_pack_conv_weight_ups2(void* stream, const float* w, float* wf_ph, float* 
     CG_REQUIRE(Cout > 0 && Cin > 0 && k > 0 && (k & 1) == 1 && pad == (k - 1) / 2,
                "cg_pack_conv_weight_ups2: needs an odd kernel with pad=(k-1)/2");
     const int kp = phase_kp(k, pad);
-    const long total = 4L * kp * kp * Cin * Cout;
-    hipLaunchKernelGGL(pack_weight_ups2_kernel, dim3(cg::ew_grid(total)), dim3(256), 0, cg::S(stream), w, wf_ph, wb_ph, Cout,
-                       Cin, k, pad, kp);
+    CG_REQUIRE(k * k <= 448, "cg_pack_conv_weight_ups2: kernel too large (%d taps)", k * k);
+    const dim3 fgrid(cg::cdiv(Cin, 32), cg::cdiv(Cout, 32));
+    if (k == 3 || k == 5) {
+        if (k == 3)
+            hipLaunchKernelGGL(pack_weight_ups2_fast_kernel<3>, fgrid, dim3(256), 0, cg::S(stream), w, wf_ph, wb_ph, Cout, Cin);
+        else
+            hipLaunchKernelGGL(pack_weight_ups2_fast_kernel<5>, fgrid, dim3(256), 0, cg::S(stream), w, wf_ph, wb_ph, Cout, Cin);
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
+    const int ci_t = pack_ci_tile(Cin, k * k);
+    hipLaunchKernelGGL(pack_weight_ups2_kernel, dim3(cg::cdiv(Cin, ci_t), cg::cdiv(Cout, 32)), dim3(256),
+                       (size_t)32 * (ci_t * k * k + 1) * sizeof(float), cg::S(stream), w, wf_ph, wb_ph, Cout, Cin, k, pad, kp,
+                       ci_t);
     CG_LAUNCH_CHECK();
     return 0;
 }
