@@ -789,7 +789,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float*
     __shared__ float sh[32][33];
     const int lo = threadIdx.x & 31, hi = threadIdx.x >> 5;
     const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
-    for (int tap = 0; tap < KK; ++tap) {
+    {
+        const int tap = blockIdx.z;  // one tap plane per workgroup: KK independent workgroups instead of KK serial rounds
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ci = ci0 + lo, co_l = hi + 8 * j, co = co0 + co_l;
@@ -807,7 +808,6 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float*
                 const int co = co0 + lo, ci_l = hi + 8 * j, ci = ci0 + ci_l;
                 if (ci < Cin && co < Cout) wf[((long)tap * Cin + ci) * Cout + co] = sh[ci_l][lo];
             }
-            __syncthreads();
         }
     }
 }
@@ -1274,8 +1274,8 @@ int cg_pack_conv_weight(void* stream, const float* w, float* wf, float* wb, int 
     CG_REQUIRE(w && (wf || wb), "cg_pack_conv_weight: null pointer");
     CG_REQUIRE(Cout > 0 && Cin > 0 && kH > 0 && kW > 0, "cg_pack_conv_weight: bad dims");
     const int KK = kH * kW;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(cg::cdiv(Cin, 32), cg::cdiv(Cout, 32)), dim3(256), 0, cg::S(stream), w, wf,
-                       wb, Cout, Cin, KK);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(cg::cdiv(Cin, 32), cg::cdiv(Cout, 32), KK), dim3(256), 0, cg::S(stream), w,
+                       wf, wb, Cout, Cin, KK);
     CG_LAUNCH_CHECK();
     return 0;
 }

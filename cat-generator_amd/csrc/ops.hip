@@ -4,6 +4,7 @@
 // Each kernel cites the reference module it stands in for (see catgan.h).
 #include "common.h"
 #include <stdarg.h>
+#include <algorithm>
 
 namespace cg {
 char* err_buf() {
@@ -45,8 +46,7 @@ __global__ void prelu_fwd_v4k(const float* x, const float* alpha, float* y, long
         stv(y, i, v);
     }
 }
-__global__ void prelu_bwd_v4k(const float* x, const float* dy, const float* alpha, float* dx, float* galpha, float scale,
-                              long n4) {
+__global__ void prelu_bwd_v4k(const float* x, const float* dy, const float* alpha, float* dx, double* gpart, long n4) {
     __shared__ double sh[4];
     const float a = *alpha;
     float s = 0.f;
@@ -59,8 +59,9 @@ __global__ void prelu_bwd_v4k(const float* x, const float* dy, const float* alph
         s += (v.x <= 0.f ? v.x * g.x : 0.f) + (v.y <= 0.f ? v.y * g.y : 0.f) + (v.z <= 0.f ? v.z * g.z : 0.f) +
              (v.w <= 0.f ? v.w * g.w : 0.f);
     }
+    if (!gpart) return;
     const double t = block_sum_256((double)s, sh);
-    if (threadIdx.x == 0 && galpha) atomicAdd(galpha, (float)(t * scale));
+    if (threadIdx.x == 0) gpart[blockIdx.x] = t;
 }
 __global__ void lrelu_fwd_v4k(const float* x, float* y, float s, long n4) {
     V4_LOOP(i, n4) {
@@ -150,8 +151,7 @@ __global__ void prelu_fwd_k(const float* x, const float* alpha, float* y, long n
         y[i] = v > 0.f ? v : a * v;
     }
 }
-__global__ void prelu_bwd_k(const float* x, const float* dy, const float* alpha, float* dx, float* galpha, float scale,
-                            long n) {
+__global__ void prelu_bwd_k(const float* x, const float* dy, const float* alpha, float* dx, double* gpart, long n) {
     __shared__ double sh[4];
     const float a = *alpha;
     float s = 0.f;
@@ -160,8 +160,18 @@ __global__ void prelu_bwd_k(const float* x, const float* dy, const float* alpha,
         dx[i] = v > 0.f ? g : a * g;
         if (v <= 0.f) s += v * g;
     }
+    if (!gpart) return;
     const double t = block_sum_256((double)s, sh);
-    if (threadIdx.x == 0 && galpha) atomicAdd(galpha, (float)(t * scale));
+    if (threadIdx.x == 0) gpart[blockIdx.x] = t;
+}
+// *galpha += scale * sum of the per-workgroup partials, in a fixed order (one same-address float atomic per
+// workgroup costs ~12 ns each on this part: 25 us for a 2048-workgroup launch, and is order-dependent)
+__global__ void prelu_galpha_reduce_k(const double* gpart, int nparts, float* galpha, float scale) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += gpart[i];
+    const double t = block_sum_256(s, sh);
+    if (threadIdx.x == 0) *galpha += (float)(t * scale);
 }
 __global__ void lrelu_fwd_k(const float* x, float* y, float s, long n) {
     GRID_STRIDE(i, n) {
@@ -244,6 +254,62 @@ __global__ __launch_bounds__(256) void colreduce_k(const float* x, const float* 
         const double t2 = sh2[0][cl] + sh2[1][cl] + sh2[2][cl] + sh2[3][cl];
         atomicAdd(&sums[c], t1);
         if (MODE != 2) atomicAdd(&sums[C + c], t2);
+    }
+}
+
+// float4 form (C % 4 == 0, 16-byte aligned rows): block = QB channel quads x RL row lanes (QB*RL = 256), four
+// independent row loads in flight per thread, fp32 partials of <= 64 rows folded into doubles.
+template <int MODE, int QB>
+__global__ __launch_bounds__(256) void colreduce4_k(const float* x, const float* dy, const float* mean,
+                                                    const float* invstd, long M, int C, long rows_per_block,
+                                                    double* sums) {
+    constexpr int RL = 256 / QB;
+    __shared__ double sh[2][RL][QB * 4 + 2];
+    const int ql = threadIdx.x % QB, rl = threadIdx.x / QB;
+    const int q = blockIdx.x * QB + ql;          // channel quad
+    const int cq = C >> 2;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (q < cq) {
+        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+        if (MODE == 1) { mu = ldc(mean, q); is = ldc(invstd, q); }
+        for (long rb = r0 + rl; rb < r1; rb += 64L * RL) {
+            const long re = min(r1, rb + 64L * RL);
+            float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll 4
+            for (long r = rb; r < re; r += RL) {
+                const long i = r * cq + q;
+                if (MODE == 0) {
+                    const float4 v = ldv(x, i);
+                    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                    s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+                } else if (MODE == 1) {
+                    const float4 g = ldv(dy, i), v = ldv(x, i);
+                    s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+                    s2.x += g.x * ((v.x - mu.x) * is.x); s2.y += g.y * ((v.y - mu.y) * is.y);
+                    s2.z += g.z * ((v.z - mu.z) * is.z); s2.w += g.w * ((v.w - mu.w) * is.w);
+                } else {
+                    const float4 g = ldv(dy, i);
+                    s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+                }
+            }
+            a1[0] += s1.x; a1[1] += s1.y; a1[2] += s1.z; a1[3] += s1.w;
+            a2[0] += s2.x; a2[1] += s2.y; a2[2] += s2.z; a2[3] += s2.w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh[0][rl][ql * 4 + k] = a1[k]; sh[1][rl][ql * 4 + k] = a2[k]; }
+    __syncthreads();
+    // 256 threads finish QB*4 channels x 2 sums
+    for (int idx = threadIdx.x; idx < QB * 4 * (MODE == 2 ? 1 : 2); idx += 256) {
+        const int which = idx / (QB * 4), cl = idx % (QB * 4);
+        const int c = blockIdx.x * QB * 4 + cl;
+        if (c >= C) continue;
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < RL; ++r) t += sh[which][r][cl];
+        atomicAdd(&sums[which * C + c], t);
     }
 }
 
@@ -605,29 +671,43 @@ __global__ void bilinear_fwd_k(const float* img, const float* grid, float* out, 
         out[i] = v;
     }
 }
-// one wave per output pixel; lanes stride the channels
+// G lanes per output pixel (64/G pixels per wave), lanes stride the channels; G = smallest power of two >= min(C, 64)
+template <int G>
 __global__ __launch_bounds__(256) void bilinear_bwd_k(const float* img, const float* grid, const float* gout,
                                                       float* gimg, float* ggrid, int N, int Hi, int Wi, int C, int Ho,
                                                       int Wo) {
     const long npix = (long)N * Ho * Wo;
-    const int lane = threadIdx.x & 63;
-    const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
-    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-    for (long pix = wave0; pix < npix; pix += nwaves) {
-        const long n = pix / ((long)Ho * Wo);
-        const BilinTaps t = bilin_taps(grid[pix * 2], grid[pix * 2 + 1], Hi, Wi);
+    const int sub = threadIdx.x & (G - 1);
+    const long grp0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) / G;
+    const long ngrp = ((long)gridDim.x * blockDim.x) / G;
+    const long iters = (npix + ngrp - 1) / ngrp;   // same trip count for every lane of a wave (shuffles below)
+    for (long it = 0; it < iters; ++it) {
+        const long pix = grp0 + it * ngrp;
+        const bool live = pix < npix;
+        BilinTaps t;
+        t.in00 = t.in01 = t.in10 = t.in11 = false; t.x0 = t.y0 = 0; t.wx0 = t.wy0 = 0.f;
+        long n = 0;
+        if (live) {
+            n = pix / ((long)Ho * Wo);
+            t = bilin_taps(grid[pix * 2], grid[pix * 2 + 1], Hi, Wi);
+        }
         const long b = ((n * Hi + t.y0) * (long)Wi + t.x0) * C;
         const long o01 = C, o10 = (long)Wi * C, o11 = (long)Wi * C + C;
         float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
-        for (int c = lane; c < C; c += 64) {
-            const float g = gout[pix * C + c];
-            if (t.in00) { d00 += img[b + c] * g;       atomicAdd(&gimg[b + c], t.wx0 * t.wy0 * g); }
-            if (t.in01) { d01 += img[b + o01 + c] * g; atomicAdd(&gimg[b + o01 + c], (1.f - t.wx0) * t.wy0 * g); }
-            if (t.in10) { d10 += img[b + o10 + c] * g; atomicAdd(&gimg[b + o10 + c], t.wx0 * (1.f - t.wy0) * g); }
-            if (t.in11) { d11 += img[b + o11 + c] * g; atomicAdd(&gimg[b + o11 + c], (1.f - t.wx0) * (1.f - t.wy0) * g); }
+        if (live)
+            for (int c = sub; c < C; c += G) {
+                const float g = gout[pix * C + c];
+                if (t.in00) { d00 += img[b + c] * g;       atomicAdd(&gimg[b + c], t.wx0 * t.wy0 * g); }
+                if (t.in01) { d01 += img[b + o01 + c] * g; atomicAdd(&gimg[b + o01 + c], (1.f - t.wx0) * t.wy0 * g); }
+                if (t.in10) { d10 += img[b + o10 + c] * g; atomicAdd(&gimg[b + o10 + c], t.wx0 * (1.f - t.wy0) * g); }
+                if (t.in11) { d11 += img[b + o11 + c] * g; atomicAdd(&gimg[b + o11 + c], (1.f - t.wx0) * (1.f - t.wy0) * g); }
+            }
+#pragma unroll
+        for (int off = G >> 1; off > 0; off >>= 1) {
+            d00 += __shfl_down(d00, off, G); d01 += __shfl_down(d01, off, G);
+            d10 += __shfl_down(d10, off, G); d11 += __shfl_down(d11, off, G);
         }
-        d00 = wave_sum(d00); d01 = wave_sum(d01); d10 = wave_sum(d10); d11 = wave_sum(d11);
-        if (lane == 0) {
+        if (live && sub == 0) {
             const float gy = -t.wx0 * d00 + t.wx0 * d10 - (1.f - t.wx0) * d01 + (1.f - t.wx0) * d11;
             const float gx = -t.wy0 * d00 + t.wy0 * d01 - (1.f - t.wy0) * d10 + (1.f - t.wy0) * d11;
             ggrid[pix * 2 + 0] = gy * (float)(Hi - 1) * 0.5f;
@@ -741,13 +821,26 @@ int cg_prelu_forward(void* stream, const float* x, const float* alpha, float* y,
     if (n % 4 == 0 && al16(x) && al16(y)) { EW_LAUNCH(prelu_fwd_v4k, n / 4, x, alpha, y, n / 4); return 0; }
     EW_LAUNCH(prelu_fwd_k, n, x, alpha, y, n); return 0;
 }
+size_t cg_prelu_backward_workspace_bytes(long n) { return n > 0 ? sizeof(double) * (size_t)cg::ew_grid(n) : 0; }
 int cg_prelu_backward(void* stream, const float* x, const float* dy, const float* alpha, float* dx, float* galpha,
-                      float scale, long n) {
+                      float scale, long n, void* ws, size_t ws_bytes) {
     CG_REQUIRE(x && dy && alpha && dx, "cg_prelu_backward: null pointer");
-    if (n % 4 == 0 && al16(x) && al16(dy) && al16(dx)) {
-        EW_LAUNCH(prelu_bwd_v4k, n / 4, x, dy, alpha, dx, galpha, scale, n / 4); return 0;
+    if (n <= 0) return 0;
+    const bool v4 = n % 4 == 0 && al16(x) && al16(dy) && al16(dx);
+    const int nblk = cg::ew_grid(v4 ? n / 4 : n);
+    double* gpart = nullptr;
+    if (galpha) {
+        CG_REQUIRE(ws && ws_bytes >= sizeof(double) * nblk && ((uintptr_t)ws % 8) == 0,
+                   "cg_prelu_backward: workspace too small (%zu < %zu)", ws_bytes, sizeof(double) * nblk);
+        gpart = (double*)ws;
     }
-    EW_LAUNCH(prelu_bwd_k, n, x, dy, alpha, dx, galpha, scale, n); return 0;
+    if (v4) EW_LAUNCH(prelu_bwd_v4k, n / 4, x, dy, alpha, dx, gpart, n / 4);
+    else EW_LAUNCH(prelu_bwd_k, n, x, dy, alpha, dx, gpart, n);
+    if (galpha) {
+        hipLaunchKernelGGL(prelu_galpha_reduce_k, dim3(1), dim3(256), 0, cg::S(stream), gpart, nblk, galpha, scale);
+        CG_LAUNCH_CHECK();
+    }
+    return 0;
 }
 int cg_leakyrelu_forward(void* stream, const float* x, float* y, float slope, long n) {
     CG_REQUIRE(x && y, "cg_leakyrelu_forward: null pointer");
@@ -781,18 +874,26 @@ static int colreduce_launch(void* stream, int mode, const float* x, const float*
                             const float* invstd, long M, int C, double* sums, int nsums) {
     CG_HIP(hipMemsetAsync(sums, 0, sizeof(double) * nsums * C, cg::S(stream)));
     if (M <= 0) return 0;
-    const int cblocks = cg::cdiv(C, 64);
-    long rows_per_block = 256;
-    long chunks = (M + rows_per_block - 1) / rows_per_block;
-    const long max_chunks = (long)cg::kNumCU * 8 / cblocks > 0 ? (long)cg::kNumCU * 8 / cblocks : 1;
-    if (chunks > max_chunks) {
-        rows_per_block = ((M + max_chunks - 1) / max_chunks + 3) / 4 * 4;
-        chunks = (M + rows_per_block - 1) / rows_per_block;
-    }
+    const bool v4 = C % 4 == 0 && (!x || al16(x)) && (!dy || al16(dy));
+    const int qb = C >= 128 ? 32 : 16;   // channel quads per block in the float4 form
+    const int cblocks = v4 ? cg::cdiv(C / 4, qb) : cg::cdiv(C, 64);
+    // row chunks: every chunk ends in one double atomic per channel, and same-address atomics serialise (~10 ns each),
+    // so aim at one workgroup per CU in total (CG_COLREDUCE_WGS_PER_CU) rather than at maximum occupancy
+    static int cmul = -1;
+    if (cmul < 0) { const char* e = getenv("CG_COLREDUCE_WGS_PER_CU"); cmul = e ? atoi(e) : 1; }
+    long chunks = std::max(1L, std::min((M + 63) / 64, (long)cg::kNumCU * cmul / cblocks));
+    const long rows_per_block = ((M + chunks - 1) / chunks + 3) / 4 * 4;
+    chunks = (M + rows_per_block - 1) / rows_per_block;
     dim3 grid(cblocks, (unsigned)chunks);
-    if (mode == 0) hipLaunchKernelGGL(colreduce_k<0>, grid, dim3(256), 0, cg::S(stream), x, dy, mean, invstd, M, C, rows_per_block, sums);
-    else if (mode == 1) hipLaunchKernelGGL(colreduce_k<1>, grid, dim3(256), 0, cg::S(stream), x, dy, mean, invstd, M, C, rows_per_block, sums);
-    else hipLaunchKernelGGL(colreduce_k<2>, grid, dim3(256), 0, cg::S(stream), x, dy, mean, invstd, M, C, rows_per_block, sums);
+#define CG_COLRED(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, cg::S(stream), x, dy, mean, invstd, M, C, rows_per_block, sums)
+    if (v4 && qb == 32) {
+        if (mode == 0) CG_COLRED((colreduce4_k<0, 32>)); else if (mode == 1) CG_COLRED((colreduce4_k<1, 32>)); else CG_COLRED((colreduce4_k<2, 32>));
+    } else if (v4) {
+        if (mode == 0) CG_COLRED((colreduce4_k<0, 16>)); else if (mode == 1) CG_COLRED((colreduce4_k<1, 16>)); else CG_COLRED((colreduce4_k<2, 16>));
+    } else {
+        if (mode == 0) CG_COLRED(colreduce_k<0>); else if (mode == 1) CG_COLRED(colreduce_k<1>); else CG_COLRED(colreduce_k<2>);
+    }
+#undef CG_COLRED
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -1016,11 +1117,21 @@ int cg_bilinear_sampler_backward(void* stream, const float* img, const float* gr
     CG_REQUIRE(img && grid && gout && gimg && ggrid, "cg_bilinear_sampler_backward: null pointer");
     CG_HIP(hipMemsetAsync(gimg, 0, sizeof(float) * (size_t)N * Hi * Wi * C, cg::S(stream)));
     const long npix = (long)N * Ho * Wo;
-    long blocks = (npix + 3) / 4;
+    int G = 4;
+    while (G < 64 && G < C) G <<= 1;
+    long blocks = (npix * G + 255) / 256;
     if (blocks > cg::kNumCU * 8) blocks = cg::kNumCU * 8;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bilinear_bwd_k, dim3((unsigned)blocks), dim3(256), 0, cg::S(stream), img, grid, gout, gimg, ggrid,
-                       N, Hi, Wi, C, Ho, Wo);
+    const dim3 grd((unsigned)blocks), blk(256);
+#define CG_BILIN_BWD(GG) hipLaunchKernelGGL(bilinear_bwd_k<GG>, grd, blk, 0, cg::S(stream), img, grid, gout, gimg, ggrid, N, Hi, Wi, C, Ho, Wo)
+    switch (G) {
+        case 4: CG_BILIN_BWD(4); break;
+        case 8: CG_BILIN_BWD(8); break;
+        case 16: CG_BILIN_BWD(16); break;
+        case 32: CG_BILIN_BWD(32); break;
+        default: CG_BILIN_BWD(64); break;
+    }
+#undef CG_BILIN_BWD
     CG_LAUNCH_CHECK(); return 0;
 }
 

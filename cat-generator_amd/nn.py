@@ -791,7 +791,9 @@ class PReLU(Module):
         x = self._x
         dy = gradOutput if gradOutput.fmt == x.fmt else (as_nhwc(gradOutput) if x.fmt == "nhwc" else as_plain(gradOutput))
         gi = self._get("gin", x.shape, x.fmt)
-        lib().prelu_backward(stream(), x.ptr, dy.ptr, self.weight.ptr, gi.ptr, galpha, float(scale), x.phys_numel())
+        n = x.phys_numel()
+        ws, wsb = WS.get(lib().prelu_backward_workspace_bytes(n)) if galpha else (None, 0)
+        lib().prelu_backward(stream(), x.ptr, dy.ptr, self.weight.ptr, gi.ptr, galpha, float(scale), n, ws, wsb)
         self.gradInput = gi
         return gi
 

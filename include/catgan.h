@@ -134,8 +134,10 @@ int cg_pack_conv_weight_ups2(void* stream, const float* w_canonical, float* wf_p
  * nn.PReLU(nil,nil,true): one shared slope (models.lua:201,208,214,220,647..698).
  * y = x>0 ? x : a*x ; dx = x>0 ? dy : a*dy ; *galpha += scale*sum_{x<=0} x*dy. */
 int cg_prelu_forward(void* stream, const float* x, const float* alpha, float* y, long n);
+/* galpha may be NULL (updateGradInput only); otherwise ws holds one double per workgroup (deterministic 2-stage sum). */
+size_t cg_prelu_backward_workspace_bytes(long n);
 int cg_prelu_backward(void* stream, const float* x, const float* dy, const float* alpha,
-                      float* dx, float* galpha, float scale, long n);
+                      float* dx, float* galpha, float scale, long n, void* ws, size_t ws_bytes);
 /* nn.LeakyReLU (LeakyReLU.lua:13-31): y = x>=0 ? x : s*x ; dx = x>=0 ? dy : s*dy. */
 int cg_leakyrelu_forward(void* stream, const float* x, float* y, float slope, long n);
 int cg_leakyrelu_backward(void* stream, const float* x, const float* dy, float* dx, float slope, long n);

@@ -152,7 +152,8 @@ function PReLU:updateOutput(x)
 end
 function PReLU:backward(x, dy, scale)
    self.gradInput = self.gradInput or Tensor.new(x.shape, x.fmt)
-   check(C.cg_prelu_backward(stream, x.ptr, dy.ptr, self.weight.ptr, self.gradInput.ptr, self.gradWeight.ptr, scale or 1, x.n))
+   local ws, wsb = workspace(C.cg_prelu_backward_workspace_bytes(x.n))
+   check(C.cg_prelu_backward(stream, x.ptr, dy.ptr, self.weight.ptr, self.gradInput.ptr, self.gradWeight.ptr, scale or 1, x.n, ws, wsb))
    return self.gradInput
 end
 M.nn.PReLU = PReLU
