@@ -28,6 +28,7 @@
 // <= 128 registers per workgroup -> 4 workgroups per CU.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -901,6 +902,151 @@ __global__ __launch_bounds__(256) void pack_weight_ups2_kernel(const float* w, f
     }
 }
 
+// ---------------------------------------------------------------------------
+// Skinny 3x3 convolution, Cout <= 4 (G's last layer 128 -> 3, and D's first layer seen from its data gradient
+// 64 -> 3): 2.3 kFLOP per 512-byte pixel, i.e. HBM-bound; an MFMA tile would spend >= 90 % of its columns on
+// padding.  LP lanes share a pixel, each lane owns one channel quad (Cin = 4*LP) whose 9 x 4 x CO weights
+// (weight-gradient: accumulators) live in registers; pixel loads are coalesced float4 rows.
+// ---------------------------------------------------------------------------
+template <int CO, int LP>
+__global__ __launch_bounds__(256) void skinny_conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y, int N,
+                                                             int H, int W) {
+    constexpr int Cin = 4 * LP;
+    const int sub = threadIdx.x & (LP - 1);
+    float wr[9][4][CO];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int co = 0; co < CO; ++co) wr[t][j][co] = w[((long)t * Cin + sub * 4 + j) * CO + co];
+    const long npix = (long)N * H * W;
+    const long grp0 = (blockIdx.x * 256L + threadIdx.x) / LP;
+    const long ngrp = gridDim.x * 256L / LP;
+    const long iters = (npix + ngrp - 1) / ngrp;   // uniform trip count: the shuffles below need every lane
+    for (long it = 0; it < iters; ++it) {
+        const long pix = grp0 + it * ngrp;
+        const bool live = pix < npix;
+        const unsigned pc = live ? (unsigned)pix : 0u;   // npix < 2^31 (checked by the host): 32-bit divisions
+        const unsigned row = pc / (unsigned)W;
+        const int ox = (int)(pc - row * (unsigned)W), oy = (int)(row % (unsigned)H);
+        const long n = row / (unsigned)H;
+        float acc[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+        float4 v[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+            const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+            const float4 q = ld4(x + ((n * H + cy) * (long)W + cx) * Cin + sub * 4);
+            v[t] = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int co = 0; co < CO; ++co)
+                acc[co] += v[t].x * wr[t][0][co] + v[t].y * wr[t][1][co] + v[t].z * wr[t][2][co] + v[t].w * wr[t][3][co];
+#pragma unroll
+        for (int off = LP >> 1; off > 0; off >>= 1)
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[co] += __shfl_down(acc[co], off, LP);
+        if (live && sub == 0) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) y[pix * CO + co] = acc[co] + (bias ? bias[co] : 0.f);
+        }
+    }
+}
+
+// weight/bias gradient partials of the same layer: part[block][(t*Cin+ci)][co], bias_part[block][co]
+template <int CO, int LP>
+__global__ __launch_bounds__(256) void skinny_wgrad3x3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ part, float* __restrict__ bias_part, int N,
+                                                              int H, int W, long pix_per_block) {
+    constexpr int Cin = 4 * LP, NGL = 256 / LP, PER = 36 * CO;
+    extern __shared__ float sk_sh[];   // [4 waves][LP][PER + 1]
+    const int sub = threadIdx.x & (LP - 1), gl = threadIdx.x / LP;
+    const long npix = (long)N * H * W;
+    const long p0 = blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+    float acc[9][4][CO];
+    float bacc[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        bacc[co] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][j][co] = 0.f;
+    }
+    for (long pix = p0 + gl; pix < p1; pix += NGL) {
+        const unsigned row = (unsigned)pix / (unsigned)W;
+        const int ox = (int)((unsigned)pix - row * (unsigned)W), oy = (int)(row % (unsigned)H);
+        const long n = row / (unsigned)H;
+        float d[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) { d[co] = dy[pix * CO + co]; bacc[co] += d[co]; }
+        float4 v[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+            const float4 q = ld4(x + ((n * H + cy) * (long)W + cx) * Cin + sub * 4);
+            v[t] = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int co = 0; co < CO; ++co) {
+                acc[t][0][co] += v[t].x * d[co]; acc[t][1][co] += v[t].y * d[co];
+                acc[t][2][co] += v[t].z * d[co]; acc[t][3][co] += v[t].w * d[co];
+            }
+    }
+    // fold the pixel groups of a wave (lanes with equal sub), then the four waves through LDS
+#pragma unroll
+    for (int off = LP; off < 64; off <<= 1) {
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            bacc[co] += __shfl_xor(bacc[co], off, 64);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][j][co] += __shfl_xor(acc[t][j][co], off, 64);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < LP) {
+        float* dst = sk_sh + ((long)wave * LP + sub) * (PER + CO + 1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int co = 0; co < CO; ++co) dst[(t * 4 + j) * CO + co] = acc[t][j][co];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) dst[PER + co] = bacc[co];
+    }
+    __syncthreads();
+    float* pout = part + (long)blockIdx.x * 9 * Cin * CO;
+    for (int idx = threadIdx.x; idx < LP * PER; idx += 256) {
+        const int sb = idx / PER, r = idx % PER;           // r = (t*4+j)*CO+co
+        const int co = r % CO, tj = r / CO, t = tj >> 2, j = tj & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) s += sk_sh[((long)wv * LP + sb) * (PER + CO + 1) + r];
+        pout[((long)t * Cin + sb * 4 + j) * CO + co] = s;
+    }
+    if (bias_part && threadIdx.x < CO) {
+        float s = 0.f;
+        // every lane group saw the same dy values of its own pixels; sub == 0 of each wave holds the wave total
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) s += sk_sh[((long)wv * LP + 0) * (PER + CO + 1) + PER + threadIdx.x];
+        bias_part[(long)blockIdx.x * CO + threadIdx.x] = s;
+    }
+}
+
 // ---- host-side dispatch -----------------------------------------------------
 struct TileCfg { int bm, bn; };
 
@@ -1062,6 +1208,36 @@ static size_t tn_ws_bytes(const Geom& g, const TNPlan& p, int ngroups) {
     return (size_t)p.splits * ngroups * g.nphase * ((size_t)g.Ktot + 1) * g.Cout * sizeof(float);
 }
 
+// ---- skinny 3x3 path (see skinny_conv3x3_kernel) ----
+constexpr int kSkinnyWgradBlocks = 512;
+static bool skinny_ok(int ngroups, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("CG_SKINNY"); on = e ? atoi(e) : 1; }
+    return on && ngroups == 1 && ups == 0 && kH == 3 && kW == 3 && padH == 1 && padW == 1 && (Cout == 3 || Cout == 1) &&
+           (Cin == 64 || Cin == 128);
+}
+static size_t skinny_wgrad_ws_bytes(int Cin, int Cout) {
+    return (size_t)kSkinnyWgradBlocks * (9 * (size_t)Cin + 1) * Cout * sizeof(float);
+}
+template <int CO>
+static void skinny_forward_launch(hipStream_t st, const float* x, const float* w, const float* bias, float* y, int N, int H,
+                                  int W, int Cin) {
+    const long npix = (long)N * H * W;
+    const int lp = Cin / 4;
+    long blocks = (npix * lp + 255) / 256;
+    if (blocks > cg::kNumCU * 2) blocks = cg::kNumCU * 2;
+    if (lp == 32) hipLaunchKernelGGL((skinny_conv3x3_kernel<CO, 32>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, bias, y, N, H, W);
+    else hipLaunchKernelGGL((skinny_conv3x3_kernel<CO, 16>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, bias, y, N, H, W);
+}
+template <int CO>
+static void skinny_wgrad_launch(hipStream_t st, const float* x, const float* dy, float* part, float* bias_part, int N, int H,
+                                int W, int Cin, int blocks, long ppb) {
+    const int lp = Cin / 4;
+    const size_t shb = (size_t)4 * lp * (36 * CO + CO + 1) * sizeof(float);
+    if (lp == 32) hipLaunchKernelGGL((skinny_wgrad3x3_kernel<CO, 32>), dim3(blocks), dim3(256), shb, st, x, dy, part, bias_part, N, H, W, ppb);
+    else hipLaunchKernelGGL((skinny_wgrad3x3_kernel<CO, 16>), dim3(blocks), dim3(256), shb, st, x, dy, part, bias_part, N, H, W, ppb);
+}
+
 static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const* x, const float* const* w,
                   const float* const* bias, float* const* y, void* ws, size_t ws_bytes, const char* who) {
     CG_REQUIRE(ngroups >= 1 && ngroups <= MAXG, "%s: 1..%d groups per launch", who, MAXG);
@@ -1135,15 +1311,21 @@ int cg_conv2d_forward_grouped(void* stream, int ngroups, const float* const* x, 
     CG_REQUIRE(x && wpk && y, "cg_conv2d_forward_grouped: null pointer");
     Geom g;
     if (conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
+    if (skinny_ok(ngroups, Cin, Cout, kH, kW, padH, padW, ups) && x[0] && wpk[0] && y[0] && (uintptr_t)x[0] % 16 == 0 &&
+        (long)N * Hp * Wp < 0x7fffffffL) {
+        const float* b0 = bias ? bias[0] : nullptr;
+        if (Cout == 3) skinny_forward_launch<3>(cg::S(stream), x[0], wpk[0], b0, y[0], N, Hp, Wp, Cin);
+        else skinny_forward_launch<1>(cg::S(stream), x[0], wpk[0], b0, y[0], N, Hp, Wp, Cin);
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
     return run_nn(cg::S(stream), g, ngroups, x, wpk, bias, y, ws, ws_bytes, "cg_conv2d_forward_grouped");
 }
 
 int cg_conv2d_forward(void* stream, const float* x, const float* wpk, const float* bias, float* y, int N, int Hp, int Wp,
                       int Cin, int Cout, int kH, int kW, int padH, int padW, int ups, void* ws, size_t ws_bytes) {
-    CG_REQUIRE(x && wpk && y, "cg_conv2d_forward: null pointer");
-    Geom g;
-    if (conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
-    return run_nn(cg::S(stream), g, 1, &x, &wpk, bias ? &bias : nullptr, &y, ws, ws_bytes, "cg_conv2d_forward");
+    return cg_conv2d_forward_grouped(stream, 1, &x, &wpk, bias ? &bias : nullptr, &y, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW,
+                                     ups, ws, ws_bytes);
 }
 
 size_t cg_conv2d_dgrad_ups2_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int k, int pad) {
@@ -1166,7 +1348,8 @@ size_t cg_conv2d_wgrad_workspace_bytes_grouped(int ngroups, int N, int Hp, int W
                                                int padH, int padW, int ups) {
     Geom g;
     if (ngroups < 1 || ngroups > MAXG || conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
-    return tn_ws_bytes(g, plan_tn(g, ngroups), ngroups);
+    const size_t reg = tn_ws_bytes(g, plan_tn(g, ngroups), ngroups);
+    return skinny_ok(ngroups, Cin, Cout, kH, kW, padH, padW, ups) ? std::max(reg, skinny_wgrad_ws_bytes(Cin, Cout)) : reg;
 }
 size_t cg_conv2d_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW,
                                        int ups) {
@@ -1182,6 +1365,28 @@ int cg_conv2d_wgrad_grouped(void* stream, int ngroups, const float* const* x, co
     memset(&a, 0, sizeof(a));
     if (conv_geom(a.g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
     const Geom& g = a.g;
+    if (skinny_ok(ngroups, Cin, Cout, kH, kW, padH, padW, ups) && x[0] && dy[0] && gw[0] && (uintptr_t)x[0] % 16 == 0 && ws &&
+        ws_bytes >= skinny_wgrad_ws_bytes(Cin, Cout) && (long)N * Hp * Wp < 0x7fffffffL) {
+        hipStream_t st = cg::S(stream);
+        const long npix = (long)N * Hp * Wp;
+        const long ppb = (npix + kSkinnyWgradBlocks - 1) / kSkinnyWgradBlocks;
+        const int blocks = (int)((npix + ppb - 1) / ppb);
+        float* part = (float*)ws;
+        float* bpart = part + (size_t)kSkinnyWgradBlocks * 9 * Cin * Cout;
+        float* gb0 = gb ? gb[0] : nullptr;
+        if (Cout == 3) skinny_wgrad_launch<3>(st, x[0], dy[0], part, gb0 ? bpart : nullptr, N, Hp, Wp, Cin, blocks, ppb);
+        else skinny_wgrad_launch<1>(st, x[0], dy[0], part, gb0 ? bpart : nullptr, N, Hp, Wp, Cin, blocks, ppb);
+        CG_LAUNCH_CHECK();
+        RedPtrs rp;
+        memset(&rp, 0, sizeof(rp));
+        rp.gw0 = gw[0]; rp.gb0 = gb0;
+        const int wblocks = cg::cdiv(9L * Cin * Cout, 32), bblocks = gb0 ? cg::cdiv(Cout, 32) : 0;
+        hipLaunchKernelGGL(wgrad_reduce_small_kernel<false>, dim3(wblocks + bblocks, 1), dim3(256), 0, st, (const float*)part,
+                           (const float*)bpart, rp, Cin, Cout, 3, 9, 1, 0, blocks, 1, scale, 9L * Cin * Cout, 0L, (long)Cout,
+                           wblocks);
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
     TNPlan p = plan_tn(g, ngroups);
     const size_t need = tn_ws_bytes(g, p, ngroups);
     CG_REQUIRE(ws && ws_bytes >= need, "cg_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
