@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcatgan_hip.so")
-SOURCES = ["gemm.hip", "ops.hip"]
+SOURCES = ["gemm.hip", "winograd.hip", "ops.hip"]
 ARCH = "gfx950"
 
 

@@ -1,0 +1,338 @@
+// Winograd F(2x2,3x3) for nn.SpatialUpSamplingNearest(2) -> 5x5 convolution (models.lua:217-218, G's
+// 256 -> 128 layer: 60 % of the generator's FLOPs).
+//
+// After the phase folding of gemm.hip, output phase (a,b) of that layer is a plain 3x3 / pad-1 convolution of the
+// LOW-RESOLUTION input with the phase-summed kernel g_p (both phases of a 5-tap axis reach rows i-1..i+1).  All
+// four phases therefore share their 4x4 input tiles, and each is computed as
+//     Y_p = A^T [ (G g_p G^T) .* (B^T d B) ] A            (Lavin & Gray, F(2x2,3x3): 16 multiplies per 4 outputs
+// instead of 36, i.e. 2.25x fewer MFMA FLOPs on top of the 2.78x of the phase folding)
+// as 16 GEMMs  M_xi[tile][co] = sum_ci V_xi[tile][ci] U_p,xi[ci][co]  whose output transform happens in registers:
+// one workgroup walks xi = 0..15 for its (tile block, co block, phase), folding every finished M_xi into the four
+// output accumulators with the +-1/0 coefficients of A^T (x) A^T.  Nothing Winograd-domain but V is ever written.
+//
+// The data gradient w.r.t. the low-res input is the same machinery on dy: one 3x3 convolution with 4*Cout input
+// planes (the four phase sub-lattices of dy) and flipped kernels.  The weight gradient is taken in the Winograd
+// domain (dU_xi = V_xi^T (A dY A^T)_xi, 16 plain TN GEMMs through cg_conv2d_wgrad) and brought back by G^T . G.
+//
+// Numerics: exact-fp32 MFMA as everywhere; the transforms add a few ulp (entries 0, +-1, +-1/2), the parity
+// tests hold the layer to the same 2e-5*sqrt(K/1024) bound as the direct path.
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// ---------------------------------------------------------------------------
+// V[xi][tile][c] = (B^T d B)[xi] of the 4x4 patch around tile (n, ti, tj): rows 2ti-1 .. 2ti+2.
+// MODE 0: d from a plain NHWC tensor [N][Hl][Wl][C].
+// MODE 1: d from the phase sub-lattices of dy [N][2Hl][2Wl][Cs]: channel c = p*Cs + co reads dy[2i+a][2j+b][co].
+// One thread per (tile, channel quad): 16 float4 loads, 16 float4 stores, coalesced along the channels.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* __restrict__ src, float* __restrict__ V,
+                                                                   int N, int Hl, int Wl, int C, int Cs) {
+    const int cq_n = C >> 2;
+    const int tH = Hl >> 1, tW = Wl >> 1;
+    const long T = (long)N * tH * tW;
+    const long total = T * cq_n;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+        const int cq = (int)(idx % cq_n);
+        const long tile = idx / cq_n;
+        const int tj = (int)(tile % tW);
+        const int ti = (int)((tile / tW) % tH);
+        const long n = tile / ((long)tW * tH);
+        int pa = 0, pb = 0, cs = cq * 4;
+        if (MODE == 1) {
+            const int p = cs / Cs;
+            cs -= p * Cs;
+            pa = p >> 1; pb = p & 1;
+        }
+        float4 d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int iy = 2 * ti - 1 + r, ix = 2 * tj - 1 + c;
+                const bool ok = iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
+                const int cy = min(max(iy, 0), Hl - 1), cx = min(max(ix, 0), Wl - 1);
+                const float* ptr = MODE == 0 ? src + ((n * Hl + cy) * (long)Wl + cx) * C + cs
+                                             : src + ((n * 2 * Hl + 2 * cy + pa) * (long)(2 * Wl) + 2 * cx + pb) * Cs + cs;
+                const float4 q = ld4(ptr);
+                d[r][c] = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        float4 t[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {  // B^T d
+            t[0][c] = f4sub(d[0][c], d[2][c]);
+            t[1][c] = f4add(d[1][c], d[2][c]);
+            t[2][c] = f4sub(d[2][c], d[1][c]);
+            t[3][c] = f4sub(d[1][c], d[3][c]);
+        }
+        float* out = V + tile * C + cq * 4;
+        const long xs = T * C;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // (.) B
+            *reinterpret_cast<float4*>(out + (r * 4 + 0) * xs) = f4sub(t[r][0], t[r][2]);
+            *reinterpret_cast<float4*>(out + (r * 4 + 1) * xs) = f4add(t[r][1], t[r][2]);
+            *reinterpret_cast<float4*>(out + (r * 4 + 2) * xs) = f4sub(t[r][2], t[r][1]);
+            *reinterpret_cast<float4*>(out + (r * 4 + 3) * xs) = f4sub(t[r][1], t[r][3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// U = G g G^T of the phase kernels.
+// FWD: src = wf_ph [p][tp][ci][co]  ->  U[p][xi][ci][co]
+// BWD: src = wb_ph [p][tp][co][ci]  ->  U[xi][p*Cout+co][ci] of the FLIPPED kernel (data gradient operand)
+// One thread per (p, row, column quad) of the [rows][cols] plane (rows x cols = Cin x Cout or Cout x Cin).
+// ---------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void wino_filter_transform_kernel(const float* __restrict__ src, float* __restrict__ U,
+                                                                    int rows, int cols) {
+    const int cqn = cols >> 2;
+    const long plane = (long)rows * cols;
+    const long total = 4L * rows * cqn;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+        const int cq = (int)(idx % cqn);
+        const int row = (int)((idx / cqn) % rows);
+        const int p = (int)(idx / ((long)cqn * rows));
+        float4 g[3][3];
+#pragma unroll
+        for (int ry = 0; ry < 3; ++ry)
+#pragma unroll
+            for (int rx = 0; rx < 3; ++rx) {
+                const int tp = BWD ? (2 - ry) * 3 + (2 - rx) : ry * 3 + rx;
+                g[ry][rx] = ld4(src + ((long)p * 9 + tp) * plane + (long)row * cols + cq * 4);
+            }
+        float4 t[4][3];  // G g
+#pragma unroll
+        for (int rx = 0; rx < 3; ++rx) {
+            const float4 s = f4add(g[0][rx], g[2][rx]);
+            t[0][rx] = g[0][rx];
+            t[1][rx] = make_float4(0.5f * (s.x + g[1][rx].x), 0.5f * (s.y + g[1][rx].y), 0.5f * (s.z + g[1][rx].z), 0.5f * (s.w + g[1][rx].w));
+            t[2][rx] = make_float4(0.5f * (s.x - g[1][rx].x), 0.5f * (s.y - g[1][rx].y), 0.5f * (s.z - g[1][rx].z), 0.5f * (s.w - g[1][rx].w));
+            t[3][rx] = g[2][rx];
+        }
+#pragma unroll
+        for (int xy = 0; xy < 4; ++xy) {
+            const float4 s = f4add(t[xy][0], t[xy][2]);
+            float4 o[4];
+            o[0] = t[xy][0];
+            o[1] = make_float4(0.5f * (s.x + t[xy][1].x), 0.5f * (s.y + t[xy][1].y), 0.5f * (s.z + t[xy][1].z), 0.5f * (s.w + t[xy][1].w));
+            o[2] = make_float4(0.5f * (s.x - t[xy][1].x), 0.5f * (s.y - t[xy][1].y), 0.5f * (s.z - t[xy][1].z), 0.5f * (s.w - t[xy][1].w));
+            o[3] = t[xy][2];
+#pragma unroll
+            for (int xx = 0; xx < 4; ++xx) {
+                const int xi = xy * 4 + xx;
+                float* dst = BWD ? U + ((long)xi * 4 * rows + (long)p * rows + row) * cols + cq * 4
+                                 : U + (((long)p * 16 + xi) * rows + row) * cols + cq * 4;
+                *reinterpret_cast<float4*>(dst) = o[xx];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The 16 GEMMs + output transform.  Block tile 64 tiles x 128 columns, K step 16, 4 waves of 32 x 64.
+// grid = (T/64 * Nc/128, 1, P).  LDS: A [k][m] XOR-swizzled, B [k][n], double buffered (same scheme as gemm.hip).
+// ---------------------------------------------------------------------------
+struct WinoArgs {
+    const float* V;      // [16][T][K]
+    const float* U;      // [P][16][K][Nc]
+    const float* bias;   // [Nc] or null
+    float* y;            // [N][Ho][Wo][Nc]
+    int T, K, Nc;
+    int tH, tW;          // tiles per image
+    int so;              // 2: output pixel (2i+a, 2j+b) of phase (a,b) = blockIdx.z; 1: pixel (i, j)
+    int Ho, Wo;
+};
+
+__global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoArgs a) {
+    constexpr int BM = 64, BN = 128, BK = 16;
+    constexpr int A_TILE = BK * BM, B_TILE = BK * BN;
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_TILE + 2 * B_TILE];
+    float* As = smem;
+    float* Bs = smem + 2 * A_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm0 = (wave & 1) * 32, wn0 = (wave >> 1) * 64;
+    const int ntn = a.Nc / BN;
+    const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int phase = blockIdx.z;
+    const int KT = a.K / BK, IT = 16 * KT;
+
+    // staging: A one float4 per thread (row a_r, k quad a_kv); B two float4 per thread
+    const int a_r = tid >> 2, a_kv = tid & 3;
+    const int a_row = min(m0 + a_r, a.T - 1);
+    const int b_kr = tid >> 5, b_nv = tid & 31;
+    const float* Ap = a.V + (long)a_row * a.K + 4 * a_kv;
+    const float* Bp = a.U + (long)phase * 16 * a.K * a.Nc + (long)b_kr * a.Nc + n0 + 4 * b_nv;
+    const long a_xi = (long)a.T * a.K;            // V stride between xi
+    const long b_half = 8L * a.Nc;                // second B float4: k row + 8
+    float4 areg, breg0, breg1;
+    auto load_tile = [&](int it) {
+        const int xi = it / KT, k0 = (it - xi * KT) * BK;
+        areg = ld4(Ap + xi * a_xi + k0);
+        const float* bp = Bp + ((long)xi * a.K + k0) * a.Nc;
+        breg0 = ld4(bp);
+        breg1 = ld4(bp + b_half);
+    };
+    auto store_tile = [&](int buf) {
+        float* A = As + buf * A_TILE;
+        float* B = Bs + buf * B_TILE;
+        const int rs = a_r ^ ((a_kv & 3) << 3);
+        A[(4 * a_kv + 0) * BM + rs] = areg.x;
+        A[(4 * a_kv + 1) * BM + rs] = areg.y;
+        A[(4 * a_kv + 2) * BM + rs] = areg.z;
+        A[(4 * a_kv + 3) * BM + rs] = areg.w;
+        *reinterpret_cast<float4*>(B + b_kr * BN + 4 * b_nv) = breg0;
+        *reinterpret_cast<float4*>(B + (b_kr + 8) * BN + 4 * b_nv) = breg1;
+    };
+
+    f32x16 accM[2], accY[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accM[j][r] = 0.f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) accY[o][j][r] = 0.f;
+        }
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int kt = 0, xi = 0;
+    for (int it = 0; it < IT; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < IT) load_tile(it + 1);
+        const float* A = As + buf * A_TILE + wm0;
+        const float* B = Bs + buf * B_TILE + wn0 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float av = A[(kk + h) * BM + (l31 ^ (((kk >> 2) & 3) << 3))];
+            const float b0 = B[(kk + h) * BN], b1 = B[(kk + h) * BN + 32];
+            accM[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, accM[0], 0, 0, 0);
+            accM[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, accM[1], 0, 0, 0);
+        }
+        if (++kt == KT) {  // M_xi complete: fold into the outputs, A^T = [1 1 1 0; 0 1 -1 -1]
+            const int xy = xi >> 2, xx = xi & 3;
+            const float cy0 = xy < 3 ? 1.f : 0.f, cy1 = xy == 0 ? 0.f : (xy == 1 ? 1.f : -1.f);
+            const float cx0 = xx < 3 ? 1.f : 0.f, cx1 = xx == 0 ? 0.f : (xx == 1 ? 1.f : -1.f);
+            const float c00 = cy0 * cx0, c01 = cy0 * cx1, c10 = cy1 * cx0, c11 = cy1 * cx1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float m = accM[j][r];
+                    accY[0][j][r] += c00 * m; accY[1][j][r] += c01 * m;
+                    accY[2][j][r] += c10 * m; accY[3][j][r] += c11 * m;
+                    accM[j][r] = 0.f;
+                }
+            kt = 0; ++xi;
+        }
+        if (it + 1 < IT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*h (tile), j = l31 (column)
+    const int pa = a.so == 2 ? (phase >> 1) : 0, pb = a.so == 2 ? (phase & 1) : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= a.T) continue;
+        const int tj = m % a.tW;
+        const int ti = (m / a.tW) % a.tH;
+        const long n = m / (a.tW * a.tH);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int oy = (2 * ti + (o >> 1)) * a.so + pa, ox = (2 * tj + (o & 1)) * a.so + pb;
+            float* row = a.y + ((n * a.Ho + oy) * (long)a.Wo + ox) * a.Nc + n0 + wn0 + l31;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) row[j * 32] = accY[o][j][r] + (a.bias ? a.bias[n0 + wn0 + j * 32 + l31] : 0.f);
+        }
+    }
+}
+
+static bool wino_dims_ok(int N, int Hp, int Wp, int Cin, int Cout) {
+    return N > 0 && Hp > 0 && Wp > 0 && (Hp & 1) == 0 && (Wp & 1) == 0 && Cin > 0 && Cout > 0 && Cin % 128 == 0 &&
+           Cout % 128 == 0 && (long)N * Hp * Wp * std::max(Cin, 4 * Cout) * 4L < (1L << 40);
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 if the Winograd path covers upsample2 -> conv 5x5 (pad 2) at these dimensions
+size_t cg_conv2d_ups2_wino_supported(int N, int Hp, int Wp, int Cin, int Cout, int k, int pad) {
+    return k == 5 && pad == 2 && wino_dims_ok(N, Hp, Wp, Cin, Cout) ? 1 : 0;
+}
+size_t cg_conv2d_ups2_wino_v_floats(int N, int Hp, int Wp, int C) {  // C = Cin (forward) or 4*Cout (data gradient)
+    return (size_t)16 * ((size_t)N * (Hp / 2) * (Wp / 2)) * C;
+}
+size_t cg_conv2d_ups2_wino_u_floats(int Cin, int Cout) { return (size_t)4 * 16 * Cin * Cout; }
+
+int cg_conv2d_ups2_wino_pack(void* stream, const float* wf_ph, const float* wb_ph, float* u_fwd, float* u_bwd, int Cout,
+                             int Cin) {
+    CG_REQUIRE((wf_ph && u_fwd) || (wb_ph && u_bwd), "cg_conv2d_ups2_wino_pack: null pointer");
+    CG_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "cg_conv2d_ups2_wino_pack: channel counts must be multiples of 4");
+    if (wf_ph && u_fwd) {
+        const long total = 4L * Cin * (Cout / 4);
+        hipLaunchKernelGGL(wino_filter_transform_kernel<false>, dim3(cg::ew_grid(total)), dim3(256), 0, cg::S(stream), wf_ph,
+                           u_fwd, Cin, Cout);
+        CG_LAUNCH_CHECK();
+    }
+    if (wb_ph && u_bwd) {
+        const long total = 4L * Cout * (Cin / 4);
+        hipLaunchKernelGGL(wino_filter_transform_kernel<true>, dim3(cg::ew_grid(total)), dim3(256), 0, cg::S(stream), wb_ph,
+                           u_bwd, Cout, Cin);
+        CG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// y[N][2Hp][2Wp][Cout] = bias + conv5x5(upsample2(x_lo)); v (cg_conv2d_ups2_wino_v_floats(..., Cin) floats) receives
+// the transformed input and is what the weight gradient consumes later.
+int cg_conv2d_ups2_wino_forward(void* stream, const float* x_lo, const float* u_fwd, const float* bias, float* y, float* v,
+                                int N, int Hp, int Wp, int Cin, int Cout) {
+    CG_REQUIRE(x_lo && u_fwd && y && v, "cg_conv2d_ups2_wino_forward: null pointer");
+    CG_REQUIRE(wino_dims_ok(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino_forward: unsupported dimensions");
+    hipStream_t st = cg::S(stream);
+    const int T = N * (Hp / 2) * (Wp / 2);
+    hipLaunchKernelGGL(wino_input_transform_kernel<0>, dim3(cg::ew_grid((long)T * (Cin / 4))), dim3(256), 0, st, x_lo, v, N, Hp,
+                       Wp, Cin, Cin);
+    CG_LAUNCH_CHECK();
+    WinoArgs a;
+    a.V = v; a.U = u_fwd; a.bias = bias; a.y = y;
+    a.T = T; a.K = Cin; a.Nc = Cout; a.tH = Hp / 2; a.tW = Wp / 2; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp;
+    hipLaunchKernelGGL(wino_gemm_kernel, dim3(cg::cdiv(T, 64) * (Cout / 128), 1, 4), dim3(256), 0, st, a);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx_lo[N][Hp][Wp][Cin] = gradient w.r.t. the low-res input (the upsampling's 2x2 block sum folded in);
+// v_dy: scratch of cg_conv2d_ups2_wino_v_floats(..., 4*Cout) floats.
+int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy, int N, int Hp,
+                              int Wp, int Cin, int Cout) {
+    CG_REQUIRE(dy && u_bwd && dx_lo && v_dy, "cg_conv2d_ups2_wino_dgrad: null pointer");
+    CG_REQUIRE(wino_dims_ok(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino_dgrad: unsupported dimensions");
+    hipStream_t st = cg::S(stream);
+    const int T = N * (Hp / 2) * (Wp / 2);
+    hipLaunchKernelGGL(wino_input_transform_kernel<1>, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, st, dy, v_dy, N, Hp, Wp,
+                       4 * Cout, Cout);
+    CG_LAUNCH_CHECK();
+    WinoArgs a;
+    a.V = v_dy; a.U = u_bwd; a.bias = nullptr; a.y = dx_lo;
+    a.T = T; a.K = 4 * Cout; a.Nc = Cin; a.tH = Hp / 2; a.tW = Wp / 2; a.so = 1; a.Ho = Hp; a.Wo = Wp;
+    hipLaunchKernelGGL(wino_gemm_kernel, dim3(cg::cdiv(T, 64) * (Cin / 128), 1, 1), dim3(256), 0, st, a);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

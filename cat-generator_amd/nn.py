@@ -12,6 +12,8 @@ Nothing here computes: every method is one or more launches through the ABI.
 Feature maps stay NHWC between modules; nn.View / nn.Transpose / nn.Copy are
 the points where the logical Torch7 layout is (re)established.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -541,6 +543,13 @@ class _GemmLayer(Module):
         lib().pack_conv_weight_ups2(stream(), self.weight.ptr, self._wf_ph.data_ptr(), self._wb_ph.data_ptr(), Cout, Cin,
                                     kH, (kH - 1) // 2)
         self._ph_epoch, self._ph_ptr = ep, self.weight.ptr
+        if getattr(self, "_wino", False):  # Winograd-domain phase kernels (winograd.hip), same refresh rule
+            nu = lib().conv2d_ups2_wino_u_floats(Cin, Cout)
+            if getattr(self, "_u_fwd", None) is None or self._u_fwd.numel() != nu:
+                self._u_fwd = torch.empty(nu, dtype=torch.float32, device=self.weight.t.device)
+                self._u_bwd = torch.empty(nu, dtype=torch.float32, device=self.weight.t.device)
+            lib().conv2d_ups2_wino_pack(stream(), self._wf_ph.data_ptr(), self._wb_ph.data_ptr(), self._u_fwd.data_ptr(),
+                                        self._u_bwd.data_ptr(), Cout, Cin)
 
     def _wb_ptr(self):
         # 1x1 / linear: the canonical [out][in] matrix already is the backward operand [K=out][N=in]
@@ -681,6 +690,32 @@ class SpatialConvolution(_GemmLayer):
     def _can_fold_ups(self):
         return self.kH == self.kW and self.kH % 2 == 1 and self.padH == self.padW == (self.kH - 1) // 2
 
+    winograd = os.environ.get("CG_WINOGRAD", "1") != "0"   # F(2x2,3x3) on the phase convolutions of upsample2 -> conv5x5
+
+    def _use_wino(self, x):
+        """Winograd path (csrc/winograd.hip) for a lazily upsampled input: 5x5, pad 2, even low-res grid, planes % 128."""
+        if not (self.winograd and x.ups and self.kH == self.kW == 5 and self.padH == self.padW == 2):
+            return False
+        N, Hp, Wp, _, _ = self._geom(x)
+        ok = bool(lib().conv2d_ups2_wino_supported(N, Hp, Wp, self.nInputPlane, self.nOutputPlane, 5, 2))
+        if ok and not getattr(self, "_wino", False):
+            self._wino = True
+            self._ph_epoch = None   # repack, this time with the Winograd-domain copies
+        return ok
+
+    def updateOutput(self, input):
+        x = as_nhwc(to_device(input), keep_ups=True)
+        if not self._use_wino(x):
+            return super().updateOutput(x)
+        N, Hp, Wp, Ho, Wo = self._geom(x)
+        self._ensure_packed_ups()
+        out = self._get("out", (N, self.nOutputPlane, Ho, Wo), "nhwc")
+        v = self._get("wino_v", (lib().conv2d_ups2_wino_v_floats(N, Hp, Wp, self.nInputPlane),))
+        lib().conv2d_ups2_wino_forward(stream(), x.ptr, self._u_fwd.data_ptr(), self.bias.ptr, out.ptr, v.ptr, N, Hp, Wp,
+                                       self.nInputPlane, self.nOutputPlane)
+        self._x, self.output = x, out
+        return out
+
     def _prep_fwd(self, input):
         x = as_nhwc(to_device(input), keep_ups=True)
         if x.ups and not self._can_fold_ups():
@@ -720,6 +755,12 @@ class SpatialConvolution(_GemmLayer):
             Hp, Wp = Hl >> 1, Wl >> 1
             lo = self._get("gin_lo", (N, self.nInputPlane, Hp, Wp), "nhwc")
             k, pad = self.kH, self.padH
+            if self._use_wino(x):
+                vdy = self._get("wino_vdy", (lib().conv2d_ups2_wino_v_floats(N, Hp, Wp, 4 * self.nOutputPlane),))
+                lib().conv2d_ups2_wino_dgrad(stream(), dy.ptr, self._u_bwd.data_ptr(), lo.ptr, vdy.ptr, N, Hp, Wp,
+                                             self.nInputPlane, self.nOutputPlane)
+                self.gradInput = Tensor(lo.t, (N, self.nInputPlane, Hl, Wl), "nhwc", 1)
+                return self.gradInput
             ws, wsb = WS.get(lib().conv2d_dgrad_ups2_workspace_bytes(N, Hp, Wp, self.nInputPlane, self.nOutputPlane, k, pad))
             lib().conv2d_dgrad_ups2(stream(), dy.ptr, self._wb_ph.data_ptr(), lo.ptr, N, Hp, Wp, self.nInputPlane,
                                     self.nOutputPlane, k, pad, ws, wsb)

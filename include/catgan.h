@@ -130,6 +130,22 @@ size_t cg_pack_conv_weight_ups2_floats(int Cout, int Cin, int k, int pad);
 int cg_pack_conv_weight_ups2(void* stream, const float* w_canonical, float* wf_ph, float* wb_ph,
                              int Cout, int Cin, int k, int pad);
 
+/* ---- Winograd F(2x2,3x3) path for upsample2 -> conv 5x5 pad 2 (models.lua:217-218) ------------------------
+ * Each output phase of that layer is a 3x3 convolution of the low-res input (see cg_pack_conv_weight_ups2);
+ * the four phases share their input tiles.  u_fwd / u_bwd: Winograd-domain phase kernels (from wf_ph / wb_ph,
+ * cg_conv2d_ups2_wino_u_floats() floats each); v: transformed input, cg_conv2d_ups2_wino_v_floats(N,Hp,Wp,C)
+ * floats with C = Cin (forward; kept for the weight gradient) or 4*Cout (data gradient scratch).
+ * Same results as cg_conv2d_forward(ups=1) / cg_conv2d_dgrad_ups2 up to fp32 re-association. */
+size_t cg_conv2d_ups2_wino_supported(int N, int Hp, int Wp, int Cin, int Cout, int k, int pad);
+size_t cg_conv2d_ups2_wino_v_floats(int N, int Hp, int Wp, int C);
+size_t cg_conv2d_ups2_wino_u_floats(int Cin, int Cout);
+int cg_conv2d_ups2_wino_pack(void* stream, const float* wf_ph, const float* wb_ph, float* u_fwd, float* u_bwd,
+                             int Cout, int Cin);
+int cg_conv2d_ups2_wino_forward(void* stream, const float* x_lo, const float* u_fwd, const float* bias, float* y,
+                                float* v, int N, int Hp, int Wp, int Cin, int Cout);
+int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy,
+                              int N, int Hp, int Wp, int Cin, int Cout);
+
 /* ---- activations --------------------------------------------------------
  * nn.PReLU(nil,nil,true): one shared slope (models.lua:201,208,214,220,647..698).
  * y = x>0 ? x : a*x ; dx = x>0 ? dy : a*dy ; *galpha += scale*sum_{x<=0} x*dy. */

@@ -56,6 +56,7 @@ CONV_CASES = [
     (2, 512, 4, 4, 512, 3, 1),   # G conv1 with folded upsampling (models.lua:205-206), split-K
     (1, 256, 16, 16, 128, 5, 1), # G conv3 (models.lua:217-218)
     (3, 16, 3, 5, 8, 3, 1),      # folded upsampling on a ragged, non-power-of-two grid
+    (3, 128, 6, 4, 128, 5, 1),   # Winograd F(2x2,3x3) path (planes % 128, even grid), ragged tile count, borders
     (2, 8, 4, 4, 4, 5, 1),       # 5x5 phases through the generic (Cin % 16 != 0) gather
     (2, 32, 4, 4, 32, 7, 1),     # 7x7 -> 4x4 phase kernels
     (2, 128, 32, 32, 3, 3, 0),   # G conv4, Cout = 3 (models.lua:222)
@@ -95,6 +96,32 @@ def test_spatial_convolution_fwd_bwd(cg, N, Cin, H, W, Cout, k, ups):
         g_lo = up.updateGradInput(None, m.gradInput).numpy()
         ref = O.UpSample2().backward(O.conv2d_backward_data(dy, w, xl.shape, pad))
         close(g_lo, ref, K=4 * Cout * k * k, what="upsample backward")
+
+
+def test_winograd_path_matches_direct_phase_path(cg):
+    """csrc/winograd.hip vs the direct phase-folded kernels on G's 5x5 layer shape (models.lua:217-218)."""
+    rs = np.random.RandomState(5)
+    N, Cin, H, Cout = 4, 256, 16, 128
+    x = cg.Tensor.from_numpy(rs.randn(N, Cin, H, H).astype(f32))
+    dy = cg.Tensor.from_numpy(rs.randn(N, Cout, 2 * H, 2 * H).astype(f32))
+    res = {}
+    for wino in (True, False):
+        cg.nn.SpatialConvolution.winograd = wino
+        try:
+            m = cg.nn.SpatialConvolution(Cin, Cout, 5, 5, 1, 1, 2)
+            m.weight.copy((np.random.RandomState(6).randn(Cout, Cin, 5, 5) / 80).astype(f32))
+            m.bias.copy(np.random.RandomState(7).randn(Cout).astype(f32))
+            up = cg.nn.SpatialUpSamplingNearest(2)
+            y = m.forward(up.forward(x)).numpy()
+            m.gradWeight.zero(); m.gradBias.zero()
+            gi = up.updateGradInput(None, m.backward(up.output, dy)).numpy()
+            assert bool(getattr(m, "_wino", False)) == wino
+            res[wino] = (y, gi, m.gradWeight.numpy(), m.gradBias.numpy())
+        finally:
+            cg.nn.SpatialConvolution.winograd = True
+    for a, b, K, what in zip(res[True], res[False], (Cin * 9, 4 * Cout * 9, N * 4 * H * H, N * 4 * H * H),
+                             ("output", "gradInput", "gradWeight", "gradBias")):
+        close(a, b, K=K, what=f"winograd vs direct: {what}")
 
 
 @pytest.mark.parametrize("N,i,o", [(128, 100, 8192), (6, 20480, 256), (5, 64, 4), (3, 256, 1), (64, 1024, 64)])
