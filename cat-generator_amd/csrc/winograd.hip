@@ -260,6 +260,94 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradient, Winograd domain.  dM = A dY_p A^T per tile and phase (A = [1 0; 1 1; 1 -1; 0 -1]):
+//   Mdy[xi][tile][p*Cout+co]; then dU_xi = V_xi^T Mdy_xi (plain TN GEMMs), and G^T dU G maps back to the 3x3 phase
+//   kernels, whose taps are scattered onto the canonical 5x5 taps exactly like the direct path's reduce.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_dy_transform_kernel(const float* __restrict__ dy, float* __restrict__ Mdy, int N,
+                                                                int Hl, int Wl, int Cout) {
+    const int C = 4 * Cout, cq_n = C >> 2;
+    const int tH = Hl >> 1, tW = Wl >> 1;
+    const long T = (long)N * tH * tW;
+    const long total = T * cq_n;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+        const int cq = (int)(idx % cq_n);
+        const long tile = idx / cq_n;
+        const int tj = (int)(tile % tW);
+        const int ti = (int)((tile / tW) % tH);
+        const long n = tile / ((long)tW * tH);
+        const int p = (cq * 4) / Cout, co = cq * 4 - p * Cout;
+        const int pa = p >> 1, pb = p & 1;
+        float4 e[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+                e[u][v] = ld4(dy + ((n * 2 * Hl + 2 * (2 * ti + u) + pa) * (long)(2 * Wl) + 2 * (2 * tj + v) + pb) * Cout + co);
+        float4 r[4][2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            r[0][v] = e[0][v];
+            r[1][v] = f4add(e[0][v], e[1][v]);
+            r[2][v] = f4sub(e[0][v], e[1][v]);
+            r[3][v] = make_float4(-e[1][v].x, -e[1][v].y, -e[1][v].z, -e[1][v].w);
+        }
+        float* out = Mdy + tile * C + cq * 4;
+        const long xs = T * C;
+#pragma unroll
+        for (int xy = 0; xy < 4; ++xy) {
+            *reinterpret_cast<float4*>(out + (xy * 4 + 0) * xs) = r[xy][0];
+            *reinterpret_cast<float4*>(out + (xy * 4 + 1) * xs) = f4add(r[xy][0], r[xy][1]);
+            *reinterpret_cast<float4*>(out + (xy * 4 + 2) * xs) = f4sub(r[xy][0], r[xy][1]);
+            *reinterpret_cast<float4*>(out + (xy * 4 + 3) * xs) = make_float4(-r[xy][1].x, -r[xy][1].y, -r[xy][1].z, -r[xy][1].w);
+        }
+    }
+}
+
+__device__ __host__ __forceinline__ int wino_phase_map(int a, int d) { return ((a + d - 2) >> 1) - ((a - 2) >> 1); }
+
+// gw[co][ci][5][5] += scale * sum_p (G^T dU_p G)[map_p(dy,dx)];  dUt layout [xi][p*Cout+co][ci].  One thread per (co, ci).
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ dUt, float* __restrict__ gw, int Cout,
+                                                                int Cin, float scale) {
+    const long total = (long)Cout * Cin;
+    const long xs = 4L * Cout * Cin;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+        const int ci = (int)(idx % Cin);
+        const int co = (int)(idx / Cin);
+        float acc[25];
+#pragma unroll
+        for (int t = 0; t < 25; ++t) acc[t] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float u[4][4];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) u[xi >> 2][xi & 3] = dUt[xi * xs + ((long)p * Cout + co) * Cin + ci];
+            float t[3][4];  // G^T u, G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                t[0][c] = u[0][c] + 0.5f * (u[1][c] + u[2][c]);
+                t[1][c] = 0.5f * (u[1][c] - u[2][c]);
+                t[2][c] = 0.5f * (u[1][c] + u[2][c]) + u[3][c];
+            }
+            float g[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                g[r][0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+                g[r][1] = 0.5f * (t[r][1] - t[r][2]);
+                g[r][2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+            }
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 5; ++dx) acc[dy * 5 + dx] += g[wino_phase_map(p >> 1, dy)][wino_phase_map(p & 1, dx)];
+        }
+        float* dst = gw + idx * 25;
+#pragma unroll
+        for (int t = 0; t < 25; ++t) dst[t] += scale * acc[t];
+    }
+}
+
 static bool wino_dims_ok(int N, int Hp, int Wp, int Cin, int Cout) {
     return N > 0 && Hp > 0 && Wp > 0 && (Hp & 1) == 0 && (Wp & 1) == 0 && Cin > 0 && Cout > 0 && Cin % 128 == 0 &&
            Cout % 128 == 0 && (long)N * Hp * Wp * std::max(Cin, 4 * Cout) * 4L < (1L << 40);
@@ -332,6 +420,53 @@ int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd,
     a.T = T; a.K = 4 * Cout; a.Nc = Cin; a.tH = Hp / 2; a.tW = Wp / 2; a.so = 1; a.Ho = Hp; a.Wo = Wp;
     hipLaunchKernelGGL(wino_gemm_kernel, dim3(cg::cdiv(T, 64) * (Cin / 128), 1, 1), dim3(256), 0, st, a);
     CG_LAUNCH_CHECK();
+    return 0;
+}
+
+static size_t wino_align(size_t b) { return (b + 255) / 256 * 256; }
+
+size_t cg_conv2d_ups2_wino_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout) {
+    if (!wino_dims_ok(N, Hp, Wp, Cin, Cout)) return 0;
+    const size_t T = (size_t)N * (Hp / 2) * (Wp / 2);
+    return wino_align(16 * T * 4 * Cout * sizeof(float)) + wino_align((size_t)16 * 4 * Cout * Cin * sizeof(float)) +
+           wino_align(sizeof(double) * Cout) +
+           cg_conv2d_wgrad_workspace_bytes_grouped(4, (int)T, 1, 1, Cin, 4 * Cout, 1, 1, 0, 0, 0);
+}
+
+// gw_canonical[Cout][Cin][5][5] += scale * dW, gb += scale * sum dy, from the transformed input v the forward left behind.
+int cg_conv2d_ups2_wino_wgrad(void* stream, const float* v, const float* dy, float* gw_canonical, float* gb, int N, int Hp,
+                              int Wp, int Cin, int Cout, float scale, void* ws, size_t ws_bytes) {
+    CG_REQUIRE(v && dy && gw_canonical, "cg_conv2d_ups2_wino_wgrad: null pointer");
+    CG_REQUIRE(wino_dims_ok(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino_wgrad: unsupported dimensions");
+    const size_t need = cg_conv2d_ups2_wino_wgrad_workspace_bytes(N, Hp, Wp, Cin, Cout);
+    CG_REQUIRE(ws && ws_bytes >= need && (uintptr_t)ws % 16 == 0, "cg_conv2d_ups2_wino_wgrad: workspace too small (%zu < %zu)",
+               ws_bytes, need);
+    hipStream_t st = cg::S(stream);
+    const int T = N * (Hp / 2) * (Wp / 2);
+    const int C4 = 4 * Cout;
+    char* base = (char*)ws;
+    float* mdy = (float*)base;                    base += wino_align((size_t)16 * T * C4 * sizeof(float));
+    float* dut = (float*)base;                    base += wino_align((size_t)16 * C4 * Cin * sizeof(float));
+    void* bws = base;                             base += wino_align(sizeof(double) * Cout);
+    void* tws = base;
+    const size_t tws_bytes = ws_bytes - (size_t)(base - (char*)ws);
+    hipLaunchKernelGGL(wino_dy_transform_kernel, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, st, dy, mdy, N, Hp, Wp, Cout);
+    CG_LAUNCH_CHECK();
+    CG_HIP(hipMemsetAsync(dut, 0, (size_t)16 * C4 * Cin * sizeof(float), st));
+    for (int q = 0; q < 4; ++q) {  // 16 TN GEMMs dU_xi^T[pco][ci] = sum_tile Mdy_xi[tile][pco] V_xi[tile][ci], four per launch
+        const float* xs[4]; const float* ds[4]; float* gs[4];
+        for (int g = 0; g < 4; ++g) {
+            const long xi = q * 4 + g;
+            xs[g] = v + xi * (long)T * Cin;
+            ds[g] = mdy + xi * (long)T * C4;
+            gs[g] = dut + xi * (long)C4 * Cin;
+        }
+        if (cg_conv2d_wgrad_grouped(stream, 4, xs, ds, gs, nullptr, T, 1, 1, Cin, C4, 1, 1, 0, 0, 0, 1.f, tws, tws_bytes)) return 1;
+    }
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(cg::ew_grid((long)Cout * Cin)), dim3(256), 0, st, dut, gw_canonical, Cout,
+                       Cin, scale);
+    CG_LAUNCH_CHECK();
+    if (gb) return cg_bias_grad(stream, dy, gb, (long)N * 4 * Hp * Wp, Cout, scale, bws, wino_align(sizeof(double) * Cout));
     return 0;
 }
 

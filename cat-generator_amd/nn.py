@@ -691,12 +691,15 @@ class SpatialConvolution(_GemmLayer):
         return self.kH == self.kW and self.kH % 2 == 1 and self.padH == self.padW == (self.kH - 1) // 2
 
     winograd = os.environ.get("CG_WINOGRAD", "1") != "0"   # F(2x2,3x3) on the phase convolutions of upsample2 -> conv5x5
+    winograd_min_tiles = 2048   # below this many 2x2 tiles (N*Hp*Wp/4) the direct kernels win (one workgroup per 64 tiles)
 
     def _use_wino(self, x):
         """Winograd path (csrc/winograd.hip) for a lazily upsampled input: 5x5, pad 2, even low-res grid, planes % 128."""
         if not (self.winograd and x.ups and self.kH == self.kW == 5 and self.padH == self.padW == 2):
             return False
         N, Hp, Wp, _, _ = self._geom(x)
+        if N * Hp * Wp // 4 < self.winograd_min_tiles:
+            return False
         ok = bool(lib().conv2d_ups2_wino_supported(N, Hp, Wp, self.nInputPlane, self.nOutputPlane, 5, 2))
         if ok and not getattr(self, "_wino", False):
             self._wino = True
@@ -729,6 +732,18 @@ class SpatialConvolution(_GemmLayer):
             wf = self._wf.data_ptr()
         out = self._get("out", (N, self.nOutputPlane, Ho, Wo), "nhwc")
         return x, wf, out, (N, Hp, Wp, self.nInputPlane, self.nOutputPlane, self.kH, self.kW, self.padH, self.padW, x.ups)
+
+    def accGradParameters(self, input, gradOutput, scale=1.0):
+        x = self._x
+        if not (x.ups and self._use_wino(x)):
+            return super().accGradParameters(input, gradOutput, scale)
+        # Winograd-domain weight gradient from the transformed input the forward of this batch left in wino_v
+        dy = as_nhwc(gradOutput)
+        N, Hp, Wp, _, _ = self._geom(x)
+        v = self._get("wino_v", (lib().conv2d_ups2_wino_v_floats(N, Hp, Wp, self.nInputPlane),))
+        ws, wsb = WS.get(lib().conv2d_ups2_wino_wgrad_workspace_bytes(N, Hp, Wp, self.nInputPlane, self.nOutputPlane))
+        lib().conv2d_ups2_wino_wgrad(stream(), v.ptr, dy.ptr, self.gradWeight.ptr, self.gradBias.ptr, N, Hp, Wp,
+                                     self.nInputPlane, self.nOutputPlane, float(scale), ws, wsb)
 
     def _prep_gin(self, gradOutput):
         x = self._x

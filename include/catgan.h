@@ -145,6 +145,11 @@ int cg_conv2d_ups2_wino_forward(void* stream, const float* x_lo, const float* u_
                                 float* v, int N, int Hp, int Wp, int Cin, int Cout);
 int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy,
                               int N, int Hp, int Wp, int Cin, int Cout);
+/* accGradParameters in the Winograd domain, from the v the forward wrote: gw_canonical[Cout][Cin][5][5] += scale*dW,
+ * gb (may be NULL) += scale * sum dy.  16 plain weight-gradient GEMMs (cg_conv2d_wgrad_grouped) + G^T . G. */
+size_t cg_conv2d_ups2_wino_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout);
+int cg_conv2d_ups2_wino_wgrad(void* stream, const float* v, const float* dy, float* gw_canonical, float* gb,
+                              int N, int Hp, int Wp, int Cin, int Cout, float scale, void* ws, size_t ws_bytes);
 
 /* ---- activations --------------------------------------------------------
  * nn.PReLU(nil,nil,true): one shared slope (models.lua:201,208,214,220,647..698).

@@ -23,6 +23,7 @@ def cg():
     mod = importlib.import_module("cat-generator_amd")
     assert torch.cuda.is_available(), "these tests need the MI355X"
     mod.lib()  # fails loudly if the HIP extension is missing
+    mod.nn.SpatialConvolution.winograd_min_tiles = 0  # small test shapes must exercise the Winograd kernels too
     return mod
 
 
