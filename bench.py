@@ -43,19 +43,32 @@ def time_kernel(fn, iters=20, warm=3):
 
 
 def dominant_kernel_roofline(cg, N):
-    """The dominant kernel is the implicit-GEMM of G's 5x5 256->128 convolution on the upsampled 32x32 map
-    (models.lua:217-218; 65 % of G's FLOPs): time its forward / data-grad / weight-grad launches in isolation."""
+    """The dominant layer is G's 5x5 256->128 convolution on the upsampled 32x32 map (models.lua:217-218; 65 % of G's
+    FLOPs).  It runs as Winograd F(2x2,3x3) on the four phase convolutions (csrc/winograd.hip); its dominant kernel is
+    wino_gemm_kernel (16 GEMMs + in-register output transform).  Timed in isolation with HIP events on the launch
+    stream: that kernel alone (forward and data-gradient geometry), and the three module-level launch groups."""
+    lib, stream = cg.tensor.lib(), cg.tensor.stream()
     m = cg.nn.SpatialConvolution(256, 128, 5, 5, 1, 1, 2)
     x = cg.Tensor(torch.rand(N * 16 * 16 * 256, device="cuda") - 0.5, (N, 256, 16, 16), "nhwc")
     dy = cg.Tensor(torch.rand(N * 32 * 32 * 128, device="cuda") - 0.5, (N, 128, 32, 32), "nhwc")
     xin = cg.nn.SpatialUpSamplingNearest(2).forward(x)
-    m.forward(xin)
-    flop = 2.0 * N * 32 * 32 * 128 * 256 * 25
-    out = {}
-    out["igemm_nn_fwd"] = time_kernel(lambda: m.updateOutput(xin))
-    out["igemm_nn_dgrad"] = time_kernel(lambda: m.updateGradInput(xin, dy))
-    out["igemm_tn_wgrad"] = time_kernel(lambda: m.accGradParameters(xin, dy))
-    return flop, out
+    y = m.forward(xin)
+    wino = bool(getattr(m, "_wino", False))
+    out = {"layer_fwd": time_kernel(lambda: m.updateOutput(xin)),
+           "layer_dgrad": time_kernel(lambda: m.updateGradInput(xin, dy)),
+           "layer_wgrad": time_kernel(lambda: m.accGradParameters(xin, dy))}
+    if wino:
+        v = m._get("wino_v", (lib.conv2d_ups2_wino_v_floats(N, 16, 16, 256),))
+        vdy = m._get("wino_vdy", (lib.conv2d_ups2_wino_v_floats(N, 16, 16, 512),))
+        gi = m._get("gin_lo", (N, 256, 16, 16), "nhwc")
+        out["wino_gemm_fwd"] = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(
+            stream, v.ptr, m._u_fwd.data_ptr(), m.bias.ptr, y.ptr, N, 16, 16, 256, 128, 0))
+        out["wino_gemm_dgrad"] = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(
+            stream, vdy.ptr, m._u_bwd.data_ptr(), None, gi.ptr, N, 16, 16, 256, 128, 1))
+    flop_direct = 2.0 * N * 32 * 32 * 128 * 256 * 25           # 5x5 taps on the materialised 32x32 map
+    flop_phase = flop_direct * 36.0 / 100.0                     # 4 phases x 3x3 taps per low-res pixel
+    flop_wino = flop_phase * 16.0 / 36.0                        # F(2x2,3x3): 16 multiplies per 2x2 tile instead of 36
+    return wino, {"direct": flop_direct, "phase_folded": flop_phase, "winograd": flop_wino}, out
 
 
 def cpu_baseline(steps=16, N=16):
@@ -155,35 +168,42 @@ def main():
                        "ms_per_sample_reference_unit": 1e3 * dt / args.steps / (N * world / 2)},
             "step_roofline": {"bound": "mfma", "work_gflop_per_image": W_STEP / 1e9,
                               "note": "direct-count necessary work W = 3.5 F_G + 5 F_D (SURVEY.md 8d); the engine "
-                                      "executes ~5.42 GFLOP/image after folding the upsamplings",
+                                      "executes ~4.3 GFLOP/image after folding the upsamplings into phase convolutions "
+                                      "and running the 5x5 layer's phases as Winograd F(2x2,3x3), so this fraction is not "
+                                      "an MFMA utilisation (see `roofline` for the dominant kernel's)",
                               "achieved": per_gpu * W_STEP / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
                               "unit": "TFLOP/s", "frac": per_gpu * W_STEP / PEAK_FP32_MFMA},
             "event_ms_per_step": e0.elapsed_time(e1) / args.steps, "finite": finite,
         }
         if not args.no_kernel_roofline:
-            flop, t = dominant_kernel_roofline(cg, N)
-            # HBM traffic of that launch from the PMC pass committed under profiles/ (2*FETCH_SIZE + WRITE_SIZE,
-            # the gfx950 correction of MI355X_MICROARCH.md); bench.py cannot run rocprofv3 on itself
+            wino, flops, t = dominant_kernel_roofline(cg, N)
+            # HBM traffic / MFMA utilisation of that launch from the PMC pass committed under profiles/
+            # (2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); bench.py cannot run
+            # rocprofv3 on itself
             traffic, util = None, None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_dominant_conv.json")))
-                k = [v for name, v in pmc.items() if "igemm_nn" in name and "grid=262144" in name][0]
-                traffic, util = k["hbm_bytes_per_launch_corrected"], k["mfma_pipe_util"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_dominant_kernel.json")))
+                traffic, util = pmc["hbm_bytes_per_launch_corrected"], pmc["mfma_pipe_util"]
             except Exception:
                 pass
-            # executed FLOPs: the 4-phase form of upsample2 -> conv5x5 runs 4 x 3x3 taps per low-res pixel
-            flop_exec = flop * 36.0 / 100.0
-            res["roofline"] = {"bound": "mfma", "kernel": "igemm_nn_kernel<128,128,2,2,FAST> (G conv5x5 256->128 @32x32 "
-                               "with the 2x nearest upsampling folded in as 4 phase convs, batch %d)" % N,
-                               "achieved": flop_exec / t["igemm_nn_fwd"] / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
-                               "unit": "TFLOP/s", "frac": flop_exec / t["igemm_nn_fwd"] / PEAK_FP32_MFMA,
-                               "traffic": traffic, "mfma_pipe_util_pmc": util,
-                               "note": "achieved/frac count EXECUTED MFMA FLOPs (2.78x fewer than the direct-count "
-                                       "algorithmic FLOPs of the layer); direct-count rate in `tflops_direct`",
-                               "flop_per_launch": flop_exec, "flop_per_launch_direct": flop,
+            if wino:
+                kname, tk_, fl = "wino_gemm_kernel", t["wino_gemm_fwd"], flops["winograd"]
+                what = ("wino_gemm_kernel (winograd.hip): the 16 Winograd-domain GEMMs + in-register output transform of G's "
+                        "upsample2->conv5x5 256->128 layer, forward geometry, batch %d" % N)
+            else:
+                kname, tk_, fl = "igemm_nn_kernel<128,128>", t["layer_fwd"], flops["phase_folded"]
+                what = "igemm_nn_kernel<128,128,2,2,FAST> (phase-folded upsample2->conv5x5 256->128, batch %d)" % N
+            res["roofline"] = {"bound": "mfma", "kernel": what,
+                               "achieved": fl / tk_ / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
+                               "frac": fl / tk_ / PEAK_FP32_MFMA, "traffic": traffic, "mfma_pipe_util_pmc": util,
+                               "note": "achieved/frac count the MFMA FLOPs the kernel EXECUTES; the same launch expressed in "
+                                       "the layer's direct-count FLOPs (5x5 taps on the 32x32 map) is `tflops_direct_equiv`",
+                               "flop_per_launch": fl, "flop_per_launch_direct": flops["direct"],
+                               "flop_per_launch_phase_folded": flops["phase_folded"],
                                "launch_ms": {k: 1e3 * v for k, v in t.items()},
-                               "tflops_direct": {k: flop / v / 1e12 for k, v in t.items()},
-                               "tflops_executed": {k: flop_exec / v / 1e12 for k, v in t.items()}}
+                               "tflops_direct_equiv": flops["direct"] / tk_ / 1e12,
+                               "layer_tflops_direct_equiv": {k: flops["direct"] / v / 1e12 for k, v in t.items()
+                                                             if k.startswith("layer_")}}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

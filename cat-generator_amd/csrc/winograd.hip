@@ -18,6 +18,8 @@
 // tests hold the layer to the same 2e-5*sqrt(K/1024) bound as the direct path.
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -152,52 +154,61 @@ struct WinoArgs {
     int Ho, Wo;
 };
 
-__global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoArgs a) {
-    constexpr int BM = 64, BN = 128, BK = 16;
+template <int NW>   // waves per workgroup: 4 (wave tile 32x64) or 8 (wave tile 32x32: twice the waves per tile for latency hiding)
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(WinoArgs a) {
+    constexpr int BM = 64, BN = 128, BK = 16, NI = 8 / NW;
     constexpr int A_TILE = BK * BM, B_TILE = BK * BN;
     __shared__ __attribute__((aligned(16))) float smem[2 * A_TILE + 2 * B_TILE];
     float* As = smem;
     float* Bs = smem + 2 * A_TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int wm0 = (wave & 1) * 32, wn0 = (wave >> 1) * 64;
+    const int wm0 = (wave & 1) * 32, wn0 = (wave >> 1) * (32 * NI);
     const int ntn = a.Nc / BN;
     const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int phase = blockIdx.z;
-    const int KT = a.K / BK, IT = 16 * KT;
+    const int KT = a.K / BK;
 
     // staging: A one float4 per thread (row a_r, k quad a_kv); B two float4 per thread
-    const int a_r = tid >> 2, a_kv = tid & 3;
+    const int a_r = (tid & 255) >> 2, a_kv = tid & 3;
+    const bool a_thr = tid < 256;                 // NW == 8: the upper four waves stage only B
     const int a_row = min(m0 + a_r, a.T - 1);
-    const int b_kr = tid >> 5, b_nv = tid & 31;
+    const int b_kr = tid >> 5, b_nv = tid & 31;   // NW == 4: k rows b_kr and b_kr + 8; NW == 8: k row b_kr (0..15)
     const float* Ap = a.V + (long)a_row * a.K + 4 * a_kv;
     const float* Bp = a.U + (long)phase * 16 * a.K * a.Nc + (long)b_kr * a.Nc + n0 + 4 * b_nv;
     const long a_xi = (long)a.T * a.K;            // V stride between xi
     const long b_half = 8L * a.Nc;                // second B float4: k row + 8
     float4 areg, breg0, breg1;
-    auto load_tile = [&](int it) {
-        const int xi = it / KT, k0 = (it - xi * KT) * BK;
-        areg = ld4(Ap + xi * a_xi + k0);
-        const float* bp = Bp + ((long)xi * a.K + k0) * a.Nc;
-        breg0 = ld4(bp);
-        breg1 = ld4(bp + b_half);
+    // running operand pointers: U is contiguous over (xi, k), V jumps to the next xi plane after the last K tile
+    const float* Ac = Ap;
+    const float* Bc = Bp;
+    const long b_step = (long)BK * a.Nc;
+    const long a_jump = a_xi - a.K + BK;
+    auto load_next = [&](bool last_kt) {
+        Ac += last_kt ? a_jump : (long)BK;
+        Bc += b_step;
+        if (NW == 4 || a_thr) areg = ld4(Ac);
+        breg0 = ld4(Bc);
+        if (NW == 4) breg1 = ld4(Bc + b_half);
     };
+    const int a_so = a_r ^ ((a_kv & 3) << 3);
     auto store_tile = [&](int buf) {
         float* A = As + buf * A_TILE;
         float* B = Bs + buf * B_TILE;
-        const int rs = a_r ^ ((a_kv & 3) << 3);
-        A[(4 * a_kv + 0) * BM + rs] = areg.x;
-        A[(4 * a_kv + 1) * BM + rs] = areg.y;
-        A[(4 * a_kv + 2) * BM + rs] = areg.z;
-        A[(4 * a_kv + 3) * BM + rs] = areg.w;
+        if (NW == 4 || a_thr) {
+            A[(4 * a_kv + 0) * BM + a_so] = areg.x;
+            A[(4 * a_kv + 1) * BM + a_so] = areg.y;
+            A[(4 * a_kv + 2) * BM + a_so] = areg.z;
+            A[(4 * a_kv + 3) * BM + a_so] = areg.w;
+        }
         *reinterpret_cast<float4*>(B + b_kr * BN + 4 * b_nv) = breg0;
-        *reinterpret_cast<float4*>(B + (b_kr + 8) * BN + 4 * b_nv) = breg1;
+        if (NW == 4) *reinterpret_cast<float4*>(B + (b_kr + 8) * BN + 4 * b_nv) = breg1;
     };
 
-    f32x16 accM[2], accY[4][2];
+    f32x16 accM[NI], accY[4][NI];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             accM[j][r] = 0.f;
@@ -205,40 +216,47 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoArgs a) {
             for (int o = 0; o < 4; ++o) accY[o][j][r] = 0.f;
         }
 
-    load_tile(0);
+    areg = ld4(Ac);
+    breg0 = ld4(Bc);
+    breg1 = ld4(Bc + b_half);
     store_tile(0);
     __syncthreads();
-    int kt = 0, xi = 0;
-    for (int it = 0; it < IT; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < IT) load_tile(it + 1);
-        const float* A = As + buf * A_TILE + wm0;
-        const float* B = Bs + buf * B_TILE + wn0 + l31;
+    // one K tile from LDS buffer BUF (compile-time, so every ds_read offset is an immediate)
+    auto k_tile = [&](auto bufc, bool more, bool last_kt) {
+        constexpr int BUF = decltype(bufc)::value;
+        if (more) load_next(last_kt);
+        const float* A = As + BUF * A_TILE + wm0;
+        const float* B = Bs + BUF * B_TILE + wn0 + l31;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const float av = A[(kk + h) * BM + (l31 ^ (((kk >> 2) & 3) << 3))];
-            const float b0 = B[(kk + h) * BN], b1 = B[(kk + h) * BN + 32];
-            accM[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, accM[0], 0, 0, 0);
-            accM[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, accM[1], 0, 0, 0);
-        }
-        if (++kt == KT) {  // M_xi complete: fold into the outputs, A^T = [1 1 1 0; 0 1 -1 -1]
-            const int xy = xi >> 2, xx = xi & 3;
-            const float cy0 = xy < 3 ? 1.f : 0.f, cy1 = xy == 0 ? 0.f : (xy == 1 ? 1.f : -1.f);
-            const float cx0 = xx < 3 ? 1.f : 0.f, cx1 = xx == 0 ? 0.f : (xx == 1 ? 1.f : -1.f);
-            const float c00 = cy0 * cx0, c01 = cy0 * cx1, c10 = cy1 * cx0, c11 = cy1 * cx1;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float m = accM[j][r];
-                    accY[0][j][r] += c00 * m; accY[1][j][r] += c01 * m;
-                    accY[2][j][r] += c10 * m; accY[3][j][r] += c11 * m;
-                    accM[j][r] = 0.f;
-                }
-            kt = 0; ++xi;
+            for (int j = 0; j < NI; ++j)
+                accM[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B[(kk + h) * BN + j * 32], accM[j], 0, 0, 0);
         }
-        if (it + 1 < IT) store_tile(buf ^ 1);
+        if (more) store_tile(BUF ^ 1);
         __syncthreads();
+    };
+    for (int xi = 0; xi < 16; ++xi) {
+        for (int kt = 0; kt < KT; kt += 2) {   // KT is even (host checks K % 32 == 0)
+            k_tile(std::integral_constant<int, 0>{}, true, false);
+            const bool last = kt + 2 == KT;
+            k_tile(std::integral_constant<int, 1>{}, !(last && xi == 15), last);
+        }
+        // M_xi complete: fold it into the four outputs, A^T = [1 1 1 0; 0 1 -1 -1]
+        const int xy = xi >> 2, xx = xi & 3;
+        const float cy0 = xy < 3 ? 1.f : 0.f, cy1 = xy == 0 ? 0.f : (xy == 1 ? 1.f : -1.f);
+        const float cx0 = xx < 3 ? 1.f : 0.f, cx1 = xx == 0 ? 0.f : (xx == 1 ? 1.f : -1.f);
+        const float c00 = cy0 * cx0, c01 = cy0 * cx1, c10 = cy1 * cx0, c11 = cy1 * cx1;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m = accM[j][r];
+                accY[0][j][r] += c00 * m; accY[1][j][r] += c01 * m;
+                accY[2][j][r] += c10 * m; accY[3][j][r] += c11 * m;
+                accM[j][r] = 0.f;
+            }
     }
 
     // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*h (tile), j = l31 (column)
@@ -255,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(WinoArgs a) {
             const int oy = (2 * ti + (o >> 1)) * a.so + pa, ox = (2 * tj + (o & 1)) * a.so + pb;
             float* row = a.y + ((n * a.Ho + oy) * (long)a.Wo + ox) * a.Nc + n0 + wn0 + l31;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) row[j * 32] = accY[o][j][r] + (a.bias ? a.bias[n0 + wn0 + j * 32 + l31] : 0.f);
+            for (int j = 0; j < NI; ++j) row[j * 32] = accY[o][j][r] + (a.bias ? a.bias[n0 + wn0 + j * 32 + l31] : 0.f);
         }
     }
 }
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
 
 static bool wino_dims_ok(int N, int Hp, int Wp, int Cin, int Cout) {
     return N > 0 && Hp > 0 && Wp > 0 && (Hp & 1) == 0 && (Wp & 1) == 0 && Cin > 0 && Cout > 0 && Cin % 128 == 0 &&
-           Cout % 128 == 0 && (long)N * Hp * Wp * std::max(Cin, 4 * Cout) * 4L < (1L << 40);
+           Cout % 128 == 0 /* K % 32, Nc % 128 for both GEMM geometries */ && (long)N * Hp * Wp * std::max(Cin, 4 * Cout) * 4L < (1L << 40);
 }
 
 }  // namespace
@@ -385,6 +403,27 @@ int cg_conv2d_ups2_wino_pack(void* stream, const float* wf_ph, const float* wb_p
     return 0;
 }
 
+// The 16 GEMMs + output transform alone, on an already transformed input (what the two entry points below launch after
+// their input transform; exported so that it can be timed / profiled in isolation).
+// dgrad == 0: v [16][T][Cin], u = u_fwd, y [N][2Hp][2Wp][Cout];  dgrad == 1: v [16][T][4*Cout], u = u_bwd, y [N][Hp][Wp][Cin].
+int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
+                             int Cin, int Cout, int dgrad) {
+    CG_REQUIRE(v && u && y, "cg_conv2d_ups2_wino_gemm: null pointer");
+    CG_REQUIRE(wino_dims_ok(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino_gemm: unsupported dimensions");
+    const int T = N * (Hp / 2) * (Wp / 2);
+    WinoArgs a;
+    a.V = v; a.U = u; a.bias = bias; a.y = y; a.T = T; a.tH = Hp / 2; a.tW = Wp / 2;
+    if (dgrad) { a.K = 4 * Cout; a.Nc = Cin; a.so = 1; a.Ho = Hp; a.Wo = Wp; }
+    else { a.K = Cin; a.Nc = Cout; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp; }
+    static int nw = -1;
+    if (nw < 0) { const char* e = getenv("CG_WINO_WAVES"); nw = e ? atoi(e) : 8; }
+    const dim3 grid(cg::cdiv(T, 64) * (a.Nc / 128), 1, dgrad ? 1 : 4);
+    if (nw == 4) hipLaunchKernelGGL(wino_gemm_kernel<4>, grid, dim3(256), 0, cg::S(stream), a);
+    else hipLaunchKernelGGL(wino_gemm_kernel<8>, grid, dim3(512), 0, cg::S(stream), a);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
 // y[N][2Hp][2Wp][Cout] = bias + conv5x5(upsample2(x_lo)); v (cg_conv2d_ups2_wino_v_floats(..., Cin) floats) receives
 // the transformed input and is what the weight gradient consumes later.
 int cg_conv2d_ups2_wino_forward(void* stream, const float* x_lo, const float* u_fwd, const float* bias, float* y, float* v,
@@ -396,12 +435,7 @@ int cg_conv2d_ups2_wino_forward(void* stream, const float* x_lo, const float* u_
     hipLaunchKernelGGL(wino_input_transform_kernel<0>, dim3(cg::ew_grid((long)T * (Cin / 4))), dim3(256), 0, st, x_lo, v, N, Hp,
                        Wp, Cin, Cin);
     CG_LAUNCH_CHECK();
-    WinoArgs a;
-    a.V = v; a.U = u_fwd; a.bias = bias; a.y = y;
-    a.T = T; a.K = Cin; a.Nc = Cout; a.tH = Hp / 2; a.tW = Wp / 2; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp;
-    hipLaunchKernelGGL(wino_gemm_kernel, dim3(cg::cdiv(T, 64) * (Cout / 128), 1, 4), dim3(256), 0, st, a);
-    CG_LAUNCH_CHECK();
-    return 0;
+    return cg_conv2d_ups2_wino_gemm(stream, v, u_fwd, bias, y, N, Hp, Wp, Cin, Cout, 0);
 }
 
 // dx_lo[N][Hp][Wp][Cin] = gradient w.r.t. the low-res input (the upsampling's 2x2 block sum folded in);
@@ -415,12 +449,7 @@ int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd,
     hipLaunchKernelGGL(wino_input_transform_kernel<1>, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, st, dy, v_dy, N, Hp, Wp,
                        4 * Cout, Cout);
     CG_LAUNCH_CHECK();
-    WinoArgs a;
-    a.V = v_dy; a.U = u_bwd; a.bias = nullptr; a.y = dx_lo;
-    a.T = T; a.K = 4 * Cout; a.Nc = Cin; a.tH = Hp / 2; a.tW = Wp / 2; a.so = 1; a.Ho = Hp; a.Wo = Wp;
-    hipLaunchKernelGGL(wino_gemm_kernel, dim3(cg::cdiv(T, 64) * (Cin / 128), 1, 1), dim3(256), 0, st, a);
-    CG_LAUNCH_CHECK();
-    return 0;
+    return cg_conv2d_ups2_wino_gemm(stream, v_dy, u_bwd, nullptr, dx_lo, N, Hp, Wp, Cin, Cout, 1);
 }
 
 static size_t wino_align(size_t b) { return (b + 255) / 256 * 256; }

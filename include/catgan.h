@@ -141,6 +141,9 @@ size_t cg_conv2d_ups2_wino_v_floats(int N, int Hp, int Wp, int C);
 size_t cg_conv2d_ups2_wino_u_floats(int Cin, int Cout);
 int cg_conv2d_ups2_wino_pack(void* stream, const float* wf_ph, const float* wb_ph, float* u_fwd, float* u_bwd,
                              int Cout, int Cin);
+/* the 16 GEMMs + in-register output transform alone, on an already transformed input (dgrad: 0 forward, 1 data gradient) */
+int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const float* bias, float* y,
+                             int N, int Hp, int Wp, int Cin, int Cout, int dgrad);
 int cg_conv2d_ups2_wino_forward(void* stream, const float* x_lo, const float* u_fwd, const float* bias, float* y,
                                 float* v, int N, int Hp, int Wp, int Cin, int Cout);
 int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy,

@@ -29,3 +29,9 @@ for k, c in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0))[
     for name, v in sorted(c.items()):
         print(f"    {name:28s} {v / n:16.1f} per launch")
 PY
+
+# optional: JSON of one kernel for bench.py / profiles  (PMC_JSON_KERNEL=<substring> [PMC_JSON_GRID=<threads>])
+if [ -n "${PMC_JSON_KERNEL:-}" ]; then
+  python3 "$ROOTD/scripts/pmc_json.py" "$ROOTD/gpurun_out/pmc" "$tag" "$PMC_JSON_KERNEL" ${PMC_JSON_GRID:-} > "$ROOTD/gpurun_out/pmc/${tag}.json"
+  cat "$ROOTD/gpurun_out/pmc/${tag}.json"
+fi
