@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import nn, nn_utils, optim, parallel
-from .tensor import Tensor, lib, rng, stream
+from .tensor import Tensor, has_gpu, lib, rng, stream
 
 DEFAULT_OPT = dict(  # train.lua:15-49
     batchSize=32, N_epoch=1000, G_L1=0.0, G_L2=0.0, D_L1=0.0, D_L2=1e-4, D_iterations=1, G_iterations=1,
@@ -192,7 +192,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         # Fork: the G-step's generator forward (fresh noise) depends only on G's parameters, not on anything the
         # D update does, and D's many small kernels leave CUs idle -> run it on a side HIP stream concurrently
         # with fevalD / D's Adam.  It must follow the fake-generation forward (shared BN statistics buffers).
-        if (OPT.get("concurrent_g_forward", False) and torch.cuda.is_available() and OPT["D_iterations"] == 1
+        if (OPT.get("concurrent_g_forward", False) and has_gpu() and OPT["D_iterations"] == 1
                 and OPT["G_iterations"] == 1):
             if S._side is None:
                 S._side = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import parallel
-from .tensor import Tensor, WS, lib, rng, stream
+from .tensor import Tensor, WS, has_gpu, lib, rng, stream
 
 
 # ------------------------------------------------------------------ layout helpers
@@ -131,7 +131,9 @@ class Module:
         # one persistent buffer per (role, size): the half-batch (fake generation) and full-batch passes of the
         # same module keep separate storage, nothing is freed while another stream may still read it
         shape = tuple(int(s) for s in shape)
-        n = int(np.prod(shape))
+        n = 1
+        for d in shape:
+            n *= d
         key = (key, n)
         b = self._bufs.get(key)
         if b is None:
@@ -387,7 +389,7 @@ class Concat(Sequential):
     def _fork_join(self, fns):
         """Run the thunks concurrently, one side stream per branch; results in order.  The branches of D32_st3 are
         dozens of tiny kernels each (localisation nets), so their fixed per-kernel costs overlap."""
-        if not (self.concurrent and torch.cuda.is_available() and len(fns) > 1):
+        if not (self.concurrent and has_gpu() and len(fns) > 1):
             return [f() for f in fns]
         if self._streams is None:
             self._streams = [(torch.cuda.Stream(), torch.cuda.Event()) for _ in fns]
@@ -420,7 +422,7 @@ class Concat(Sequential):
         """Branch outputs in order.  Groups of identical branches run layer by layer (GEMMs as one grouped launch);
         the first pass at a given input shape runs branch after branch and records how many counter-stream draws each
         branch consumes, so that lockstep passes can place every branch at exactly the same stream position."""
-        if not (self.grouped and torch.cuda.is_available()):
+        if not (self.grouped and has_gpu()):
             return self._fork_join([(lambda m=m: as_nhwc(m.updateOutput(input))) for m in self.modules])
         groups = self._branch_groups()
         key = (tuple(input.shape), self.modules[0].train)
@@ -451,7 +453,7 @@ class Concat(Sequential):
         return outs
 
     def _backward_branches(self, input, slices, scale, acc):
-        if not (self.grouped and torch.cuda.is_available()):
+        if not (self.grouped and has_gpu()):
             if acc:
                 return self._fork_join([(lambda m=m, s=s: as_nhwc(m.backward(input, s, scale))) for m, s in slices])
             return self._fork_join([(lambda m=m, s=s: as_nhwc(m.updateGradInput(input, s))) for m, s in slices])

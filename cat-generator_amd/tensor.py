@@ -11,6 +11,8 @@ Physical layouts:
   ups = 1     : logical H,W are 2x the physical ones (virtual nearest upsampling,
                 consumed by the convolution's gather; nn.SpatialUpSamplingNearest)
 """
+import math
+
 import numpy as np
 import torch
 
@@ -28,17 +30,28 @@ class Epoch:
         self.v += 1
 
 
+_HAS_GPU = torch.cuda.is_available()   # constant for the process; the query itself costs ~2 us (getenv + driver probe)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def has_gpu():
+    return _HAS_GPU
+
+
 def device():
-    if torch.cuda.is_available():
+    if _HAS_GPU:
         return torch.device("cuda", torch.cuda.current_device())
     return torch.device("cpu")
 
 
 def stream():
-    """hipStream_t of torch's current stream (kernels, events and collectives share it)."""
-    if torch.cuda.is_available():
-        return torch.cuda.current_stream().cuda_stream
-    return 0
+    """hipStream_t of torch's current stream (kernels, events and collectives share it).  Called once per launch
+    (~600 times per training step), hence the raw-handle fast path instead of torch.cuda.current_stream()."""
+    if not _HAS_GPU:
+        return 0
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def lib():
@@ -111,12 +124,12 @@ class Tensor:
     @staticmethod
     def empty(shape, fmt="plain"):
         shape = tuple(int(s) for s in shape)
-        return Tensor(torch.empty(int(np.prod(shape)), dtype=torch.float32, device=device()), shape, fmt)
+        return Tensor(torch.empty(math.prod(shape), dtype=torch.float32, device=device()), shape, fmt)
 
     @staticmethod
     def zeros(shape, fmt="plain"):
         shape = tuple(int(s) for s in shape)
-        return Tensor(torch.zeros(int(np.prod(shape)), dtype=torch.float32, device=device()), shape, fmt)
+        return Tensor(torch.zeros(math.prod(shape), dtype=torch.float32, device=device()), shape, fmt)
 
     @staticmethod
     def from_numpy(a, fmt=None):
@@ -134,7 +147,7 @@ class Tensor:
         return self.t.data_ptr()
 
     def nElement(self):
-        return int(np.prod(self.shape))
+        return math.prod(self.shape)
 
     numel = nElement
 
@@ -165,7 +178,7 @@ class Tensor:
     def view(self, *shape):
         assert self.fmt == "plain" and self.ups == 0
         shape = tuple(int(s) for s in shape)
-        assert int(np.prod(shape)) == self.nElement()
+        assert math.prod(shape) == self.nElement()
         return Tensor(self.t, shape, "plain", 0, self.epoch)
 
     def rows(self, a, b):
