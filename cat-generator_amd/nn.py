@@ -86,6 +86,89 @@ def _ptr_array(ptrs):
     return (ctypes.c_void_p * len(ptrs))(*[int(p) if p else None for p in ptrs])
 
 
+def _split(Y, G):
+    """A stacked tensor ([G*N, ...], branch-major) as its G per-branch slices, each remembering the block it came from."""
+    n, N = Y.t.numel() // G, Y.shape[0] // G
+    return [Tensor(Y.t[i * n:(i + 1) * n], (N,) + tuple(Y.shape[1:]), Y.fmt, Y.ups, grp=(Y.t, i, G)) for i in range(G)]
+
+
+def _stacked(xs):
+    """The block behind G per-branch tensors if they are exactly its G slices in order (else None)."""
+    g0 = xs[0].grp if isinstance(xs[0], Tensor) else None
+    if g0 is None or g0[2] != len(xs):
+        return None
+    x0 = xs[0]
+    for i, x in enumerate(xs):
+        if (not isinstance(x, Tensor) or x.grp is None or x.grp[0] is not g0[0] or x.grp[1] != i or x.shape != x0.shape
+                or x.fmt != x0.fmt or x.ups):
+            return None
+    return Tensor(g0[0], (len(xs) * x0.shape[0],) + tuple(x0.shape[1:]), x0.fmt)
+
+
+def _seed_slices(mods, role, shape, fmt):
+    """Make the `role` buffers of sibling modules the slices of one block (owned by the first sibling), so that modules
+    which must run one launch per branch (own parameters) still hand a stacked tensor to what follows."""
+    shape = tuple(int(d) for d in shape)
+    n = 1
+    for d in shape:
+        n *= d
+    cur = [m._bufs.get((role, n)) for m in mods]
+    if all(c is not None and c.shape == shape and c.fmt == fmt for c in cur) and _stacked(cur) is not None:
+        return
+    block = mods[0]._get((role, "block"), (len(mods) * shape[0],) + shape[1:], fmt)
+    for m, sl in zip(mods, _split(block, len(mods))):
+        m._bufs[(role, n)] = sl
+
+
+def _restack(owner, xs, like):
+    """Copy G per-branch tensors into one block (used when a stacked module receives gradients from an unstacked one)."""
+    xs = [x if x.fmt == like.fmt else (as_nhwc(x) if like.fmt == "nhwc" else as_plain(x)) for x in xs]
+    x0 = xs[0]
+    block = owner._get(("restack", "block"), (len(xs) * x0.shape[0],) + tuple(x0.shape[1:]), x0.fmt)
+    nb = x0.t.numel() * 4
+    for i, x in enumerate(xs):
+        lib().memcpy_d2d(stream(), block.ptr + i * nb, x.ptr, nb)
+    return block
+
+
+class _Stackable:
+    """Mixin for parameter-free modules: when the inputs of G sibling instances are the slices of one block, the first
+    sibling runs ONE launch over the stacked batch and every sibling's output / gradInput is a slice of its result."""
+    stacking = True
+
+    @staticmethod
+    def _group_forward(mods, inputs, ctx):
+        m0 = mods[0]
+        X = _stacked(inputs) if _Stackable.stacking else None
+        if X is None:
+            m0._stk = None
+            return Module._group_forward(mods, inputs, ctx)
+        ys = _split(m0.updateOutput(X), len(mods))
+        m0._stk = ys[0].grp[0]   # the block of this stacked forward; a later per-module forward replaces m0.output
+        for m, y in zip(mods, ys):
+            m.output = y
+        return ys
+
+    @staticmethod
+    def _ran_stacked(m0):
+        o = m0.output
+        return isinstance(o, Tensor) and o.grp is not None and o.grp[0] is getattr(m0, "_stk", None)
+
+    @staticmethod
+    def _group_backward(mods, inputs, gouts, scale, acc, ctx):
+        m0 = mods[0]
+        if not _Stackable._ran_stacked(m0):
+            return Module._group_backward(mods, inputs, gouts, scale, acc, ctx)
+        X = _stacked(inputs)
+        Gd = _stacked(gouts)
+        if Gd is None:
+            Gd = _restack(m0, gouts, m0.output if isinstance(m0.output, Tensor) else gouts[0])
+        gs = _split(m0.updateGradInput(X, Gd), len(mods))
+        for m, g in zip(mods, gs):
+            m.gradInput = g
+        return gs
+
+
 def group_forward(mods, inputs, ctx):
     return type(mods[0])._group_forward(mods, inputs, ctx)
 
@@ -141,7 +224,7 @@ class Module:
             self._bufs[key] = b
             return b
         if b.shape != shape or b.fmt != fmt:
-            b = Tensor(b.t, shape, fmt)
+            b = Tensor(b.t, shape, fmt, grp=b.grp if len(shape) and len(b.shape) and shape[0] == b.shape[0] else None)
             self._bufs[key] = b
         return b
 
@@ -372,6 +455,13 @@ class ConcatTable(Sequential):
     def _group_backward(mods, inputs, gouts, scale, acc, ctx):
         per_child = [group_backward([m.modules[j] for m in mods], list(inputs), [g[j] for g in gouts], scale, acc, ctx)
                      for j in range(len(mods[0].modules))]
+        blocks = [_stacked(c) if (_Stackable.stacking and all(isinstance(t, Tensor) for t in c)) else None for c in per_child]
+        if all(b is not None for b in blocks):   # one add per pair of children over the stacked batch
+            tot = mods[0]._sum(blocks)
+            outs = _split(tot, len(mods)) if tot.grp is None else list(per_child[0])
+            for m, o in zip(mods, outs):
+                m.gradInput = o
+            return outs
         return [m._sum([per_child[j][b] for j in range(len(per_child))]) for b, m in enumerate(mods)]
 
 
@@ -576,6 +666,9 @@ class _GemmLayer(Module):
         preps = [m._prep_fwd(x) for m, x in zip(mods, inputs)]
         if len({p[3] for p in preps}) != 1:
             return Module._group_forward(mods, inputs, ctx)
+        if _Stackable.stacking and _stacked([p_[2] for p_ in preps]) is None:   # outputs as slices of one block
+            _seed_slices(mods, "out", preps[0][2].shape, preps[0][2].fmt)
+            preps = [m._prep_fwd(x) for m, x in zip(mods, inputs)]
         a, G = preps[0][3], len(mods)
         ws, wsb = WS.get(lib().conv2d_workspace_bytes_grouped(G, *a))
         lib().conv2d_forward_grouped(stream(), G, _ptr_array([p[0].ptr for p in preps]), _ptr_array([p[1] for p in preps]),
@@ -590,6 +683,9 @@ class _GemmLayer(Module):
         gin = [m._prep_gin(g) for m, g in zip(mods, gouts)]
         if any(p_ is None for p_ in gin) or len({p_[3] for p_ in gin}) != 1:
             return Module._group_backward(mods, inputs, gouts, scale, acc, ctx)
+        if _Stackable.stacking and _stacked([p_[2] for p_ in gin]) is None:
+            _seed_slices(mods, "gin", gin[0][2].shape, gin[0][2].fmt)
+            gin = [m._prep_gin(g) for m, g in zip(mods, gouts)]
         a = gin[0][3]
         ws, wsb = WS.get(lib().conv2d_workspace_bytes_grouped(G, *a))
         lib().conv2d_forward_grouped(stream(), G, _ptr_array([p_[0].ptr for p_ in gin]), _ptr_array([p_[1] for p_ in gin]),
@@ -864,13 +960,25 @@ class PReLU(Module):
     def backward(self, input, gradOutput, scale=1.0):  # one fused pass for dx and dalpha
         return self._bwd(gradOutput, self.gradWeight.ptr, scale)
 
+    @staticmethod
+    def _group_forward(mods, inputs, ctx):
+        if _Stackable.stacking and all(isinstance(x, Tensor) and not x.ups for x in inputs):
+            _seed_slices(mods, "out", inputs[0].shape, inputs[0].fmt)
+        return Module._group_forward(mods, inputs, ctx)
+
+    @staticmethod
+    def _group_backward(mods, inputs, gouts, scale, acc, ctx):
+        if _Stackable.stacking:
+            _seed_slices(mods, "gin", mods[0]._x.shape, mods[0]._x.fmt)
+        return Module._group_backward(mods, inputs, gouts, scale, acc, ctx)
+
 
 class _Elementwise(Module):
     def _match(self, g, x):
         return g if g.fmt == x.fmt else (as_nhwc(g) if x.fmt == "nhwc" else as_plain(g))
 
 
-class LeakyReLU(_Elementwise):
+class LeakyReLU(_Stackable, _Elementwise):
     """LeakyReLU.lua:5-31 (negative_scale 0.333; x == 0 takes the positive branch)."""
     _typename = "nn.LeakyReLU"
 
@@ -987,7 +1095,7 @@ class SpatialBatchNormalization(Module):
 
 
 # ------------------------------------------------------------ shape / data movement
-class View(Module):
+class View(_Stackable, Module):
     """nn.View(...): the logical NCHW reinterpretation; with NHWC storage this is where the permutation lives."""
     _typename = "nn.View"
 
@@ -1055,11 +1163,11 @@ class Transpose(Module):
         if order == (0, 2, 3, 1):  # NCHW -> BHWD
             x = as_nhwc(to_device(x))
             N, C, H, W = x.shape
-            return Tensor(x.t, (N, H, W, C), "plain", 0, x.epoch)
+            return Tensor(x.t, (N, H, W, C), "plain", 0, x.epoch, grp=x.grp)
         if order == (0, 3, 1, 2):  # BHWD -> NCHW
             assert x.fmt == "plain"
             N, H, W, C = x.shape
-            return Tensor(x.t, (N, C, H, W), "nhwc", 0, x.epoch)
+            return Tensor(x.t, (N, C, H, W), "nhwc", 0, x.epoch, grp=x.grp)
         raise NotImplementedError(f"nn.Transpose{self.permutations}: permutation {order} is not on the path")
 
     def updateOutput(self, input):
@@ -1099,7 +1207,7 @@ class SpatialUpSamplingNearest(Module):
         return gi
 
 
-class _Pool2(Module):
+class _Pool2(_Stackable, Module):
     def __init__(self, kW, kH, dW=None, dH=None):
         super().__init__()
         dW, dH = dW or kW, dH or kH
@@ -1144,9 +1252,46 @@ class SpatialMaxPooling(_Pool2):
         return gi
 
 
-class SpatialDropout(Module):
+class SpatialDropout(_Stackable, Module):
     """nn.SpatialDropout(p) [upstream, era]: train y = x * mask[n,c] (no rescale); evaluate y = (1-p) x."""
     _typename = "nn.SpatialDropout"
+
+    @staticmethod
+    def _group_forward(mods, inputs, ctx):
+        """Stacked form: every branch draws its own [N,C] mask at its own position of the counter stream (one tiny
+        launch each, into one block), then a single mask multiply runs over the stacked batch."""
+        m0 = mods[0]
+        X = _stacked(inputs) if _Stackable.stacking else None
+        if X is None or any(m.fixed_noise is not None for m in mods):
+            m0._stk = None
+            return Module._group_forward(mods, inputs, ctx)
+        if not m0.train:
+            return _Stackable._group_forward(mods, inputs, ctx)
+        G = len(mods)
+        N, C, H, W = inputs[0].shape
+        noise = m0._get(("noise", "block"), (G * N, C))
+        r = rng()
+        for b in range(G):
+            lib().rng_bernoulli_dev(stream(), noise.ptr + 4 * b * N * C, N * C, 1.0 - m0.p, 1.0, r.seed, ctx.cur[b], r.base_ptr())
+            ctx.cur[b] += N * C
+        out = m0._get("out", X.shape, "nhwc")
+        lib().mask_mul(stream(), X.ptr, noise.ptr, out.ptr, G * N, H * W, C, 1)
+        ys = _split(out, G)
+        m0._stk, m0._noise_block = ys[0].grp[0], noise
+        for m, y, nz in zip(mods, ys, _split(noise, G)):
+            m.output, m.noise = y, nz
+        return ys
+
+    @staticmethod
+    def _group_backward(mods, inputs, gouts, scale, acc, ctx):
+        m0 = mods[0]
+        if not (_Stackable._ran_stacked(m0) and m0.train):
+            return _Stackable._group_backward(mods, inputs, gouts, scale, acc, ctx)
+        own, m0.noise = m0.noise, m0._noise_block   # the stacked mask for the one stacked multiply
+        try:
+            return _Stackable._group_backward(mods, inputs, gouts, scale, acc, ctx)
+        finally:
+            m0.noise = own
 
     def __init__(self, p=0.5):
         super().__init__()
@@ -1223,7 +1368,7 @@ class Dropout(Module):
 
 
 # ----------------------------------------------------------- spatial transformer (stn)
-class AffineTransformMatrixGenerator(Module):
+class AffineTransformMatrixGenerator(_Stackable, Module):
     _typename = "nn.AffineTransformMatrixGenerator"
 
     def __init__(self, useRotation, useScale, useTranslation):
@@ -1247,7 +1392,7 @@ class AffineTransformMatrixGenerator(Module):
         return gi
 
 
-class AffineGridGeneratorBHWD(Module):
+class AffineGridGeneratorBHWD(_Stackable, Module):
     _typename = "nn.AffineGridGeneratorBHWD"
 
     def __init__(self, height, width):
@@ -1296,6 +1441,19 @@ class BilinearSamplerBHWD(Module):
         lib().bilinear_sampler_backward(stream(), img.ptr, grid.ptr, g.ptr, gimg.ptr, ggrid.ptr, N, Hi, Wi, C, Ho, Wo)
         self.gradInput = [gimg, ggrid]
         return self.gradInput
+
+    @staticmethod
+    def _group_forward(mods, inputs, ctx):
+        if _Stackable.stacking:
+            (N, _, _, C), (_, Ho, Wo, _) = inputs[0][0].shape, inputs[0][1].shape
+            _seed_slices(mods, "out", (N, Ho, Wo, C), "plain")
+        return Module._group_forward(mods, inputs, ctx)
+
+    @staticmethod
+    def _group_backward(mods, inputs, gouts, scale, acc, ctx):
+        if _Stackable.stacking:
+            _seed_slices(mods, "ggrid", inputs[0][1].shape, "plain")
+        return Module._group_backward(mods, inputs, gouts, scale, acc, ctx)
 
 
 # -------------------------------------------------------------------------- criterion
