@@ -132,7 +132,10 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         if maxAccuracyD <= 1.0:  # the gate can trigger: read this batch's accuracy back (:115-166)
             o = nn.as_plain(outputs).numpy().reshape(-1)
             t = targets.numpy().reshape(-1)
-            tV = float(np.mean((o > 0.5) == (t > 0.5)))
+            # every rank must take the same decision (a rank that skipped the update would desynchronise the
+            # parameters): accuracy over the GLOBAL batch
+            hits, tot = parallel.allreduce_sum_host([float(np.sum((o > 0.5) == (t > 0.5))), float(o.size)])
+            tV = hits / tot
             S.accs.append(tV)
             if len(S.accs) > accsInterval:
                 S.accs.pop(0)

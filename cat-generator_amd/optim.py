@@ -99,16 +99,26 @@ class ConfusionMatrix:
 
     def zero(self):
         self.counts.zero_()
+        self._last_global = None
 
     def batchAdd(self, outputs, targets):
         lib().confusion_update(stream(), outputs.ptr, targets.ptr, self.counts.data_ptr(), targets.nElement())
 
+    def _global_counts(self):
+        """counts summed over the data-parallel ranks (every rank sees 1/R of the batch)."""
+        from . import parallel
+        import numpy as np
+        return np.asarray(parallel.allreduce_sum_host(self.counts.cpu().numpy().tolist()))
+
     def updateValids(self):
-        c = self.counts.cpu().numpy().astype(float)
+        """Collective under data parallelism: every rank calls it (adversarial.train does, at the end of the epoch)."""
+        self._last_global = self._global_counts()
+        c = self._last_global.astype(float)
         tot = c.sum()
         self.totalValid = float((c[0] + c[3]) / tot) if tot > 0 else 0.0
         return self.totalValid
 
-    def __repr__(self):
-        c = self.counts.cpu().numpy()
+    def __repr__(self):  # never a collective: the counts of the last updateValids(), else this rank's own
+        g = getattr(self, "_last_global", None)
+        c = (g if g is not None else self.counts.cpu().numpy()).astype(int)
         return f"ConfusionMatrix(pred0/t0={c[0]}, pred0/t1={c[1]}, pred1/t0={c[2]}, pred1/t1={c[3]})"

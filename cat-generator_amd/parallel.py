@@ -102,6 +102,16 @@ def allreduce_mean_async(t):
     return _Pending(t, None)
 
 
+def allreduce_sum_host(values):
+    """SUM over ranks of a few host scalars (accuracy gate, confusion counts): returns a list of floats."""
+    if _S["world"] <= 1:
+        return [float(v) for v in values]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.cpu().tolist()]
+
+
 def barrier():
     if _S["world"] > 1:
         dist.barrier()
