@@ -83,6 +83,9 @@ def _worker(rank, world, port, q):
         return buf[:k].numpy().copy(), buf[k:].numpy().copy(), cnt * par.world_size()
 
     assert par.sync_bn_active()
+    # host-scalar reduction behind the accuracy gate / confusion counts: identical global values on every rank
+    hits, tot = par.allreduce_sum_host([float(rank + 1), 2.0])
+    assert (hits, tot) == (3.0, 4.0)
     T = _run_step(O, G, D, x[rows], t[rows], z[rows], dict(grad=grad_hook, bn=bn_hook))
     q.put((rank, T.pD.copy(), T.pG.copy(), T.stD["m"].copy(), T.stG["m"].copy()))
     dist.barrier()
