@@ -163,8 +163,11 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         else:
             S.MODEL_D.updateGradInput(samples, df_samples)
         df_do = S.MODEL_D.modules[0].gradInput
-        S.MODEL_G.backward(st["noiseInputs"], df_do)
-        parallel.allreduce_mean_(S.GRAD_PARAMETERS_G.t)
+        if parallel.world_size() > 1 and OPT.get("overlap_comm", True) and _bucketable(S.MODEL_G):
+            _backward_bucketed(S, st["noiseInputs"], df_do)
+        else:
+            S.MODEL_G.backward(st["noiseInputs"], df_do)
+            parallel.allreduce_mean_(S.GRAD_PARAMETERS_G.t)
         if not OPT["fused_update"]:
             if OPT["G_L1"] != 0 or OPT["G_L2"] != 0:
                 f = float(f) + OPT["G_L1"] * S.PARAMETERS_G.norm(1) + OPT["G_L2"] * S.PARAMETERS_G.norm(2) ** 2 / 2
@@ -235,6 +238,47 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         assert m in ("sgd", "adagrad", "adam"), "[Warning] Unknown optimizer method chosen for G."
         getattr(optim, m)(fevalG_on_D, S.PARAMETERS_G, S.OPTSTATE[m]["G"], fused=fused)
     return st["doTrainD"]
+
+
+def _bucketable(G):
+    return isinstance(G, nn.Sequential) and type(G) is nn.Sequential and len(G.modules) > 1
+
+
+def _g_buckets(S):
+    """Contiguous ranges of G's flat gradient, one per convolution / linear layer together with the parameters of the
+    modules up to the next one (BN, PReLU): [(first module index, offset, count)], in forward order."""
+    if getattr(S, "_gbuckets", None) is None:
+        G = S.MODEL_G
+        starts, off = [], 0
+        for i, m in enumerate(G.modules):
+            n = sum(getattr(mm, p).nElement() for mm, p, _ in m.param_refs())
+            if isinstance(m, nn._GemmLayer) or not starts:
+                starts.append([i, off, 0])
+            starts[-1][2] += n
+            off += n
+        assert off == S.GRAD_PARAMETERS_G.nElement()
+        S._gbuckets = [tuple(b) for b in starts if b[2] > 0]
+    return S._gbuckets
+
+
+def _backward_bucketed(S, noise, df_do):
+    """G:backward module by module (same order as nn.Sequential:backward); as soon as a bucket's gradients are complete
+    its slice of the flat vector starts its all-reduce on RCCL's stream, under the backward of the layers before it
+    (G's all-reduce is otherwise on the critical path - the next fake generation needs the updated G)."""
+    G = S.MODEL_G
+    flat = S.GRAD_PARAMETERS_G.t
+    first = {b[0]: b for b in _g_buckets(S)}
+    pending = []
+    cur = df_do
+    for i in range(len(G.modules) - 1, -1, -1):
+        m = G.modules[i]
+        cur = m.backward(G.modules[i - 1].output if i > 0 else noise, cur)
+        b = first.get(i)
+        if b is not None:
+            pending.append(parallel.allreduce_mean_async(flat[b[1]:b[1] + b[2]]))
+    G.gradInput = cur
+    for p_ in pending:
+        p_.finish()
 
 
 class GraphedIteration:

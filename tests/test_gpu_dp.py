@@ -41,9 +41,7 @@ def _worker(rank, world, port, backend, overlap, q):
         q.put((rank, None, None, f"{type(e).__name__}: {e}"))
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("backend,overlap", [("gloo", True), ("gloo", False)])
-def test_two_ranks_stay_replicas(backend, overlap):
+def _run(backend, overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + os.getpid() % 200 + (50 if overlap else 0)
@@ -61,3 +59,16 @@ def test_two_ranks_stay_replicas(backend, overlap):
     assert np.isfinite(g0).all() and np.isfinite(d0).all()
     np.testing.assert_array_equal(g0, g1)
     np.testing.assert_array_equal(d0, d1)
+    return g0, d0
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_stay_replicas_and_overlap_is_result_neutral():
+    """Two ranks on the GPU box through the product's DP iteration: replicas stay bit-equal, with the blocking
+    collectives and with the overlapped ones (D's all-reduce under the G-step's generator forward, G's all-reduce in
+    buckets under G's backward); both schedules give the same parameters up to the usual atomics-order drift."""
+    g_o, d_o = _run("gloo", True)
+    g_b, d_b = _run("gloo", False)
+    for a, b in ((g_o, g_b), (d_o, d_b)):
+        d = np.abs(a - b)
+        assert d.max() <= 2 * 2.5e-3 and d.mean() <= 2e-5, (d.max(), d.mean())
