@@ -154,9 +154,13 @@ struct WinoArgs {
     int Ho, Wo;
 };
 
-template <int NW>   // waves per workgroup: 4 (wave tile 32x64) or 8 (wave tile 32x32: twice the waves per tile for latency hiding)
+// NW waves per workgroup: 4 (wave tile 32x64) or 8 (wave tile 32x32: twice the waves per tile for latency hiding); BK = K step
+template <int NW, int BK>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(WinoArgs a) {
-    constexpr int BM = 64, BN = 128, BK = 16, NI = 8 / NW;
+    constexpr int BM = 64, BN = 128, NI = 8 / NW, NT = 64 * NW;
+    constexpr int KV = BK / 4;                 // float4 per A row per K tile
+    constexpr int BQ = BK * 32 / NT;           // B float4 per thread (1 or 2), NT/32 rows apart
+    static_assert(BM * KV <= NT && (BQ == 1 || BQ == 2), "staging layout");
     constexpr int A_TILE = BK * BM, B_TILE = BK * BN;
     __shared__ __attribute__((aligned(16))) float smem[2 * A_TILE + 2 * B_TILE];
     float* As = smem;
@@ -171,14 +175,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(Win
     const int KT = a.K / BK;
 
     // staging: A one float4 per thread (row a_r, k quad a_kv); B two float4 per thread
-    const int a_r = (tid & 255) >> 2, a_kv = tid & 3;
-    const bool a_thr = tid < 256;                 // NW == 8: the upper four waves stage only B
+    const int a_kv = tid % KV, a_r = (tid / KV) % BM;
+    const bool a_thr = tid < BM * KV;             // 8 waves, K step 16: the upper four waves stage only B
     const int a_row = min(m0 + a_r, a.T - 1);
-    const int b_kr = tid >> 5, b_nv = tid & 31;   // NW == 4: k rows b_kr and b_kr + 8; NW == 8: k row b_kr (0..15)
+    const int b_kr = tid >> 5, b_nv = tid & 31;   // k rows b_kr (and b_kr + NT/32 when BQ == 2)
     const float* Ap = a.V + (long)a_row * a.K + 4 * a_kv;
     const float* Bp = a.U + (long)phase * 16 * a.K * a.Nc + (long)b_kr * a.Nc + n0 + 4 * b_nv;
     const long a_xi = (long)a.T * a.K;            // V stride between xi
-    const long b_half = 8L * a.Nc;                // second B float4: k row + 8
+    const long b_half = (long)(NT / 32) * a.Nc;   // second B float4: k row + NT/32
     float4 areg, breg0, breg1;
     // running operand pointers: U is contiguous over (xi, k), V jumps to the next xi plane after the last K tile
     const float* Ac = Ap;
@@ -188,22 +192,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(Win
     auto load_next = [&](bool last_kt) {
         Ac += last_kt ? a_jump : (long)BK;
         Bc += b_step;
-        if (NW == 4 || a_thr) areg = ld4(Ac);
+        if (BM * KV == NT || a_thr) areg = ld4(Ac);
         breg0 = ld4(Bc);
-        if (NW == 4) breg1 = ld4(Bc + b_half);
+        if (BQ == 2) breg1 = ld4(Bc + b_half);
     };
     const int a_so = a_r ^ ((a_kv & 3) << 3);
     auto store_tile = [&](int buf) {
         float* A = As + buf * A_TILE;
         float* B = Bs + buf * B_TILE;
-        if (NW == 4 || a_thr) {
+        if (BM * KV == NT || a_thr) {
             A[(4 * a_kv + 0) * BM + a_so] = areg.x;
             A[(4 * a_kv + 1) * BM + a_so] = areg.y;
             A[(4 * a_kv + 2) * BM + a_so] = areg.z;
             A[(4 * a_kv + 3) * BM + a_so] = areg.w;
         }
         *reinterpret_cast<float4*>(B + b_kr * BN + 4 * b_nv) = breg0;
-        if (NW == 4) *reinterpret_cast<float4*>(B + (b_kr + 8) * BN + 4 * b_nv) = breg1;
+        if (BQ == 2) *reinterpret_cast<float4*>(B + (b_kr + NT / 32) * BN + 4 * b_nv) = breg1;
     };
 
     f32x16 accM[NI], accY[4][NI];
@@ -415,11 +419,16 @@ int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const
     a.V = v; a.U = u; a.bias = bias; a.y = y; a.T = T; a.tH = Hp / 2; a.tW = Wp / 2;
     if (dgrad) { a.K = 4 * Cout; a.Nc = Cin; a.so = 1; a.Ho = Hp; a.Wo = Wp; }
     else { a.K = Cin; a.Nc = Cout; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp; }
-    static int nw = -1;
+    static int nw = -1, bk = -1;
     if (nw < 0) { const char* e = getenv("CG_WINO_WAVES"); nw = e ? atoi(e) : 8; }
+    if (bk < 0) { const char* e = getenv("CG_WINO_BK"); bk = e ? atoi(e) : 0; }
     const dim3 grid(cg::cdiv(T, 64) * (a.Nc / 128), 1, dgrad ? 1 : 4);
-    if (nw == 4) hipLaunchKernelGGL(wino_gemm_kernel<4>, grid, dim3(256), 0, cg::S(stream), a);
-    else hipLaunchKernelGGL(wino_gemm_kernel<8>, grid, dim3(512), 0, cg::S(stream), a);
+    // K step 32 (half the barriers per MFMA) pays when the launch is at most ~one workgroup per CU - the data-gradient
+    // geometry at batch 128 (0.53 -> 0.41 ms) - and costs 6 % when two workgroups per CU already hide each other's barriers
+    const bool k32 = bk == 32 || (bk == 0 && (long)grid.x * grid.z <= cg::kNumCU * 3 / 2);
+    if (nw == 4) hipLaunchKernelGGL((wino_gemm_kernel<4, 16>), grid, dim3(256), 0, cg::S(stream), a);
+    else if (k32 && a.K % 64 == 0) hipLaunchKernelGGL((wino_gemm_kernel<8, 32>), grid, dim3(512), 0, cg::S(stream), a);
+    else hipLaunchKernelGGL((wino_gemm_kernel<8, 16>), grid, dim3(512), 0, cg::S(stream), a);
     CG_LAUNCH_CHECK();
     return 0;
 }
