@@ -182,7 +182,7 @@ def main():
             # rocprofv3 on itself
             traffic, util = None, None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_dominant_kernel.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_dominant_kernel.json")))
                 traffic, util = pmc["hbm_bytes_per_launch_corrected"], pmc["mfma_pipe_util"]
             except Exception:
                 pass
