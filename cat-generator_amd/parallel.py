@@ -114,4 +114,7 @@ def allreduce_sum_host(values):
 
 def barrier():
     if _S["world"] > 1:
-        dist.barrier()
+        if torch.cuda.is_available() and dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])   # explicit device: no guessing from the rank
+        else:
+            dist.barrier()
