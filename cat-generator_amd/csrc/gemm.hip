@@ -132,6 +132,13 @@ __device__ __forceinline__ long out_row(const Geom& g, int m, int pa, int pb) {
     return ((long)(n * g.Hout + oy * g.so + pa) * g.Wout + ox * g.so + pb) * g.Cout;
 }
 
+// Column XOR of the K-major A tile, as a function of the k quad kv = k / 4: a half-wave of the transposed store holds
+// (K step / 4) quads x (128 / K step) consecutive rows and must land in 32 distinct banks; a fragment read (32 consecutive
+// rows at fixed k) must stay a permutation of them.  K step 16: 4 quads x 8 rows -> flip row bits 3,4; K step 32: 8 quads x 4
+// rows -> flip row bits 2,3,4 (PMC: the bits-3,4 form gave the K-step-32 kernel 10 % LDS bank-conflict cycles).
+template <int BKT>
+__device__ __forceinline__ int a_swizzle(int kv) { return BKT == 32 ? ((kv & 7) << 2) : ((kv & 3) << 3); }
+
 // ---------------------------------------------------------------------------
 // NN: Y[m][n] = sum_k A(m,k) * W[k][n]
 // ---------------------------------------------------------------------------
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
         float* B = Bs + buf * B_TILE;
 #pragma unroll
         for (int p = 0; p < AROWS; ++p) {
-            const int rs = (a_r + ARPP * p) ^ ((a_kv & 3) << 3);
+            const int rs = (a_r + ARPP * p) ^ a_swizzle<BK>(a_kv);
             A[(4 * a_kv + 0) * LDA + rs] = areg[p].x;
             A[(4 * a_kv + 1) * LDA + rs] = areg[p].y;
             A[(4 * a_kv + 2) * LDA + rs] = areg[p].z;
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
         for (int kk = 0; kk < BK; kk += 2) {
             float av[MI], bv[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) av[i] = A[(kk + h) * LDA + i * 32 + (l31 ^ (((kk >> 2) & 3) << 3))];
+            for (int i = 0; i < MI; ++i) av[i] = A[(kk + h) * LDA + i * 32 + (l31 ^ a_swizzle<BK>(kk >> 2))];
 #pragma unroll
             for (int j = 0; j < NI; ++j) bv[j] = B[(kk + h) * LDB + j * 32];
 #pragma unroll

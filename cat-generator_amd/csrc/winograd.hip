@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(Win
         breg0 = ld4(Bc);
         if (BQ == 2) breg1 = ld4(Bc + b_half);
     };
-    const int a_so = a_r ^ ((a_kv & 3) << 3);
+    const int a_so = a_r ^ (BK == 32 ? ((a_kv & 7) << 2) : ((a_kv & 3) << 3));   // see a_swizzle in gemm.hip
     auto store_tile = [&](int buf) {
         float* A = As + buf * A_TILE;
         float* B = Bs + buf * B_TILE;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(Win
         const float* B = Bs + BUF * B_TILE + wn0 + l31;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float av = A[(kk + h) * BM + (l31 ^ (((kk >> 2) & 3) << 3))];
+            const float av = A[(kk + h) * BM + (l31 ^ (BK == 32 ? (((kk >> 2) & 7) << 2) : (((kk >> 2) & 3) << 3)))];
 #pragma unroll
             for (int j = 0; j < NI; ++j)
                 accM[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B[(kk + h) * BN + j * 32], accM[j], 0, 0, 0);
