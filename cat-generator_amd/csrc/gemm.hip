@@ -29,6 +29,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -329,7 +330,10 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
         }
     };
 
-    auto store_tile = [&](int buf) {
+    // the LDS double-buffer index is a compile-time constant everywhere (the K loop is unrolled by two), so that every
+    // ds_read / ds_write address is a loop-invariant register plus an immediate offset - no address VALU in the loop
+    auto store_tile = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
         float* A = As + buf * A_TILE;
         float* B = Bs + buf * B_TILE;
 #pragma unroll
@@ -357,12 +361,12 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
 
     if (T > 0) {
         load_tile(ks);
-        store_tile(0);
+        store_tile(std::integral_constant<int, 0>{});
     }
     __syncthreads();
 
-    for (int t = 0; t < T; ++t) {
-        const int buf = t & 1;
+    auto k_tile = [&](auto bufc, int t) {
+        constexpr int buf = decltype(bufc)::value;
         if (t + 1 < T) load_tile(ks + (t + 1) * BK);
         const float* A = As + buf * A_TILE + wm0;
         const float* B = Bs + buf * B_TILE + wn0 + l31;
@@ -379,8 +383,12 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < T) store_tile(buf ^ 1);
+        if (t + 1 < T) store_tile(std::integral_constant<int, buf ^ 1>{});
         __syncthreads();
+    };
+    for (int t = 0; t < T; t += 2) {
+        k_tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < T) k_tile(std::integral_constant<int, 1>{}, t + 1);
     }
 
     // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*h (pixel), j = l31 (channel)
@@ -573,7 +581,8 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto bufc) {   // compile-time buffer index, as in igemm_nn_kernel
+        constexpr int buf = decltype(bufc)::value;
         float* A = As + buf * A_TILE;
         float* B = Bs + buf * B_TILE;
 #pragma unroll
@@ -601,12 +610,12 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
 
     if (T > 0) {
         load_tile(ps);
-        store_tile(0);
+        store_tile(std::integral_constant<int, 0>{});
     }
     __syncthreads();
 
-    for (int t = 0; t < T; ++t) {
-        const int buf = t & 1;
+    auto k_tile = [&](auto bufc, int t) {
+        constexpr int buf = decltype(bufc)::value;
         if (t + 1 < T) load_tile(ps + (t + 1) * BK);
         const float* A = As + buf * A_TILE + wm0 + l31;
         const float* B = Bs + buf * B_TILE + wn0 + l31;
@@ -623,8 +632,12 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < T) store_tile(buf ^ 1);
+        if (t + 1 < T) store_tile(std::integral_constant<int, buf ^ 1>{});
         __syncthreads();
+    };
+    for (int t = 0; t < T; t += 2) {
+        k_tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < T) k_tile(std::integral_constant<int, 1>{}, t + 1);
     }
 
     if (do_bias) {  // all waves are past the loop's final barrier: reuse the A tile as scratch
