@@ -497,6 +497,29 @@ class Concat(Sequential):
         return out
 
     grouped = True  # identical branches run in lockstep with grouped GEMM launches
+    overlap_groups = os.environ.get("CG_CONCAT_OVERLAP", "1") != "0"
+    # ^ groups of branches (D32_st3: the three transformer branches in lockstep / the two-convolution branch) run on two
+    #   HIP streams: the long chain of launch-bound kernels of the first hides under the big GEMMs of the second
+
+    def _run_groups(self, thunks):
+        """thunks[0] on the current stream, the others forked onto side streams and joined; results in order."""
+        if not (self.overlap_groups and has_gpu() and len(thunks) > 1):
+            return [f() for f in thunks]
+        if getattr(self, "_gstreams", None) is None or len(self._gstreams) < len(thunks) - 1:
+            self._gstreams = [(torch.cuda.Stream(), torch.cuda.Event()) for _ in thunks[1:]]
+            self._gfork = torch.cuda.Event()
+        main = torch.cuda.current_stream()
+        self._gfork.record(main)
+        out = [None] * len(thunks)
+        for k, ((st_, ev), f) in enumerate(zip(self._gstreams, thunks[1:]), start=1):
+            st_.wait_event(self._gfork)
+            with torch.cuda.stream(st_):
+                out[k] = f()
+                ev.record(st_)
+        out[0] = thunks[0]()
+        for (st_, ev), _ in zip(self._gstreams, thunks[1:]):
+            main.wait_event(ev)
+        return out
 
     def _branch_groups(self):
         if getattr(self, "_groups", None) is None:
@@ -529,7 +552,7 @@ class Concat(Sequential):
         draws = self._draws[key]
         base = [r.offset + sum(draws[:i]) for i in range(len(self.modules))]
         end = r.offset + sum(draws)
-        for idxs in groups:
+        def run(idxs):
             mods = [self.modules[i] for i in idxs]
             if len(idxs) > 1:
                 ctx = _GroupCtx([base[i] for i in idxs])
@@ -537,8 +560,11 @@ class Concat(Sequential):
             else:
                 r.offset = base[idxs[0]]
                 res = [mods[0].updateOutput(input)]
+            return [as_nhwc(o) for o in res]
+
+        for idxs, res in zip(groups, self._run_groups([(lambda g=g: run(g)) for g in groups])):
             for i, o in zip(idxs, res):
-                outs[i] = as_nhwc(o)
+                outs[i] = o
         r.offset = end
         return outs
 
@@ -548,15 +574,20 @@ class Concat(Sequential):
                 return self._fork_join([(lambda m=m, s=s: as_nhwc(m.backward(input, s, scale))) for m, s in slices])
             return self._fork_join([(lambda m=m, s=s: as_nhwc(m.updateGradInput(input, s))) for m, s in slices])
         grads = [None] * len(self.modules)
-        for idxs in self._branch_groups():
+
+        def run(idxs):
             mods = [self.modules[i] for i in idxs]
             gs = [slices[i][1] for i in idxs]
             if len(idxs) > 1:
                 res = group_backward(mods, [input] * len(idxs), gs, scale, acc, _GroupCtx([0] * len(idxs)))
             else:
                 res = [mods[0].backward(input, gs[0], scale) if acc else mods[0].updateGradInput(input, gs[0])]
+            return [as_nhwc(g) for g in res]
+
+        groups = self._branch_groups()
+        for idxs, res in zip(groups, self._run_groups([(lambda g=g: run(g)) for g in groups])):
             for i, g in zip(idxs, res):
-                grads[i] = as_nhwc(g)
+                grads[i] = g
         return grads
 
     def updateOutput(self, input):
