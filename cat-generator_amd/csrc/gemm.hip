@@ -517,7 +517,61 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
     const bool lin_src = g.td.ss == 1 && g.Hs == g.Hg && g.Ws == g.Wg;
     const bool lin_out = g.so == 1 && g.nphase == 1;
     constexpr bool SAME_ROWS = (AVEC == BVEC);
+
+    // ---- lean tile addressing for power-of-two grids (all layers of the models): a K tile is 16 consecutive grid pixels
+    // starting at a multiple of 16, so the image and the tile's first row / column are wave-uniform (SALU), while a
+    // thread's own row / column offset inside the tile, its tap and its byte offsets are loop invariants.  Per tile and
+    // operand row that leaves two adds, two compares and a select instead of ~25 VALU of pixel decoding.
+    const int HWg = g.Hg * g.Wg;
+    const bool lean = VECA && VECB && g.lgW >= 0 && g.lgHW >= 0 && HWg >= BK && lin_src && (lin_out || g.so == 2) &&
+                      (ps % BK) == 0 && (pend % BK) == 0 && APASS * ARPP == BK && BPASS * BRPP == BK;
+    int l_ay[APASS], l_ax[APASS];
+    unsigned l_avoff[APASS], l_bvoff[BPASS];
+    int l_minoff = 0;
+    __amdgpu_buffer_rsrc_t rsx_l = rsx;
+    if (lean) {
+        for (int t = 0; t < g.ntaps; ++t) {
+            int ty, tx, off;
+            tap_decode(g, t, pa, pb, ty, tx, off);
+            l_minoff = min(l_minoff, off);
+        }
+        rsx_l = __builtin_amdgcn_make_buffer_rsrc((void*)(gx + l_minoff), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < APASS; ++q) {
+            const int kr = a_kr + q * ARPP;
+            const int kyo = g.Wg >= BK ? 0 : (kr >> g.lgW), kxo = g.Wg >= BK ? kr : (kr & (g.Wg - 1));
+            l_ay[q] = kyo + c_ty[0];
+            l_ax[q] = kxo + c_tx[0];
+            l_avoff[q] = c_ok[0] ? (unsigned)(kr * g.Cin + c_off[0] - l_minoff) * 4u : OOB;
+        }
+#pragma unroll
+        for (int q = 0; q < BPASS; ++q) {
+            const int kr = b_kr + q * BRPP;
+            const int kyo = g.Wg >= BK ? 0 : (kr >> g.lgW), kxo = g.Wg >= BK ? kr : (kr & (g.Wg - 1));
+            const int rel = lin_out ? kr * g.Cout : (kyo * g.so * g.Wout + kxo * g.so) * g.Cout;
+            l_bvoff[q] = b_nok ? (unsigned)(rel + n0 + 4 * b_nv) * 4u : OOB;
+        }
+    }
     auto load_tile = [&](int p0) {
+        if (lean) {
+            const int r0 = p0 & (HWg - 1);
+            const int oyb = r0 >> g.lgW, oxb = r0 & (g.Wg - 1);
+            const int soa = p0 * g.Cin * 4;
+#pragma unroll
+            for (int q = 0; q < APASS; ++q) {
+                const bool ok = (unsigned)(oyb + l_ay[q]) < (unsigned)g.Hv && (unsigned)(oxb + l_ax[q]) < (unsigned)g.Wv;
+                areg[q] = bufld4(rsx_l, ok ? l_avoff[q] : OOB, soa);
+            }
+            int sob;
+            if (lin_out) sob = p0 * g.Cout * 4;
+            else {
+                const int nimg = p0 >> g.lgHW;
+                sob = (((nimg * g.Hout + oyb * g.so + pa) * g.Wout + oxb * g.so + pb) * g.Cout) * 4;
+            }
+#pragma unroll
+            for (int q = 0; q < BPASS; ++q) breg[q] = bufld4(rsd, l_bvoff[q], sob);
+            return;
+        }
         int rn[APASS], roy[APASS], rox[APASS];
 #pragma unroll
         for (int q = 0; q < APASS; ++q) {
