@@ -226,6 +226,8 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
             getattr(optim, m)(lambda _x: (fD, gD), S.PARAMETERS_D, S.OPTSTATE[m]["D"], fused=fused)
         else:
             getattr(optim, m)(fevalD, S.PARAMETERS_D, S.OPTSTATE[m]["D"], fused=fused)
+        if S.keep_outputs:   # tests: the gradient optim received (penalty + clamp applied), before the G-step touches D
+            S._last["gD"] = S.GRAD_PARAMETERS_D.clone()
 
     # ----------------------------------------------------------------- (2) update G (:253-266)
     for _ in range(OPT["G_iterations"]):
@@ -237,6 +239,8 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         m = OPT["G_optmethod"]  # adversarial.lua:257-265
         assert m in ("sgd", "adagrad", "adam"), "[Warning] Unknown optimizer method chosen for G."
         getattr(optim, m)(fevalG_on_D, S.PARAMETERS_G, S.OPTSTATE[m]["G"], fused=fused)
+        if S.keep_outputs:
+            S._last["gG"] = S.GRAD_PARAMETERS_G.clone()
     return st["doTrainD"]
 
 

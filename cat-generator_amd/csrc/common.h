@@ -37,6 +37,15 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 constexpr int kNumCU = 256;  // MI355X: 8 XCDs x 32 CUs
 
+// Tunables (cg_set_option / cg_get_option, catgan.h).  Default = the environment variable of the same name if set,
+// else the built-in value; cg_set_option overrides both at run time (tests force every kernel variant this way).
+enum Opt {
+    OPT_SPLIT_TARGET, OPT_SPLIT_MINK, OPT_TN_SMAX, OPT_TN_TARGET, OPT_SKINNY, OPT_GEMM_SLOW, OPT_GEMM_BK32,
+    OPT_COLREDUCE_WGS_PER_CU, OPT_WINO_WAVES, OPT_WINO_BK, OPT_NN_TILE, OPT_TN_TILE, OPT_NN_SPLITS, OPT_TN_SPLITS,
+    OPT_EPILOGUE_STATS, OPT_COUNT
+};
+long opt(Opt o);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // grid for memory-bound grid-stride kernels: enough blocks to fill 256 CUs x 8

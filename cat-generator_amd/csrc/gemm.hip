@@ -1126,7 +1126,19 @@ struct TileCfg { int bm, bn; };
 
 // pick the block tile: BN covers Cout with least padding, BM chosen so the grid
 // fills the 256 CUs at >= ~2 workgroups each when the problem allows it.
+static bool tile_forced(cg::Opt o, TileCfg& tc) {
+    // CG_NN_TILE / CG_TN_TILE = bm*1000 + bn forces one of the compiled block tiles (parity tests walk all of them)
+    const long v = cg::opt(o);
+    if (v <= 0) return false;
+    const int bm = (int)(v / 1000), bn = (int)(v % 1000);
+    if (!((bm == 128 || bm == 64) && (bn == 128 || bn == 64)) && !(bm == 128 && bn == 32)) return false;
+    tc = {bm, bn};
+    return true;
+}
+
 static TileCfg pick_tile(long M, int Cout, int nphase) {
+    TileCfg f;
+    if (tile_forced(cg::OPT_NN_TILE, f)) return f;
     int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     int bm = 128;
     if (bn == 128 || bn == 64) {
@@ -1139,11 +1151,9 @@ static TileCfg pick_tile(long M, int Cout, int nphase) {
 static int pick_splits(long tiles, long kiters) {
     // Small grids are latency-bound (one global-load round trip per K tile, nothing to overlap it with), so
     // split K until there are CG_SPLIT_TARGET workgroups per CU, keeping >= CG_SPLIT_MINK K-iterations per split.
-    static int target = -1, mink = -1;
-    if (target < 0) {
-        const char* e = getenv("CG_SPLIT_TARGET"); target = e ? atoi(e) : 2;
-        const char* f = getenv("CG_SPLIT_MINK"); mink = f ? atoi(f) : 8;
-    }
+    const int target = (int)cg::opt(cg::OPT_SPLIT_TARGET), mink = (int)cg::opt(cg::OPT_SPLIT_MINK);
+    const int forced = (int)cg::opt(cg::OPT_NN_SPLITS);
+    if (forced > 0) return (int)std::min<long>(forced, std::max<long>(1, kiters / 2));
     int s = 1;
     while (tiles * s < (long)target * cg::kNumCU && kiters / (s * 2) >= mink && s < 64) s *= 2;
     return s;
@@ -1268,11 +1278,15 @@ static TNPlan plan_tn(const Geom& g, int ngroups) {
     int bm = g.Ktot > 64 ? 128 : 64;
     if (bn == 32) bm = 128;
     p.tc = {bm, bn};
+    tile_forced(cg::OPT_TN_TILE, p.tc);
+    bm = p.tc.bm; bn = p.tc.bn;
     const long tiles = (long)cg::cdiv(g.Ktot, bm) * cg::cdiv(g.Cout, bn) * g.nphase * ngroups;
     const long piters = cg::cdiv(g.M, BK);
-    static int smax = -1, tgt = -1;
-    if (smax < 0) { const char* e = getenv("CG_TN_SMAX"); smax = e ? atoi(e) : 128; const char* f = getenv("CG_TN_TARGET"); tgt = f ? atoi(f) : 3; }
+    const int smax = (int)cg::opt(cg::OPT_TN_SMAX), tgt = (int)cg::opt(cg::OPT_TN_TARGET);
+    const int forced = (int)cg::opt(cg::OPT_TN_SPLITS);
     int s = 1;
+    if (forced > 0) s = (int)std::min<long>(forced, std::max<long>(1, piters));
+    else
     while (tiles * s < (long)tgt * cg::kNumCU && piters / (s * 2) >= 8 && s < smax) s *= 2;
     p.pchunk = cg::cdiv(piters, s) * BK;
     p.splits = cg::cdiv(g.M, p.pchunk);
@@ -1285,8 +1299,7 @@ static size_t tn_ws_bytes(const Geom& g, const TNPlan& p, int ngroups) {
 // ---- skinny 3x3 path (see skinny_conv3x3_kernel) ----
 constexpr int kSkinnyWgradBlocks = 512;
 static bool skinny_ok(int ngroups, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("CG_SKINNY"); on = e ? atoi(e) : 1; }
+    const bool on = cg::opt(cg::OPT_SKINNY) != 0;
     return on && ngroups == 1 && ups == 0 && kH == 3 && kW == 3 && padH == 1 && padW == 1 && (Cout == 3 || Cout == 1) &&
            (Cin == 64 || Cin == 128);
 }
@@ -1337,11 +1350,9 @@ static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const
     a.y0 = ys[0]; a.y1 = ys[1]; a.y2 = ys[2]; a.y3 = ys[3];
     a.part = (float*)ws; a.ngroups = ngroups; a.g = g;
     a.kchunk = p.kchunk; a.nsplit = p.splits;
-    const bool fast = (g.Cin % BK == 0) && al && (getenv("CG_GEMM_SLOW") == nullptr);
+    const bool fast = (g.Cin % BK == 0) && al && cg::opt(cg::OPT_GEMM_SLOW) == 0;
     const bool vecb = (g.Cout % 4 == 0) && alw;
-    static int use32 = -1;
-    if (use32 < 0) { const char* e = getenv("CG_GEMM_BK32"); use32 = e ? atoi(e) : 1; }
-    const bool bk32 = use32 && (g.Cin % 32 == 0) && (p.kchunk % 32 == 0);
+    const bool bk32 = cg::opt(cg::OPT_GEMM_BK32) != 0 && (g.Cin % 32 == 0) && (p.kchunk % 32 == 0);
     dim3 grid(cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, g.nphase * ngroups);
     if (p.tc.bm == 128 && p.tc.bn == 128) launch_nn<128, 128, 2, 2>(a, grid, st, fast, vecb, bk32);
     else if (p.tc.bm == 64 && p.tc.bn == 128) launch_nn<64, 128, 2, 2>(a, grid, st, fast, vecb, bk32);

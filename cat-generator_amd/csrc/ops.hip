@@ -4,6 +4,7 @@
 // Each kernel cites the reference module it stands in for (see catgan.h).
 #include "common.h"
 #include <stdarg.h>
+#include <stdlib.h>
 #include <algorithm>
 
 namespace cg {
@@ -17,6 +18,27 @@ int fail(const char* fmt, ...) {
     vsnprintf(err_buf(), 512, fmt, ap);
     va_end(ap);
     return 1;
+}
+
+namespace {
+struct OptDef { const char* name; long dflt; };
+// order = enum Opt (common.h)
+const OptDef kOptDefs[OPT_COUNT] = {
+    {"CG_SPLIT_TARGET", 2}, {"CG_SPLIT_MINK", 8}, {"CG_TN_SMAX", 128}, {"CG_TN_TARGET", 3}, {"CG_SKINNY", 1},
+    {"CG_GEMM_SLOW", 0}, {"CG_GEMM_BK32", 1}, {"CG_COLREDUCE_WGS_PER_CU", 1}, {"CG_WINO_WAVES", 8}, {"CG_WINO_BK", 0},
+    {"CG_NN_TILE", 0}, {"CG_TN_TILE", 0}, {"CG_NN_SPLITS", 0}, {"CG_TN_SPLITS", 0}, {"CG_EPILOGUE_STATS", 1},
+};
+long g_opt_val[OPT_COUNT];
+int g_opt_state[OPT_COUNT];   // 0 = not read yet, 1 = default / environment, 2 = set through the ABI
+}  // namespace
+
+long opt(Opt o) {
+    if (g_opt_state[o] == 0) {
+        const char* e = getenv(kOptDefs[o].name);
+        g_opt_val[o] = e ? atol(e) : kOptDefs[o].dflt;
+        g_opt_state[o] = 1;
+    }
+    return g_opt_val[o];
 }
 }  // namespace cg
 
@@ -790,6 +812,22 @@ static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 extern "C" {
 
 int cg_abi_version(void) { return CG_ABI_VERSION; }
+int cg_set_option(const char* name, long value) {
+    CG_REQUIRE(name, "cg_set_option: null name");
+    for (int i = 0; i < cg::OPT_COUNT; ++i)
+        if (strcmp(name, cg::kOptDefs[i].name) == 0) {
+            if (value == -1) { cg::g_opt_state[i] = 0; return 0; }   // back to the environment / built-in default
+            cg::g_opt_val[i] = value; cg::g_opt_state[i] = 2;
+            return 0;
+        }
+    return cg::fail("cg_set_option: unknown option %s", name);
+}
+int cg_get_option(const char* name, long* value) {
+    CG_REQUIRE(name && value, "cg_get_option: null pointer");
+    for (int i = 0; i < cg::OPT_COUNT; ++i)
+        if (strcmp(name, cg::kOptDefs[i].name) == 0) { *value = cg::opt((cg::Opt)i); return 0; }
+    return cg::fail("cg_get_option: unknown option %s", name);
+}
 const char* cg_last_error(void) { return cg::err_buf(); }
 int cg_device_count(int* count) { CG_REQUIRE(count, "null"); CG_HIP(hipGetDeviceCount(count)); return 0; }
 int cg_set_device(int device) { CG_HIP(hipSetDevice(device)); return 0; }
@@ -879,8 +917,7 @@ static int colreduce_launch(void* stream, int mode, const float* x, const float*
     const int cblocks = v4 ? cg::cdiv(C / 4, qb) : cg::cdiv(C, 64);
     // row chunks: every chunk ends in one double atomic per channel, and same-address atomics serialise (~10 ns each),
     // so aim at one workgroup per CU in total (CG_COLREDUCE_WGS_PER_CU) rather than at maximum occupancy
-    static int cmul = -1;
-    if (cmul < 0) { const char* e = getenv("CG_COLREDUCE_WGS_PER_CU"); cmul = e ? atoi(e) : 1; }
+    const int cmul = (int)cg::opt(cg::OPT_COLREDUCE_WGS_PER_CU);
     long chunks = std::max(1L, std::min((M + 63) / 64, (long)cg::kNumCU * cmul / cblocks));
     const long rows_per_block = ((M + chunks - 1) / chunks + 3) / 4 * 4;
     chunks = (M + rows_per_block - 1) / rows_per_block;

@@ -419,9 +419,7 @@ int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const
     a.V = v; a.U = u; a.bias = bias; a.y = y; a.T = T; a.tH = Hp / 2; a.tW = Wp / 2;
     if (dgrad) { a.K = 4 * Cout; a.Nc = Cin; a.so = 1; a.Ho = Hp; a.Wo = Wp; }
     else { a.K = Cin; a.Nc = Cout; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp; }
-    static int nw = -1, bk = -1;
-    if (nw < 0) { const char* e = getenv("CG_WINO_WAVES"); nw = e ? atoi(e) : 8; }
-    if (bk < 0) { const char* e = getenv("CG_WINO_BK"); bk = e ? atoi(e) : 0; }
+    const int nw = (int)cg::opt(cg::OPT_WINO_WAVES), bk = (int)cg::opt(cg::OPT_WINO_BK);
     const dim3 grid(cg::cdiv(T, 64) * (a.Nc / 128), 1, dgrad ? 1 : 4);
     // K step 32 (half the barriers per MFMA) pays when the launch is at most ~one workgroup per CU - the data-gradient
     // geometry at batch 128 (0.53 -> 0.41 ms) - and costs 6 % when two workgroups per CU already hide each other's barriers

@@ -44,6 +44,13 @@ extern "C" {
  * utils/nn_utils.lua:638-643). */
 int         cg_abi_version(void);
 const char* cg_last_error(void);
+/* Tunables of the kernel dispatch (block tiles, split-K targets, Winograd variants ...), named like the environment
+ * variables that set their defaults (CG_NN_TILE, CG_TN_TILE = bm*1000+bn; CG_NN_SPLITS, CG_TN_SPLITS; CG_GEMM_BK32;
+ * CG_WINO_BK; CG_WINO_WAVES; CG_SKINNY; CG_GEMM_SLOW; CG_SPLIT_TARGET; CG_SPLIT_MINK; CG_TN_SMAX; CG_TN_TARGET;
+ * CG_COLREDUCE_WGS_PER_CU; CG_EPILOGUE_STATS).  value == -1 restores the default.  Results never depend on them beyond
+ * fp32 re-association; the parity tests use them to run every compiled kernel variant against the oracle. */
+int cg_set_option(const char* name, long value);
+int cg_get_option(const char* name, long* value);
 int cg_device_count(int* count);
 int cg_set_device(int device);
 int cg_malloc(void** dptr, size_t bytes);

@@ -807,8 +807,10 @@ class Trainer:
         inputs = np.concatenate([real, fake], axis=0).astype(f32)
         targets = np.concatenate([np.ones(half, f32), np.zeros(half, f32)])
         fD, outD = self.feval_D(inputs, targets)
+        gD = self.gD.copy()   # what optim.adam receives (penalty + clamp applied); feval_G's D:backward adds to gD later
         adam(self.pD, self.gD, self.stD)
         # (2) G update: fresh noise, targets all "real" (:253-266)
         fG, samples, outG = self.feval_G(noise_g, np.ones(N, f32))
+        gG = self.gG.copy()
         adam(self.pG, self.gG, self.stG)
-        return dict(fD=fD, fG=fG, outD=outD, outG=outG, fake=fake, samples=samples)
+        return dict(fD=fD, fG=fG, outD=outD, outG=outG, fake=fake, samples=samples, gD=gD, gG=gG)

@@ -1,0 +1,328 @@
+"""Oracle-compared parity at the BENCHMARKED sizes (BASELINE.json configs[1] batch 128, configs[2] batch 256) and
+for every compiled kernel variant the dispatch can select.
+
+tests/test_gpu_parity.py compares with the oracle at batch <= 8, where `pick_tile` / `plan_nn` / the Winograd K-step
+rule select small-grid variants.  Here every convolution and linear layer of G32up-c / G32up / D32_st3
+(models.lua:138-160,196-228,640-711,814-906) runs at the batch the bench runs it (N and N/2: the fake-generation
+forward of adversarial.lua:232 is a half batch) through forward, data gradient and weight gradient against the CPU
+oracle, and `cg_set_option` forces each block tile / split-K / K-step / Winograd variant on small oracle-checked
+shapes, so that every kernel in profiles/*_bench_kernel_stats.csv also occurs inside an oracle comparison
+(scripts/kernel_coverage.py lists the two sets side by side).
+
+Tolerance (fp32, different summation orders): |d| <= 2e-5 * sqrt(K/1024) * max(1, max|ref|), K = reduction length
+(4e-5 for the weight gradient, whose K = N*H*W reaches 131072).
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def cg():
+    mod = importlib.import_module("cat-generator_amd")
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    mod.lib()
+    O.set_num_threads(O.num_threads())
+    return mod
+
+
+def close(a, b, K=1024, tol=2e-5, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    s = max(1.0, np.sqrt(K / 1024.0)) * max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert np.isfinite(a).all(), f"{what}: non-finite values"
+    assert err <= tol * s, f"{what}: max|d|={err:.3e} > {tol * s:.3e} (K={K})"
+    return err
+
+
+class options:
+    """with options(cg, CG_NN_TILE=128064, ...): force dispatch tunables through the C ABI, restore afterwards."""
+
+    def __init__(self, cg, **kv):
+        self.cg, self.kv = cg, kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.cg.lib().set_option(k.encode(), int(v))
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            self.cg.lib().set_option(k.encode(), -1)
+
+
+def run_conv(cg, N, Cin, H, W, Cout, k, ups, seed=0, wino=True, check_dgrad=True):
+    """One SpatialConvolution (optionally behind the lazy 2x upsampling) forward / backward against the oracle."""
+    rs = np.random.RandomState(seed)
+    pad = (k - 1) // 2
+    cg.nn.SpatialConvolution.winograd = wino
+    try:
+        m = cg.nn.SpatialConvolution(Cin, Cout, k, k, 1, 1, pad)
+        w = (rs.randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)).astype(f32)
+        b = rs.randn(Cout).astype(f32)
+        m.weight.copy(w); m.bias.copy(b)
+        x = rs.randn(N, Cin, H, W).astype(f32)
+        xin = cg.Tensor.from_numpy(x)
+        xl = x
+        if ups:
+            up = cg.nn.SpatialUpSamplingNearest(2)
+            xin = up.forward(xin)
+            xl = np.repeat(np.repeat(x, 2, axis=2), 2, axis=3)
+        y = m.forward(xin).numpy()
+        close(y, O.conv2d_forward(xl, w, b, pad), K=Cin * k * k, what="updateOutput")
+        dy = rs.randn(*y.shape).astype(f32)
+        m.gradWeight.zero(); m.gradBias.zero()
+        gi_t = m.backward(xin, cg.Tensor.from_numpy(dy))
+        if check_dgrad:
+            ref = O.conv2d_backward_data(dy, w, xl.shape, pad)
+            if ups:
+                gi = up.updateGradInput(None, gi_t).numpy()
+                close(gi, O.UpSample2().backward(ref), K=4 * Cout * k * k, what="updateGradInput (+2x2 block sum)")
+            else:
+                close(gi_t.numpy(), ref, K=Cout * k * k, what="updateGradInput")
+        gw, gb = np.zeros_like(w), np.zeros_like(b)
+        O.conv2d_backward_weight(xl, dy, gw, gb, pad)
+        P = y.shape[0] * y.shape[2] * y.shape[3]
+        close(m.gradWeight.numpy(), gw, K=P, tol=4e-5, what="gradWeight")
+        close(m.gradBias.numpy(), gb, K=P, tol=4e-5, what="gradBias")
+        return m
+    finally:
+        cg.nn.SpatialConvolution.winograd = True
+
+
+# ------------------------------------------------------------------ every conv layer at the benchmarked batch
+# (name, N, Cin, H, W, Cout, k, ups): H, W are the convolution's INPUT dims before the folded upsampling
+FULL_CONVS = [
+    # config #2: G32up-c, batch 128 (G-step) and 64 (fake generation for the D-step)
+    ("G32up-c conv 512->512 3x3 @4->8 (models.lua:205-206)", 128, 512, 4, 4, 512, 3, 1),
+    ("G32up-c conv 512->512, half batch", 64, 512, 4, 4, 512, 3, 1),
+    ("G32up-c conv 512->256 3x3 @8->16 (:211-212)", 128, 512, 8, 8, 256, 3, 1),
+    ("G32up-c conv 512->256, half batch", 64, 512, 8, 8, 256, 3, 1),
+    ("G32up-c conv 256->128 5x5 @16->32 (:217-218), Winograd", 128, 256, 16, 16, 128, 5, 1),
+    ("G32up-c conv 256->128 5x5, half batch", 64, 256, 16, 16, 128, 5, 1),
+    ("G32up-c conv 128->3 3x3 @32 (:222), skinny", 128, 128, 32, 32, 3, 3, 0),
+    # D32_st3, batch 128
+    ("D conv 3->64 3x3 @32 (:646)", 128, 3, 32, 32, 64, 3, 0),
+    ("D conv 64->64 3x3 @32 (:648)", 128, 64, 32, 32, 64, 3, 0),
+    ("D branch conv 64->64 3x3 @16 (:655)", 128, 64, 16, 16, 64, 3, 0),
+    ("D branch conv 64->64 3x3 @8 (:659)", 128, 64, 8, 8, 64, 3, 0),
+    ("D branch-4 conv 64->128 5x5 @16 (:681)", 128, 64, 16, 16, 128, 5, 0),
+    ("D branch-4 conv 128->128 7x7 @8 (:685)", 128, 128, 8, 8, 128, 7, 0),
+    ("ST0 loc conv 3->16 @16 (:844)", 128, 3, 16, 16, 16, 3, 0),
+    ("ST0 loc conv 16->16 @16 (:846)", 128, 16, 16, 16, 16, 3, 0),
+    ("branch ST loc conv 64->16 @8 (:844), stacked x3", 384, 64, 8, 8, 16, 3, 0),
+    ("branch ST loc conv 16->16 @8 (:846), stacked x3", 384, 16, 8, 8, 16, 3, 0),
+    # config #3: G32up grayscale, batch 256 / 128
+    ("G32up conv 128->256 5x5 @8->16 (:143-144), bs256", 256, 128, 8, 8, 256, 5, 1),
+    ("G32up conv 256->128 5x5 @16->32 (:148-149), bs256", 256, 256, 16, 16, 128, 5, 1),
+    ("G32up conv 128->1 3x3 @32 (:153), bs256", 256, 128, 32, 32, 1, 3, 0),
+    ("D conv 1->64 3x3 @32, bs256", 256, 1, 32, 32, 64, 3, 0),
+    ("D conv 64->64 3x3 @32, bs256", 256, 64, 32, 32, 64, 3, 0),
+    ("D branch-4 conv 64->128 5x5 @16, bs256", 256, 64, 16, 16, 128, 5, 0),
+    ("D branch-4 conv 128->128 7x7 @8, bs256", 256, 128, 8, 8, 128, 7, 0),
+]
+
+
+@pytest.mark.parametrize("name,N,Cin,H,W,Cout,k,ups", FULL_CONVS, ids=[c[0] for c in FULL_CONVS])
+def test_conv_layer_at_benchmarked_batch(cg, name, N, Cin, H, W, Cout, k, ups):
+    m = run_conv(cg, N, Cin, H, W, Cout, k, ups, seed=len(name))
+    if "Winograd" in name:
+        assert getattr(m, "_wino", False), "the benchmarked dispatch runs this layer on the Winograd kernels"
+
+
+FULL_LINEARS = [
+    ("G32up-c Linear 100->8192 (models.lua:199)", 128, 100, 8192),
+    ("G32up-c Linear 100->8192, half batch", 64, 100, 8192),
+    ("G32up Linear 100->8192 (:139), bs256", 256, 100, 8192),
+    ("D Linear 20480->256 (:697)", 128, 20480, 256),
+    ("D Linear 20480->256, bs256", 256, 20480, 256),
+    ("D Linear 256->1 (:700)", 128, 256, 1),
+    ("ST0 loc Linear 1024->64 (:850)", 128, 1024, 64),
+    ("ST0 loc Linear 64->1 (:853)", 128, 64, 1),
+    ("branch ST loc Linear 256->64, stacked x3", 384, 256, 64),
+    ("branch ST loc Linear 64->4", 128, 64, 4),
+]
+
+
+@pytest.mark.parametrize("name,N,i,o", FULL_LINEARS, ids=[c[0] for c in FULL_LINEARS])
+def test_linear_layer_at_benchmarked_batch(cg, name, N, i, o):
+    rs = np.random.RandomState(N + i + o)
+    m = cg.nn.Linear(i, o)
+    w = (rs.randn(o, i) / np.sqrt(i)).astype(f32); b = rs.randn(o).astype(f32)
+    m.weight.copy(w); m.bias.copy(b)
+    x = rs.randn(N, i).astype(f32); dy = rs.randn(N, o).astype(f32)
+    close(m.forward(cg.Tensor.from_numpy(x)).numpy(), O.linear_forward(x, w, b), K=i, what="forward")
+    m.gradWeight.zero(); m.gradBias.zero()
+    gi = m.backward(cg.Tensor.from_numpy(x), cg.Tensor.from_numpy(dy)).numpy()
+    close(gi, O.linear_backward_data(dy, w), K=o, what="gradInput")
+    gw, gb = np.zeros_like(w), np.zeros_like(b)
+    O.linear_backward_weight(x, dy, gw, gb)
+    close(m.gradWeight.numpy(), gw, K=N, what="gradWeight"); close(m.gradBias.numpy(), gb, K=N, what="gradBias")
+
+
+def test_grouped_branch_convs_at_benchmarked_batch(cg):
+    """D32_st3's three identical transformer branches (models.lua:653-678) run their convolutions as ONE grouped
+    launch (blockIdx.z = branch): forward, data gradient and weight gradient of the group at batch 128."""
+    rs = np.random.RandomState(12)
+    N, C, H = 128, 64, 16
+    mods, ws, bs, xs, dys = [], [], [], [], []
+    for g in range(3):
+        m = cg.nn.SpatialConvolution(C, C, 3, 3, 1, 1, 1)
+        w = (rs.randn(C, C, 3, 3) / 24).astype(f32); b = rs.randn(C).astype(f32)
+        m.weight.copy(w); m.bias.copy(b); m.gradWeight.zero(); m.gradBias.zero()
+        mods.append(m); ws.append(w); bs.append(b)
+        xs.append(rs.randn(N, C, H, H).astype(f32)); dys.append(rs.randn(N, C, H, H).astype(f32))
+    xin = [cg.nn.as_nhwc(cg.Tensor.from_numpy(x)) for x in xs]
+    ctx = cg.nn._GroupCtx([0, 0, 0])
+    outs = cg.nn.group_forward(mods, xin, ctx)
+    gins = cg.nn.group_backward(mods, xin, [cg.nn.as_nhwc(cg.Tensor.from_numpy(d)) for d in dys], 1.0, True, ctx)
+    for g in range(3):
+        close(outs[g].numpy(), O.conv2d_forward(xs[g], ws[g], bs[g], 1), K=C * 9, what=f"branch {g} output")
+        close(gins[g].numpy(), O.conv2d_backward_data(dys[g], ws[g], xs[g].shape, 1), K=C * 9, what=f"branch {g} gradInput")
+        gw, gb = np.zeros_like(ws[g]), np.zeros_like(bs[g])
+        O.conv2d_backward_weight(xs[g], dys[g], gw, gb, 1)
+        close(mods[g].gradWeight.numpy(), gw, K=N * H * H, tol=4e-5, what=f"branch {g} gradWeight")
+        close(mods[g].gradBias.numpy(), gb, K=N * H * H, tol=4e-5, what=f"branch {g} gradBias")
+
+
+# ------------------------------------------------------------------ every compiled variant, forced
+NN_TILES = [128128, 64128, 128064, 64064, 128032]
+
+
+@pytest.mark.parametrize("tile", NN_TILES)
+@pytest.mark.parametrize("bk32", [0, 1])
+@pytest.mark.parametrize("splits", [0, 3])
+def test_forced_nn_tile_variants(cg, tile, bk32, splits):
+    """igemm_nn_kernel<BM,BN,...,BK> for every block tile, K step 16 / 32, with and without split-K (+ reduce kernel),
+    on plain, upsample-folded (4 phases) and folded data-gradient (4 tap groups) geometries; ragged M and Cout."""
+    with options(cg, CG_NN_TILE=tile, CG_GEMM_BK32=bk32, CG_NN_SPLITS=splits, CG_SKINNY=0):
+        run_conv(cg, 3, 64, 10, 6, 72, 3, 0, seed=tile % 97)          # ragged M = 180, Cout = 72
+        run_conv(cg, 2, 32, 8, 8, 128, 3, 1, seed=tile % 89, wino=False)
+        run_conv(cg, 2, 64, 4, 4, 32, 5, 1, seed=tile % 83, wino=False)
+
+
+@pytest.mark.parametrize("tile", NN_TILES)
+@pytest.mark.parametrize("splits", [0, 5])
+def test_forced_tn_tile_variants(cg, tile, splits):
+    """igemm_tn_kernel<BM,BN> (weight gradient) for every block tile, default and forced pixel splits; the lean
+    power-of-two addressing (16x16 grid) and the generic one (10x6 grid)."""
+    with options(cg, CG_TN_TILE=tile, CG_TN_SPLITS=splits, CG_SKINNY=0):
+        run_conv(cg, 3, 64, 10, 6, 72, 3, 0, seed=tile % 97, check_dgrad=False)
+        run_conv(cg, 2, 64, 16, 16, 64, 3, 0, seed=tile % 89, check_dgrad=False)
+        run_conv(cg, 2, 32, 8, 8, 128, 3, 1, seed=tile % 83, wino=False, check_dgrad=False)
+
+
+def test_generic_gather_variants(cg):
+    """The non-FAST (scalar gather) and non-vector-B template instances: Cin % 16 != 0, Cout % 4 != 0, and the FAST path
+    switched off (CG_GEMM_SLOW) on an aligned shape."""
+    run_conv(cg, 2, 24, 8, 8, 10, 3, 0, seed=1)
+    run_conv(cg, 2, 16, 8, 8, 10, 3, 0, seed=2)
+    with options(cg, CG_GEMM_SLOW=1):
+        run_conv(cg, 2, 64, 8, 8, 64, 3, 0, seed=3)
+
+
+@pytest.mark.parametrize("waves,bk", [(8, 16), (8, 32), (4, 16)])
+def test_forced_winograd_variants(cg, waves, bk):
+    """wino_gemm_kernel<8,16>, <8,32>, <4,16> on the F(2x2,3x3) path of upsample2 -> conv5x5 (models.lua:217-218),
+    forward + data gradient + weight gradient, ragged tile count."""
+    cg.nn.SpatialConvolution.winograd_min_tiles = 0
+    try:
+        with options(cg, CG_WINO_WAVES=waves, CG_WINO_BK=bk):
+            m = run_conv(cg, 3, 128, 6, 4, 128, 5, 1, seed=waves + bk)
+            assert getattr(m, "_wino", False)
+            m = run_conv(cg, 2, 256, 8, 8, 128, 5, 1, seed=waves * bk)
+            assert getattr(m, "_wino", False)
+    finally:
+        cg.nn.SpatialConvolution.winograd_min_tiles = 2048
+
+
+# ------------------------------------------------------------------ the training step: gradients and Adam moments
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _grad_report(tag, a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    d = np.abs(a - b)
+    scale = max(float(np.abs(b).max()), 1e-30)
+    q = np.quantile(d, [0.5, 0.99, 0.999])
+    print(f"[grad] {tag}: rel-l2 {_rel(a, b):.2e} median {q[0] / scale:.2e} p99 {q[1] / scale:.2e} p99.9 {q[2] / scale:.2e} "
+          f"max {d.max() / scale:.2e} (scale {scale:.2e})")
+    return q / scale, d.max() / scale
+
+
+@pytest.mark.parametrize("N", [8, 128])
+def test_training_steps_gradients_and_adam_state(cg, N):
+    """adversarial.lua:51-275 x3 against the oracle Trainer on identical batches / noise / masks, comparing what a
+    wrong gradient cannot hide in: the flat gradient optim.adam receives (after penalty and clamp, :92-112) and Adam's
+    m / v after the update, for D and for G, at EVERY step, tight on the bulk of the entries and per parameter tensor.
+    N = 128 is BASELINE configs[1] itself (the oracle needs ~20 s per step there).
+
+    Why not exact: engine and oracle are both fp32 with different summation orders, so activations differ by ~1e-6
+    relative; an activation within that distance of a PReLU / max-pool / clamp kink takes the other branch, which moves
+    a few gradient entries by O(1e-3) of the scale (bounded below: p99.9 and max).  From step 1 on the parameters
+    themselves differ by +-2 lr on the few weights whose step-0 gradient was ~0 (Adam's first update is lr*sign(g))."""
+    seed = 31
+    cg.manual_seed(seed); rng = O.RNG(seed)
+    G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
+    Go, Do = O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng)
+    S = cg.adversarial.State(dict(batchSize=N), G, D)
+    S.keep_outputs = True
+    T = O.Trainer(Go, Do)
+    np.testing.assert_array_equal(S.PARAMETERS_D.numpy(), T.pD)
+    np.testing.assert_array_equal(S.PARAMETERS_G.numpy(), T.pG)
+    rs = np.random.RandomState(9)
+    P = 2 * N
+    pool = rs.rand(P, 3, 32, 32).astype(f32)
+    data = cg.adversarial.TrainData(pool)
+    steps = 3 if N <= 16 else 2
+    slices = {"D": [], "G": []}
+    for key, net in (("D", Do), ("G", Go)):
+        off = 0
+        for p_, _ in net.parameters():
+            slices[key].append((off, p_.size, p_.shape)); off += p_.size
+    for step in range(steps):
+        idx = rs.randint(0, P, size=N // 2)
+        nd = (rs.rand(N // 2, 100) * 2 - 1).astype(f32); ng = (rs.rand(N, 100) * 2 - 1).astype(f32)
+        cg.adversarial.iteration(S, data, N, real_idx=idx, noise_D=nd, noise_G=ng)
+        r = T.step(pool[idx], nd, ng)
+        loose = step > 0
+        for key, g_eng, g_orc, st_e, st_o in (("D", S._last["gD"].numpy(), r["gD"], S.OPTSTATE["adam"]["D"], T.stD),
+                                              ("G", S._last["gG"].numpy(), r["gG"], S.OPTSTATE["adam"]["G"], T.stG)):
+            q, mx = _grad_report(f"N={N} step {step} g{key}", g_eng, g_orc)
+            # bulk: half of the entries agree to fp32 rounding of a long sum, 99 % to 1e-3 of the largest entry
+            assert q[0] <= (2e-5 if not loose else 2e-4), f"g{key} step {step}: median rel diff {q[0]:.2e}"
+            assert q[1] <= (1e-3 if not loose else 1e-2), f"g{key} step {step}: p99 rel diff {q[1]:.2e}"
+            assert mx <= (5e-2 if not loose else 2e-1), f"g{key} step {step}: max rel diff {mx:.2e}"
+            assert _rel(g_eng, g_orc) <= (2e-3 if not loose else 3e-2), f"g{key} step {step}: rel l2 {_rel(g_eng, g_orc):.2e}"
+            # per parameter tensor (a wrong layer cannot hide behind the big ones)
+            for off, n, shape in slices[key]:
+                a, b = g_eng[off:off + n], g_orc[off:off + n]
+                nb = float(np.linalg.norm(b))
+                if nb < 1e-6 * max(float(np.linalg.norm(g_orc)), 1e-30) or n < 2:
+                    continue   # e.g. the zero-initialised transformer classifiers' inputs, single PReLU slopes
+                e = _rel(a, b)
+                assert e <= (2e-2 if not loose else 2e-1), f"g{key} step {step} tensor {shape} @{off}: rel l2 {e:.2e}"
+            # Adam moments after the update: m and v are linear / quadratic in the gradients seen so far
+            m_e, v_e = st_e["m"].numpy(), st_e["v"].numpy()
+            assert st_e["t"] == st_o["t"] == step + 1
+            em, ev = _rel(m_e, st_o["m"]), _rel(v_e, st_o["v"])
+            print(f"[adam] N={N} step {step} {key}: rel-l2 m {em:.2e} v {ev:.2e}")
+            assert em <= (2e-3 if not loose else 3e-2) and ev <= (4e-3 if not loose else 6e-2), (key, step, em, ev)
+        # single-weight check scalars: PReLU slopes are one number each - compare them directly at step 0
+        if step == 0:
+            for key, g_eng, g_orc in (("D", S._last["gD"].numpy(), r["gD"]), ("G", S._last["gG"].numpy(), r["gG"])):
+                for off, n, shape in slices[key]:
+                    if n == 1:
+                        a, b = float(g_eng[off]), float(g_orc[off])
+                        assert abs(a - b) <= 2e-3 * max(abs(b), 1e-3 * float(np.abs(g_orc).max())), (key, off, a, b)
+        d_img = np.abs(S._last_fake.numpy() - r["fake"]).max()
+        assert d_img <= (2e-4 if step == 0 else 4e-2), f"step {step}: fake images differ by {d_img:.2e}"
