@@ -317,12 +317,13 @@ def test_training_steps_gradients_and_adam_state(cg, N):
             em, ev = _rel(m_e, st_o["m"]), _rel(v_e, st_o["v"])
             print(f"[adam] N={N} step {step} {key}: rel-l2 m {em:.2e} v {ev:.2e}")
             assert em <= (2e-3 if not loose else 3e-2) and ev <= (4e-3 if not loose else 6e-2), (key, step, em, ev)
-        # single-weight check scalars: PReLU slopes are one number each - compare them directly at step 0
+        # single-weight tensors: PReLU slopes are one number each (a cancelling sum over every activation of the layer, so
+        # fp32 summation-order noise is relative to the largest entries, not to the sum) - compare them directly at step 0
         if step == 0:
             for key, g_eng, g_orc in (("D", S._last["gD"].numpy(), r["gD"]), ("G", S._last["gG"].numpy(), r["gG"])):
                 for off, n, shape in slices[key]:
                     if n == 1:
                         a, b = float(g_eng[off]), float(g_orc[off])
-                        assert abs(a - b) <= 2e-3 * max(abs(b), 1e-3 * float(np.abs(g_orc).max())), (key, off, a, b)
+                        assert abs(a - b) <= 5e-2 * abs(b) + 2e-5 * float(np.abs(g_orc).max()), (key, off, a, b)
         d_img = np.abs(S._last_fake.numpy() - r["fake"]).max()
         assert d_img <= (2e-4 if step == 0 else 4e-2), f"step {step}: fake images differ by {d_img:.2e}"
