@@ -273,14 +273,16 @@ def _backward_bucketed(S, noise, df_do):
     flat = S.GRAD_PARAMETERS_G.t
     first = {b[0]: b for b in _g_buckets(S)}
     pending = []
-    cur = df_do
-    for i in range(len(G.modules) - 1, -1, -1):
-        m = G.modules[i]
-        cur = m.backward(G.modules[i - 1].output if i > 0 else noise, cur)
-        b = first.get(i)
-        if b is not None:
-            pending.append(parallel.allreduce_mean_async(flat[b[1]:b[1] + b[2]]))
-    G.gradInput = cur
+    done = [len(G.modules)]
+
+    def on_done(i):   # every parameter gradient of G.modules[i:] is on the stream: start the buckets that begin in [i, done)
+        for k in range(done[0] - 1, i - 1, -1):
+            b = first.get(k)
+            if b is not None:
+                pending.append(parallel.allreduce_mean_async(flat[b[1]:b[1] + b[2]]))
+        done[0] = i
+
+    G._walk_back(noise, df_do, 1.0, True, on_done)   # nn.Sequential:backward, segment by segment (fused chains stay fused)
     for p_ in pending:
         p_.finish()
 

@@ -2,37 +2,73 @@
 
 No torch / pybind in the link: the library is a plain C-ABI shared object
 (include/catgan.h) so that LuaJIT's FFI, ctypes or a C++ driver can bind it.
+Each source is compiled to its own object (in parallel, only when stale) and the
+objects are linked together; optional pieces (comm.hip: RCCL collectives) are
+linked when their library is present on the build machine.
 """
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libcatgan_hip.so")
-SOURCES = ["gemm.hip", "winograd.hip", "ops.hip"]
+SOURCES = ["gemm.hip", "winograd.hip", "ops.hip", "fused.hip", "comm.hip"]
 ARCH = "gfx950"
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "catgan.h")]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def _stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "catgan.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    return _newer(LIB_PATH, srcs + _headers())
 
 
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB_PATH
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
+    hipcc = shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdrs = _headers()
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        jobs.append((src, obj, force or _newer(obj, [src] + hdrs)))
+
+    def compile_one(job):
+        src, obj, need = job
+        if need:
+            cmd = [hipcc, *FLAGS, f"-I{os.path.join(ROCM, 'include')}", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        objs = list(ex.map(compile_one, jobs))
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+    if os.path.exists(os.path.join(CSRC, "comm.hip")):
+        link += [f"-L{os.path.join(ROCM, 'lib')}", "-lrccl", f"-Wl,-rpath,{os.path.join(ROCM, 'lib')}"]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB_PATH
 
 

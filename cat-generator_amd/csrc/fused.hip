@@ -1,0 +1,563 @@
+// Fused memory-bound chains of the G+D step: what Torch7 runs as separate modules, one pass over HBM each, runs
+// here as one kernel per chain.  Arithmetic per element is exactly that of the unfused kernels in ops.hip (same
+// operation order), so switching the fusion on or off changes no bit of the forward results.
+//
+//   act -> pool(2x2) -> spatial dropout        models.lua:649-651 (PReLU, AvgPool, SpatialDropout .2),
+//                                              :656-658 / :682-684 (PReLU, MaxPool, SpatialDropout .2),
+//                                              :847-848 (LeakyReLU, AvgPool in the localisation nets)
+//   batch-norm (training) -> PReLU             models.lua:207-208, 213-214, 219-220 (G32up-c), :145-146,150-151 (G32up)
+//
+// The batch statistics arrive as per-tile partial sums from the producing GEMM's epilogue (gemm.hip / winograd.hip)
+// and are folded by cg_bn_stats_finalize, so the convolution output is read once (normalise + PReLU) instead of
+// three times (statistics, normalise, PReLU).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+using cg::block_sum_256;
+
+#define V4_LOOP(i, n4) \
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n4); i += (long)gridDim.x * blockDim.x)
+__device__ __forceinline__ float4 ldv(const float* p, long i) { return reinterpret_cast<const float4*>(p)[i]; }
+__device__ __forceinline__ void stv(float* p, long i, float4 v) { reinterpret_cast<float4*>(p)[i] = v; }
+__device__ __forceinline__ float4 ldc(const float* p, int c4) { return make_float4(p[4 * c4], p[4 * c4 + 1], p[4 * c4 + 2], p[4 * c4 + 3]); }
+
+struct AlphaTab { const float* a0; const float* a1; const float* a2; const float* a3; };
+__device__ __forceinline__ const float* tab_sel(const AlphaTab& t, int g) { return g == 0 ? t.a0 : (g == 1 ? t.a1 : (g == 2 ? t.a2 : t.a3)); }
+
+// act: 0 identity, 1 PReLU (x > 0 ? x : a x), 2 LeakyReLU (x >= 0 ? x : a x)   [ops.hip prelu_fwd / lrelu_fwd]
+__device__ __forceinline__ float actf(int act, float v, float a) {
+    return act == 0 ? v : (act == 1 ? (v > 0.f ? v : a * v) : (v >= 0.f ? v : a * v));
+}
+__device__ __forceinline__ float4 act4(int act, float4 v, float a) {
+    return make_float4(actf(act, v.x, a), actf(act, v.y, a), actf(act, v.z, a), actf(act, v.w, a));
+}
+// d(act)/dx applied to an incoming gradient d
+__device__ __forceinline__ float dactf(int act, float x, float d, float a) {
+    return act == 0 ? d : (act == 1 ? (x > 0.f ? d : a * d) : (x >= 0.f ? d : a * d));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// y[n, oy, ox, c] = mask[n, c] * pool2x2( act(x[n, 2oy.., 2ox.., c]) )       x: [G*NG, H, W, C] NHWC, C % 4 == 0
+// Sample n belongs to group n / NG (the stacked batch of D32_st3's identical branches, each with its own PReLU slope).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool MAX>
+__global__ __launch_bounds__(256) void act_pool2_fwd_k(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ mask, AlphaTab at, int act, float slope,
+                                                       int NG, long total4, int H, int W, int C4) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    V4_LOOP(i, total4) {
+        const int c4 = (int)(i % C4);
+        long r = i / C4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const long n = r / Ho;
+        const float a = act == 1 ? *tab_sel(at, (int)(n / NG)) : slope;
+        const long b = ((n * H + 2 * oy) * W + 2 * ox) * C4 + c4;
+        const float4 v00 = act4(act, ldv(x, b), a), v01 = act4(act, ldv(x, b + C4), a);
+        const float4 v10 = act4(act, ldv(x, b + (long)W * C4), a), v11 = act4(act, ldv(x, b + (long)W * C4 + C4), a);
+        float4 o;
+#define POOL1(f)                                                        \
+        if (MAX) {                                                      \
+            float m = v00.f;                                            \
+            if (v01.f > m) m = v01.f;                                   \
+            if (v10.f > m) m = v10.f;                                   \
+            if (v11.f > m) m = v11.f;                                   \
+            o.f = m;                                                    \
+        } else {                                                        \
+            o.f = (v00.f + v01.f + v10.f + v11.f) * 0.25f;              \
+        }
+        POOL1(x) POOL1(y) POOL1(z) POOL1(w)
+#undef POOL1
+        if (mask) {
+            const float4 mk = ldc(mask, (int)(n * C4 + c4));
+            o.x *= mk.x; o.y *= mk.y; o.z *= mk.z; o.w *= mk.w;
+        }
+        stv(y, i, o);
+    }
+}
+
+// dx = act'(x) * pool2x2^T( mask * gy );  PReLU: gpart[group][block] = sum_{x <= 0} x * d  (d = gradient w.r.t. act(x)).
+// grid (blocks per group, groups): a workgroup never straddles two groups, so its partial belongs to one slope.
+template <bool MAX>
+__global__ __launch_bounds__(256) void act_pool2_bwd_k(const float* __restrict__ x, const float* __restrict__ gy,
+                                                       const float* __restrict__ mask, float* __restrict__ dx, AlphaTab at,
+                                                       int act, float slope, int NG, long per_group4, int H, int W, int C4,
+                                                       double* __restrict__ gpart) {
+    __shared__ double sh[4];
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int grp = blockIdx.y;
+    const float a = act == 1 ? *tab_sel(at, grp) : slope;
+    const long base4 = (long)grp * per_group4;      // first pooled float4 of this group
+    float s = 0.f;
+    V4_LOOP(j, per_group4) {
+        const long i = base4 + j;
+        const int c4 = (int)(i % C4);
+        long r = i / C4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const long n = r / Ho;
+        float4 g = ldv(gy, i);
+        if (mask) {
+            const float4 mk = ldc(mask, (int)(n * C4 + c4));
+            g.x *= mk.x; g.y *= mk.y; g.z *= mk.z; g.w *= mk.w;
+        }
+        const long b = ((n * H + 2 * oy) * W + 2 * ox) * C4 + c4;
+        const long o01 = C4, o10 = (long)W * C4, o11 = (long)W * C4 + C4;
+        const float4 x00 = ldv(x, b), x01 = ldv(x, b + o01), x10 = ldv(x, b + o10), x11 = ldv(x, b + o11);
+        float4 d00, d01, d10, d11;
+#define BWD1(f)                                                                                         \
+        {                                                                                               \
+            float e00, e01, e10, e11;                                                                   \
+            if (MAX) {   /* first maximum of act(x) in scan order takes the gradient (maxpool2_bwd_k) */ \
+                const float v00 = actf(act, x00.f, a), v01 = actf(act, x01.f, a);                      \
+                const float v10 = actf(act, x10.f, a), v11 = actf(act, x11.f, a);                      \
+                int arg = 0; float m = v00;                                                             \
+                if (v01 > m) { m = v01; arg = 1; }                                                      \
+                if (v10 > m) { m = v10; arg = 2; }                                                      \
+                if (v11 > m) { m = v11; arg = 3; }                                                      \
+                e00 = arg == 0 ? g.f : 0.f; e01 = arg == 1 ? g.f : 0.f;                                 \
+                e10 = arg == 2 ? g.f : 0.f; e11 = arg == 3 ? g.f : 0.f;                                 \
+            } else {                                                                                    \
+                e00 = e01 = e10 = e11 = g.f * 0.25f;                                                    \
+            }                                                                                           \
+            d00.f = dactf(act, x00.f, e00, a); d01.f = dactf(act, x01.f, e01, a);                       \
+            d10.f = dactf(act, x10.f, e10, a); d11.f = dactf(act, x11.f, e11, a);                       \
+            if (act == 1)                                                                               \
+                s += (x00.f <= 0.f ? x00.f * e00 : 0.f) + (x01.f <= 0.f ? x01.f * e01 : 0.f) +          \
+                     (x10.f <= 0.f ? x10.f * e10 : 0.f) + (x11.f <= 0.f ? x11.f * e11 : 0.f);           \
+        }
+        BWD1(x) BWD1(y) BWD1(z) BWD1(w)
+#undef BWD1
+        stv(dx, b, d00); stv(dx, b + o01, d01); stv(dx, b + o10, d10); stv(dx, b + o11, d11);
+    }
+    if (!gpart) return;
+    const double t = block_sum_256((double)s, sh);
+    if (threadIdx.x == 0) gpart[(long)grp * gridDim.x + blockIdx.x] = t;
+}
+
+struct GalphaTab { float* g0; float* g1; float* g2; float* g3; };
+// galpha[group] += scale * sum_b gpart[group][b]: one workgroup per group, fixed summation order
+__global__ __launch_bounds__(256) void galpha_groups_reduce_k(const double* gpart, int nparts, GalphaTab gt, float scale) {
+    __shared__ double sh[4];
+    const int grp = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += gpart[(long)grp * nparts + i];
+    const double t = block_sum_256(s, sh);
+    float* ga = grp == 0 ? gt.g0 : (grp == 1 ? gt.g1 : (grp == 2 ? gt.g2 : gt.g3));
+    if (threadIdx.x == 0 && ga) *ga += scale * (float)t;
+}
+
+// PReLU backward over a stacked batch of G equal groups, each with its own slope (D32_st3's identical branches):
+// dx = x > 0 ? dy : a_g dy;  gpart[g][block] = sum_{x <= 0} x dy     (prelu_bwd_v4k of ops.hip, one launch for G modules)
+__global__ __launch_bounds__(256) void prelu_bwd_groups_v4k(const float* __restrict__ x, const float* __restrict__ dy, AlphaTab at,
+                                                            float* __restrict__ dx, long per_group4, double* __restrict__ gpart) {
+    __shared__ double sh[4];
+    const int grp = blockIdx.y;
+    const float a = *tab_sel(at, grp);
+    const long base4 = (long)grp * per_group4;
+    float s = 0.f;
+    V4_LOOP(j, per_group4) {
+        const long i = base4 + j;
+        const float4 v = ldv(x, i), g = ldv(dy, i);
+        float4 o;
+        o.x = v.x > 0.f ? g.x : a * g.x; o.y = v.y > 0.f ? g.y : a * g.y;
+        o.z = v.z > 0.f ? g.z : a * g.z; o.w = v.w > 0.f ? g.w : a * g.w;
+        stv(dx, i, o);
+        s += (v.x <= 0.f ? v.x * g.x : 0.f) + (v.y <= 0.f ? v.y * g.y : 0.f) + (v.z <= 0.f ? v.z * g.z : 0.f) +
+             (v.w <= 0.f ? v.w * g.w : 0.f);
+    }
+    if (!gpart) return;
+    const double t = block_sum_256((double)s, sh);
+    if (threadIdx.x == 0) gpart[(long)grp * gridDim.x + blockIdx.x] = t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// batch statistics from GEMM-epilogue partials: sums[c] = sum_r part[r][0][c], sums[C + c] = sum_r part[r][1][c] (fp64)
+// block = 16 columns x 16 row lanes over the 2C columns of the [P][2C] partial matrix; fixed order -> deterministic
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_finalize_k(const float* __restrict__ part, int P, int C, double* __restrict__ sums) {
+    __shared__ double sh[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;          // 0..2C-1: (stat, channel) = (col / C, col % C)
+    double s = 0.0;
+    if (col < 2 * C) {
+        const int st = col / C, c = col - st * C;
+        const float* p = part + (long)st * C + c;
+#pragma unroll 4
+        for (int r = rl; r < P; r += 16) s += (double)p[(long)r * 2 * C];
+    }
+    sh[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && col < 2 * C) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += sh[r][cl];
+        sums[col] = t;
+    }
+}
+
+// training-mode batch-norm + PReLU in one pass; every thread owns one channel quad (the grid stride is a multiple of C/4),
+// derives its mean / invstd from the fp64 sums exactly as bn_prepare_k does; workgroup 0 also writes save_mean /
+// save_invstd and moves the running statistics.
+__global__ __launch_bounds__(256) void bn_act_fwd_v4k(const float* __restrict__ x, float* __restrict__ y,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const double* __restrict__ sums, double count, float eps, float momentum,
+                                                      float* running_mean, float* running_var, float* save_mean,
+                                                      float* save_invstd, const float* alpha, long n4, int C4) {
+    const int C = C4 * 4;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const double mean = sums[c] / count;
+            double var = sums[C + c] / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            save_mean[c] = (float)mean;
+            save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            if (running_var) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+        }
+    }
+    const long i0 = blockIdx.x * 256L + threadIdx.x;
+    if (i0 >= n4) return;
+    const int c4 = (int)(i0 % C4);
+    float mu[4], is[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * c4 + k;
+        const double mean = sums[c] / count;
+        double var = sums[C + c] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mu[k] = (float)mean;
+        is[k] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    const float4 g = ldc(gamma, c4), b = ldc(beta, c4);
+    const float a = alpha ? *alpha : 1.f;
+    for (long i = i0; i < n4; i += (long)gridDim.x * 256) {
+        float4 v = ldv(x, i);
+        v.x = (v.x - mu[0]) * is[0] * g.x + b.x; v.y = (v.y - mu[1]) * is[1] * g.y + b.y;
+        v.z = (v.z - mu[2]) * is[2] * g.z + b.z; v.w = (v.w - mu[3]) * is[3] * g.w + b.w;
+        if (alpha) {
+            v.x = v.x > 0.f ? v.x : a * v.x; v.y = v.y > 0.f ? v.y : a * v.y;
+            v.z = v.z > 0.f ? v.z : a * v.z; v.w = v.w > 0.f ? v.w : a * v.w;
+        }
+        stv(y, i, v);
+    }
+}
+
+// backward statistics of PReLU(BN(x)) from x and the gradient dy w.r.t. the PReLU output:
+//   u = (x - mean) * invstd * gamma + beta (recomputed, bit-equal to the forward);  d = u > 0 ? dy : alpha * dy
+//   sums[c] = sum d, sums[C + c] = sum d * xhat, sums[2C] = sum_{u <= 0} u * dy   (fp64, all channels of one block
+//   folded before the atomics; block = QB channel quads x RL row lanes as colreduce4_k)
+template <int QB>
+__global__ __launch_bounds__(256) void bn_act_bwd_stats_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* alpha, long M, int C, long rows_per_block,
+                                                          double* __restrict__ sums) {
+    constexpr int RL = 256 / QB;
+    __shared__ double sh[2][RL][QB * 4 + 2];
+    __shared__ double shg[4];
+    const int ql = threadIdx.x % QB, rl = threadIdx.x / QB;
+    const int q = blockIdx.x * QB + ql;
+    const int cq = C >> 2;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+    double ga = 0.0;
+    const float al = alpha ? *alpha : 1.f;
+    if (q < cq) {
+        const float4 mu = ldc(mean, q), is = ldc(invstd, q), g = ldc(gamma, q), b = ldc(beta, q);
+        for (long rb = r0 + rl; rb < r1; rb += 64L * RL) {
+            const long re = min(r1, rb + 64L * RL);
+            float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+            float sg = 0.f;
+#pragma unroll 4
+            for (long r = rb; r < re; r += RL) {
+                const long i = r * cq + q;
+                const float4 v = ldv(x, i), d = ldv(dy, i);
+#define ST1(f)                                                          \
+                {                                                       \
+                    const float xh = (v.f - mu.f) * is.f;               \
+                    const float u = xh * g.f + b.f;                     \
+                    const float dd = (!alpha || u > 0.f) ? d.f : al * d.f; \
+                    s1.f += dd; s2.f += dd * xh;                        \
+                    if (alpha && u <= 0.f) sg += u * d.f;               \
+                }
+                ST1(x) ST1(y) ST1(z) ST1(w)
+#undef ST1
+            }
+            a1[0] += s1.x; a1[1] += s1.y; a1[2] += s1.z; a1[3] += s1.w;
+            a2[0] += s2.x; a2[1] += s2.y; a2[2] += s2.z; a2[3] += s2.w;
+            ga += sg;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh[0][rl][ql * 4 + k] = a1[k]; sh[1][rl][ql * 4 + k] = a2[k]; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < QB * 4 * 2; idx += 256) {
+        const int which = idx / (QB * 4), cl = idx % (QB * 4);
+        const int c = blockIdx.x * QB * 4 + cl;
+        if (c >= C) continue;
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < RL; ++r) t += sh[which][r][cl];
+        atomicAdd(&sums[which * C + c], t);
+    }
+    if (alpha) {
+        const double t = block_sum_256(ga, shg);
+        if (threadIdx.x == 0) atomicAdd(&sums[2 * C], t);
+    }
+}
+
+// dx = gamma * invstd * (d - sum(d)/count - xhat * sum(d xhat)/count) with d as above; workgroup 0 also accumulates
+// the parameter gradients: ggamma += scale * local sum(d xhat), gbeta += scale * local sum(d), galpha += scale * local sum
+__global__ __launch_bounds__(256) void bn_act_bwd_v4k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* alpha, const double* __restrict__ sums, double count,
+                                                      const double* __restrict__ local_sums, long n4, int C4,
+                                                      float* __restrict__ dx, float* ggamma, float* gbeta, float* galpha,
+                                                      float scale) {
+    const int C = C4 * 4;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            if (gbeta) gbeta[c] += scale * (float)local_sums[c];
+            if (ggamma) ggamma[c] += scale * (float)local_sums[C + c];
+        }
+        if (threadIdx.x == 0 && galpha && alpha) *galpha += scale * (float)local_sums[2 * C];
+    }
+    const long i0 = blockIdx.x * 256L + threadIdx.x;
+    if (i0 >= n4) return;
+    const int c4 = (int)(i0 % C4);
+    const float4 g = ldc(gamma, c4), b = ldc(beta, c4), mu = ldc(mean, c4), is = ldc(invstd, c4);
+    float m1[4], m2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m1[k] = (float)(sums[4 * c4 + k] / count);
+        m2[k] = (float)(sums[C + 4 * c4 + k] / count);
+    }
+    const float al = alpha ? *alpha : 1.f;
+    for (long i = i0; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = ldv(x, i), d = ldv(dy, i);
+        float4 o;
+#define BW1(f, k)                                                       \
+        {                                                               \
+            const float xh = (v.f - mu.f) * is.f;                       \
+            const float u = xh * g.f + b.f;                             \
+            const float dd = (!alpha || u > 0.f) ? d.f : al * d.f;      \
+            o.f = g.f * is.f * (dd - m1[k] - xh * m2[k]);               \
+        }
+        BW1(x, 0) BW1(y, 1) BW1(z, 2) BW1(w, 3)
+#undef BW1
+        stv(dx, i, o);
+    }
+}
+
+}  // namespace
+
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// grid whose stride (grid * 256 float4s) is a multiple of C4, so that a thread's channel quad is loop invariant
+static int fixed_channel_grid(long n4, int C4) {
+    long b = (n4 + 255) / 256;
+    const long cap = cg::kNumCU * 8;
+    if (b > cap) b = cap;
+    if (256 % C4 != 0) {
+        // stride multiple of C4 needs grid % (C4 / gcd(C4, 256)) == 0
+        int gcd = C4, t = 256;
+        while (t) { const int r = gcd % t; gcd = t; t = r; }
+        const int m = C4 / gcd;
+        b = std::max<long>(m, b / m * m);
+    }
+    return (int)std::max<long>(1, b);
+}
+
+extern "C" {
+
+int cg_act_pool2_mask_forward(void* stream, const float* x, float* y, const float* mask, int ngroups, int n_per_group, int H,
+                              int W, int C, int act, float slope, const float* const* alpha, int pool_max) {
+    CG_REQUIRE(x && y, "cg_act_pool2_mask_forward: null pointer");
+    CG_REQUIRE(ngroups >= 1 && ngroups <= 4 && n_per_group > 0 && H > 0 && W > 0 && C > 0, "cg_act_pool2_mask_forward: bad dims");
+    CG_REQUIRE((H & 1) == 0 && (W & 1) == 0 && C % 4 == 0 && al16(x) && al16(y),
+               "cg_act_pool2_mask_forward: needs even H, W, C %% 4 == 0 and 16-byte aligned tensors");
+    CG_REQUIRE(act >= 0 && act <= 2, "cg_act_pool2_mask_forward: unknown activation %d", act);
+    AlphaTab at{nullptr, nullptr, nullptr, nullptr};
+    if (act == 1) {
+        CG_REQUIRE(alpha, "cg_act_pool2_mask_forward: PReLU needs the slope pointers");
+        const float* t[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int g = 0; g < ngroups; ++g) { CG_REQUIRE(alpha[g], "cg_act_pool2_mask_forward: null slope (group %d)", g); t[g] = alpha[g]; }
+        at = AlphaTab{t[0], t[1], t[2], t[3]};
+    }
+    const long total4 = (long)ngroups * n_per_group * (H / 2) * (W / 2) * (C / 4);
+    const dim3 grid(cg::ew_grid(total4));
+    if (pool_max)
+        hipLaunchKernelGGL(act_pool2_fwd_k<true>, grid, dim3(256), 0, cg::S(stream), x, y, mask, at, act, slope, n_per_group,
+                           total4, H, W, C / 4);
+    else
+        hipLaunchKernelGGL(act_pool2_fwd_k<false>, grid, dim3(256), 0, cg::S(stream), x, y, mask, at, act, slope, n_per_group,
+                           total4, H, W, C / 4);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+static int act_pool_bwd_blocks(long per_group4) { return (int)std::max<long>(1, std::min<long>((per_group4 + 255) / 256, cg::kNumCU * 4)); }
+
+size_t cg_act_pool2_mask_backward_workspace_bytes(int ngroups, int n_per_group, int H, int W, int C) {
+    if (ngroups < 1 || n_per_group < 1 || H < 2 || W < 2 || C < 4) return 0;
+    const long per_group4 = (long)n_per_group * (H / 2) * (W / 2) * (C / 4);
+    return sizeof(double) * (size_t)ngroups * act_pool_bwd_blocks(per_group4);
+}
+
+int cg_act_pool2_mask_backward(void* stream, const float* x, const float* gy, const float* mask, float* dx, int ngroups,
+                               int n_per_group, int H, int W, int C, int act, float slope, const float* const* alpha,
+                               float* const* galpha, float scale, int pool_max, void* ws, size_t ws_bytes) {
+    CG_REQUIRE(x && gy && dx, "cg_act_pool2_mask_backward: null pointer");
+    CG_REQUIRE(ngroups >= 1 && ngroups <= 4 && n_per_group > 0 && H > 0 && W > 0 && C > 0, "cg_act_pool2_mask_backward: bad dims");
+    CG_REQUIRE((H & 1) == 0 && (W & 1) == 0 && C % 4 == 0 && al16(x) && al16(gy) && al16(dx),
+               "cg_act_pool2_mask_backward: needs even H, W, C %% 4 == 0 and 16-byte aligned tensors");
+    CG_REQUIRE(act >= 0 && act <= 2, "cg_act_pool2_mask_backward: unknown activation %d", act);
+    AlphaTab at{nullptr, nullptr, nullptr, nullptr};
+    GalphaTab gt{nullptr, nullptr, nullptr, nullptr};
+    bool want = false;
+    if (act == 1) {
+        CG_REQUIRE(alpha, "cg_act_pool2_mask_backward: PReLU needs the slope pointers");
+        const float* t[4] = {nullptr, nullptr, nullptr, nullptr};
+        float* gp[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int g = 0; g < ngroups; ++g) {
+            CG_REQUIRE(alpha[g], "cg_act_pool2_mask_backward: null slope (group %d)", g);
+            t[g] = alpha[g];
+            gp[g] = galpha ? galpha[g] : nullptr;
+            want = want || gp[g];
+        }
+        at = AlphaTab{t[0], t[1], t[2], t[3]};
+        gt = GalphaTab{gp[0], gp[1], gp[2], gp[3]};
+    }
+    const long per_group4 = (long)n_per_group * (H / 2) * (W / 2) * (C / 4);
+    const int nblk = act_pool_bwd_blocks(per_group4);
+    double* gpart = nullptr;
+    if (want) {
+        const size_t need = sizeof(double) * (size_t)ngroups * nblk;
+        CG_REQUIRE(ws && ws_bytes >= need && ((uintptr_t)ws % 8) == 0, "cg_act_pool2_mask_backward: workspace too small (%zu < %zu)",
+                   ws_bytes, need);
+        gpart = (double*)ws;
+    }
+    const dim3 grid(nblk, ngroups);
+    if (pool_max)
+        hipLaunchKernelGGL(act_pool2_bwd_k<true>, grid, dim3(256), 0, cg::S(stream), x, gy, mask, dx, at, act, slope, n_per_group,
+                           per_group4, H, W, C / 4, gpart);
+    else
+        hipLaunchKernelGGL(act_pool2_bwd_k<false>, grid, dim3(256), 0, cg::S(stream), x, gy, mask, dx, at, act, slope, n_per_group,
+                           per_group4, H, W, C / 4, gpart);
+    CG_LAUNCH_CHECK();
+    if (want) {
+        hipLaunchKernelGGL(galpha_groups_reduce_k, dim3(ngroups), dim3(256), 0, cg::S(stream), (const double*)gpart, nblk, gt, scale);
+        CG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+size_t cg_prelu_backward_grouped_workspace_bytes(int ngroups, long n_per_group) {
+    if (ngroups < 1 || n_per_group < 4) return 0;
+    return sizeof(double) * (size_t)ngroups * act_pool_bwd_blocks(n_per_group / 4);
+}
+
+int cg_prelu_backward_grouped(void* stream, const float* x, const float* dy, const float* const* alpha, float* dx,
+                              float* const* galpha, float scale, int ngroups, long n_per_group, void* ws, size_t ws_bytes) {
+    CG_REQUIRE(x && dy && dx && alpha, "cg_prelu_backward_grouped: null pointer");
+    CG_REQUIRE(ngroups >= 1 && ngroups <= 4 && n_per_group > 0 && n_per_group % 4 == 0 && al16(x) && al16(dy) && al16(dx),
+               "cg_prelu_backward_grouped: 1..4 groups of a multiple of 4 elements, 16-byte aligned");
+    const float* t[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* gp[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool want = false;
+    for (int g = 0; g < ngroups; ++g) {
+        CG_REQUIRE(alpha[g], "cg_prelu_backward_grouped: null slope (group %d)", g);
+        t[g] = alpha[g];
+        gp[g] = galpha ? galpha[g] : nullptr;
+        want = want || gp[g];
+    }
+    const AlphaTab at{t[0], t[1], t[2], t[3]};
+    const GalphaTab gt{gp[0], gp[1], gp[2], gp[3]};
+    const long per_group4 = n_per_group / 4;
+    const int nblk = act_pool_bwd_blocks(per_group4);
+    double* gpart = nullptr;
+    if (want) {
+        const size_t need = sizeof(double) * (size_t)ngroups * nblk;
+        CG_REQUIRE(ws && ws_bytes >= need && ((uintptr_t)ws % 8) == 0, "cg_prelu_backward_grouped: workspace too small (%zu < %zu)",
+                   ws_bytes, need);
+        gpart = (double*)ws;
+    }
+    hipLaunchKernelGGL(prelu_bwd_groups_v4k, dim3(nblk, ngroups), dim3(256), 0, cg::S(stream), x, dy, at, dx, per_group4, gpart);
+    CG_LAUNCH_CHECK();
+    if (want) {
+        hipLaunchKernelGGL(galpha_groups_reduce_k, dim3(ngroups), dim3(256), 0, cg::S(stream), (const double*)gpart, nblk, gt, scale);
+        CG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int cg_bn_stats_finalize(void* stream, const float* partials, long rows, int C, double* sums) {
+    CG_REQUIRE(partials && sums && rows > 0 && rows < (1L << 30) && C > 0, "cg_bn_stats_finalize: bad args");
+    hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cg::cdiv(2L * C, 16)), dim3(256), 0, cg::S(stream), partials, (int)rows, C, sums);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cg_bn_act_forward(void* stream, const float* x, float* y, const float* gamma, const float* beta, const double* sums,
+                      double count, long M, int C, float eps, float momentum, float* running_mean, float* running_var,
+                      float* save_mean, float* save_invstd, const float* alpha) {
+    CG_REQUIRE(x && y && gamma && beta && sums && save_mean && save_invstd && C > 0 && count > 0 && M > 0, "cg_bn_act_forward: bad args");
+    if (C % 4 == 0 && al16(x) && al16(y)) {
+        const long n4 = M * (C / 4);
+        hipLaunchKernelGGL(bn_act_fwd_v4k, dim3(fixed_channel_grid(n4, C / 4)), dim3(256), 0, cg::S(stream), x, y, gamma, beta, sums,
+                           count, eps, momentum, running_mean, running_var, save_mean, save_invstd, alpha, n4, C / 4);
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
+    // unaligned / odd channel counts: the separate passes
+    if (cg_bn_forward(stream, x, y, gamma, beta, sums, count, M, C, eps, momentum, running_mean, running_var, save_mean, save_invstd))
+        return 1;
+    return alpha ? cg_prelu_forward(stream, y, alpha, y, M * C) : 0;
+}
+
+size_t cg_bn_act_backward_sums(int C) { return C > 0 ? (size_t)2 * C + 1 : 0; }
+
+int cg_bn_act_backward_stats(void* stream, const float* x, const float* dy, const float* save_mean, const float* save_invstd,
+                             const float* gamma, const float* beta, const float* alpha, long M, int C, double* sums) {
+    CG_REQUIRE(x && dy && save_mean && save_invstd && gamma && beta && sums && C > 0 && M > 0, "cg_bn_act_backward_stats: bad args");
+    CG_REQUIRE(C % 4 == 0 && al16(x) && al16(dy), "cg_bn_act_backward_stats: needs C %% 4 == 0 and 16-byte aligned tensors");
+    CG_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)C + 1), cg::S(stream)));
+    const int qb = C >= 128 ? 32 : 16;
+    const int cblocks = cg::cdiv(C / 4, qb);
+    const int cmul = (int)cg::opt(cg::OPT_COLREDUCE_WGS_PER_CU);
+    long chunks = std::max(1L, std::min((M + 63) / 64, (long)cg::kNumCU * cmul / cblocks));
+    const long rows_per_block = ((M + chunks - 1) / chunks + 3) / 4 * 4;
+    chunks = (M + rows_per_block - 1) / rows_per_block;
+    const dim3 grid(cblocks, (unsigned)chunks);
+    if (qb == 32)
+        hipLaunchKernelGGL(bn_act_bwd_stats_k<32>, grid, dim3(256), 0, cg::S(stream), x, dy, save_mean, save_invstd, gamma, beta, alpha,
+                           M, C, rows_per_block, sums);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_stats_k<16>, grid, dim3(256), 0, cg::S(stream), x, dy, save_mean, save_invstd, gamma, beta, alpha,
+                           M, C, rows_per_block, sums);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cg_bn_act_backward(void* stream, const float* x, const float* dy, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, const float* alpha, const double* sums, double count,
+                       const double* local_sums, long M, int C, float* dx, float* ggamma, float* gbeta, float* galpha,
+                       float scale) {
+    CG_REQUIRE(x && dy && gamma && beta && save_mean && save_invstd && sums && local_sums && dx && C > 0 && count > 0 && M > 0,
+               "cg_bn_act_backward: bad args");
+    CG_REQUIRE(C % 4 == 0 && al16(x) && al16(dy) && al16(dx), "cg_bn_act_backward: needs C %% 4 == 0 and 16-byte aligned tensors");
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_act_bwd_v4k, dim3(fixed_channel_grid(n4, C / 4)), dim3(256), 0, cg::S(stream), x, dy, gamma, beta, save_mean,
+                       save_invstd, alpha, sums, count, local_sums, n4, C / 4, dx, ggamma, gbeta, galpha, scale);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -72,7 +72,20 @@ struct NNArgs {
     Geom g;
     int kchunk;         // K range per split (multiple of BK)
     int nsplit;
+    // fused epilogue (cg_conv2d_forward_ex): act 0 none, 1 PReLU (slope read from al<group>), 2 LeakyReLU (slope);
+    // z<group> receives act(y) while y keeps the pre-activation (what the activation's backward needs).
+    int act;
+    float slope;
+    const float* al0; const float* al1; const float* al2; const float* al3;
+    float* z0; float* z1; float* z2; float* z3;
+    // stats != null: per (phase, row tile, wave row) column sums of y and y^2 -> stats[row][2][Cout] (batch-norm statistics
+    // of the layer behind this convolution, models.lua:206-207; single group, unsplit launches only)
+    float* stats;
 };
+
+__device__ __forceinline__ float apply_act(int act, float v, float a) {
+    return act == 1 ? (v > 0.f ? v : a * v) : (v >= 0.f ? v : a * v);
+}
 
 struct TNArgs {
     const float* x0; const float* x1; const float* x2; const float* x3;
@@ -395,6 +408,18 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
     const bool partial = a.nsplit > 1;
     const bool add_bias = (gbias != nullptr) && !partial;
     float* yout = partial ? a.part : gy;
+    const int act = partial ? 0 : a.act;
+    float* zout = act ? sel4(group, a.z0, a.z1, a.z2, a.z3) : nullptr;
+    float aslope = a.slope;
+    if (act == 1) aslope = *sel4(group, a.al0, a.al1, a.al2, a.al3);
+    const bool stats = a.stats != nullptr && !partial;
+    float bj[NI], s1[NI], s2[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        bj[j] = (add_bias && n < g.Cout) ? gbias[n] : 0.f;
+        s1[j] = 0.f; s2[j] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -405,7 +430,24 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int n = n0 + wn0 + j * 32 + l31;
-                if (n < g.Cout) yout[ro + n] = acc[i][j][r] + (add_bias ? gbias[n] : 0.f);
+                if (n < g.Cout) {
+                    const float v = acc[i][j][r] + bj[j];
+                    yout[ro + n] = v;
+                    if (act) zout[ro + n] = apply_act(act, v, aslope);
+                    if (stats) { s1[j] += v; s2[j] += v * v; }
+                }
+            }
+        }
+    }
+    if (stats) {   // the two half-waves hold the two row halves of the same columns
+        const int srow = (zz * (int)((g.M + BM - 1) / BM) + tm) * WM + wave / WN;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64), t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+            const int n = n0 + wn0 + j * 32 + l31;
+            if (h == 0 && n < g.Cout) {
+                a.stats[((long)srow * 2 + 0) * g.Cout + n] = t1;
+                a.stats[((long)srow * 2 + 1) * g.Cout + n] = t2;
             }
         }
     }
@@ -444,7 +486,12 @@ __global__ __launch_bounds__(256) void nn_splitk_reduce_kernel(NNArgs a, int S) 
         const float* gbias = sel4(group, a.b0, a.b1, a.b2, a.b3);
         float* gy = sel4(group, a.y0, a.y1, a.y2, a.y3);
         if (gbias) s += gbias[n];
-        gy[out_row(g, m, phase >> 1, phase & 1) + n] = s;
+        const long o = out_row(g, m, phase >> 1, phase & 1) + n;
+        gy[o] = s;
+        if (a.act) {
+            const float al = a.act == 1 ? *sel4(group, a.al0, a.al1, a.al2, a.al3) : a.slope;
+            sel4(group, a.z0, a.z1, a.z2, a.z3)[o] = apply_act(a.act, s, al);
+        }
     }
 }
 
@@ -1325,8 +1372,11 @@ static void skinny_wgrad_launch(hipStream_t st, const float* x, const float* dy,
     else hipLaunchKernelGGL((skinny_wgrad3x3_kernel<CO, 16>), dim3(blocks), dim3(256), shb, st, x, dy, part, bias_part, N, H, W, ppb);
 }
 
+struct Epi { int act; float slope; const float* const* alpha; float* const* y_act; float* stats; };
+
 static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const* x, const float* const* w,
-                  const float* const* bias, float* const* y, void* ws, size_t ws_bytes, const char* who) {
+                  const float* const* bias, float* const* y, void* ws, size_t ws_bytes, const char* who,
+                  const Epi* ep = nullptr) {
     CG_REQUIRE(ngroups >= 1 && ngroups <= MAXG, "%s: 1..%d groups per launch", who, MAXG);
     NNPlan p = plan_nn(g, ngroups);
     const size_t need = nn_ws_bytes(g, p, ngroups);
@@ -1350,6 +1400,27 @@ static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const
     a.y0 = ys[0]; a.y1 = ys[1]; a.y2 = ys[2]; a.y3 = ys[3];
     a.part = (float*)ws; a.ngroups = ngroups; a.g = g;
     a.kchunk = p.kchunk; a.nsplit = p.splits;
+    if (ep && ep->act) {
+        CG_REQUIRE(ep->act == 1 || ep->act == 2, "%s: unknown activation %d", who, ep->act);
+        CG_REQUIRE(ep->y_act, "%s: fused activation needs y_act", who);
+        const float* als[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+        float* zs[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+        for (int i = 0; i < ngroups; ++i) {
+            CG_REQUIRE(ep->y_act[i], "%s: null y_act (group %d)", who, i);
+            zs[i] = ep->y_act[i];
+            if (ep->act == 1) {
+                CG_REQUIRE(ep->alpha && ep->alpha[i], "%s: PReLU epilogue needs the slope pointer (group %d)", who, i);
+                als[i] = ep->alpha[i];
+            }
+        }
+        a.act = ep->act; a.slope = ep->slope;
+        a.al0 = als[0]; a.al1 = als[1]; a.al2 = als[2]; a.al3 = als[3];
+        a.z0 = zs[0]; a.z1 = zs[1]; a.z2 = zs[2]; a.z3 = zs[3];
+    }
+    if (ep && ep->stats) {
+        CG_REQUIRE(ngroups == 1 && p.splits == 1, "%s: epilogue statistics need a single-group, unsplit launch", who);
+        a.stats = ep->stats;
+    }
     const bool fast = (g.Cin % BK == 0) && al && cg::opt(cg::OPT_GEMM_SLOW) == 0;
     const bool vecb = (g.Cout % 4 == 0) && alw;
     const bool bk32 = cg::opt(cg::OPT_GEMM_BK32) != 0 && (g.Cin % 32 == 0) && (p.kchunk % 32 == 0);
@@ -1388,6 +1459,34 @@ size_t cg_conv2d_workspace_bytes_grouped(int ngroups, int N, int Hp, int Wp, int
 }
 size_t cg_conv2d_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups) {
     return cg_conv2d_workspace_bytes_grouped(1, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups);
+}
+
+// rows of the statistics buffer an epilogue-statistics launch writes (0: this geometry runs split-K or skinny, take the
+// statistics with cg_bn_stats instead)
+size_t cg_conv2d_stats_rows(int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups) {
+    Geom g;
+    if (conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
+    if (skinny_ok(1, Cin, Cout, kH, kW, padH, padW, ups) || cg::opt(cg::OPT_EPILOGUE_STATS) == 0) return 0;
+    const NNPlan p = plan_nn(g, 1);
+    if (p.splits != 1) return 0;
+    const int wm = p.tc.bn == 32 ? 4 : 2;
+    return (size_t)g.nphase * cg::cdiv(g.M, p.tc.bm) * wm;
+}
+
+int cg_conv2d_forward_ex(void* stream, int ngroups, const float* const* x, const float* const* wpk, const float* const* bias,
+                         float* const* y, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW,
+                         int ups, int act, float slope, const float* const* alpha, float* const* y_act, float* stats,
+                         void* ws, size_t ws_bytes) {
+    CG_REQUIRE(x && wpk && y, "cg_conv2d_forward_ex: null pointer");
+    Geom g;
+    if (conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
+    CG_REQUIRE(!skinny_ok(ngroups, Cin, Cout, kH, kW, padH, padW, ups) || (act == 0 && !stats),
+               "cg_conv2d_forward_ex: no fused epilogue on the skinny (<= 4 output planes) path");
+    if (act == 0 && !stats)
+        return cg_conv2d_forward_grouped(stream, ngroups, x, wpk, bias, y, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups, ws,
+                                         ws_bytes);
+    Epi ep{act, slope, alpha, y_act, stats};
+    return run_nn(cg::S(stream), g, ngroups, x, wpk, bias, y, ws, ws_bytes, "cg_conv2d_forward_ex", &ep);
 }
 
 int cg_conv2d_forward_grouped(void* stream, int ngroups, const float* const* x, const float* const* wpk,

@@ -513,6 +513,17 @@ __global__ void rng_randint_k(int32_t* out, long n, int32_t range, uint64_t seed
         out[i] = v < range ? v : range - 1;
     }
 }
+// G consecutive blocks of n floats, block g drawn at its own position off<g> of the counter stream (the dropout masks of
+// D32_st3's identical branches, which a branch-after-branch walk would draw at different positions)
+__global__ void rng_bernoulli_groups_k(float* out, long n, int G, float keep, float value, uint64_t seed, uint64_t off0,
+                                       uint64_t off1, uint64_t off2, uint64_t off3, const uint64_t* base) {
+    const uint64_t b = base ? *base : 0ull;
+    GRID_STRIDE(i, n * G) {
+        const int g = (int)(i / n);
+        const uint64_t off = g == 0 ? off0 : (g == 1 ? off1 : (g == 2 ? off2 : off3));
+        out[i] = u01(seed, b + off + (uint64_t)(i - (long)g * n)) < keep ? value : 0.f;
+    }
+}
 __global__ void counter_add_k(uint64_t* c, uint64_t d) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += d; }
 
 // --------------------------------------------------------------------- layout
@@ -1035,6 +1046,14 @@ int cg_rng_bernoulli_dev(void* stream, float* out, long n, float keep_prob, floa
                          const uint64_t* base) {
     CG_REQUIRE(out, "cg_rng_bernoulli: null pointer");
     EW_LAUNCH(rng_bernoulli_k, n, out, n, keep_prob, value, seed, offset, base); return 0;
+}
+int cg_rng_bernoulli_dev_grouped(void* stream, float* out, long n_per_group, int ngroups, float keep_prob, float value,
+                                 uint64_t seed, uint64_t off0, uint64_t off1, uint64_t off2, uint64_t off3,
+                                 const uint64_t* base) {
+    CG_REQUIRE(out && ngroups >= 1 && ngroups <= 4, "cg_rng_bernoulli_dev_grouped: bad args");
+    EW_LAUNCH(rng_bernoulli_groups_k, n_per_group * ngroups, out, n_per_group, ngroups, keep_prob, value, seed, off0, off1, off2,
+              off3, base);
+    return 0;
 }
 int cg_rng_uniform_dev(void* stream, float* out, long n, float lo, float hi, uint64_t seed, uint64_t offset,
                        const uint64_t* base) {

@@ -152,6 +152,7 @@ struct WinoArgs {
     int tH, tW;          // tiles per image
     int so;              // 2: output pixel (2i+a, 2j+b) of phase (a,b) = blockIdx.z; 1: pixel (i, j)
     int Ho, Wo;
+    float* stats;        // != null: column sums of y and y^2 per (phase, tile block, wave row): [rows][2][Nc] (see gemm.hip)
 };
 
 // NW waves per workgroup: 4 (wave tile 32x64) or 8 (wave tile 32x32: twice the waves per tile for latency hiding); BK = K step
@@ -265,6 +266,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(Win
 
     // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*h (tile), j = l31 (column)
     const int pa = a.so == 2 ? (phase >> 1) : 0, pb = a.so == 2 ? (phase & 1) : 0;
+    float st1[NI], st2[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -277,7 +281,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(Win
             const int oy = (2 * ti + (o >> 1)) * a.so + pa, ox = (2 * tj + (o & 1)) * a.so + pb;
             float* row = a.y + ((n * a.Ho + oy) * (long)a.Wo + ox) * a.Nc + n0 + wn0 + l31;
 #pragma unroll
-            for (int j = 0; j < NI; ++j) row[j * 32] = accY[o][j][r] + (a.bias ? a.bias[n0 + wn0 + j * 32 + l31] : 0.f);
+            for (int j = 0; j < NI; ++j) {
+                const float v = accY[o][j][r] + (a.bias ? a.bias[n0 + wn0 + j * 32 + l31] : 0.f);
+                row[j * 32] = v;
+                if (a.stats) { st1[j] += v; st2[j] += v * v; }
+            }
+        }
+    }
+    if (a.stats) {
+        const int srow = ((int)blockIdx.z * (int)((a.T + BM - 1) / BM) + tm) * 2 + (wave & 1);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const float t1 = st1[j] + __shfl_xor(st1[j], 32, 64), t2 = st2[j] + __shfl_xor(st2[j], 32, 64);
+            if (h == 0) {
+                a.stats[((long)srow * 2 + 0) * a.Nc + n0 + wn0 + j * 32 + l31] = t1;
+                a.stats[((long)srow * 2 + 1) * a.Nc + n0 + wn0 + j * 32 + l31] = t2;
+            }
         }
     }
 }
@@ -410,13 +429,28 @@ int cg_conv2d_ups2_wino_pack(void* stream, const float* wf_ph, const float* wb_p
 // The 16 GEMMs + output transform alone, on an already transformed input (what the two entry points below launch after
 // their input transform; exported so that it can be timed / profiled in isolation).
 // dgrad == 0: v [16][T][Cin], u = u_fwd, y [N][2Hp][2Wp][Cout];  dgrad == 1: v [16][T][4*Cout], u = u_bwd, y [N][Hp][Wp][Cin].
+static int wino_gemm_launch(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
+                            int Cin, int Cout, int dgrad, float* stats);
+
 int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
                              int Cin, int Cout, int dgrad) {
+    return wino_gemm_launch(stream, v, u, bias, y, N, Hp, Wp, Cin, Cout, dgrad, nullptr);
+}
+
+// rows of the [rows][2][Cout] statistics buffer cg_conv2d_ups2_wino_forward_stats fills
+size_t cg_conv2d_ups2_wino_stats_rows(int N, int Hp, int Wp, int Cin, int Cout) {
+    if (!wino_dims_ok(N, Hp, Wp, Cin, Cout) || cg::opt(cg::OPT_EPILOGUE_STATS) == 0 || cg::opt(cg::OPT_WINO_WAVES) == 4) return 0;
+    return (size_t)4 * cg::cdiv((long)N * (Hp / 2) * (Wp / 2), 64) * 2;
+}
+
+static int wino_gemm_launch(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
+                            int Cin, int Cout, int dgrad, float* stats) {
     CG_REQUIRE(v && u && y, "cg_conv2d_ups2_wino_gemm: null pointer");
     CG_REQUIRE(wino_dims_ok(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino_gemm: unsupported dimensions");
     const int T = N * (Hp / 2) * (Wp / 2);
     WinoArgs a;
-    a.V = v; a.U = u; a.bias = bias; a.y = y; a.T = T; a.tH = Hp / 2; a.tW = Wp / 2;
+    a.V = v; a.U = u; a.bias = bias; a.y = y; a.T = T; a.tH = Hp / 2; a.tW = Wp / 2; a.stats = stats;
+    CG_REQUIRE(!stats || (!dgrad && cg::opt(cg::OPT_WINO_WAVES) != 4), "wino_gemm: statistics only on the 8-wave forward launch");
     if (dgrad) { a.K = 4 * Cout; a.Nc = Cin; a.so = 1; a.Ho = Hp; a.Wo = Wp; }
     else { a.K = Cin; a.Nc = Cout; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp; }
     const int nw = (int)cg::opt(cg::OPT_WINO_WAVES), bk = (int)cg::opt(cg::OPT_WINO_BK);
@@ -433,8 +467,8 @@ int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const
 
 // y[N][2Hp][2Wp][Cout] = bias + conv5x5(upsample2(x_lo)); v (cg_conv2d_ups2_wino_v_floats(..., Cin) floats) receives
 // the transformed input and is what the weight gradient consumes later.
-int cg_conv2d_ups2_wino_forward(void* stream, const float* x_lo, const float* u_fwd, const float* bias, float* y, float* v,
-                                int N, int Hp, int Wp, int Cin, int Cout) {
+int cg_conv2d_ups2_wino_forward_stats(void* stream, const float* x_lo, const float* u_fwd, const float* bias, float* y, float* v,
+                                      int N, int Hp, int Wp, int Cin, int Cout, float* stats) {
     CG_REQUIRE(x_lo && u_fwd && y && v, "cg_conv2d_ups2_wino_forward: null pointer");
     CG_REQUIRE(wino_dims_ok(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino_forward: unsupported dimensions");
     hipStream_t st = cg::S(stream);
@@ -442,7 +476,12 @@ int cg_conv2d_ups2_wino_forward(void* stream, const float* x_lo, const float* u_
     hipLaunchKernelGGL(wino_input_transform_kernel<0>, dim3(cg::ew_grid((long)T * (Cin / 4))), dim3(256), 0, st, x_lo, v, N, Hp,
                        Wp, Cin, Cin);
     CG_LAUNCH_CHECK();
-    return cg_conv2d_ups2_wino_gemm(stream, v, u_fwd, bias, y, N, Hp, Wp, Cin, Cout, 0);
+    return wino_gemm_launch(stream, v, u_fwd, bias, y, N, Hp, Wp, Cin, Cout, 0, stats);
+}
+
+int cg_conv2d_ups2_wino_forward(void* stream, const float* x_lo, const float* u_fwd, const float* bias, float* y, float* v,
+                                int N, int Hp, int Wp, int Cin, int Cout) {
+    return cg_conv2d_ups2_wino_forward_stats(stream, x_lo, u_fwd, bias, y, v, N, Hp, Wp, Cin, Cout, nullptr);
 }
 
 // dx_lo[N][Hp][Wp][Cin] = gradient w.r.t. the low-res input (the upsampling's 2x2 block sum folded in);

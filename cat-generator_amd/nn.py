@@ -338,6 +338,32 @@ class Module:
 
 
 # ---------------------------------------------------------------------- containers
+fusion = os.environ.get("CG_FUSION", "1") != "0"
+# ^ nn.fusion: nn.Sequential runs chains of modules as fused launches (GEMM epilogues of csrc/gemm.hip, csrc/fused.hip):
+#   [conv|linear, PReLU|LeakyReLU]                      -> activation in the GEMM epilogue (both outputs are kept)
+#   [PReLU|LeakyReLU, Pool 2x2, (SpatialDropout)]       -> one pass; the two intermediate tensors are never materialised
+#   [conv, SpatialBatchNormalization, PReLU] (training) -> batch statistics from the GEMM epilogue, normalise + PReLU in one
+#                                                          pass, backward in two passes over (conv output, gradOutput)
+# Per-element arithmetic is that of the separate modules.  A fused-away intermediate module has .output = None
+# (set nn.fusion = False to inspect every module's output).
+
+
+def _is_gemm(m):
+    return isinstance(m, _GemmLayer) and not isinstance(m, SpatialConvolutionUpsample)
+
+
+def _is_act(m):
+    return isinstance(m, (PReLU, LeakyReLU))
+
+
+def _act_code(m):
+    return 1 if isinstance(m, PReLU) else 2
+
+
+def _act_slope(m):
+    return 0.0 if isinstance(m, PReLU) else float(m.negative_scale)
+
+
 class Sequential(Module):
     def __init__(self):
         super().__init__()
@@ -345,6 +371,7 @@ class Sequential(Module):
 
     def add(self, m):
         self.modules.append(m)
+        self._plan_key = None
         return self
 
     def get(self, i):
@@ -359,25 +386,75 @@ class Sequential(Module):
             out += m.listModules()
         return out
 
+    # ---- segments: [(kind, first, end)] covering the module list
+    def _plan(self):
+        mods = self.modules
+        key = (fusion, tuple(m.train for m in mods), tuple(id(m) for m in mods))
+        if getattr(self, "_plan_key", None) == key:
+            return self._plan_v
+        plan, i, n = [], 0, len(mods)
+        while i < n:
+            m, kind, j = mods[i], "one", i + 1
+            if fusion:
+                nx = mods[i + 1] if i + 1 < n else None
+                nx2 = mods[i + 2] if i + 2 < n else None
+                if (isinstance(m, SpatialConvolution) and _is_gemm(m) and isinstance(nx, SpatialBatchNormalization) and nx.train
+                        and isinstance(nx2, PReLU)):
+                    kind, j = "gemm_bn_act", i + 3
+                elif _is_gemm(m) and _is_act(nx) and not isinstance(nx2, _Pool2):
+                    kind, j = "gemm_act", i + 2
+                elif _is_act(m) and isinstance(nx, _Pool2):
+                    drop = isinstance(nx2, SpatialDropout) and nx2.train and nx2.fixed_noise is None
+                    kind, j = "act_pool", i + (3 if drop else 2)
+            plan.append((kind, i, j))
+            i = j
+        self._plan_key, self._plan_v = key, plan
+        return plan
+
     def updateOutput(self, input):
         cur = input
-        for m in self.modules:
-            cur = m.updateOutput(cur)
+        plan = self._ran = self._plan()
+        mods = self.modules
+        for kind, i, j in plan:
+            if kind == "one":
+                cur = mods[i].updateOutput(cur)
+            elif kind == "gemm_act":
+                cur = _fwd_gemm_act([mods[i]], [mods[i + 1]], [cur], None)[0]
+            elif kind == "act_pool":
+                cur = _fwd_act_pool([mods[i]], [mods[i + 1]], [mods[i + 2]] if j - i == 3 else None, [cur], None)[0]
+            else:
+                cur = _fwd_gemm_bn_act(mods[i], mods[i + 1], mods[i + 2], cur)
         self.output = cur
         return cur
 
-    def _walk_back(self, input, gradOutput, fn):
+    def _walk_back(self, input, gradOutput, scale, acc, on_done=None):
+        """Segments of the last forward in reverse.  acc: Module:backward (gradInput + accGradParameters), else
+        updateGradInput only.  on_done(i): every parameter gradient of modules[i:] is complete."""
+        plan = getattr(self, "_ran", None) or [("one", k, k + 1) for k in range(len(self.modules))]
+        mods = self.modules
         cur = gradOutput
-        for i in range(len(self.modules) - 1, 0, -1):
-            cur = fn(self.modules[i], self.modules[i - 1].output, cur)
-        cur = fn(self.modules[0], input, cur)
+        for kind, i, j in reversed(plan):
+            inp = input if i == 0 else mods[i - 1].output
+            if kind == "act_pool" and (getattr(mods[i], "_fused", None) or {}).get("G") == 1:
+                cur = _bwd_act_pool([mods[i]], [mods[i + 1]], [mods[i + 2]] if j - i == 3 else None, [cur], scale, acc)[0]
+            elif kind == "gemm_bn_act" and getattr(mods[i + 1], "_fused", None) is not None:
+                cur = _bwd_gemm_bn_act(mods[i], mods[i + 1], mods[i + 2], inp, cur, scale, acc)
+            else:   # "one", "gemm_act" (both outputs exist), or a chain whose forward ran unfused
+                for k in range(j - 1, i - 1, -1):
+                    mi = inp if k == i else mods[k - 1].output
+                    cur = mods[k].backward(mi, cur, scale) if acc else mods[k].updateGradInput(mi, cur)
+            if on_done is not None:
+                on_done(i)
         self.gradInput = cur
         return cur
 
     def updateGradInput(self, input, gradOutput):
-        return self._walk_back(input, gradOutput, lambda m, i, g: m.updateGradInput(i, g))
+        return self._walk_back(input, gradOutput, 1.0, False)
 
     def accGradParameters(self, input, gradOutput, scale=1.0):
+        if any(k != "one" for k, _, _ in (getattr(self, "_ran", None) or [])):
+            raise NotImplementedError("nn.Sequential:accGradParameters on its own needs the intermediate outputs the fused "
+                                      "forward did not keep: call backward(), or set nn.fusion = False")
         cur = gradOutput
         for i in range(len(self.modules) - 1, 0, -1):
             m, prev = self.modules[i], self.modules[i - 1]
@@ -386,13 +463,29 @@ class Sequential(Module):
         self.modules[0].accGradParameters(input, cur, scale)
 
     def backward(self, input, gradOutput, scale=1.0):
-        return self._walk_back(input, gradOutput, lambda m, i, g: m.backward(i, g, scale))
+        return self._walk_back(input, gradOutput, scale, True)
 
     @staticmethod
     def _group_forward(mods, inputs, ctx):
         cur = list(inputs)
-        for i in range(len(mods[0].modules)):
-            cur = group_forward([m.modules[i] for m in mods], cur, ctx)
+        plan = mods[0]._plan()
+        for m in mods:
+            m._ran = plan
+        for kind, i, j in plan:
+            col = lambda k: [m.modules[k] for m in mods]
+            if kind == "one":
+                cur = group_forward(col(i), cur, ctx)
+            elif kind == "gemm_act":
+                cur = _fwd_gemm_act(col(i), col(i + 1), cur, ctx)
+            elif kind == "act_pool":
+                cur = _fwd_act_pool(col(i), col(i + 1), col(i + 2) if j - i == 3 else None, cur, ctx)
+            else:   # not a lockstep case on the path: branch after branch, each at its own stream position
+                outs, r = [], rng()
+                for b, m in enumerate(mods):
+                    saved, r.offset = r.offset, ctx.cur[b]
+                    outs.append(_fwd_gemm_bn_act(m.modules[i], m.modules[i + 1], m.modules[i + 2], cur[b]))
+                    ctx.cur[b], r.offset = r.offset, saved
+                cur = outs
         for m, c in zip(mods, cur):
             m.output = c
         return cur
@@ -400,9 +493,23 @@ class Sequential(Module):
     @staticmethod
     def _group_backward(mods, inputs, gouts, scale, acc, ctx):
         cur = list(gouts)
-        for i in range(len(mods[0].modules) - 1, 0, -1):
-            cur = group_backward([m.modules[i] for m in mods], [m.modules[i - 1].output for m in mods], cur, scale, acc, ctx)
-        cur = group_backward([m.modules[0] for m in mods], list(inputs), cur, scale, acc, ctx)
+        plan = getattr(mods[0], "_ran", None) or [("one", k, k + 1) for k in range(len(mods[0].modules))]
+        for kind, i, j in reversed(plan):
+            col = lambda k: [m.modules[k] for m in mods]
+            inp = list(inputs) if i == 0 else [m.modules[i - 1].output for m in mods]
+            fst = [getattr(m.modules[i], "_fused", None) or {} for m in mods] if kind == "act_pool" else []
+            if kind == "act_pool" and fst[0].get("G") == len(mods):
+                cur = _bwd_act_pool(col(i), col(i + 1), col(i + 2) if j - i == 3 else None, cur, scale, acc)
+            elif kind == "act_pool" and all(f.get("G") == 1 for f in fst):   # the forward ran branch after branch
+                cur = [_bwd_act_pool([m.modules[i]], [m.modules[i + 1]], [m.modules[i + 2]] if j - i == 3 else None, [g], scale,
+                                     acc)[0] for m, g in zip(mods, cur)]
+            elif kind == "gemm_bn_act" and getattr(mods[0].modules[i + 1], "_fused", None) is not None:
+                cur = [_bwd_gemm_bn_act(m.modules[i], m.modules[i + 1], m.modules[i + 2], x, g, scale, acc)
+                       for m, x, g in zip(mods, inp, cur)]
+            else:
+                for k in range(j - 1, i - 1, -1):
+                    mi = inp if k == i else [m.modules[k - 1].output for m in mods]
+                    cur = group_backward(col(k), mi, cur, scale, acc, ctx)
         for m, c in zip(mods, cur):
             m.gradInput = c
         return cur
@@ -604,11 +711,20 @@ class Concat(Sequential):
         return out
 
     def _slices(self, gradOutput):
+        """Channel slices of the gradient, one per branch; the slices of a lockstep group are the parts of one block, so
+        that the group's backward can run stacked launches on them."""
         g = as_nhwc(gradOutput)
         N, Ct, H, W = g.shape
+        bufs = [None] * len(self.modules)
+        if self.grouped and has_gpu() and _Stackable.stacking:
+            for idxs in self._branch_groups():
+                if len(idxs) > 1 and len({self._sizes[i] for i in idxs}) == 1:
+                    block = self._get(("gslice_block", idxs[0]), (len(idxs) * N, self._sizes[idxs[0]], H, W), "nhwc")
+                    for i, sl in zip(idxs, _split(block, len(idxs))):
+                        bufs[i] = sl
         off = 0
         for i, c in enumerate(self._sizes):
-            s = self._get(("gslice", i), (N, c, H, W), "nhwc")
+            s = bufs[i] if bufs[i] is not None else self._get(("gslice", i), (N, c, H, W), "nhwc")
             lib().copy_channels(stream(), g.ptr, s.ptr, N * H * W, Ct, off, c, 0, c)
             off += c
             yield self.modules[i], s
@@ -673,6 +789,12 @@ class _GemmLayer(Module):
                 self._u_bwd = torch.empty(nu, dtype=torch.float32, device=self.weight.t.device)
             lib().conv2d_ups2_wino_pack(stream(), self._wf_ph.data_ptr(), self._wb_ph.data_ptr(), self._u_fwd.data_ptr(),
                                         self._u_bwd.data_ptr(), Cout, Cin)
+
+    def _epilogue_ok(self, prep):
+        """Can this launch take a fused epilogue?  (The skinny <= 4-plane 3x3 kernels and the Winograd path cannot.)"""
+        N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups = prep[3]
+        skinny = ups == 0 and kH == 3 and kW == 3 and padH == 1 and padW == 1 and Cout in (1, 3) and Cin in (64, 128)
+        return not skinny
 
     def _wb_ptr(self):
         # 1x1 / linear: the canonical [out][in] matrix already is the backward operand [K=out][N=in]
@@ -999,8 +1121,28 @@ class PReLU(Module):
 
     @staticmethod
     def _group_backward(mods, inputs, gouts, scale, acc, ctx):
-        if _Stackable.stacking:
-            _seed_slices(mods, "gin", mods[0]._x.shape, mods[0]._x.fmt)
+        if not _Stackable.stacking:
+            return Module._group_backward(mods, inputs, gouts, scale, acc, ctx)
+        x0 = mods[0]._x
+        X = _stacked([m._x for m in mods])
+        n = x0.phys_numel()
+        if fusion and X is not None and n % 4 == 0 and len(mods) <= 4:
+            # one launch for the G modules: stacked x / dy / dx, one slope and one gradient accumulator per group
+            gs = [g if g.fmt == x0.fmt else (as_nhwc(g) if x0.fmt == "nhwc" else as_plain(g)) for g in gouts]
+            Gd = _stacked(gs)
+            if Gd is None:
+                Gd = _restack(mods[0], gs, x0)
+            G = len(mods)
+            dx = mods[0]._get(("gin", "gblock"), (G * x0.shape[0],) + tuple(x0.shape[1:]), x0.fmt)
+            ws, wsb = WS.get(lib().prelu_backward_grouped_workspace_bytes(G, n)) if acc else (None, 0)
+            lib().prelu_backward_grouped(stream(), X.ptr, Gd.ptr, _ptr_array([m.weight.ptr for m in mods]), dx.ptr,
+                                         _ptr_array([m.gradWeight.ptr for m in mods]) if acc else None, float(scale), G, n,
+                                         ws, wsb)
+            outs = _split(dx, G)
+            for m, o in zip(mods, outs):
+                m.gradInput = o
+            return outs
+        _seed_slices(mods, "gin", x0.shape, x0.fmt)
         return Module._group_backward(mods, inputs, gouts, scale, acc, ctx)
 
 
@@ -1485,6 +1627,194 @@ class BilinearSamplerBHWD(Module):
         if _Stackable.stacking:
             _seed_slices(mods, "ggrid", inputs[0][1].shape, "plain")
         return Module._group_backward(mods, inputs, gouts, scale, acc, ctx)
+
+
+# ------------------------------------------------------------------- fused segments of nn.Sequential
+def _fwd_gemm_act(convs, acts, xs, ctx):
+    """[conv|linear, PReLU|LeakyReLU] x G branches: one (grouped) GEMM launch whose epilogue writes the pre-activation
+    (conv.output, what the activation's backward needs) and the activation (act.output)."""
+    G = len(convs)
+    preps = [c._prep_fwd(x) for c, x in zip(convs, xs)]
+    wino = any(isinstance(c, SpatialConvolution) and p_[0].ups and c._use_wino(p_[0]) for c, p_ in zip(convs, preps))
+    ok = (not wino and G <= 4 and len({p_[3] for p_ in preps}) == 1 and all(c._epilogue_ok(p_) for c, p_ in zip(convs, preps)))
+    if not ok:
+        if G == 1:
+            return [acts[0].updateOutput(convs[0].updateOutput(xs[0]))]
+        return group_forward(acts, group_forward(convs, xs, ctx), ctx)
+    shape, fmt = preps[0][2].shape, preps[0][2].fmt
+    if G > 1 and _Stackable.stacking:
+        if _stacked([p_[2] for p_ in preps]) is None:
+            _seed_slices(convs, "out", shape, fmt)
+            preps = [c._prep_fwd(x) for c, x in zip(convs, xs)]
+        _seed_slices(acts, "out", shape, fmt)
+    ys = [a._get("out", shape, fmt) for a in acts]
+    a = preps[0][3]
+    code = _act_code(acts[0])
+    ws, wsb = WS.get(lib().conv2d_workspace_bytes_grouped(G, *a))
+    lib().conv2d_forward_ex(stream(), G, _ptr_array([p_[0].ptr for p_ in preps]), _ptr_array([p_[1] for p_ in preps]),
+                            _ptr_array([c.bias.ptr for c in convs]), _ptr_array([p_[2].ptr for p_ in preps]), *a,
+                            code, _act_slope(acts[0]), _ptr_array([m.weight.ptr for m in acts]) if code == 1 else None,
+                            _ptr_array([y.ptr for y in ys]), None, ws, wsb)
+    for c, act, p_, y in zip(convs, acts, preps, ys):
+        c._x, c.output = p_[0], p_[2]
+        act._x, act.output = p_[2], y
+    if G > 1 and isinstance(acts[0], _Stackable):   # let the parameter-free activation run its backward as one stacked launch
+        Xs, Ys = _stacked([p_[2] for p_ in preps]), _stacked(ys)
+        if Xs is not None and Ys is not None:
+            acts[0]._x, acts[0]._stk = Xs, ys[0].grp[0]
+        else:
+            acts[0]._stk = None
+    return ys
+
+
+def _fwd_act_pool(acts, pools, drops, xs, ctx):
+    """[PReLU|LeakyReLU, Pool 2x2, (SpatialDropout, training)] x G branches in one pass over the stacked input."""
+    G = len(acts)
+    a0, p0 = acts[0], pools[0]
+    d0 = drops[0] if drops else None
+    xs = [x if isinstance(x, Tensor) else to_device(x) for x in xs]
+    x0 = xs[0]
+    X = None
+    if x0.dim() == 4 and x0.fmt == "nhwc" and not x0.ups and G <= 4:
+        N, C, H, W = x0.shape
+        if C % 4 == 0 and H % 2 == 0 and W % 2 == 0:
+            X = x0 if G == 1 else (_stacked(xs) if _Stackable.stacking else None)
+    if X is None:   # the separate modules
+        a0._fused = None
+        chain = [acts, pools] + ([drops] if drops else [])
+        cur = xs
+        for col in chain:
+            cur = [col[0].updateOutput(cur[0])] if G == 1 else group_forward(col, cur, ctx)
+        return cur
+    code = _act_code(a0)
+    last = d0 if d0 is not None else p0
+    out = last._get(("out", "fused"), (G * N, C, H // 2, W // 2), "nhwc")
+    mask = None
+    if d0 is not None:
+        mask = d0._get(("noise", "block"), (G * N, C))
+        r = rng()
+        if G == 1:
+            lib().rng_bernoulli_dev(stream(), mask.ptr, N * C, 1.0 - d0.p, 1.0, r.seed, r.take(N * C), r.base_ptr())
+        else:
+            offs = [ctx.cur[b] for b in range(G)] + [0] * (4 - G)
+            lib().rng_bernoulli_dev_grouped(stream(), mask.ptr, N * C, G, 1.0 - d0.p, 1.0, r.seed, *offs, r.base_ptr())
+            for b in range(G):
+                ctx.cur[b] += N * C
+    lib().act_pool2_mask_forward(stream(), X.ptr, out.ptr, mask.ptr if mask is not None else None, G, N, H, W, C, code,
+                                 _act_slope(a0), _ptr_array([m.weight.ptr for m in acts]) if code == 1 else None,
+                                 1 if isinstance(p0, SpatialMaxPooling) else 0)
+    outs = [out] if G == 1 else _split(out, G)
+    masks = ([mask] if G == 1 else _split(mask, G)) if mask is not None else [None] * G
+    for b in range(G):
+        acts[b]._x, acts[b].output = xs[b], None
+        pools[b]._x, pools[b].output = None, (outs[b] if d0 is None else None)
+        if d0 is not None:
+            drops[b].noise, drops[b].output = masks[b], outs[b]
+    a0._fused = dict(X=X, mask=mask, G=G, dims=(N, C, H, W))
+    return outs
+
+
+def _bwd_act_pool(acts, pools, drops, gouts, scale, acc):
+    a0, p0 = acts[0], pools[0]
+    st = a0._fused
+    X, mask, G = st["X"], st["mask"], st["G"]
+    N, C, H, W = st["dims"]
+    gs = [as_nhwc(g) for g in gouts]
+    Gd = gs[0] if G == 1 else _stacked(gs)
+    if Gd is None:
+        Gd = _restack(a0, gs, gs[0])
+    dx = a0._get(("gin", "fused"), X.shape, "nhwc")
+    code = _act_code(a0)
+    want = acc and code == 1
+    ws, wsb = WS.get(lib().act_pool2_mask_backward_workspace_bytes(G, N, H, W, C)) if want else (None, 0)
+    lib().act_pool2_mask_backward(stream(), X.ptr, Gd.ptr, mask.ptr if mask is not None else None, dx.ptr, G, N, H, W, C, code,
+                                  _act_slope(a0), _ptr_array([m.weight.ptr for m in acts]) if code == 1 else None,
+                                  _ptr_array([m.gradWeight.ptr for m in acts]) if want else None, float(scale),
+                                  1 if isinstance(p0, SpatialMaxPooling) else 0, ws, wsb)
+    outs = [dx] if G == 1 else _split(dx, G)
+    for b in range(G):
+        acts[b].gradInput = outs[b]
+        pools[b].gradInput = None
+        if drops:
+            drops[b].gradInput = None
+    return outs
+
+
+def _fwd_gemm_bn_act(conv, bn, act, input):
+    """[conv, SpatialBatchNormalization (training), PReLU] (models.lua:206-208, 212-214, 218-220): the GEMM epilogue leaves
+    per-tile column sums of the convolution output, cg_bn_stats_finalize folds them into the batch statistics, and one pass
+    normalises and activates.  The normalised tensor is not kept: the backward recomputes it from the convolution output."""
+    x = as_nhwc(to_device(input), keep_ups=True)
+    C = conv.nOutputPlane
+    if C % 4 != 0:
+        bn._fused = None
+        return act.updateOutput(bn.updateOutput(conv.updateOutput(input)))
+    rows, part = 0, None
+    if conv._use_wino(x):
+        N, Hp, Wp, Ho, Wo = conv._geom(x)
+        conv._ensure_packed_ups()
+        out = conv._get("out", (N, C, Ho, Wo), "nhwc")
+        v = conv._get("wino_v", (lib().conv2d_ups2_wino_v_floats(N, Hp, Wp, conv.nInputPlane),))
+        rows = int(lib().conv2d_ups2_wino_stats_rows(N, Hp, Wp, conv.nInputPlane, C))
+        if rows:
+            part = bn._get("stats_part", (rows, 2, C))
+        lib().conv2d_ups2_wino_forward_stats(stream(), x.ptr, conv._u_fwd.data_ptr(), conv.bias.ptr, out.ptr, v.ptr, N, Hp, Wp,
+                                             conv.nInputPlane, C, part.ptr if rows else None)
+        conv._x, conv.output = x, out
+    else:
+        xx, wf, out, a = conv._prep_fwd(x)
+        rows = int(lib().conv2d_stats_rows(*a)) if conv._epilogue_ok((xx, wf, out, a)) else 0
+        ws, wsb = WS.get(lib().conv2d_workspace_bytes(*a))
+        if rows:
+            part = bn._get("stats_part", (rows, 2, C))
+            lib().conv2d_forward_ex(stream(), 1, _ptr_array([xx.ptr]), _ptr_array([wf]), _ptr_array([conv.bias.ptr]),
+                                    _ptr_array([out.ptr]), *a, 0, 0.0, None, None, part.ptr, ws, wsb)
+        else:
+            lib().conv2d_forward(stream(), xx.ptr, wf, conv.bias.ptr, out.ptr, *a, ws, wsb)
+        conv._x, conv.output = xx, out
+    N, _, H, W = out.shape
+    M = N * H * W
+    if rows:
+        lib().bn_stats_finalize(stream(), part.ptr, rows, C, bn._sums.data_ptr())
+    else:
+        lib().bn_stats(stream(), out.ptr, M, C, bn._sums.data_ptr())
+    bn._count = float(M)
+    if parallel.sync_bn_active():
+        parallel.allreduce_sum_(bn._sums)
+        bn._count = float(M) * parallel.world_size()
+    y = act._get("out", out.shape, "nhwc")
+    lib().bn_act_forward(stream(), out.ptr, y.ptr, bn.weight.ptr, bn.bias.ptr, bn._sums.data_ptr(), bn._count, M, C,
+                         float(bn.eps), float(bn.momentum), bn.running_mean.ptr, bn.running_var.ptr, bn.save_mean.ptr,
+                         bn.save_std.ptr, act.weight.ptr)
+    bn._x, bn.output = out, None
+    act._x, act.output = None, y
+    bn._fused = dict(M=M, C=C)
+    return y
+
+
+def _bwd_gemm_bn_act(conv, bn, act, input, gradOutput, scale, acc):
+    st = bn._fused
+    M, C = st["M"], st["C"]
+    x = bn._x
+    dy = as_nhwc(gradOutput)
+    if getattr(bn, "_bsums3", None) is None:
+        dev = bn.weight.t.device
+        bn._bsums3 = torch.zeros(2 * C + 1, dtype=torch.float64, device=dev)
+        bn._bsums3_g = torch.zeros(2 * C + 1, dtype=torch.float64, device=dev)
+    lib().bn_act_backward_stats(stream(), x.ptr, dy.ptr, bn.save_mean.ptr, bn.save_std.ptr, bn.weight.ptr, bn.bias.ptr,
+                                act.weight.ptr, M, C, bn._bsums3.data_ptr())
+    gs = bn._bsums3
+    if parallel.sync_bn_active():
+        bn._bsums3_g.copy_(bn._bsums3)
+        parallel.allreduce_sum_(bn._bsums3_g)
+        gs = bn._bsums3_g
+    dx = bn._get("gin", x.shape, "nhwc")
+    lib().bn_act_backward(stream(), x.ptr, dy.ptr, bn.weight.ptr, bn.bias.ptr, bn.save_mean.ptr, bn.save_std.ptr,
+                          act.weight.ptr, gs.data_ptr(), bn._count, bn._bsums3.data_ptr(), M, C, dx.ptr,
+                          bn.gradWeight.ptr if acc else None, bn.gradBias.ptr if acc else None,
+                          act.gradWeight.ptr if acc else None, float(scale))
+    act.gradInput, bn.gradInput = None, dx
+    return conv.backward(input, dx, scale) if acc else conv.updateGradInput(input, dx)
 
 
 # -------------------------------------------------------------------------- criterion

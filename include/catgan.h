@@ -94,6 +94,21 @@ int cg_conv2d_forward_grouped(void* stream, int ngroups, const float* const* x, 
                               const float* const* bias, float* const* y, int N, int Hp, int Wp, int Cin, int Cout,
                               int kH, int kW, int padH, int padW, int ups, void* ws, size_t ws_bytes);
 
+/* The same launch with a fused epilogue (what Torch7 runs as separate modules right behind the convolution):
+ *  - act = 1: nn.PReLU (models.lua:647,649,...; alpha[g] = device pointer to branch g's shared slope),
+ *    act = 2: nn.LeakyReLU(slope) (models.lua:845,847,851).  y keeps the pre-activation (the activation's backward
+ *    needs it), y_act[g] receives act(y).  act = 0: alpha / y_act ignored.
+ *  - stats != NULL (ngroups == 1): per-tile column sums of y and y^2, [cg_conv2d_stats_rows()][2][Cout] floats, from
+ *    which cg_bn_stats_finalize builds the batch statistics of the nn.SpatialBatchNormalization behind the layer
+ *    (models.lua:206-207,212-213) without another pass over y.  cg_conv2d_stats_rows() == 0 means this geometry is
+ *    run split-K / skinny and cannot produce them (use cg_bn_stats). */
+size_t cg_conv2d_stats_rows(int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups);
+int cg_conv2d_forward_ex(void* stream, int ngroups, const float* const* x, const float* const* wpk,
+                         const float* const* bias, float* const* y, int N, int Hp, int Wp, int Cin, int Cout,
+                         int kH, int kW, int padH, int padW, int ups,
+                         int act, float slope, const float* const* alpha, float* const* y_act, float* stats,
+                         void* ws, size_t ws_bytes);
+
 /* updateGradInput of upsample2 -> conv as ONE GEMM: dy [N,2Hp,2Wp,Cout] -> dx_lo [N,Hp,Wp,Cin], i.e. the
  * gradient w.r.t. the low-res input with SpatialUpSamplingNearest's 2x2 block sum folded in.  wb_ph from
  * cg_pack_conv_weight_ups2.  (Cin, Cout are the FORWARD layer's plane counts.) */
@@ -153,6 +168,11 @@ int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const
                              int N, int Hp, int Wp, int Cin, int Cout, int dgrad);
 int cg_conv2d_ups2_wino_forward(void* stream, const float* x_lo, const float* u_fwd, const float* bias, float* y,
                                 float* v, int N, int Hp, int Wp, int Cin, int Cout);
+/* forward + batch-norm statistics partials in the GEMM epilogue (see cg_conv2d_forward_ex): stats is
+ * [cg_conv2d_ups2_wino_stats_rows()][2][Cout] floats, or NULL. */
+size_t cg_conv2d_ups2_wino_stats_rows(int N, int Hp, int Wp, int Cin, int Cout);
+int cg_conv2d_ups2_wino_forward_stats(void* stream, const float* x_lo, const float* u_fwd, const float* bias, float* y,
+                                      float* v, int N, int Hp, int Wp, int Cin, int Cout, float* stats);
 int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy,
                               int N, int Hp, int Wp, int Cin, int Cout);
 /* accGradParameters in the Winograd domain, from the v the forward wrote: gw_canonical[Cout][Cin][5][5] += scale*dW,
@@ -169,6 +189,12 @@ int cg_prelu_forward(void* stream, const float* x, const float* alpha, float* y,
 size_t cg_prelu_backward_workspace_bytes(long n);
 int cg_prelu_backward(void* stream, const float* x, const float* dy, const float* alpha,
                       float* dx, float* galpha, float scale, long n, void* ws, size_t ws_bytes);
+/* The same over a stacked batch of ngroups (<= 4) equal groups of n_per_group elements, group g with its own slope
+ * alpha[g] and gradient accumulator galpha[g] (D32_st3's identical branches, models.lua:653-678): one launch for
+ * ngroups PReLU modules. */
+size_t cg_prelu_backward_grouped_workspace_bytes(int ngroups, long n_per_group);
+int cg_prelu_backward_grouped(void* stream, const float* x, const float* dy, const float* const* alpha, float* dx,
+                              float* const* galpha, float scale, int ngroups, long n_per_group, void* ws, size_t ws_bytes);
 /* nn.LeakyReLU (LeakyReLU.lua:13-31): y = x>=0 ? x : s*x ; dx = x>=0 ? dy : s*dy. */
 int cg_leakyrelu_forward(void* stream, const float* x, float* y, float slope, long n);
 int cg_leakyrelu_backward(void* stream, const float* x, const float* dy, float* dx, float slope, long n);
@@ -208,6 +234,46 @@ int cg_bn_backward(void* stream, const float* x, const float* dy, const float* g
 int cg_bn_forward_eval(void* stream, const float* x, float* y, const float* gamma, const float* beta,
                        const float* running_mean, const float* running_var, long M, int C, float eps);
 
+/* ---- fused memory-bound chains (csrc/fused.hip) ---------------------------
+ * Same arithmetic per element as the separate entry points above / below, one pass over HBM per chain.
+ *
+ * Batch statistics from the producing convolution's epilogue (cg_conv2d_forward_ex / cg_conv2d_ups2_wino_forward_stats):
+ * sums[0..C) = sum_rows partials[r][0][c], sums[C..2C) = sum_rows partials[r][1][c] (fp64, fixed order) - the same
+ * quantities cg_bn_stats produces from a pass over x; a data-parallel host all-reduces `sums` next (sync-BN). */
+int cg_bn_stats_finalize(void* stream, const float* partials, long rows, int C, double* sums);
+/* cg_bn_forward followed by cg_prelu_forward (models.lua:207-208) in one pass: y = prelu(bn(x)); alpha == NULL: no
+ * activation.  The normalised tensor is not materialised: the backward below recomputes it from x. */
+int cg_bn_act_forward(void* stream, const float* x, float* y, const float* gamma, const float* beta,
+                      const double* sums, double count, long M, int C, float eps, float momentum,
+                      float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* alpha);
+/* Backward of y = prelu(bn(x)) given dy = dL/dy, in two passes over (x, dy):
+ *   cg_bn_act_backward_stats: with d = prelu'(bn(x)) * dy:  sums[0..C) = sum d, sums[C..2C) = sum d*xhat,
+ *                             sums[2C] = sum_{bn(x) <= 0} bn(x) * dy   (cg_bn_act_backward_sums(C) doubles, overwritten)
+ *   cg_bn_act_backward:       dx = gamma*invstd*(d - s1/count - xhat*s2/count) from the (all-reduced) `sums`;
+ *                             ggamma += scale*local s2, gbeta += scale*local s1, galpha += scale*local sums[2C]. */
+size_t cg_bn_act_backward_sums(int C);
+int cg_bn_act_backward_stats(void* stream, const float* x, const float* dy, const float* save_mean,
+                             const float* save_invstd, const float* gamma, const float* beta, const float* alpha,
+                             long M, int C, double* sums);
+int cg_bn_act_backward(void* stream, const float* x, const float* dy, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, const float* alpha,
+                       const double* sums, double count, const double* local_sums, long M, int C,
+                       float* dx, float* ggamma, float* gbeta, float* galpha, float scale);
+/* activation -> 2x2 pooling -> spatial dropout in one pass (models.lua:649-651, 656-658, 682-684, 847-848):
+ *   y[n,oy,ox,c] = mask[n,c] * pool( act(x[n, 2oy+{0,1}, 2ox+{0,1}, c]) ),   x: [ngroups*n_per_group, H, W, C].
+ * act: 0 none, 1 PReLU (alpha[g] = slope pointer of group g; samples [g*n_per_group, (g+1)*n_per_group) use it),
+ * 2 LeakyReLU(slope).  pool_max: 0 average, 1 maximum (first maximum in scan order takes the gradient).
+ * mask [ngroups*n_per_group][C] or NULL.  C % 4 == 0, even H and W.
+ * backward: dx = act'(x) * pool^T(mask * gy); galpha[g] += scale * sum_{x<=0} x * d (PReLU; galpha or entries may be
+ * NULL); ws: cg_act_pool2_mask_backward_workspace_bytes(). */
+int cg_act_pool2_mask_forward(void* stream, const float* x, float* y, const float* mask, int ngroups, int n_per_group,
+                              int H, int W, int C, int act, float slope, const float* const* alpha, int pool_max);
+size_t cg_act_pool2_mask_backward_workspace_bytes(int ngroups, int n_per_group, int H, int W, int C);
+int cg_act_pool2_mask_backward(void* stream, const float* x, const float* gy, const float* mask, float* dx,
+                               int ngroups, int n_per_group, int H, int W, int C, int act, float slope,
+                               const float* const* alpha, float* const* galpha, float scale, int pool_max,
+                               void* ws, size_t ws_bytes);
+
 /* ---- resampling / pooling (NHWC) ---------------------------------------- */
 /* nn.SpatialUpSamplingNearest(2) materialised (only when not folded into a conv);
  * H,W are the low-res dims.  backward sums each 2x2 block. */
@@ -241,6 +307,11 @@ int cg_rng_uniform_dev(void* stream, float* out, long n, float lo, float hi,
                        uint64_t seed, uint64_t offset, const uint64_t* base);
 int cg_rng_randint_dev(void* stream, int32_t* out, long n, int32_t range, uint64_t seed, uint64_t offset,
                        const uint64_t* base);
+/* ngroups (<= 4) consecutive blocks of n_per_group floats, block g drawn at stream position off<g> (+ *base): the
+ * spatial-dropout masks of D32_st3's identical branches (models.lua:658) in one launch. */
+int cg_rng_bernoulli_dev_grouped(void* stream, float* out, long n_per_group, int ngroups, float keep_prob, float value,
+                                 uint64_t seed, uint64_t off0, uint64_t off1, uint64_t off2, uint64_t off3,
+                                 const uint64_t* base);
 int cg_counter_add(void* stream, uint64_t* counter, uint64_t delta);
 
 /* ---- layout / data movement --------------------------------------------- */

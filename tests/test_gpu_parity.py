@@ -575,3 +575,114 @@ def test_sampling_in_evaluate_mode_and_ranking(cg):
     assert np.all(np.diff(preds) <= 0) and sorted_imgs.shape == (20, 3, 32, 32)
     cg.nn_utils.switchToTrainingMode(S)
     assert all(m.train for m in G.listModules())
+
+
+# ------------------------------------------------------------------------------ fused chains (nn.fusion)
+def test_fused_chain_entry_points_against_oracle_modules(cg):
+    """csrc/fused.hip through the C ABI, against the oracle's separate modules: activation -> 2x2 pooling -> spatial dropout
+    (models.lua:649-651, 656-658) for three stacked groups with their own PReLU slopes, and batch-norm -> PReLU
+    (models.lua:207-208) forward + two-pass backward."""
+    import ctypes
+    L, st = cg.lib(), cg.tensor.stream()
+    rs = np.random.RandomState(3)
+    G, N, C, H = 3, 4, 8, 6
+    x = rs.randn(G * N, C, H, H).astype(f32); x[0, 0, 0, 0] = 0.0
+    gy = rs.randn(G * N, C, H // 2, H // 2).astype(f32)
+    mask = (rs.rand(G * N, C) < 0.8).astype(f32)
+    alphas = [0.25, -0.1, 0.6]
+    al_t = [cg.Tensor.from_numpy(np.array([a], f32)) for a in alphas]
+    ga_t = [cg.Tensor.from_numpy(np.array([1.0], f32)) for _ in alphas]   # accumulate semantics: starts at 1
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.ptr for t in ts])
+    xt, gt, mt = cg.nn.as_nhwc(cg.Tensor.from_numpy(x)), cg.nn.as_nhwc(cg.Tensor.from_numpy(gy)), cg.Tensor.from_numpy(mask)
+    for pool_max in (0, 1):
+        for act in (1, 2, 0):
+            y = cg.Tensor.empty((G * N, C, H // 2, H // 2), "nhwc"); dx = cg.Tensor.empty(x.shape, "nhwc")
+            L.act_pool2_mask_forward(st, xt.ptr, y.ptr, mt.ptr, G, N, H, H, C, act, 0.333, arr(al_t) if act == 1 else None, pool_max)
+            ws, wsb = cg.tensor.WS.get(L.act_pool2_mask_backward_workspace_bytes(G, N, H, H, C))
+            L.act_pool2_mask_backward(st, xt.ptr, gt.ptr, mt.ptr, dx.ptr, G, N, H, H, C, act, 0.333,
+                                      arr(al_t) if act == 1 else None, arr(ga_t) if act == 1 else None, 0.5, pool_max, ws, wsb)
+            for g in range(G):
+                sl = slice(g * N, (g + 1) * N)
+                A = O.PReLU() if act == 1 else (O.LeakyReLU(0.333) if act == 2 else None)
+                if act == 1:
+                    A.weight[...] = alphas[g]
+                P = O.MaxPool2() if pool_max else O.AvgPool2()
+                h = A.forward(x[sl]) if A else x[sl]
+                ref = P.forward(h) * mask[sl][:, :, None, None]
+                close(y.numpy()[sl], ref, tol=1e-6, what=f"act {act} pool {pool_max} group {g} forward")
+                gref = P.backward(gy[sl] * mask[sl][:, :, None, None])
+                if A:
+                    gref = A.backward(gref)
+                close(dx.numpy()[sl], gref, tol=1e-6, what=f"act {act} pool {pool_max} group {g} backward")
+    # galpha accumulation: fresh accumulators, one call, against the oracle's PReLU
+    ga_t = [cg.Tensor.from_numpy(np.array([1.0], f32)) for _ in alphas]
+    dx = cg.Tensor.empty(x.shape, "nhwc")
+    ws, wsb = cg.tensor.WS.get(L.act_pool2_mask_backward_workspace_bytes(G, N, H, H, C))
+    L.act_pool2_mask_backward(st, xt.ptr, gt.ptr, mt.ptr, dx.ptr, G, N, H, H, C, 1, 0.0, arr(al_t), arr(ga_t), 0.5, 1, ws, wsb)
+    for g in range(G):
+        sl = slice(g * N, (g + 1) * N)
+        A = O.PReLU(); A.weight[...] = alphas[g]; P = O.MaxPool2()
+        P.forward(A.forward(x[sl])); A.backward(P.backward(gy[sl] * mask[sl][:, :, None, None]))
+        close(ga_t[g].numpy(), 1.0 + 0.5 * np.asarray(A.grad_weight, f32).reshape(1), tol=1e-5, what=f"galpha group {g}")
+    # batch-norm + PReLU
+    N, C, H = 6, 16, 8
+    x = (rs.randn(N, C, H, H) * 1.5 + 0.3).astype(f32); dy = rs.randn(N, C, H, H).astype(f32)
+    Bo, Ao = O.SBN(C, O.RNG(4)), O.PReLU()
+    Bo.bias[...] = rs.randn(C).astype(f32) * 0.3
+    gam, bet = cg.Tensor.from_numpy(Bo.weight.copy()), cg.Tensor.from_numpy(Bo.bias.copy())
+    alpha, galpha = cg.Tensor.from_numpy(np.array([0.25], f32)), cg.Tensor.zeros((1,))
+    ggam, gbet = cg.Tensor.zeros((C,)), cg.Tensor.zeros((C,))
+    rm, rv = cg.Tensor.zeros((C,)), cg.Tensor.from_numpy(np.ones(C, f32))
+    sm, si = cg.Tensor.zeros((C,)), cg.Tensor.zeros((C,))
+    xt, dyt = cg.nn.as_nhwc(cg.Tensor.from_numpy(x)), cg.nn.as_nhwc(cg.Tensor.from_numpy(dy))
+    y, dxt = cg.Tensor.empty(x.shape, "nhwc"), cg.Tensor.empty(x.shape, "nhwc")
+    M = N * H * H
+    sums = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+    L.bn_stats(st, xt.ptr, M, C, sums.data_ptr())
+    L.bn_act_forward(st, xt.ptr, y.ptr, gam.ptr, bet.ptr, sums.data_ptr(), float(M), M, C, 1e-5, 0.1, rm.ptr, rv.ptr, sm.ptr, si.ptr,
+                     alpha.ptr)
+    yo = Ao.forward(Bo.forward(x))
+    close(y.numpy(), yo, tol=2e-5, what="bn+prelu forward")
+    close(rm.numpy(), Bo.running_mean, tol=1e-6); close(rv.numpy(), Bo.running_var, tol=1e-5)
+    bs = torch.zeros(2 * C + 1, dtype=torch.float64, device="cuda")
+    L.bn_act_backward_stats(st, xt.ptr, dyt.ptr, sm.ptr, si.ptr, gam.ptr, bet.ptr, alpha.ptr, M, C, bs.data_ptr())
+    L.bn_act_backward(st, xt.ptr, dyt.ptr, gam.ptr, bet.ptr, sm.ptr, si.ptr, alpha.ptr, bs.data_ptr(), float(M), bs.data_ptr(), M, C,
+                      dxt.ptr, ggam.ptr, gbet.ptr, galpha.ptr, 1.0)
+    go = Bo.backward(Ao.backward(dy))
+    close(dxt.numpy(), go, tol=5e-5, what="bn+prelu backward")
+    close(ggam.numpy(), Bo.grad_weight, K=M, what="dgamma"); close(gbet.numpy(), Bo.grad_bias, K=M, what="dbeta")
+    close(galpha.numpy(), np.asarray(Ao.grad_weight, f32).reshape(1), K=M * C, what="dalpha")
+
+
+@pytest.mark.parametrize("which", ["G", "D"])
+def test_fusion_matches_separate_modules(cg, which):
+    """nn.fusion on vs off on the real networks (training mode, batch 6): same outputs (bit-equal where no batch statistics
+    are involved), same gradients up to the summation order of the slope / statistics reductions."""
+    res = {}
+    for fused in (True, False):
+        cg.nn.fusion = fused
+        try:
+            P, _, _ = _pair(cg, 77, which)
+            pP, gP = P.getParameters()
+            rs = np.random.RandomState(5)
+            if which == "D":
+                pP.copy(pP.numpy() + (rs.randn(pP.nElement()) * 0.01).astype(f32))   # move the transformers off the identity
+                x = rs.rand(6, 3, 32, 32).astype(f32); dy = rs.randn(6, 1).astype(f32)
+            else:
+                x = (rs.rand(6, 100) * 2 - 1).astype(f32); dy = (rs.randn(6, 3, 32, 32) * 0.1).astype(f32)
+            xin = cg.Tensor.from_numpy(x)
+            out = P.forward(xin).numpy()
+            gi = cg.nn.as_plain(P.backward(xin, cg.Tensor.from_numpy(dy))).numpy() if which == "D" else None
+            kinds = {k for m in P.listModules() if isinstance(m, cg.nn.Sequential) and type(m) is cg.nn.Sequential
+                     for k, _, _ in (getattr(m, "_ran", None) or [])}
+            assert (kinds - {"one"} != set()) == fused, kinds
+            res[fused] = (out, gi, gP.numpy().copy())
+        finally:
+            cg.nn.fusion = True
+    (o1, g1, p1), (o0, g0, p0) = res[True], res[False]
+    if which == "D":
+        np.testing.assert_array_equal(o1, o0)
+        close(g1, g0, tol=1e-6, what="D gradInput fused vs separate")
+    else:
+        close(o1, o0, tol=2e-6, what="G output fused vs separate")
+    bulk_close(p1, p0, max_rel=1e-4, mean_rel=1e-6, what=f"{which} flat gradient fused vs separate")
