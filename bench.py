@@ -147,8 +147,8 @@ def main():
     torch.cuda.synchronize()
     cg.parallel.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:   # MAX over ranks on the host channel
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     finite = bool(np.isfinite(S.PARAMETERS_G.numpy()).all() and np.isfinite(S.PARAMETERS_D.numpy()).all())

@@ -3,8 +3,8 @@
 No torch / pybind in the link: the library is a plain C-ABI shared object
 (include/catgan.h) so that LuaJIT's FFI, ctypes or a C++ driver can bind it.
 Each source is compiled to its own object (in parallel, only when stale) and the
-objects are linked together; optional pieces (comm.hip: RCCL collectives) are
-linked when their library is present on the build machine.
+objects are linked together.  comm.hip (RCCL collectives) needs rccl.h at build time only;
+librccl.so.1 is bound with dlopen when the first cg_comm_* call is made.
 """
 import os
 import shutil
@@ -64,8 +64,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
         objs = list(ex.map(compile_one, jobs))
     link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
-    if os.path.exists(os.path.join(CSRC, "comm.hip")):
-        link += [f"-L{os.path.join(ROCM, 'lib')}", "-lrccl", f"-Wl,-rpath,{os.path.join(ROCM, 'lib')}"]
+    link += ["-ldl"]   # comm.hip binds RCCL with dlopen at run time: no link-time dependency on librccl
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)

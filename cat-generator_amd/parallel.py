@@ -1,15 +1,20 @@
-"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL/xGMI ("nccl") on the GPU box,
-gloo on CPU for the world_size-2 tests.  The reference has no multi-GPU code; the exchange
+"""Data-parallel plumbing: one process per GPU.  The reference has no multi-GPU code; the exchange
 steps are the ones §8e derives:
   * all-reduce(mean) of the flat gradient vector of a net, BEFORE penalty/clamp/Adam (adversarial.lua:92-112 order)
   * sync-BN: all-reduce(sum) of the 2C fp64 batch statistics (forward) and of (sum dy, sum dy*xhat) (backward)
+Device-side exchanges go through the C ABI (cg_comm_*, csrc/comm.hip: RCCL over xGMI on a side HIP stream with event
+fork/join; one communicator for the gradient buckets, one for the sync-BN sums) - the same entry points a LuaJIT host
+binds.  torch.distributed is the bootstrap channel (it carries the RCCL unique ids and host scalars over gloo) and the
+transport of the CPU tests (gloo, world_size 2); CG_COMM=torch forces its nccl backend for device tensors as well.
 """
+import ctypes
 import os
+import warnings
 
 import torch
 import torch.distributed as dist
 
-_S = {"world": 1, "rank": 0, "init": False, "sync_bn": True}
+_S = {"world": 1, "rank": 0, "init": False, "sync_bn": True, "comm_grad": None, "comm_bn": None}
 
 
 def init_from_env(backend=None):
@@ -22,11 +27,47 @@ def init_from_env(backend=None):
     if world > 1 and not _S["init"]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or os.environ.get("CATGAN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("CATGAN_DIST_BACKEND") or ("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         _S["init"] = True
     _S["world"], _S["rank"] = world, rank
+    if world > 1 and torch.cuda.is_available() and os.environ.get("CG_COMM", "abi") != "torch":
+        _init_abi_comms(world, rank)
     return rank, world
+
+
+def _init_abi_comms(world, rank):
+    """Two RCCL communicators through the C ABI (gradients / sync-BN sums).  Rank 0 creates the unique ids, the process
+    group ships them (host objects over gloo).  On any failure the torch.distributed backend stays in charge."""
+    from .tensor import lib
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world > torch.cuda.device_count():
+        return   # ranks share a GPU (functional tests on a 1-GPU box): RCCL refuses duplicate devices
+    try:
+        L = lib()
+        ok = ctypes.c_int(0)
+        L.comm_available(ctypes.byref(ok))
+        if not ok.value:
+            raise RuntimeError("librccl.so.1 not loadable")
+        ids = [None, None]
+        if rank == 0:
+            for k in range(2):
+                buf = ctypes.create_string_buffer(128)
+                L.comm_unique_id(buf, 128)
+                ids[k] = buf.raw
+        dist.broadcast_object_list(ids, src=0, device=torch.device("cpu"))
+        for k, name in enumerate(("comm_grad", "comm_bn")):
+            h = ctypes.c_void_p()
+            L.comm_init(ctypes.byref(h), world, rank, ids[k], 128)
+            _S[name] = h
+    except Exception as e:   # keep training possible: torch.distributed's nccl backend carries the tensors instead
+        warnings.warn(f"cg_comm_* unavailable ({e}); device collectives fall back to torch.distributed")
+        _S["comm_grad"] = _S["comm_bn"] = None
+
+
+def comm_backend():
+    """'abi' when device tensors travel through cg_comm_* (csrc/comm.hip), else 'torch'."""
+    return "abi" if _S["comm_grad"] is not None else "torch"
 
 
 def attach(world, rank):
@@ -35,6 +76,11 @@ def attach(world, rank):
 
 
 def shutdown():
+    if _S["comm_grad"] is not None:
+        from .tensor import lib
+        for name in ("comm_grad", "comm_bn"):
+            lib().comm_destroy(_S[name])
+            _S[name] = None
     if _S["init"]:
         dist.destroy_process_group()
         _S["init"] = False
@@ -58,15 +104,26 @@ def sync_bn_active():
 
 
 def allreduce_sum_(t):
-    """In-place SUM over ranks of a torch tensor (fp64 statistics)."""
+    """In-place SUM over ranks of a torch tensor (fp64 statistics); ordered on the compute stream."""
     if _S["world"] > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if t.is_cuda and _S["comm_bn"] is not None:
+            from .tensor import lib, stream
+            assert t.dtype in (torch.float64, torch.float32) and t.is_contiguous()
+            lib().comm_allreduce(_S["comm_bn"], stream(), t.data_ptr(), t.numel(), 1 if t.dtype == torch.float64 else 0, 0)
+            lib().comm_wait(_S["comm_bn"], stream())
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
 def allreduce_mean_(t):
     """In-place MEAN over ranks of a flat fp32 gradient vector (torch tensor)."""
     if _S["world"] > 1:
+        if t.is_cuda and _S["comm_grad"] is not None:
+            from .tensor import lib, stream
+            lib().comm_allreduce(_S["comm_grad"], stream(), t.data_ptr(), t.numel(), 0, 1)
+            lib().comm_wait(_S["comm_grad"], stream())
+            return t
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         if t.is_cuda:
             from .tensor import lib, stream
@@ -94,10 +151,28 @@ class _Pending:
         return self.t
 
 
+class _PendingAbi:
+    """An all-reduce(average) in flight on the gradient communicator's side stream (cg_comm_allreduce); finish() joins
+    it into the compute stream (cg_comm_wait: a device-side wait, the host does not block)."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def finish(self):
+        from .tensor import lib, stream
+        lib().comm_wait(_S["comm_grad"], stream())
+        return self.t
+
+
 def allreduce_mean_async(t):
     """Start the gradient all-reduce without blocking the compute stream (xGMI transfer overlaps the kernels
     launched until finish())."""
     if _S["world"] > 1:
+        if t.is_cuda and _S["comm_grad"] is not None:
+            from .tensor import lib, stream
+            assert t.dtype == torch.float32 and t.is_contiguous()
+            lib().comm_allreduce(_S["comm_grad"], stream(), t.data_ptr(), t.numel(), 0, 1)
+            return _PendingAbi(t)
         return _Pending(t, dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
     return _Pending(t, None)
 
@@ -107,14 +182,18 @@ def allreduce_sum_host(values):
     if _S["world"] <= 1:
         return [float(v) for v in values]
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)   # "cpu:gloo,cuda:nccl": host tensor, gloo
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(v) for v in t.cpu().tolist()]
 
 
 def barrier():
     if _S["world"] > 1:
+        if _S["comm_grad"] is not None:   # drain this rank's collectives, then meet the others on the host channel
+            from .tensor import lib
+            lib().comm_sync(_S["comm_grad"])
+            lib().comm_sync(_S["comm_bn"])
         if torch.cuda.is_available() and dist.get_backend() == "nccl":
             dist.barrier(device_ids=[torch.cuda.current_device()])   # explicit device: no guessing from the rank
         else:
-            dist.barrier()
+            dist.all_reduce(torch.zeros(1))   # host tensor: gloo under "cpu:gloo,cuda:nccl"

@@ -355,6 +355,32 @@ int cg_bilinear_sampler_backward(void* stream, const float* img, const float* gr
                                  float* gimg, float* ggrid,
                                  int N, int Hi, int Wi, int C, int Ho, int Wo);
 
+/* ---- collectives of the data-parallel step (csrc/comm.hip; RCCL over xGMI) ---------------------------------
+ * The reference is single-GPU (train.lua:108-112).  The step shards on the batch: one process per GPU,
+ * parameters replicated, and two exchanges per update:
+ *   - all-reduce(average) of the flat GRAD_PARAMETERS vector - or a contiguous bucket of it - right after backward and
+ *     BEFORE penalty / clamp / Adam (adversarial.lua:89-112), started asynchronously so that it travels under the next
+ *     kernels; cg_comm_wait joins it into the compute stream just before cg_adam_step;
+ *   - sync-BN: all-reduce(sum) of the fp64 sums between cg_bn_stats / cg_bn_stats_finalize and cg_bn_forward /
+ *     cg_bn_act_forward, and of the backward sums.  Use a second communicator for these (tiny, latency-bound) so they
+ *     never queue behind a gradient bucket.
+ * A communicator owns one side HIP stream and two events: cg_comm_allreduce forks from `compute_stream` (everything
+ * enqueued there so far is visible to the collective), runs the collective on the side stream and returns at once;
+ * cg_comm_wait makes `compute_stream` wait (device-side) for everything enqueued on the communicator.
+ * Bootstrapping: rank 0 calls cg_comm_unique_id and ships the CG_COMM_ID_BYTES bytes to the other ranks by any host
+ * channel (file, socket, MPI ...); every rank then calls cg_comm_init with its own GPU current (cg_set_device).
+ * dtype: 0 fp32, 1 fp64.  op: 0 sum, 1 average.  *available == 0: librccl.so.1 could not be loaded. */
+#define CG_COMM_ID_BYTES 128
+int cg_comm_available(int* available);
+int cg_comm_unique_id(void* id_out, size_t id_bytes);
+int cg_comm_init(void** comm, int nranks, int rank, const void* unique_id, size_t id_bytes);
+int cg_comm_destroy(void* comm);
+int cg_comm_size(void* comm, int* nranks, int* rank);
+int cg_comm_allreduce(void* comm, void* compute_stream, void* buf, size_t count, int dtype, int op);
+int cg_comm_broadcast(void* comm, void* compute_stream, void* buf, size_t count, int dtype, int root);
+int cg_comm_wait(void* comm, void* compute_stream);
+int cg_comm_sync(void* comm);
+
 /* ---- optimiser ----------------------------------------------------------
  * Fuses adversarial.lua:92-98 (L1/L2 penalty on the gradient), :110-112
  * (clamp) and optim.adam (adversarial.lua:245,262; Torch7 form: eps is added

@@ -686,3 +686,40 @@ def test_fusion_matches_separate_modules(cg, which):
     else:
         close(o1, o0, tol=2e-6, what="G output fused vs separate")
     bulk_close(p1, p0, max_rel=1e-4, mean_rel=1e-6, what=f"{which} flat gradient fused vs separate")
+
+
+def test_collectives_through_the_c_abi_single_rank(cg):
+    """csrc/comm.hip on the one GPU gpurun provides: RCCL bound at run time, a 1-rank communicator, all-reduce (sum, average,
+    fp32 and fp64) and broadcast on the side stream with event fork/join against the compute stream.  With one rank every
+    collective is the identity, so this pins the plumbing (dlopen, ncclCommInitRank, stream ordering), not the maths; the
+    sharded == full-batch identity is pinned with two ranks in tests/test_dp_gloo.py."""
+    import ctypes
+    L, st = cg.lib(), cg.tensor.stream()
+    ok = ctypes.c_int(0)
+    L.comm_available(ctypes.byref(ok))
+    assert ok.value == 1, "librccl.so.1 must be loadable on the GPU box"
+    uid = ctypes.create_string_buffer(128)
+    L.comm_unique_id(uid, 128)
+    h = ctypes.c_void_p()
+    L.comm_init(ctypes.byref(h), 1, 0, uid.raw, 128)
+    try:
+        n, r = ctypes.c_int(-1), ctypes.c_int(-1)
+        L.comm_size(h, ctypes.byref(n), ctypes.byref(r))
+        assert (n.value, r.value) == (1, 0)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        a = torch.randn(1 << 20, device="cuda", generator=g)
+        ref = (a * 2).cpu()
+        a.mul_(2.0)                                           # producer kernel on the compute stream ...
+        L.comm_allreduce(h, st, a.data_ptr(), a.numel(), 0, 1)    # ... must be visible to the collective (fork)
+        L.comm_wait(h, st)                                    # ... and the consumer must see the collective's result (join)
+        b = a + 0.0
+        torch.cuda.synchronize()
+        assert torch.equal(b.cpu(), ref)
+        d = torch.arange(257, dtype=torch.float64, device="cuda")
+        L.comm_allreduce(h, st, d.data_ptr(), d.numel(), 1, 0)
+        L.comm_broadcast(h, st, d.data_ptr(), d.numel(), 1, 0)
+        L.comm_wait(h, st)
+        L.comm_sync(h)
+        assert torch.equal(d.cpu(), torch.arange(257, dtype=torch.float64))
+    finally:
+        L.comm_destroy(h)
