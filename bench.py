@@ -7,6 +7,8 @@ dropout masks, parameters initialised as weight-init.lua + Torch7 defaults.
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps 20 --warmup 5
+    python bench.py --config 3        # BASELINE configs[2]: G32up, grayscale, batch 256
+    python bench.py --config 5        # per-GPU share of configs[4]: G32up-c scaled to 64x64, 64 images per GPU
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,9 +25,48 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F_G, F_D = 2592.4e6, 374.0e6           # fwd FLOP / image
-W_STEP = 3.5 * F_G + 5.0 * F_D          # necessary work per batch-image per step = 10.943 GFLOP
 PEAK_FP32_MFMA = 157.3e12               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM = 8.0e12                       # HBM3E spec (6.29 TB/s measured with a float4 copy)
+
+CONFIGS = {   # BASELINE.json configs (index + 1)
+    2: dict(name="BASELINE configs[1]: G32up-c + D32_st3, 32x32 RGB, batch 128 per GPU", gen="G32up-c", ch=3, size=32, batch=128,
+            metric="images/sec per G+D step, G32up-c 32x32 RGB bs=128 per GPU"),
+    3: dict(name="BASELINE configs[2]: G32up + D32_st3, 32x32 grayscale (--colorSpace=y), batch 256", gen="G32up", ch=1, size=32,
+            batch=256, metric="images/sec per G+D step, G32up 32x32 grayscale bs=256 per GPU"),
+    5: dict(name="per-GPU share of BASELINE configs[4]: G32up-c scaled to 64x64 RGB + D32_st3 at 64x64, 64 images per GPU "
+                 "(global 512 on 8 GPUs)", gen="G32up-c", ch=3, size=64, batch=64,
+            metric="images/sec per G+D step, G32up-c@64 64x64 RGB bs=64 per GPU"),
+}
+
+
+def step_work(cfg, N):
+    """Forward FLOPs per image (2 x MAC) of the generator and the discriminator, direct count and as
+    EXECUTED by the engine: a 3x3 (5x5) convolution behind nn.SpatialUpSamplingNearest(2) runs as four phase convolutions
+    with 2x2 (3x3) taps on the low-res grid (16/36 resp. 36/100 of the MACs), and the 5x5 layers' phases run as Winograd
+    F(2x2,3x3) (16/36 of those) when the Winograd path takes them (planes % 128 == 0, >= 2048 tiles)."""
+    C, s = cfg["ch"], cfg["size"]
+    conv = lambda ci, co, k, ho: 2.0 * ci * co * k * k * ho * ho
+    lin = lambda i, o: 2.0 * i * o
+
+    def ups(ci, co, k, ho, n):
+        d = conv(ci, co, k, ho)
+        if k == 3:
+            return d, d * 16 / 36
+        wino = ci % 128 == 0 and co % 128 == 0 and n * (ho // 2) ** 2 // 4 >= 2048
+        return d, d * 36 / 100 * (16 / 36 if wino else 1.0)
+
+    if cfg["gen"] == "G32up-c":
+        b = s // 8
+        layers = [(lin(100, 512 * b * b),) * 2, ups(512, 512, 3, 2 * b, N), ups(512, 256, 3, 4 * b, N), ups(256, 128, 5, 8 * b, N),
+                  (conv(128, C, 3, 8 * b),) * 2]
+    else:
+        layers = [(lin(100, 128 * 64),) * 2, ups(128, 256, 5, 16, N), ups(256, 128, 5, 32, N), (conv(128, C, 3, 32),) * 2]
+    fg, fg_x = sum(l[0] for l in layers), sum(l[1] for l in layers)
+    loc = lambda ci, sz, p: conv(ci, 16, 3, sz // 2) + conv(16, 16, 3, sz // 2) + lin(16 * (sz // 4) ** 2, 64) + lin(64, p)
+    fd = (loc(C, s, 1) + conv(C, 64, 3, s) + conv(64, 64, 3, s)
+          + 3 * (loc(64, s // 2, 4) + conv(64, 64, 3, s // 2) + conv(64, 64, 3, s // 4))
+          + conv(64, 128, 5, s // 2) + conv(128, 128, 7, s // 4) + lin(320 * (s // 4) ** 2, 256) + lin(256, 1))
+    return dict(F_G=fg, F_D=fd, W=3.5 * fg + 5.0 * fd, W_executed=3.5 * fg_x + 5.0 * fd)
 
 
 def time_kernel(fn, iters=20, warm=3):
@@ -42,59 +83,121 @@ def time_kernel(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def dominant_kernel_roofline(cg, N):
-    """The dominant layer is G's 5x5 256->128 convolution on the upsampled 32x32 map (models.lua:217-218; 65 % of G's
-    FLOPs).  It runs as Winograd F(2x2,3x3) on the four phase convolutions (csrc/winograd.hip); its dominant kernel is
-    wino_gemm_kernel (16 GEMMs + in-register output transform).  Timed in isolation with HIP events on the launch
-    stream: that kernel alone (forward and data-gradient geometry), and the three module-level launch groups."""
+def kernel_rooflines(cg, N):
+    """The kernels that carry the step (time shares from profiles/r02*_per_step_breakdown.txt), each timed in isolation with
+    HIP events on the launch stream at the benchmarked batch, EXECUTED MFMA FLOPs per launch / duration against the fp32 MFMA
+    peak.  `traffic` / MFMA-pipe utilisation come from the committed PMC pass of the same launches (profiles/r02_pmc_kernels.json,
+    scripts/pmc_kernels.sh; bench.py cannot run rocprofv3 on itself) and carry their source."""
     lib, stream = cg.tensor.lib(), cg.tensor.stream()
-    m = cg.nn.SpatialConvolution(256, 128, 5, 5, 1, 1, 2)
-    x = cg.Tensor(torch.rand(N * 16 * 16 * 256, device="cuda") - 0.5, (N, 256, 16, 16), "nhwc")
-    dy = cg.Tensor(torch.rand(N * 32 * 32 * 128, device="cuda") - 0.5, (N, 128, 32, 32), "nhwc")
-    xin = cg.nn.SpatialUpSamplingNearest(2).forward(x)
-    y = m.forward(xin)
-    wino = bool(getattr(m, "_wino", False))
-    out = {"layer_fwd": time_kernel(lambda: m.updateOutput(xin)),
-           "layer_dgrad": time_kernel(lambda: m.updateGradInput(xin, dy)),
-           "layer_wgrad": time_kernel(lambda: m.accGradParameters(xin, dy))}
-    if wino:
-        v = m._get("wino_v", (lib.conv2d_ups2_wino_v_floats(N, 16, 16, 256),))
-        vdy = m._get("wino_vdy", (lib.conv2d_ups2_wino_v_floats(N, 16, 16, 512),))
-        gi = m._get("gin_lo", (N, 256, 16, 16), "nhwc")
-        out["wino_gemm_fwd"] = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(
-            stream, v.ptr, m._u_fwd.data_ptr(), m.bias.ptr, y.ptr, N, 16, 16, 256, 128, 0))
-        out["wino_gemm_dgrad"] = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(
-            stream, vdy.ptr, m._u_bwd.data_ptr(), None, gi.ptr, N, 16, 16, 256, 128, 1))
-    flop_direct = 2.0 * N * 32 * 32 * 128 * 256 * 25           # 5x5 taps on the materialised 32x32 map
-    flop_phase = flop_direct * 36.0 / 100.0                     # 4 phases x 3x3 taps per low-res pixel
-    flop_wino = flop_phase * 16.0 / 36.0                        # F(2x2,3x3): 16 multiplies per 2x2 tile instead of 36
-    return wino, {"direct": flop_direct, "phase_folded": flop_phase, "winograd": flop_wino}, out
+    out = []
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))
+    except Exception:
+        pass
+
+    def entry(key, kernel, what, flop, t, direct=None, share=None, extra=None):
+        e = {"bound": "mfma", "kernel": kernel, "launch": what, "flop_per_launch": flop, "launch_ms": 1e3 * t,
+             "achieved": flop / t / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s", "frac": flop / t / PEAK_FP32_MFMA,
+             "traffic": None}
+        if direct:
+            e["flop_per_launch_direct_count"] = direct
+        if share:
+            e["step_time_share_profiled"] = share
+        p_ = pmc.get(key)
+        if p_:
+            e["traffic"] = p_.get("hbm_bytes_per_launch_corrected")
+            e["mfma_pipe_util_pmc"] = p_.get("mfma_pipe_util")
+            e["valu_per_mfma_pmc"] = p_.get("valu_per_mfma")
+            e["pmc_source"] = p_.get("source", "profiles/r02_pmc_kernels.json")
+        if extra:
+            e.update(extra)
+        out.append(e)
+
+    def conv(ci, co, k, h, n, ups):
+        m = cg.nn.SpatialConvolution(ci, co, k, k, 1, 1, (k - 1) // 2)
+        x = cg.Tensor(torch.rand(n * h * h * ci, device="cuda") - 0.5, (n, ci, h, h), "nhwc")
+        ho = h << ups
+        dy = cg.Tensor(torch.rand(n * ho * ho * co, device="cuda") - 0.5, (n, co, ho, ho), "nhwc")
+        xin = cg.nn.SpatialUpSamplingNearest(2).forward(x) if ups else x
+        m.forward(xin)
+        return m, xin, dy
+
+    # (1) igemm_nn_kernel<64,128,2,2,FAST,VECB,32>: largest launch = data gradient of G's 512->256 3x3 layer behind the 2x
+    #     upsampling (models.lua:211-212), one GEMM over the 4 phases' taps: M = N*8*8, K = 16 taps * 256, Cout = 512
+    m, xin, dy = conv(512, 256, 3, 8, N, 1)
+    t = time_kernel(lambda: m.updateGradInput(xin, dy))
+    direct = 2.0 * N * 16 * 16 * 256 * 512 * 9
+    entry("nn64x128", "igemm_nn_kernel<64,128,2,2,true,true,32> (gemm.hip)",
+          f"updateGradInput of upsample2 -> conv3x3 512->256 @8->16, batch {N}: one implicit GEMM, M={N * 64} K=4096 N=512",
+          2.0 * N * 64 * 4096 * 512, t, direct, "19 % of the step's kernel time (16 launches)")
+    # (2) igemm_tn_kernel<128,128>: weight gradient of the same layer (4 phases, split over pixels) + its reduce kernels
+    t = time_kernel(lambda: m.accGradParameters(xin, dy))
+    entry("tn128x128", "igemm_tn_kernel<128,128,2,2,true,true> + wgrad_reduce_kernel<true> + bias_part_reduce_kernel (gemm.hip)",
+          f"accGradParameters of the same layer, batch {N}: launch GROUP (TN GEMM + deterministic split reduce)",
+          2.0 * N * 64 * 4 * 2048 * 256, t, direct, "12 % (10 launches)", {"timed": "launch group, not the GEMM kernel alone"})
+    # (3) igemm_nn_kernel<128,64,...,16>: D's 64->64 3x3 convolution at 32x32 (models.lua:648)
+    m2, x2, dy2 = conv(64, 64, 3, 32, N, 0)
+    t = time_kernel(lambda: m2.updateOutput(x2))
+    f2 = 2.0 * N * 32 * 32 * 64 * 64 * 9
+    entry("nn128x64", "igemm_nn_kernel<128,64,2,2,true,true,16> (gemm.hip)",
+          f"updateOutput of conv3x3 64->64 @32x32, batch {N}: M={N * 1024} K=576 N=64", f2, t, f2, "9 % (8 launches)")
+    # (4) wino_gemm_kernel<8,16>: the 16 Winograd-domain GEMMs + in-register output transform of G's upsample2 -> conv5x5
+    m3, x3, dy3 = conv(256, 128, 5, 16, N, 1)
+    if getattr(m3, "_wino", False):
+        y = m3.output
+        v = m3._get("wino_v", (lib.conv2d_ups2_wino_v_floats(N, 16, 16, 256),))
+        t = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(stream, v.ptr, m3._u_fwd.data_ptr(), m3.bias.ptr, y.ptr, N, 16, 16, 256, 128, 0))
+        d3 = 2.0 * N * 32 * 32 * 128 * 256 * 25
+        entry("wino8x16", "wino_gemm_kernel<8,16> (winograd.hip)",
+              f"forward of upsample2 -> conv5x5 256->128 @16->32 (models.lua:217-218), batch {N}: 4 phases x 16 GEMMs [tiles x 256].[256 x 128]",
+              d3 * 36 / 100 * 16 / 36, t, d3, "9 % (3 launches of the two wino_gemm variants)",
+              {"layer_ms": {"fwd": 1e3 * time_kernel(lambda: m3.updateOutput(x3)), "dgrad": 1e3 * time_kernel(lambda: m3.updateGradInput(x3, dy3)),
+                            "wgrad": 1e3 * time_kernel(lambda: m3.accGradParameters(x3, dy3))}})
+    return out
 
 
-def cpu_baseline(steps=16, N=16):
-    """The oracle (a port: im2col + blocked SGEMM + OpenMP, the algorithm class of THNN SpatialConvolutionMM)
-    timed on this box's host cores on a bounded sample: `steps` iterations at batch 16 (BASELINE configs[0])."""
+def cpu_baselines():
+    """CPU baselines on this box's host cores, bounded samples of configs[0] (batch 16):
+    the oracle (a port: im2col + blocked SGEMM + OpenMP, the algorithm class of THNN SpatialConvolutionMM) at the reference's
+    default 4 threads (train.lua:39) and at as many threads as its batch-parallel loops can use, and PyTorch-CPU eager on the
+    same graphs (oracle/torch_ref.py) as the best-available-library line."""
     from oracle import oracle as O
-    # the port parallelises its convolutions over the N samples of the batch: more threads than that only spin
-    O.set_num_threads(min(os.cpu_count() or 1, N))
-    rng = O.RNG(1)
-    T = O.Trainer(O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng))
+    from oracle import torch_ref as TR
+    N = 16
+    nproc = os.cpu_count() or 1
     rs = np.random.RandomState(0)
 
-    def one():
-        real = rs.rand(N // 2, 3, 32, 32).astype(np.float32)
-        nd = (rs.rand(N // 2, 100) * 2 - 1).astype(np.float32)
-        ng = (rs.rand(N, 100) * 2 - 1).astype(np.float32)
-        T.step(real, nd, ng)
+    def batch():
+        return (rs.rand(N // 2, 3, 32, 32).astype(np.float32), (rs.rand(N // 2, 100) * 2 - 1).astype(np.float32),
+                (rs.rand(N, 100) * 2 - 1).astype(np.float32))
 
-    one()
-    t0 = time.time()
-    for _ in range(steps):
-        one()
-    dt = time.time() - t0
-    return {"value": N * steps / dt, "unit": "images/sec", "cores": O.num_threads(), "kind": "port",
-            "sample": f"{steps} G+D steps of G32up-c/D32_st3 at batch {N} (configs[0]) after 1 warm-up, "
-                      f"oracle/ (C im2col+SGEMM, OpenMP {O.num_threads()} threads), {dt:.1f} s"}
+    def run(T, steps):
+        T.step(*batch())
+        t0 = time.time()
+        for _ in range(steps):
+            T.step(*batch())
+        return time.time() - t0
+
+    res = []
+    for threads, steps in ((min(nproc, N), 8), (min(nproc, 4), 3)):
+        O.set_num_threads(threads)
+        rng = O.RNG(1)
+        dt = run(O.Trainer(O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng)), steps)
+        res.append({"value": N * steps / dt, "unit": "images/sec", "cores": O.num_threads(), "nproc": nproc, "kind": "port",
+                    "sample": f"{steps} G+D steps of G32up-c/D32_st3 at batch {N} (configs[0]) after 1 warm-up, oracle/ (C im2col+SGEMM, "
+                              f"OpenMP {O.num_threads()} threads" + (", the reference's default --threads" if threads == 4 else
+                                                                     ", one per sample of the batch") + f"), {dt:.1f} s"})
+    torch.set_num_threads(min(nproc, 64))
+    rng = O.RNG(1)
+    steps = 6
+    dt = run(TR.TorchTrainer(O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng)), steps)
+    res.append({"value": N * steps / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "nproc": nproc, "kind": "port",
+                "sample": f"{steps} G+D steps at batch {N}, PyTorch-CPU eager ({torch.__version__}, autograd, {torch.get_num_threads()} threads) on "
+                          f"the same graphs (oracle/torch_ref.py), {dt:.1f} s"})
+    best = dict(res[0])
+    best["others"] = res[1:]
+    return best
 
 
 def main():
@@ -102,7 +205,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-per-gpu", type=int, default=128)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config number (1-based)")
+    ap.add_argument("--batch-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay also for N > 1")
@@ -115,13 +219,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     cg.lib()
 
-    N = args.batch_per_gpu
+    cfg = CONFIGS[args.config]
+    N = args.batch_per_gpu or cfg["batch"]
+    dims = (cfg["ch"], cfg["size"], cfg["size"])
     cg.manual_seed(1)  # identical parameters on every rank
-    G = cg.models.create_G((3, 32, 32), 100)
-    D = cg.models.create_D((3, 32, 32))
+    G = cg.models.create_G(dims, 100) if cfg["gen"] == "G32up-c" else cg.models.create_G_decoder_upsampling32(dims, 100)
+    D = cg.models.create_D(dims)
     S = cg.adversarial.State(dict(batchSize=N, seed=1 + rank), G, D)
     cg.tensor.rng().offset += rank << 40  # rank-private noise / mask stream
-    pool = np.random.RandomState(100 + rank).rand(1024, 3, 32, 32).astype(np.float32)
+    pool = np.random.RandomState(100 + rank).rand(1024, *dims).astype(np.float32)
     data = cg.adversarial.TrainData(pool)
 
     use_graph = (world == 1 and not args.no_graph) or args.graph
@@ -157,55 +263,33 @@ def main():
         ms = 1e3 * dt / args.steps
         value = N * world * args.steps / dt
         per_gpu = value / world
+        w = step_work(cfg, N)
         res = {
-            "metric": "images/sec per G+D step, G32up-c 32x32 RGB bs=128 per GPU",
-            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": cfg["metric"], "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: G32up-c + D32_st3, 32x32 RGB, batch 128 per GPU, one "
-                                   "adversarial.lua D+G update (Adam, D_L2=1e-4, clamps 1/5)",
-                       "global_batch": N * world, "parallelism": f"dp{world}", "launch": launch,
+            "config": {"workload": cfg["name"] + ", one adversarial.lua D+G update (Adam, D_L2=1e-4, clamps 1/5)",
+                       "global_batch": N * world, "parallelism": f"dp{world}", "launch": launch, "fusion": bool(cg.nn.fusion),
+                       "collectives": cg.parallel.comm_backend() if world > 1 else None,
                        "ms_per_sample_reference_unit": 1e3 * dt / args.steps / (N * world / 2)},
-            "step_roofline": {"bound": "mfma", "work_gflop_per_image": W_STEP / 1e9,
-                              "note": "direct-count necessary work W = 3.5 F_G + 5 F_D (SURVEY.md 8d); the engine "
-                                      "executes ~4.3 GFLOP/image after folding the upsamplings into phase convolutions "
-                                      "and running the 5x5 layer's phases as Winograd F(2x2,3x3), so this fraction is not "
-                                      "an MFMA utilisation (see `roofline` for the dominant kernel's)",
-                              "achieved": per_gpu * W_STEP / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
-                              "unit": "TFLOP/s", "frac": per_gpu * W_STEP / PEAK_FP32_MFMA},
+            "parity": "oracle unpinned by the reference (it holds no vectors); pinned against PyTorch-CPU autograd at operator and "
+                      "whole-step level (tests/test_oracle_vs_torch.py)",
+            "step_work": {"gflop_per_image_direct_count": w["W"] / 1e9, "gflop_per_image_executed": w["W_executed"] / 1e9,
+                          "F_G_mflop": w["F_G"] / 1e6, "F_D_mflop": w["F_D"] / 1e6,
+                          "note": "W = 3.5 F_G + 5 F_D (SURVEY.md 8d).  `executed` counts the MFMA FLOPs the engine issues after folding "
+                                  "the 2x upsamplings into phase convolutions and running the 5x5 phases as Winograd F(2x2,3x3); "
+                                  "`executed_frac` = executed FLOP/s / fp32 MFMA peak is the step-level MFMA utilisation, "
+                                  "`direct_count_tflops` is the reference-equivalent rate (not a utilisation, may exceed the peak)",
+                          "executed_tflops": per_gpu * w["W_executed"] / 1e12, "executed_frac": per_gpu * w["W_executed"] / PEAK_FP32_MFMA,
+                          "direct_count_tflops": per_gpu * w["W"] / 1e12, "peak_tflops": PEAK_FP32_MFMA / 1e12},
             "event_ms_per_step": e0.elapsed_time(e1) / args.steps, "finite": finite,
         }
-        if not args.no_kernel_roofline:
-            wino, flops, t = dominant_kernel_roofline(cg, N)
-            # HBM traffic / MFMA utilisation of that launch from the PMC pass committed under profiles/
-            # (2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); bench.py cannot run
-            # rocprofv3 on itself
-            traffic, util = None, None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_dominant_kernel.json")))
-                traffic, util = pmc["hbm_bytes_per_launch_corrected"], pmc["mfma_pipe_util"]
-            except Exception:
-                pass
-            if wino:
-                kname, tk_, fl = "wino_gemm_kernel", t["wino_gemm_fwd"], flops["winograd"]
-                what = ("wino_gemm_kernel (winograd.hip): the 16 Winograd-domain GEMMs + in-register output transform of G's "
-                        "upsample2->conv5x5 256->128 layer, forward geometry, batch %d" % N)
-            else:
-                kname, tk_, fl = "igemm_nn_kernel<128,128>", t["layer_fwd"], flops["phase_folded"]
-                what = "igemm_nn_kernel<128,128,2,2,FAST> (phase-folded upsample2->conv5x5 256->128, batch %d)" % N
-            res["roofline"] = {"bound": "mfma", "kernel": what,
-                               "achieved": fl / tk_ / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-                               "frac": fl / tk_ / PEAK_FP32_MFMA, "traffic": traffic, "mfma_pipe_util_pmc": util,
-                               "note": "achieved/frac count the MFMA FLOPs the kernel EXECUTES; the same launch expressed in "
-                                       "the layer's direct-count FLOPs (5x5 taps on the 32x32 map) is `tflops_direct_equiv`",
-                               "flop_per_launch": fl, "flop_per_launch_direct": flops["direct"],
-                               "flop_per_launch_phase_folded": flops["phase_folded"],
-                               "launch_ms": {k: 1e3 * v for k, v in t.items()},
-                               "tflops_direct_equiv": flops["direct"] / tk_ / 1e12,
-                               "layer_tflops_direct_equiv": {k: flops["direct"] / v / 1e12 for k, v in t.items()
-                                                             if k.startswith("layer_")}}
+        if not args.no_kernel_roofline and args.config == 2:
+            top = kernel_rooflines(cg, N)
+            res["roofline"] = top[0]          # the kernel with the largest share of the step
+            res["roofline_top"] = top
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baselines()
         print(json.dumps(res), flush=True)
     cg.parallel.shutdown()
 

@@ -75,7 +75,9 @@ def main():
                   lambda: lin_case("D.linear 20480->256", N, 20480, 256)]
     named = {"conv3": lambda: conv_case("G.conv3 5x5 256->128 @16^2 ups", N, 256, 16, 128, 5, 1),
              "b4": lambda: conv_case("D.b4 7x7 128->128 @8^2", N, 128, 8, 128, 7, 0),
-             "conv1": lambda: conv_case("G.conv1 3x3 512->512 @4^2 ups", N, 512, 4, 512, 3, 1)}
+             "conv1": lambda: conv_case("G.conv1 3x3 512->512 @4^2 ups", N, 512, 4, 512, 3, 1),
+             "conv2": lambda: conv_case("G.conv2 3x3 512->256 @8^2 ups", N, 512, 8, 256, 3, 1),
+             "dconv2": lambda: conv_case("D.conv2 3x3 64->64 @32^2", N, 64, 32, 64, 3, 0)}
     if only:
         cases = [named[o] for o in only.split(",")]
     print(f"{'layer':34s} {'GFLOP':>8s}  " + "  ".join(f"{p:>16s}" for p in ("fwd ms / TF", "dgrad ms / TF", "wgrad ms / TF")))

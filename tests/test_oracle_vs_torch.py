@@ -258,3 +258,54 @@ def test_full_G_matches_torch_autograd():
         assert np.abs(a - b).max() <= 3e-2 * scale
         if a.size > 1:
             assert np.abs(a - b).mean() <= 2e-3 * scale
+
+
+def test_whole_step_gradients_match_torch_autograd():
+    """The oracle's D-step and G-step gradients (adversarial.lua:72-112, 171-215: D32_st3 with three spatial transformers,
+    G32up-c with training-mode batch-norm, BCE, L2 penalty, clamps) against PyTorch-CPU autograd evaluating the same module
+    trees on the same parameters and dropout masks (oracle/torch_ref.py).  With no reference fixtures to pin the oracle
+     this is the strongest available anchor: an independent implementation of every operator AND of the
+    chain rule through the whole graph."""
+    from oracle import torch_ref as TR
+    rng = O.RNG(5)
+    G, D = O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng)
+    T = O.Trainer(G, D)
+    rs = np.random.RandomState(1)
+    T.pD += (rs.randn(T.pD.size) * 0.01).astype(f32)       # move the transformers off their identity initialisation
+    N = 4
+    real = rs.rand(N // 2, 3, 32, 32).astype(f32)
+    nd = (rs.rand(N // 2, 100) * 2 - 1).astype(f32); ng = (rs.rand(N, 100) * 2 - 1).astype(f32)
+    fake = G.forward(nd)
+    inputs = np.concatenate([real, fake]).astype(f32)
+    targets = np.concatenate([np.ones(N // 2, f32), np.zeros(N // 2, f32)])
+    # ---- D step
+    fD, outD = T.feval_D(inputs, targets)
+    tD = TR.Tape(D)
+    out_t = TR.run(D, torch.tensor(inputs), tD, TR.oracle_masks(D))
+    loss_t = TR.bce(out_t, torch.tensor(targets))
+    loss_t.backward()
+    close(outD, out_t.detach().numpy(), atol=2e-5)
+    g_t = tD.flat_grad() + f32(1e-4) * T.pD
+    np.clip(g_t, -1.0, 1.0, out=g_t)
+    _bulk(T.gD, g_t, "D-step gradient")
+    assert abs(float(loss_t.detach()) + 1e-4 * float((T.pD.astype(np.float64) ** 2).sum()) / 2 - fD) < 1e-4
+    # ---- G step (through D)
+    fG, samples, outG = T.feval_G(ng, np.ones(N, f32))
+    tG, tD2 = TR.Tape(G), TR.Tape(D)
+    s_t = TR.run(G, torch.tensor(ng), tG)
+    close(samples, s_t.detach().numpy(), atol=2e-5)
+    o_t = TR.run(D, s_t, tD2, TR.oracle_masks(D))
+    TR.bce(o_t, torch.ones(N)).backward()
+    gG_t = tG.flat_grad()
+    np.clip(gG_t, -5.0, 5.0, out=gG_t)
+    _bulk(T.gG, gG_t, "G-step gradient")
+
+
+def _bulk(a, b, what):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = max(float(np.abs(b).max()), 1e-30)
+    d = np.abs(a - b) / scale
+    rel = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    q = np.quantile(d, [0.5, 0.99])
+    print(f"[{what}] rel-l2 {rel:.2e} median {q[0]:.2e} p99 {q[1]:.2e} max {d.max():.2e}")
+    assert rel <= 2e-3 and q[0] <= 1e-5 and q[1] <= 1e-3 and d.max() <= 5e-2, (what, rel, q, d.max())
