@@ -308,8 +308,11 @@ class GraphedIteration:
             self._eager()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        ts = {k: S.OPTSTATE["adam"][k]["t"] for k in ("D", "G")}
         with torch.cuda.graph(self.graph):
             self._body()
+        for k in ("D", "G"):   # capture launched nothing: the host step count must not move (it is what a checkpoint stores)
+            S.OPTSTATE["adam"][k]["t"] = ts[k]
         self.replays = 0
 
     def _body(self):
@@ -318,6 +321,7 @@ class GraphedIteration:
         iteration(self.S, self.data, self.N)
         self.stride = r.offset - self.off0
         lib().counter_add(stream(), self.base.data_ptr(), self.stride)
+        r.offset = self.off0   # between steps the stream position is r.offset + *base (what a checkpoint stores)
 
     def _eager(self):
         self._body()

@@ -27,6 +27,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"CG_SPLIT_TARGET", 2}, {"CG_SPLIT_MINK", 8}, {"CG_TN_SMAX", 128}, {"CG_TN_TARGET", 3}, {"CG_SKINNY", 1},
     {"CG_GEMM_SLOW", 0}, {"CG_GEMM_BK32", 1}, {"CG_COLREDUCE_WGS_PER_CU", 1}, {"CG_WINO_WAVES", 8}, {"CG_WINO_BK", 0},
     {"CG_NN_TILE", 0}, {"CG_TN_TILE", 0}, {"CG_NN_SPLITS", 0}, {"CG_TN_SPLITS", 0}, {"CG_EPILOGUE_STATS", 1},
+    {"CG_SAMPLER_ATOMICS", 0},
 };
 long g_opt_val[OPT_COUNT];
 int g_opt_state[OPT_COUNT];   // 0 = not read yet, 1 = default / environment, 2 = set through the ABI
@@ -749,6 +750,99 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const float* img, const fl
     }
 }
 
+// Deterministic backward (no float atomics): the reference pins this module to the CPU because stn's GPU scatter was
+// "non-reproducible" (models.lua:889-899).  One workgroup = one sample x 64 pixel slots.  It stages the taps of ALL the
+// sample's output pixels in LDS, then
+//   (A) for its 64 OUTPUT pixels: ggrid from the channel dot products (lanes over channels, wave reduction), and
+//   (B) for its 64 SOURCE pixels: gimg[q] = sum over the output pixels whose 2x2 footprint covers q, found by scanning
+//       the staged taps 64 at a time (ballot) and accumulated in ascending output-pixel order - a gather, so every
+//       gimg element is written exactly once (no memset) by one lane in a fixed order.
+template <int CACC>   // channels per lane: C <= 64 * CACC
+__global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restrict__ img, const float* __restrict__ grid,
+                                                          const float* __restrict__ gout, float* __restrict__ gimg,
+                                                          float* __restrict__ ggrid, int Hi, int Wi, int C, int Ho, int Wo,
+                                                          int nchunks) {
+    extern __shared__ float bl_sh[];
+    const int P = Ho * Wo, Q = Hi * Wi;
+    int* ty0 = reinterpret_cast<int*>(bl_sh);
+    int* tx0 = ty0 + P;
+    float* twy = bl_sh + 2 * P;
+    float* twx = bl_sh + 3 * P;
+    const long n = blockIdx.x / nchunks;
+    const int chunk = blockIdx.x % nchunks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const BilinTaps t = bilin_taps(grid[(n * P + p) * 2], grid[(n * P + p) * 2 + 1], Hi, Wi);
+        ty0[p] = t.y0; tx0[p] = t.x0; twy[p] = t.wy0; twx[p] = t.wx0;
+    }
+    __syncthreads();
+    const float* gsample = gout + n * (long)P * C;
+    const float* isample = img + n * (long)Q * C;
+    // ---- (A) grid gradient of this workgroup's output pixels
+    for (int j = wave; j < 64; j += 4) {
+        const int p = chunk * 64 + j;
+        if (p >= P) break;
+        const int y0 = ty0[p], x0 = tx0[p];
+        const float wy0 = twy[p], wx0 = twx[p];
+        const bool xin0 = x0 >= 0 && x0 <= Wi - 1, xin1 = x0 + 1 >= 0 && x0 + 1 <= Wi - 1;
+        const bool yin0 = y0 >= 0 && y0 <= Hi - 1, yin1 = y0 + 1 >= 0 && y0 + 1 <= Hi - 1;
+        const long b = ((long)y0 * Wi + x0) * C;
+        const long o01 = C, o10 = (long)Wi * C, o11 = (long)Wi * C + C;
+        float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float g = gsample[(long)p * C + c];
+            if (yin0 && xin0) d00 += isample[b + c] * g;
+            if (yin0 && xin1) d01 += isample[b + o01 + c] * g;
+            if (yin1 && xin0) d10 += isample[b + o10 + c] * g;
+            if (yin1 && xin1) d11 += isample[b + o11 + c] * g;
+        }
+        d00 = wave_sum(d00); d01 = wave_sum(d01); d10 = wave_sum(d10); d11 = wave_sum(d11);
+        if (lane == 0) {
+            const float gy = -wx0 * d00 + wx0 * d10 - (1.f - wx0) * d01 + (1.f - wx0) * d11;
+            const float gx = -wy0 * d00 + wy0 * d01 - (1.f - wy0) * d10 + (1.f - wy0) * d11;
+            ggrid[(n * P + p) * 2 + 0] = gy * (float)(Hi - 1) * 0.5f;
+            ggrid[(n * P + p) * 2 + 1] = gx * (float)(Wi - 1) * 0.5f;
+        }
+    }
+    // ---- (B) image gradient of this workgroup's source pixels
+    for (int j = wave; j < 64; j += 4) {
+        const int q = chunk * 64 + j;
+        if (q >= Q) break;
+        const int y = q / Wi, x = q - y * Wi;
+        float acc[CACC];
+#pragma unroll
+        for (int k = 0; k < CACC; ++k) acc[k] = 0.f;
+        for (int p0 = 0; p0 < P; p0 += 64) {
+            const int p = p0 + lane;
+            bool hit = false;
+            if (p < P) {
+                const int dy = y - ty0[p], dx = x - tx0[p];
+                hit = (dy == 0 || dy == 1) && (dx == 0 || dx == 1);
+            }
+            unsigned long long m = __ballot(hit);
+            while (m) {   // wave-uniform: ascending output-pixel order
+                const int bpos = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int ph = p0 + bpos;
+                const float wy = (y == ty0[ph]) ? twy[ph] : 1.f - twy[ph];
+                const float wx = (x == tx0[ph]) ? twx[ph] : 1.f - twx[ph];
+                // same product order as the forward: (x weight) * (y weight)
+                const float w = wx * wy;
+#pragma unroll
+                for (int k = 0; k < CACC; ++k) {
+                    const int c = lane + 64 * k;
+                    if (c < C) acc[k] += w * gsample[(long)ph * C + c];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CACC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) gimg[(n * Q + q) * C + c] = acc[k];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ optimiser
 __global__ void adam_k(float* p, float* g, float* m, float* v, long n, float step, float b1, float b2, float eps,
                        float l1, float l2, float clampv, int write_back, float lr, const uint64_t* t_dev) {
@@ -1171,6 +1265,17 @@ int cg_bilinear_sampler_forward(void* stream, const float* img, const float* gri
 int cg_bilinear_sampler_backward(void* stream, const float* img, const float* grid, const float* gout, float* gimg,
                                  float* ggrid, int N, int Hi, int Wi, int C, int Ho, int Wo) {
     CG_REQUIRE(img && grid && gout && gimg && ggrid, "cg_bilinear_sampler_backward: null pointer");
+    const long P = (long)Ho * Wo, Q = (long)Hi * Wi;
+    if (cg::opt(cg::OPT_SAMPLER_ATOMICS) == 0 && P <= 8192 && C <= 256 && N > 0) {   // deterministic gather form
+        const int nchunks = cg::cdiv(std::max(P, Q), 64);
+        const size_t shb = (size_t)P * 16;
+        const dim3 grd((unsigned)((long)N * nchunks)), blk(256);
+#define CG_BILIN_DET(K) hipLaunchKernelGGL(bilinear_bwd_det_k<K>, grd, blk, shb, cg::S(stream), img, grid, gout, gimg, ggrid, Hi, Wi, C, Ho, Wo, nchunks)
+        if (C <= 64) CG_BILIN_DET(1); else if (C <= 128) CG_BILIN_DET(2); else CG_BILIN_DET(4);
+#undef CG_BILIN_DET
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
     CG_HIP(hipMemsetAsync(gimg, 0, sizeof(float) * (size_t)N * Hi * Wi * C, cg::S(stream)));
     const long npix = (long)N * Ho * Wo;
     int G = 4;

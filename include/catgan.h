@@ -47,7 +47,7 @@ const char* cg_last_error(void);
 /* Tunables of the kernel dispatch (block tiles, split-K targets, Winograd variants ...), named like the environment
  * variables that set their defaults (CG_NN_TILE, CG_TN_TILE = bm*1000+bn; CG_NN_SPLITS, CG_TN_SPLITS; CG_GEMM_BK32;
  * CG_WINO_BK; CG_WINO_WAVES; CG_SKINNY; CG_GEMM_SLOW; CG_SPLIT_TARGET; CG_SPLIT_MINK; CG_TN_SMAX; CG_TN_TARGET;
- * CG_COLREDUCE_WGS_PER_CU; CG_EPILOGUE_STATS).  value == -1 restores the default.  Results never depend on them beyond
+ * CG_COLREDUCE_WGS_PER_CU; CG_EPILOGUE_STATS; CG_SAMPLER_ATOMICS).  value == -1 restores the default.  Results never depend on them beyond
  * fp32 re-association; the parity tests use them to run every compiled kernel variant against the oracle. */
 int cg_set_option(const char* name, long value);
 int cg_get_option(const char* name, long* value);
@@ -348,7 +348,10 @@ int cg_affine_matrix_backward(void* stream, const float* params, const float* gT
 int cg_affine_grid_forward(void* stream, const float* T, float* grid, int N, int H, int W);
 int cg_affine_grid_backward(void* stream, const float* ggrid, float* gT, int N, int H, int W);
 /* BilinearSamplerBHWD: img[N,Hi,Wi,C], grid[N,Ho,Wo,2] (y,x) in [-1,1], corner aligned,
- * out-of-range taps contribute 0.  backward overwrites gimg and ggrid. */
+ * out-of-range taps contribute 0.  backward overwrites gimg and ggrid.  The backward is deterministic: gimg is GATHERED per
+ * source pixel over the output pixels whose footprint covers it, in a fixed order (the reference keeps this module on the
+ * CPU because stn's GPU scatter was non-reproducible, models.lua:889-899); CG_SAMPLER_ATOMICS=1 selects the atomic scatter
+ * (also used beyond 8192 output pixels per image or 256 channels). */
 int cg_bilinear_sampler_forward(void* stream, const float* img, const float* grid, float* out,
                                 int N, int Hi, int Wi, int C, int Ho, int Wo);
 int cg_bilinear_sampler_backward(void* stream, const float* img, const float* grid, const float* gout,

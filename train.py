@@ -50,12 +50,12 @@ def main():
     print("Number of free parameters in D: %d" % cg.nn_utils.getNumberOfParameters(MODEL_D))
     print("Number of free parameters in G: %d" % cg.nn_utils.getNumberOfParameters(MODEL_G))
     S = cg.adversarial.State(vars(o), MODEL_G, MODEL_D)            # criterion, getParameters, OPTSTATE: :181-207
-    if o.network:
-        print(f"<trainer> reloading previously trained network: {o.network}")
-        cg.checkpoint.load(o.network, S)
     ds = importlib.import_module("cat-generator_amd.dataset")
     ds.colorSpace = o.colorSpace; ds.setFileExtension("jpg"); ds.setHeight(o.scale); ds.setWidth(o.scale)
     ds.setDirs([o.dataDir]); ds.seed(o.seed)
+    if o.network:   # after every generator was seeded: the checkpoint puts each of them back where the run stopped
+        print(f"<trainer> reloading previously trained network: {o.network}")
+        cg.checkpoint.load(o.network, S)
     n_pool = o.N_epoch if o.N_epoch > 0 else 10000
     while True:                                                    # train.lua:223
         print("Loading new training data...")
