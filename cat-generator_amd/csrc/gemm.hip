@@ -81,6 +81,7 @@ struct NNArgs {
     // stats != null: per (phase, row tile, wave row) column sums of y and y^2 -> stats[row][2][Cout] (batch-norm statistics
     // of the layer behind this convolution, models.lua:206-207; single group, unsplit launches only)
     float* stats;
+    int xcd_swizzle;
 };
 
 __device__ __forceinline__ float apply_act(int act, float v, float a) {
@@ -95,6 +96,7 @@ struct TNArgs {
     float* bias_part;   // [S][ngroups*nphase][Cout] column sums of dy (gradBias partials) or null
     Geom g;
     int pchunk;         // pixels per split (multiple of BK)
+    int xcd_swizzle;
 };
 
 template <typename T>
@@ -187,7 +189,11 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
     const int wn0 = (wave % WN) * (BN / WN);
 
     const int ntn = (g.Cout + BN - 1) / BN;
-    const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
+    // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (each XCD has its own L2), so hand every XCD a CONTIGUOUS
+    // range of tiles - neighbours then share their A rows / B columns through one L2 instead of eight
+    int bid = blockIdx.x;
+    if (a.xcd_swizzle && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int tn = bid % ntn, tm = bid / ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
     const int zz = blockIdx.z;
@@ -521,7 +527,9 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
     const int wn0 = (wave % WN) * (BN / WN);
 
     const int ntn = (g.Cout + BN - 1) / BN;
-    const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
+    int bid = blockIdx.x;
+    if (a.xcd_swizzle && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // see igemm_nn_kernel
+    const int tn = bid % ntn, tm = bid / ntn;
     const int m0 = tm * BM, n0 = tn * BN;  // m0: row of dW (tap,ci)
     const int split = blockIdx.y;
     const int zz = blockIdx.z;
@@ -1400,6 +1408,7 @@ static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const
     a.y0 = ys[0]; a.y1 = ys[1]; a.y2 = ys[2]; a.y3 = ys[3];
     a.part = (float*)ws; a.ngroups = ngroups; a.g = g;
     a.kchunk = p.kchunk; a.nsplit = p.splits;
+    a.xcd_swizzle = (int)cg::opt(cg::OPT_XCD_SWIZZLE);
     if (ep && ep->act) {
         CG_REQUIRE(ep->act == 1 || ep->act == 2, "%s: unknown activation %d", who, ep->act);
         CG_REQUIRE(ep->y_act, "%s: fused activation needs y_act", who);
@@ -1587,6 +1596,7 @@ int cg_conv2d_wgrad_grouped(void* stream, int ngroups, const float* const* x, co
     a.x0 = xs[0]; a.x1 = xs[1]; a.x2 = xs[2]; a.x3 = xs[3];
     a.d0 = ds[0]; a.d1 = ds[1]; a.d2 = ds[2]; a.d3 = ds[3];
     a.ngroups = ngroups; a.part = (float*)ws; a.pchunk = p.pchunk;
+    a.xcd_swizzle = (int)cg::opt(cg::OPT_XCD_SWIZZLE);
     const int ZP = ngroups * g.nphase;
     const long wplane = (long)g.Ktot * g.Cout;              // one (group, phase) slab of weight partials
     a.bias_part = any_gb ? (float*)ws + (size_t)p.splits * ZP * wplane : nullptr;

@@ -27,7 +27,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"CG_SPLIT_TARGET", 2}, {"CG_SPLIT_MINK", 8}, {"CG_TN_SMAX", 128}, {"CG_TN_TARGET", 3}, {"CG_SKINNY", 1},
     {"CG_GEMM_SLOW", 0}, {"CG_GEMM_BK32", 1}, {"CG_COLREDUCE_WGS_PER_CU", 1}, {"CG_WINO_WAVES", 8}, {"CG_WINO_BK", 0},
     {"CG_NN_TILE", 0}, {"CG_TN_TILE", 0}, {"CG_NN_SPLITS", 0}, {"CG_TN_SPLITS", 0}, {"CG_EPILOGUE_STATS", 1},
-    {"CG_SAMPLER_ATOMICS", 0},
+    {"CG_SAMPLER_ATOMICS", 0}, {"CG_XCD_SWIZZLE", 0},
 };
 long g_opt_val[OPT_COUNT];
 int g_opt_state[OPT_COUNT];   // 0 = not read yet, 1 = default / environment, 2 = set through the ABI
@@ -751,53 +751,108 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const float* img, const fl
 }
 
 // Deterministic backward (no float atomics): the reference pins this module to the CPU because stn's GPU scatter was
-// "non-reproducible" (models.lua:889-899).  One workgroup = one sample x 64 pixel slots.  It stages the taps of ALL the
-// sample's output pixels in LDS, then
-//   (A) for its 64 OUTPUT pixels: ggrid from the channel dot products (lanes over channels, wave reduction), and
-//   (B) for its 64 SOURCE pixels: gimg[q] = sum over the output pixels whose 2x2 footprint covers q, found by scanning
-//       the staged taps 64 at a time (ballot) and accumulated in ascending output-pixel order - a gather, so every
-//       gimg element is written exactly once (no memset) by one lane in a fixed order.
-template <int CACC>   // channels per lane: C <= 64 * CACC
+// "non-reproducible" (models.lua:889-899).  One workgroup = one sample x S pixel slots.  It stages the taps of ALL the
+// sample's output pixels in LDS and buckets them by their top-left source cell (y0, x0) - counting sort with integer LDS
+// atomics, every bucket then sorted by output-pixel index, so the bucket contents AND their order are reproducible.  Then
+//   (A) for its S OUTPUT pixels: ggrid from the channel dot products (G lanes per pixel, sub-wave reduction), and
+//   (B) for its S SOURCE pixels: gimg[q] = sum over the output pixels in the four buckets (y-1..y, x-1..x) that cover q,
+//       in bucket order - a gather: every gimg element is written exactly once (no memset), in a fixed summation order.
+// G = lanes per pixel (smallest power of two >= min(C, 64)); CACC = channels per lane.
+template <int G, int CACC>
 __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restrict__ img, const float* __restrict__ grid,
                                                           const float* __restrict__ gout, float* __restrict__ gimg,
                                                           float* __restrict__ ggrid, int Hi, int Wi, int C, int Ho, int Wo,
-                                                          int nchunks) {
+                                                          int nchunks, int S) {
     extern __shared__ float bl_sh[];
     const int P = Ho * Wo, Q = Hi * Wi;
+    const int CW = Wi + 1, NC = (Hi + 1) * CW;        // buckets: (y0 + 1, x0 + 1), y0 in [-1, Hi-1], x0 in [-1, Wi-1]
     int* ty0 = reinterpret_cast<int*>(bl_sh);
     int* tx0 = ty0 + P;
     float* twy = bl_sh + 2 * P;
     float* twx = bl_sh + 3 * P;
+    int* list = reinterpret_cast<int*>(bl_sh) + 4 * P;  // [P] output pixels grouped by bucket
+    int* cstart = list + P;                              // [NC + 1]
+    int* ccnt = cstart + NC + 1;                         // [NC]
+    __shared__ int part[256];
     const long n = blockIdx.x / nchunks;
     const int chunk = blockIdx.x % nchunks;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int p = threadIdx.x; p < P; p += 256) {
+    const int tid = threadIdx.x;
+    for (int c = tid; c < NC; c += 256) ccnt[c] = 0;
+    __syncthreads();
+    for (int p = tid; p < P; p += 256) {
         const BilinTaps t = bilin_taps(grid[(n * P + p) * 2], grid[(n * P + p) * 2 + 1], Hi, Wi);
         ty0[p] = t.y0; tx0[p] = t.x0; twy[p] = t.wy0; twx[p] = t.wx0;
+        if (t.y0 >= -1 && t.y0 <= Hi - 1 && t.x0 >= -1 && t.x0 <= Wi - 1) atomicAdd(&ccnt[(t.y0 + 1) * CW + t.x0 + 1], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts: per-thread chunk sums, serial scan of the 256 partials, chunk-local offsets
+    const int per = (NC + 255) / 256;
+    int mine = 0;
+    for (int c = tid * per; c < min(NC, (tid + 1) * per); ++c) mine += ccnt[c];
+    part[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        cstart[NC] = run;
+    }
+    __syncthreads();
+    {
+        int run = part[tid];
+        for (int c = tid * per; c < min(NC, (tid + 1) * per); ++c) { cstart[c] = run; run += ccnt[c]; ccnt[c] = 0; }
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += 256) {
+        const int y0 = ty0[p], x0 = tx0[p];
+        if (y0 >= -1 && y0 <= Hi - 1 && x0 >= -1 && x0 <= Wi - 1) {
+            const int c = (y0 + 1) * CW + x0 + 1;
+            list[cstart[c] + atomicAdd(&ccnt[c], 1)] = p;    // arrival order is arbitrary ...
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < NC; c += 256) {                    // ... so sort every (short) bucket by output-pixel index
+        const int b = cstart[c], e = b + ccnt[c];
+        for (int i = b + 1; i < e; ++i) {
+            const int v = list[i];
+            int j = i - 1;
+            while (j >= b && list[j] > v) { list[j + 1] = list[j]; --j; }
+            list[j + 1] = v;
+        }
     }
     __syncthreads();
     const float* gsample = gout + n * (long)P * C;
     const float* isample = img + n * (long)Q * C;
-    // ---- (A) grid gradient of this workgroup's output pixels
-    for (int j = wave; j < 64; j += 4) {
-        const int p = chunk * 64 + j;
-        if (p >= P) break;
-        const int y0 = ty0[p], x0 = tx0[p];
-        const float wy0 = twy[p], wx0 = twx[p];
-        const bool xin0 = x0 >= 0 && x0 <= Wi - 1, xin1 = x0 + 1 >= 0 && x0 + 1 <= Wi - 1;
-        const bool yin0 = y0 >= 0 && y0 <= Hi - 1, yin1 = y0 + 1 >= 0 && y0 + 1 <= Hi - 1;
-        const long b = ((long)y0 * Wi + x0) * C;
-        const long o01 = C, o10 = (long)Wi * C, o11 = (long)Wi * C + C;
+    const int sub = tid & (G - 1), grp = tid / G, ngrp = 256 / G;
+    // ---- (A) grid gradient of this workgroup's output pixels (every lane of a wave runs the same trip count)
+    for (int j0 = 0; j0 < S; j0 += ngrp) {
+        const int p = chunk * S + j0 + grp;
+        const bool live = j0 + grp < S && p < P;
         float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
-        for (int c = lane; c < C; c += 64) {
-            const float g = gsample[(long)p * C + c];
-            if (yin0 && xin0) d00 += isample[b + c] * g;
-            if (yin0 && xin1) d01 += isample[b + o01 + c] * g;
-            if (yin1 && xin0) d10 += isample[b + o10 + c] * g;
-            if (yin1 && xin1) d11 += isample[b + o11 + c] * g;
+        float wy0 = 0.f, wx0 = 0.f;
+        if (live) {
+            const int y0 = ty0[p], x0 = tx0[p];
+            wy0 = twy[p]; wx0 = twx[p];
+            const bool xin0 = x0 >= 0 && x0 <= Wi - 1, xin1 = x0 + 1 >= 0 && x0 + 1 <= Wi - 1;
+            const bool yin0 = y0 >= 0 && y0 <= Hi - 1, yin1 = y0 + 1 >= 0 && y0 + 1 <= Hi - 1;
+            const long b = ((long)y0 * Wi + x0) * C;
+            const long o01 = C, o10 = (long)Wi * C, o11 = (long)Wi * C + C;
+#pragma unroll
+            for (int k = 0; k < CACC; ++k) {
+                const int c = sub + G * k;
+                if (c < C) {
+                    const float g = gsample[(long)p * C + c];
+                    const float i00 = (yin0 && xin0) ? isample[b + c] : 0.f, i01 = (yin0 && xin1) ? isample[b + o01 + c] : 0.f;
+                    const float i10 = (yin1 && xin0) ? isample[b + o10 + c] : 0.f, i11 = (yin1 && xin1) ? isample[b + o11 + c] : 0.f;
+                    d00 += i00 * g; d01 += i01 * g; d10 += i10 * g; d11 += i11 * g;
+                }
+            }
         }
-        d00 = wave_sum(d00); d01 = wave_sum(d01); d10 = wave_sum(d10); d11 = wave_sum(d11);
-        if (lane == 0) {
+#pragma unroll
+        for (int off = G >> 1; off > 0; off >>= 1) {
+            d00 += __shfl_down(d00, off, G); d01 += __shfl_down(d01, off, G);
+            d10 += __shfl_down(d10, off, G); d11 += __shfl_down(d11, off, G);
+        }
+        if (live && sub == 0) {
             const float gy = -wx0 * d00 + wx0 * d10 - (1.f - wx0) * d01 + (1.f - wx0) * d11;
             const float gx = -wy0 * d00 + wy0 * d01 - (1.f - wy0) * d10 + (1.f - wy0) * d11;
             ggrid[(n * P + p) * 2 + 0] = gy * (float)(Hi - 1) * 0.5f;
@@ -805,39 +860,52 @@ __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restric
         }
     }
     // ---- (B) image gradient of this workgroup's source pixels
-    for (int j = wave; j < 64; j += 4) {
-        const int q = chunk * 64 + j;
-        if (q >= Q) break;
+    for (int j0 = 0; j0 < S; j0 += ngrp) {
+        const int q = chunk * S + j0 + grp;
+        if (!(j0 + grp < S && q < Q)) continue;
         const int y = q / Wi, x = q - y * Wi;
+        // the four buckets whose 2x2 footprint contains (y, x): (y0, x0) = (y-1, x-1), (y-1, x), (y, x-1), (y, x)
+        const int c00 = y * CW + x;                      // bucket index of (y0 = y-1, x0 = x-1)
+        const int s0 = cstart[c00], n0 = ccnt[c00];
+        const int s1 = cstart[c00 + 1], n1 = ccnt[c00 + 1];
+        const int s2 = cstart[c00 + CW], n2 = ccnt[c00 + CW];
+        const int s3 = cstart[c00 + CW + 1], n3 = ccnt[c00 + CW + 1];
+        const int e1 = n0, e2 = n0 + n1, e3 = n0 + n1 + n2, total = e3 + n3;
         float acc[CACC];
 #pragma unroll
         for (int k = 0; k < CACC; ++k) acc[k] = 0.f;
-        for (int p0 = 0; p0 < P; p0 += 64) {
-            const int p = p0 + lane;
-            bool hit = false;
-            if (p < P) {
-                const int dy = y - ty0[p], dx = x - tx0[p];
-                hit = (dy == 0 || dy == 1) && (dx == 0 || dx == 1);
-            }
-            unsigned long long m = __ballot(hit);
-            while (m) {   // wave-uniform: ascending output-pixel order
-                const int bpos = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int ph = p0 + bpos;
-                const float wy = (y == ty0[ph]) ? twy[ph] : 1.f - twy[ph];
-                const float wx = (x == tx0[ph]) ? twx[ph] : 1.f - twx[ph];
-                // same product order as the forward: (x weight) * (y weight)
-                const float w = wx * wy;
+        for (int i0 = 0; i0 < total; i0 += 4) {          // four gradient loads in flight, consumed in bucket order
+            int ph[4];
+            float w[4];
 #pragma unroll
-                for (int k = 0; k < CACC; ++k) {
-                    const int c = lane + 64 * k;
-                    if (c < C) acc[k] += w * gsample[(long)ph * C + c];
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                if (i < total) {
+                    const int e = i < e1 ? s0 + i : (i < e2 ? s1 + i - e1 : (i < e3 ? s2 + i - e2 : s3 + i - e3));
+                    ph[u] = list[e];
+                    const float wy = (y == ty0[ph[u]]) ? twy[ph[u]] : 1.f - twy[ph[u]];
+                    const float wx = (x == tx0[ph[u]]) ? twx[ph[u]] : 1.f - twx[ph[u]];
+                    w[u] = wx * wy;                       // same product order as the forward: (x weight) * (y weight)
+                } else {
+                    ph[u] = ph[0]; w[u] = 0.f;            // padding: adds an exact +0
                 }
             }
+            float g[4][CACC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < CACC; ++k) {
+                    const int c = sub + G * k;
+                    g[u][k] = c < C ? gsample[(long)ph[u] * C + c] : 0.f;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < CACC; ++k) acc[k] += w[u] * g[u][k];
         }
 #pragma unroll
         for (int k = 0; k < CACC; ++k) {
-            const int c = lane + 64 * k;
+            const int c = sub + G * k;
             if (c < C) gimg[(n * Q + q) * C + c] = acc[k];
         }
     }
@@ -1266,12 +1334,22 @@ int cg_bilinear_sampler_backward(void* stream, const float* img, const float* gr
                                  float* ggrid, int N, int Hi, int Wi, int C, int Ho, int Wo) {
     CG_REQUIRE(img && grid && gout && gimg && ggrid, "cg_bilinear_sampler_backward: null pointer");
     const long P = (long)Ho * Wo, Q = (long)Hi * Wi;
-    if (cg::opt(cg::OPT_SAMPLER_ATOMICS) == 0 && P <= 8192 && C <= 256 && N > 0) {   // deterministic gather form
-        const int nchunks = cg::cdiv(std::max(P, Q), 64);
-        const size_t shb = (size_t)P * 16;
+    const size_t shb = ((size_t)5 * P + 2 * ((size_t)(Hi + 1) * (Wi + 1)) + 1) * 4;
+    if (cg::opt(cg::OPT_SAMPLER_ATOMICS) == 0 && shb <= 150 * 1024 && C <= 256 && N > 0) {   // deterministic gather form
+        int G = 4;
+        while (G < 64 && G < C) G <<= 1;
+        // pixel slots per workgroup: at most 16 workgroups per sample (every workgroup stages and buckets all P taps again)
+        const int S = std::max(std::max(32, 256 / G), cg::cdiv(std::max(P, Q), 16));
+        const int nchunks = cg::cdiv(std::max(P, Q), S);
         const dim3 grd((unsigned)((long)N * nchunks)), blk(256);
-#define CG_BILIN_DET(K) hipLaunchKernelGGL(bilinear_bwd_det_k<K>, grd, blk, shb, cg::S(stream), img, grid, gout, gimg, ggrid, Hi, Wi, C, Ho, Wo, nchunks)
-        if (C <= 64) CG_BILIN_DET(1); else if (C <= 128) CG_BILIN_DET(2); else CG_BILIN_DET(4);
+#define CG_BILIN_DET(GG, K) hipLaunchKernelGGL((bilinear_bwd_det_k<GG, K>), grd, blk, shb, cg::S(stream), img, grid, gout, gimg, ggrid, Hi, Wi, C, Ho, Wo, nchunks, S)
+        if (G == 4) CG_BILIN_DET(4, 1);
+        else if (G == 8) CG_BILIN_DET(8, 1);
+        else if (G == 16) CG_BILIN_DET(16, 1);
+        else if (G == 32) CG_BILIN_DET(32, 1);
+        else if (C <= 64) CG_BILIN_DET(64, 1);
+        else if (C <= 128) CG_BILIN_DET(64, 2);
+        else CG_BILIN_DET(64, 4);
 #undef CG_BILIN_DET
         CG_LAUNCH_CHECK();
         return 0;
