@@ -10,7 +10,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "catgan.h")
-LIB_PATH = os.path.join(HERE, "lib", "libcatgan_hip.so")
+LIB_PATH = os.environ.get("CATGAN_LIB") or os.path.join(HERE, "lib", "libcatgan_hip.so")   # CATGAN_LIB: A/B another build
 
 _CTYPES = {
     "void*": C.c_void_p, "const void*": C.c_void_p, "void**": C.POINTER(C.c_void_p),
