@@ -4,7 +4,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-.}"; ROOTD=$PWD
 SRC=${1:-r02}
 for k in conv2 dconv2 conv3; do
-  bash scripts/pmc.sh k_$k python scripts/kbench.py 128 --only $k > gpurun_out/pmc_k_$k.txt 2>&1
+  bash scripts/pmc.sh k_$k python $ROOTD/scripts/kbench.py 128 --only $k > gpurun_out/pmc_k_$k.txt 2>&1
   tail -3 gpurun_out/pmc_k_$k.txt
 done
 python3 - "$ROOTD" "$SRC" <<'PY'
