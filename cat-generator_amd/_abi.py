@@ -58,6 +58,7 @@ class Lib:
                 f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
                 f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
         self._dll = C.CDLL(LIB_PATH)
+        self.trace = None
         self.protos = parse_header()
         for name, (ret, args) in self.protos.items():
             try:
@@ -77,7 +78,11 @@ class Lib:
         last_error = self._dll.cg_last_error
         last_error.restype = C.c_char_p
 
+        lib = self
+
         def call(*a):
+            if lib.trace is not None:      # tools/abi_replay: every state-changing entry point with its arguments
+                lib.trace.append((name, a))
             rc = fn(*a)
             if rc != 0:
                 raise CatganError(f"{name}: {last_error().decode()}")

@@ -68,7 +68,23 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
+    build_tools(hipcc, verbose)
     return LIB_PATH
+
+
+def build_tools(hipcc, verbose=False):
+    """tools/abi_replay: the interpreter-free host that replays a recorded call sequence (tests/test_abi_step.py)."""
+    import importlib.util
+    root = os.path.join(HERE, "..")
+    spec = importlib.util.spec_from_file_location("gen_abi_dispatch", os.path.join(root, "scripts", "gen_abi_dispatch.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gen.main(os.path.join(root, "tools", "abi_dispatch.inc"))
+    cmd = [hipcc, "-O2", "-std=c++17", "-x", "c++", os.path.join(root, "tools", "abi_replay.cpp"), "-o", os.path.join(root, "tools", "abi_replay"),
+           f"-L{LIB_DIR}", "-lcatgan_hip", f"-Wl,-rpath,{LIB_DIR}"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
 
 
 if __name__ == "__main__":

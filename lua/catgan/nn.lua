@@ -87,7 +87,20 @@ end
 function Module:listModules() return { self } end
 function Module:training() for _, m in ipairs(self:listModules()) do m.train = true end; return self end
 function Module:evaluate() for _, m in ipairs(self:listModules()) do m.train = false end; return self end
-function Module:cuda() return self end
+-- :cuda() moves host-side parameter tensors to the device (models.lua:860 REPLACES the classifier's bias by a
+-- torch.Tensor(init_bias), a host FloatTensor, before conv:cuda() at :706); everything else already lives there
+function Module:cuda()
+   for _, m in ipairs(self:listModules()) do
+      for _, ref in ipairs(m:own_parameters()) do
+         local w = m[ref[2]]
+         if w.__typename == 'torch.FloatTensor' then
+            m[ref[2]] = Device.new(w.shape):copy(w)
+            m[ref[3]] = Device.new(w.shape):zero()
+         end
+      end
+   end
+   return self
+end
 function Module:float() return self end
 function Module:type() return self end
 function Module:reset() end
@@ -117,7 +130,8 @@ function Module:getParameters()
       local m, p, g = ref[1], ref[2], ref[3]
       local w = m[p]
       local view = Device.view_of(flat.store, off, w.shape, 'plain', 0)
-      check(C.cg_memcpy_d2d(S(), view.ptr, w.ptr, w.n * 4))
+      if w.__typename == 'torch.FloatTensor' then view:copy(w)   -- a host tensor someone assigned (models.lua:860)
+      else check(C.cg_memcpy_d2d(S(), view.ptr, w.ptr, w.n * 4)) end
       m[p] = view
       m[g] = Device.view_of(gflat.store, off, w.shape, 'plain', 0)
       off = off + w.n
