@@ -18,7 +18,7 @@ _CTYPES = {
     "const float* const*": C.c_void_p, "float* const*": C.c_void_p,
     "double*": C.c_void_p, "const double*": C.c_void_p,
     "int32_t*": C.c_void_p, "const int32_t*": C.c_void_p, "uint64_t*": C.c_void_p, "const uint64_t*": C.c_void_p,
-    "int32_t": C.c_int32, "int*": C.POINTER(C.c_int), "long*": C.POINTER(C.c_long),
+    "int32_t": C.c_int32, "int*": C.POINTER(C.c_int), "long*": C.POINTER(C.c_long), "const int*": C.POINTER(C.c_int),
     "int": C.c_int, "long": C.c_long, "float": C.c_float, "double": C.c_double,
     "size_t": C.c_size_t, "uint64_t": C.c_uint64, "const char*": C.c_char_p, "void": None,
 }

@@ -157,6 +157,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
             torch.cuda.current_stream().wait_event(st.pop("join"))
         if samples is None:
             samples = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
+        nn.repack(S.MODEL_D)   # D's parameters moved in this step's D update
         outputs = S.MODEL_D.forward(samples)
         f = S.CRITERION.forward(outputs, targets)
         df_samples = S.CRITERION.backward(outputs, targets)
@@ -196,6 +197,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
             buf["idx"].copy_(torch.from_numpy(np.asarray(idx, dtype=np.int32)), non_blocking=True)
         lib().gather_rows(stream(), trainData.pool.ptr, buf["idx"].data_ptr(), inputs.ptr, half, rowlen)
         # (1.2) sampled data
+        nn.repack(S.MODEL_G)   # G's parameters moved in the previous step's Adam: one launch re-packs all its plain layers
         noise = nn.to_device(noise_D) if noise_D is not None else nn_utils.createNoiseInputs(S, half)
         samples = nn.as_nhwc(nn_utils.createImagesFromNoise(S, noise, False))
         lib().memcpy_d2d(stream(), inputs.ptr + half * rowlen * 4, samples.ptr, half * rowlen * 4)

@@ -942,6 +942,47 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float*
     }
 }
 
+// The same for up to kPackBatch layers in ONE launch (all of D32_st3's 28 convolution / linear layers re-pack after every
+// Adam step: 28 launches of a few microseconds each otherwise).  A workgroup finds its layer by its block index.
+constexpr int kPackBatch = 48;
+struct PackBatch {
+    const float* w[kPackBatch]; float* wf[kPackBatch]; float* wb[kPackBatch];
+    int Cout[kPackBatch], Cin[kPackBatch], KK[kPackBatch], first[kPackBatch + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(PackBatch b) {
+    __shared__ float sh[32][33];
+    int e = 0;
+    while (e + 1 < b.n && (int)blockIdx.x >= b.first[e + 1]) ++e;
+    const float* w = b.w[e]; float* wf = b.wf[e]; float* wb = b.wb[e];
+    const int Cout = b.Cout[e], Cin = b.Cin[e], KK = b.KK[e];
+    const int nbx = (Cin + 31) / 32, nby = (Cout + 31) / 32;
+    int r = (int)blockIdx.x - b.first[e];
+    const int bx = r % nbx; r /= nbx;
+    const int by = r % nby;
+    const int tap = r / nby;
+    const int lo = threadIdx.x & 31, hi = threadIdx.x >> 5;
+    const int ci0 = bx * 32, co0 = by * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + lo, co_l = hi + 8 * j, co = co0 + co_l;
+        float v = 0.f;
+        if (ci < Cin && co < Cout) {
+            v = w[((long)co * Cin + ci) * KK + tap];
+            if (wb) wb[((long)(KK - 1 - tap) * Cout + co) * Cin + ci] = v;
+        }
+        sh[lo][co_l] = v;
+    }
+    if (wf) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = co0 + lo, ci_l = hi + 8 * j, ci = ci0 + ci_l;
+            if (ci < Cin && co < Cout) wf[((long)tap * Cin + ci) * Cout + co] = sh[ci_l][lo];
+        }
+    }
+}
+
 // phase-summed weights, k in {3, 5} (the generator's layers): same 32x32 blocking as pack_weight_kernel, the tap
 // sums fully unrolled so every accumulator index is a compile-time constant.
 template <int K>
@@ -1676,6 +1717,30 @@ int cg_pack_conv_weight(void* stream, const float* w, float* wf, float* wb, int 
     hipLaunchKernelGGL(pack_weight_kernel, dim3(cg::cdiv(Cin, 32), cg::cdiv(Cout, 32), KK), dim3(256), 0, cg::S(stream), w,
                        wf, wb, Cout, Cin, KK);
     CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cg_pack_conv_weight_batch(void* stream, int n, const float* const* w_canonical, float* const* wf, float* const* wb,
+                              const int* Cout, const int* Cin, const int* kH, const int* kW) {
+    CG_REQUIRE(n >= 0 && w_canonical && wf && wb && Cout && Cin && kH && kW, "cg_pack_conv_weight_batch: null pointer");
+    for (int i0 = 0; i0 < n; i0 += kPackBatch) {
+        PackBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = std::min(kPackBatch, n - i0);
+        int blocks = 0;
+        for (int e = 0; e < b.n; ++e) {
+            const int i = i0 + e;
+            CG_REQUIRE(w_canonical[i] && (wf[i] || wb[i]) && Cout[i] > 0 && Cin[i] > 0 && kH[i] > 0 && kW[i] > 0,
+                       "cg_pack_conv_weight_batch: bad layer %d", i);
+            b.w[e] = w_canonical[i]; b.wf[e] = wf[i]; b.wb[e] = wb[i];
+            b.Cout[e] = Cout[i]; b.Cin[e] = Cin[i]; b.KK[e] = kH[i] * kW[i];
+            b.first[e] = blocks;
+            blocks += cg::cdiv(Cin[i], 32) * cg::cdiv(Cout[i], 32) * b.KK[e];
+        }
+        b.first[b.n] = blocks;
+        hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(blocks), dim3(256), 0, cg::S(stream), b);
+        CG_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -1441,6 +1441,40 @@ class _Pool2(_Stackable, Module):
         dW, dH = dW or kW, dH or kH
         assert (kW, kH, dW, dH) == (2, 2, 2, 2), "the path only pools 2x2 stride 2"
 
+    # Sibling instances fed the SAME tensor (the localisation nets of D32_st3's three transformer branches all start by
+    # pooling the trunk's output, models.lua:843) compute the same thing: run one launch and share the result.
+    @staticmethod
+    def _group_forward(mods, inputs, ctx):
+        m0 = mods[0]
+        if (fusion and len(mods) > 1 and isinstance(inputs[0], Tensor) and all(x is inputs[0] for x in inputs[1:])
+                and os.environ.get("CG_SHARE_POOL", "1") != "0"):
+            y = m0.updateOutput(inputs[0])
+            for m in mods:
+                m._x, m.output = m0._x, y
+            m0._stk, m0._shared_in = None, True
+            return [y] * len(mods)
+        m0._shared_in = False
+        return _Stackable._group_forward(mods, inputs, ctx)
+
+    @staticmethod
+    def _group_backward(mods, inputs, gouts, scale, acc, ctx):
+        m0 = mods[0]
+        if getattr(m0, "_shared_in", False) and isinstance(m0, SpatialAveragePooling):
+            gs = [as_nhwc(g) for g in gouts]
+            Gd = _stacked(gs)
+            if Gd is not None:   # the average pool's backward does not look at its input: one launch over the stacked gradients
+                G = len(mods)
+                N, C, H, W = m0._x.shape
+                gi = m0._get(("gin", "shared"), (G * N, C, H, W), "nhwc")
+                lib().avgpool2_backward(stream(), Gd.ptr, gi.ptr, G * N, H, W, C)
+                outs = _split(gi, G)
+                for m, o in zip(mods, outs):
+                    m.gradInput = o
+                return outs
+        if getattr(m0, "_shared_in", False):
+            return Module._group_backward(mods, inputs, gouts, scale, acc, ctx)
+        return _Stackable._group_backward(mods, inputs, gouts, scale, acc, ctx)
+
     def updateOutput(self, input):
         x = as_nhwc(to_device(input))
         N, C, H, W = x.shape
@@ -1682,6 +1716,31 @@ class BilinearSamplerBHWD(Module):
         if _Stackable.stacking:
             _seed_slices(mods, "ggrid", inputs[0][1].shape, "plain")
         return Module._group_backward(mods, inputs, gouts, scale, acc, ctx)
+
+
+def repack(net):
+    """Re-pack the kernel-side weight copies of every convolution / linear layer of `net` whose parameters changed, in ONE
+    launch (cg_pack_conv_weight_batch) instead of one launch per layer at its next use.  Layers that run behind a folded
+    upsampling keep their own (phase-summed / Winograd) packing.  Called by adversarial.iteration() after each net's
+    optimiser step; calling it at any other time is harmless."""
+    if not fusion or os.environ.get("CG_BATCH_PACK", "1") == "0":
+        return
+    todo = []
+    for m in net.listModules():
+        if isinstance(m, _GemmLayer) and getattr(m, "_wf", None) is not None:
+            if getattr(m, "_packed_epoch", None) != m.weight.epoch.v or getattr(m, "_packed_ptr", None) != m.weight.ptr:
+                todo.append(m)
+    if not todo:
+        return
+    import ctypes
+    n = len(todo)
+    dims = [m._wdims() for m in todo]
+    ints = lambda k: (ctypes.c_int * n)(*[d[k] for d in dims])
+    lib().pack_conv_weight_batch(stream(), n, _ptr_array([m.weight.ptr for m in todo]), _ptr_array([m._wf.data_ptr() for m in todo]),
+                                 _ptr_array([m._wb.data_ptr() if m._wb is not None else None for m in todo]),
+                                 ints(0), ints(1), ints(2), ints(3))
+    for m in todo:
+        m._packed_epoch, m._packed_ptr = m.weight.epoch.v, m.weight.ptr
 
 
 # ------------------------------------------------------------------- fused segments of nn.Sequential

@@ -145,6 +145,10 @@ int cg_bias_grad(void* stream, const float* dy, float* gb, long M, int C, float 
  * Either output may be NULL. */
 int cg_pack_conv_weight(void* stream, const float* w_canonical, float* wf, float* wb,
                         int Cout, int Cin, int kH, int kW);
+/* The same for n layers in one launch (host arrays of n entries; wb[i] may be NULL for 1x1 / linear layers): every
+ * parameter of a net changes in the same cg_adam_step, so all its layers re-pack together. */
+int cg_pack_conv_weight_batch(void* stream, int n, const float* const* w_canonical, float* const* wf, float* const* wb,
+                              const int* Cout, const int* Cin, const int* kH, const int* kW);
 /* phase-summed weights for upsample2 -> conv k x k (pad (k-1)/2), k' = (k+1)/2 rounded up (2 for 3, 3 for 5):
  * wf_ph[p][(t'*Cin+ci)][Cout], wb_ph[((p*k'*k' + t')*Cout+co)][Cin]; each holds
  * cg_pack_conv_weight_ups2_floats() floats.  Either output may be NULL. */
