@@ -915,7 +915,11 @@ __global__ __launch_bounds__(256) void bias_part_reduce_kernel(const float* bp, 
 // (the parameters change every step, so this runs every step).  One workgroup owns a 32 ci x 32 co block: thread
 // (ci_l, co_l + 8j) reads its canonical tap run, writes wb directly (ci-fastest, coalesced) and transposes the
 // 32x32 plane of each tap through LDS for wf (co-fastest).
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float* wf, float* wb, int Cout, int Cin, int KK) {
+// wb_map != 0: wb receives the row-permuted canonical matrix wbT[co][tap*Cin + ci] instead of the flipped-tap data-gradient
+// operand - the backward operand of a LINEAR layer that consumes an NHWC map directly (its canonical [out][C*H*W] weight is
+// the canonical weight of a k = H x W convolution on that map; see cg_pack_conv_weight_map).
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float* wf, float* wb, int Cout, int Cin, int KK,
+                                                          int wb_map) {
     __shared__ float sh[32][33];
     const int lo = threadIdx.x & 31, hi = threadIdx.x >> 5;
     const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
@@ -927,7 +931,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, float*
             float v = 0.f;
             if (ci < Cin && co < Cout) {
                 v = w[((long)co * Cin + ci) * KK + tap];
-                if (wb) wb[((long)(KK - 1 - tap) * Cout + co) * Cin + ci] = v;
+                if (wb) wb[wb_map ? ((long)co * KK + tap) * Cin + ci : ((long)(KK - 1 - tap) * Cout + co) * Cin + ci] = v;
             }
             sh[lo][co_l] = v;
         }
@@ -948,6 +952,7 @@ constexpr int kPackBatch = 48;
 struct PackBatch {
     const float* w[kPackBatch]; float* wf[kPackBatch]; float* wb[kPackBatch];
     int Cout[kPackBatch], Cin[kPackBatch], KK[kPackBatch], first[kPackBatch + 1];
+    unsigned long long map_mask;   // bit e: layer e wants the wbT layout (see pack_weight_kernel)
     int n;
 };
 __global__ __launch_bounds__(256) void pack_weight_batch_kernel(PackBatch b) {
@@ -956,6 +961,7 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(PackBatch b) {
     while (e + 1 < b.n && (int)blockIdx.x >= b.first[e + 1]) ++e;
     const float* w = b.w[e]; float* wf = b.wf[e]; float* wb = b.wb[e];
     const int Cout = b.Cout[e], Cin = b.Cin[e], KK = b.KK[e];
+    const bool wb_map = (b.map_mask >> e) & 1ull;
     const int nbx = (Cin + 31) / 32, nby = (Cout + 31) / 32;
     int r = (int)blockIdx.x - b.first[e];
     const int bx = r % nbx; r /= nbx;
@@ -969,7 +975,7 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(PackBatch b) {
         float v = 0.f;
         if (ci < Cin && co < Cout) {
             v = w[((long)co * Cin + ci) * KK + tap];
-            if (wb) wb[((long)(KK - 1 - tap) * Cout + co) * Cin + ci] = v;
+            if (wb) wb[wb_map ? ((long)co * KK + tap) * Cin + ci : ((long)(KK - 1 - tap) * Cout + co) * Cin + ci] = v;
         }
         sh[lo][co_l] = v;
     }
@@ -1715,13 +1721,28 @@ int cg_pack_conv_weight(void* stream, const float* w, float* wf, float* wb, int 
     CG_REQUIRE(Cout > 0 && Cin > 0 && kH > 0 && kW > 0, "cg_pack_conv_weight: bad dims");
     const int KK = kH * kW;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(cg::cdiv(Cin, 32), cg::cdiv(Cout, 32), KK), dim3(256), 0, cg::S(stream), w,
-                       wf, wb, Cout, Cin, KK);
+                       wf, wb, Cout, Cin, KK, 0);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// nn.View(C*H*W) -> nn.Linear(C*H*W -> Cout) on an NHWC map (models.lua:696-697, 849-850) without materialising the NCHW
+// view: the canonical [Cout][C*H*W] weight IS the canonical weight of a convolution C -> Cout with an H x W kernel, no
+// padding, on the H x W map (output 1 x 1).  wf (forward / weight-gradient view) is cg_pack_conv_weight's;
+// wbT[co][(h*W+w)*C + c] = w[co][c][h][w] is the [K = Cout][N = H*W*C] operand of the data gradient, run as a linear layer:
+//   cg_conv2d_forward(dy [N][Cout], wbT, NULL, dx [N][H*W*C] = NHWC, N, 1, 1, Cout, H*W*C, 1, 1, 0, 0, 0)
+int cg_pack_conv_weight_map(void* stream, const float* w, float* wf, float* wbT, int Cout, int Cin, int kH, int kW) {
+    CG_REQUIRE(w && (wf || wbT), "cg_pack_conv_weight_map: null pointer");
+    CG_REQUIRE(Cout > 0 && Cin > 0 && kH > 0 && kW > 0, "cg_pack_conv_weight_map: bad dims");
+    const int KK = kH * kW;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(cg::cdiv(Cin, 32), cg::cdiv(Cout, 32), KK), dim3(256), 0, cg::S(stream), w,
+                       wf, wbT, Cout, Cin, KK, 1);
     CG_LAUNCH_CHECK();
     return 0;
 }
 
 int cg_pack_conv_weight_batch(void* stream, int n, const float* const* w_canonical, float* const* wf, float* const* wb,
-                              const int* Cout, const int* Cin, const int* kH, const int* kW) {
+                              const int* Cout, const int* Cin, const int* kH, const int* kW, const int* wb_map) {
     CG_REQUIRE(n >= 0 && w_canonical && wf && wb && Cout && Cin && kH && kW, "cg_pack_conv_weight_batch: null pointer");
     for (int i0 = 0; i0 < n; i0 += kPackBatch) {
         PackBatch b;
@@ -1734,6 +1755,7 @@ int cg_pack_conv_weight_batch(void* stream, int n, const float* const* w_canonic
                        "cg_pack_conv_weight_batch: bad layer %d", i);
             b.w[e] = w_canonical[i]; b.wf[e] = wf[i]; b.wb[e] = wb[i];
             b.Cout[e] = Cout[i]; b.Cin[e] = Cin[i]; b.KK[e] = kH[i] * kW[i];
+            if (wb_map && wb_map[i]) b.map_mask |= 1ull << e;
             b.first[e] = blocks;
             blocks += cg::cdiv(Cin[i], 32) * cg::cdiv(Cout[i], 32) * b.KK[e];
         }

@@ -344,6 +344,8 @@ fusion = os.environ.get("CG_FUSION", "1") != "0"
 #   [PReLU|LeakyReLU, Pool 2x2, (SpatialDropout)]       -> one pass; the two intermediate tensors are never materialised
 #   [conv, SpatialBatchNormalization, PReLU] (training) -> batch statistics from the GEMM epilogue, normalise + PReLU in one
 #                                                          pass, backward in two passes over (conv output, gradOutput)
+#   [View(C*H*W), Linear, (activation)]                 -> the linear layer reads the NHWC map directly (its canonical weight is
+#                                                          that of an H x W convolution); no NCHW view is materialised
 # Per-element arithmetic is that of the separate modules.  A fused-away intermediate module has .output = None
 # (set nn.fusion = False to inspect every module's output).
 
@@ -403,6 +405,9 @@ class Sequential(Module):
                     kind, j = "gemm_bn_act", i + 3
                 elif _is_gemm(m) and _is_act(nx) and not isinstance(nx2, _Pool2):
                     kind, j = "gemm_act", i + 2
+                elif isinstance(m, View) and len(m.sizes) == 1 and type(nx) is Linear and os.environ.get("CG_VIEW_FUSE", "1") != "0":
+                    kind, j = ("view_gemm_act", i + 3) if (_is_act(nx2) and not isinstance(mods[i + 3] if i + 3 < n else None, _Pool2)) \
+                        else ("view_gemm", i + 2)
                 elif _is_act(m) and isinstance(nx, _Pool2):
                     drop = isinstance(nx2, SpatialDropout) and nx2.train and nx2.fixed_noise is None
                     kind, j = "act_pool", i + (3 if drop else 2)
@@ -422,6 +427,8 @@ class Sequential(Module):
                 cur = _fwd_gemm_act([mods[i]], [mods[i + 1]], [cur], None)[0]
             elif kind == "act_pool":
                 cur = _fwd_act_pool([mods[i]], [mods[i + 1]], [mods[i + 2]] if j - i == 3 else None, [cur], None)[0]
+            elif kind in ("view_gemm", "view_gemm_act"):
+                cur = _fwd_view_gemm([mods[i]], [mods[i + 1]], [mods[i + 2]] if kind == "view_gemm_act" else None, [cur], None)[0]
             else:
                 cur = _fwd_gemm_bn_act(mods[i], mods[i + 1], mods[i + 2], cur)
         self.output = cur
@@ -479,6 +486,8 @@ class Sequential(Module):
                 cur = _fwd_gemm_act(col(i), col(i + 1), cur, ctx)
             elif kind == "act_pool":
                 cur = _fwd_act_pool(col(i), col(i + 1), col(i + 2) if j - i == 3 else None, cur, ctx)
+            elif kind in ("view_gemm", "view_gemm_act"):
+                cur = _fwd_view_gemm(col(i), col(i + 1), col(i + 2) if kind == "view_gemm_act" else None, cur, ctx)
             else:   # not a lockstep case on the path: branch after branch, each at its own stream position
                 outs, r = [], rng()
                 for b, m in enumerate(mods):
@@ -799,18 +808,22 @@ class _GemmLayer(Module):
     """Shared by nn.Linear and nn.SpatialConvolution: canonical parameters + packed copies for the kernels."""
     _param_names = ("weight", "bias")
 
+    _map_in = None   # nn.Linear only: (C, H, W) when it consumes an NHWC map directly (a fused nn.View in front of it)
+
     def _ensure_packed(self):
         ep = self.weight.epoch.v
-        if getattr(self, "_packed_epoch", None) == ep and getattr(self, "_packed_ptr", None) == self.weight.ptr:
+        mp = self._map_in
+        if (getattr(self, "_packed_epoch", None) == ep and getattr(self, "_packed_ptr", None) == self.weight.ptr
+                and getattr(self, "_packed_map", None) == mp):
             return
         Cout, Cin, kH, kW = self._wdims()
         n = Cout * Cin * kH * kW
-        if getattr(self, "_wf", None) is None or self._wf.numel() != n:
+        if getattr(self, "_wf", None) is None or self._wf.numel() != n or (self._wb is None) != (kH * kW == 1):
             self._wf = torch.empty(n, dtype=torch.float32, device=self.weight.t.device)
             self._wb = torch.empty(n, dtype=torch.float32, device=self.weight.t.device) if kH * kW > 1 else None
-        lib().pack_conv_weight(stream(), self.weight.ptr, self._wf.data_ptr(),
-                               self._wb.data_ptr() if self._wb is not None else None, Cout, Cin, kH, kW)
-        self._packed_epoch, self._packed_ptr = ep, self.weight.ptr
+        pack = lib().pack_conv_weight_map if mp else lib().pack_conv_weight
+        pack(stream(), self.weight.ptr, self._wf.data_ptr(), self._wb.data_ptr() if self._wb is not None else None, Cout, Cin, kH, kW)
+        self._packed_epoch, self._packed_ptr, self._packed_map = ep, self.weight.ptr, mp
 
     def _ensure_packed_ups(self):
         ep = self.weight.epoch.v
@@ -931,15 +944,26 @@ class Linear(_GemmLayer):
 
     def _wdims(self):
         o, i = self.weight.shape
+        if self._map_in:   # the canonical [out][C*H*W] matrix is the canonical weight of a C -> out convolution with an H x W kernel
+            C, H, W = self._map_in
+            return o, C, H, W
         return o, i, 1, 1
 
     def _fan_in(self):
         return self.weight.shape[1]
 
     def _prep_fwd(self, input):
-        x = as_plain(to_device(input))
-        N, i = x.shape
+        x = to_device(input)
         o = self.weight.shape[0]
+        if self._map_in and not (x.dim() == 4 and x.fmt == "nhwc" and not x.ups and tuple(x.shape[1:]) == tuple(self._map_in)):
+            self._map_in = None   # used on its own again: the plain [N, in] form
+        if self._map_in:
+            C, H, W = self._map_in
+            N = x.shape[0]
+            self._ensure_packed()
+            return x, self._wf.data_ptr(), self._get("out", (N, o)), (N, H, W, C, o, H, W, 0, 0, 0)
+        x = as_plain(x)
+        N, i = x.shape
         self._ensure_packed()
         return x, self._wf.data_ptr(), self._get("out", (N, o)), (N, 1, 1, i, o, 1, 1, 0, 0, 0)
 
@@ -947,10 +971,16 @@ class Linear(_GemmLayer):
         dy = as_plain(gradOutput)
         N, o = dy.shape
         i = self.weight.shape[1]
+        if self._map_in:   # dx comes out NHWC-flattened: wbT[co][(h*W+w)*C + c] (cg_pack_conv_weight_map)
+            C, H, W = self._map_in
+            return dy, self._wb.data_ptr(), self._get("gin", (N, C, H, W), "nhwc"), (N, 1, 1, o, i, 1, 1, 0, 0, 0)
         return dy, self.weight.ptr, self._get("gin", (N, i)), (N, 1, 1, o, i, 1, 1, 0, 0, 0)
 
     def _prep_acc(self, gradOutput):
         x, dy = self._x, as_plain(gradOutput)
+        if self._map_in:
+            C, H, W = self._map_in
+            return x, dy, (x.shape[0], H, W, C, self.weight.shape[0], H, W, 0, 0, 0)
         N, i = x.shape
         return x, dy, (N, 1, 1, i, self.weight.shape[0], 1, 1, 0, 0, 0)
 
@@ -1332,6 +1362,7 @@ class View(_Stackable, Module):
         self.sizes = tuple(int(s) for s in sizes)
 
     def updateOutput(self, input):
+        self._skip = False
         x = as_plain(to_device(input))
         N = x.shape[0]
         self._in_shape = x.shape
@@ -1345,6 +1376,9 @@ class View(_Stackable, Module):
         return out
 
     def updateGradInput(self, input, gradOutput):
+        if getattr(self, "_skip", False):   # fused into the nn.Linear behind it, whose gradInput already is the NHWC map
+            self.gradInput = gradOutput
+            return gradOutput
         self.gradInput = as_plain(gradOutput).view(*self._in_shape)
         return self.gradInput
 
@@ -1736,11 +1770,12 @@ def repack(net):
     n = len(todo)
     dims = [m._wdims() for m in todo]
     ints = lambda k: (ctypes.c_int * n)(*[d[k] for d in dims])
+    maps = (ctypes.c_int * n)(*[1 if m._map_in else 0 for m in todo])
     lib().pack_conv_weight_batch(stream(), n, _ptr_array([m.weight.ptr for m in todo]), _ptr_array([m._wf.data_ptr() for m in todo]),
                                  _ptr_array([m._wb.data_ptr() if m._wb is not None else None for m in todo]),
-                                 ints(0), ints(1), ints(2), ints(3))
+                                 ints(0), ints(1), ints(2), ints(3), maps)
     for m in todo:
-        m._packed_epoch, m._packed_ptr = m.weight.epoch.v, m.weight.ptr
+        m._packed_epoch, m._packed_ptr, m._packed_map = m.weight.epoch.v, m.weight.ptr, m._map_in
 
 
 # ------------------------------------------------------------------- fused segments of nn.Sequential
@@ -1779,6 +1814,28 @@ def _fwd_gemm_act(convs, acts, xs, ctx):
         else:
             acts[0]._stk = None
     return ys
+
+
+def _fwd_view_gemm(views, lins, acts, xs, ctx):
+    """[View(C*H*W), Linear, (activation)] x G branches (models.lua:696-698, 849-851): the linear layer consumes the NHWC map
+    (cg_pack_conv_weight_map); the NCHW flattening the reference materialises never happens, forward or backward."""
+    G = len(views)
+    x0 = xs[0]
+    ok = isinstance(x0, Tensor) and x0.dim() == 4 and x0.fmt == "nhwc" and not x0.ups
+    if ok:
+        N, C, H, W = x0.shape
+        ok = (H * W <= 64 and C % 16 == 0 and views[0].sizes == (C * H * W,) and lins[0].weight.shape[1] == C * H * W
+              and all(isinstance(x, Tensor) and x.shape == x0.shape and x.fmt == "nhwc" and not x.ups for x in xs))
+    for v, l in zip(views, lins):
+        v._skip, l._map_in = ok, ((C, H, W) if ok else None)
+    if ok:
+        for v, x in zip(views, xs):
+            v.output, v._in_shape = None, x.shape
+    else:
+        xs = [views[0].updateOutput(xs[0])] if G == 1 else group_forward(views, xs, ctx)
+    if acts is not None:
+        return _fwd_gemm_act(lins, acts, xs, ctx)
+    return [lins[0].updateOutput(xs[0])] if G == 1 else group_forward(lins, xs, ctx)
 
 
 def _fwd_act_pool(acts, pools, drops, xs, ctx):

@@ -148,7 +148,14 @@ int cg_pack_conv_weight(void* stream, const float* w_canonical, float* wf, float
 /* The same for n layers in one launch (host arrays of n entries; wb[i] may be NULL for 1x1 / linear layers): every
  * parameter of a net changes in the same cg_adam_step, so all its layers re-pack together. */
 int cg_pack_conv_weight_batch(void* stream, int n, const float* const* w_canonical, float* const* wf, float* const* wb,
-                              const int* Cout, const int* Cin, const int* kH, const int* kW);
+                              const int* Cout, const int* Cin, const int* kH, const int* kW, const int* wb_map);
+/* nn.View(C*H*W) -> nn.Linear(C*H*W -> Cout) consuming the NHWC map directly (models.lua:696-697, 849-850): the canonical
+ * [Cout][C*H*W] weight is the canonical weight of a convolution C -> Cout with an H x W kernel and no padding on the H x W map.
+ * wf as cg_pack_conv_weight (forward: cg_conv2d_forward(x_nhwc, wf, ..., N, H, W, C, Cout, H, W, 0, 0, 0); weight gradient:
+ * cg_conv2d_wgrad with the same geometry, canonical gw); wbT[co][(h*W+w)*C + c] is the data-gradient operand of the linear
+ * form: cg_conv2d_forward(dy, wbT, NULL, dx_nhwc, N, 1, 1, Cout, H*W*C, 1, 1, 0, 0, 0).  wb_map[i] != 0 in the batch form
+ * selects this layout for layer i (wb_map may be NULL). */
+int cg_pack_conv_weight_map(void* stream, const float* w_canonical, float* wf, float* wbT, int Cout, int Cin, int kH, int kW);
 /* phase-summed weights for upsample2 -> conv k x k (pad (k-1)/2), k' = (k+1)/2 rounded up (2 for 3, 3 for 5):
  * wf_ph[p][(t'*Cin+ci)][Cout], wb_ph[((p*k'*k' + t')*Cout+co)][Cin]; each holds
  * cg_pack_conv_weight_ups2_floats() floats.  Either output may be NULL. */
