@@ -136,6 +136,36 @@ __global__ __launch_bounds__(256) void act_pool2_bwd_k(const float* __restrict__
     if (threadIdx.x == 0) gpart[(long)grp * gridDim.x + blockIdx.x] = t;
 }
 
+// nn.Concat(2) over <= 4 branches in one launch (models.lua:688-692): dst[m][off_b + c] = src_b[m][c]; SPLIT: the reverse
+// (the gradient slices handed to the branches); channel counts in float4 units.
+struct Cat4 { float* p0; float* p1; float* p2; float* p3; int c0, c1, c2, c3; };
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void concat4_v4k(Cat4 b, float* __restrict__ whole, long total4, int Ct4) {
+    V4_LOOP(i, total4) {
+        const int c = (int)(i % Ct4);
+        const long m = i / Ct4;
+        float* p; int cl, cw;
+        if (c < b.c0) { p = b.p0; cl = c; cw = b.c0; }
+        else if (c < b.c0 + b.c1) { p = b.p1; cl = c - b.c0; cw = b.c1; }
+        else if (c < b.c0 + b.c1 + b.c2) { p = b.p2; cl = c - b.c0 - b.c1; cw = b.c2; }
+        else { p = b.p3; cl = c - b.c0 - b.c1 - b.c2; cw = b.c3; }
+        if (SPLIT) stv(p, m * cw + cl, ldv(whole, i));
+        else stv(whole, i, ldv(p, m * cw + cl));
+    }
+}
+// out = ((a + b) + c) + d: the accumulation order of nn.Concat's gradInput (copy, then one add per further branch)
+__global__ __launch_bounds__(256) void sum4_v4k(const float* a, const float* b, const float* c, const float* d, float* out, int n,
+                                               long n4) {
+    V4_LOOP(i, n4) {
+        float4 s = ldv(a, i);
+        const float4 u = ldv(b, i);
+        s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+        if (n > 2) { const float4 v = ldv(c, i); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        if (n > 3) { const float4 v = ldv(d, i); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        stv(out, i, s);
+    }
+}
+
 struct GalphaTab { float* g0; float* g1; float* g2; float* g3; };
 // galpha[group] += scale * sum_b gpart[group][b]: one workgroup per group, fixed summation order
 __global__ __launch_bounds__(256) void galpha_groups_reduce_k(const double* gpart, int nparts, GalphaTab gt, float scale) {
@@ -495,6 +525,39 @@ int cg_prelu_backward_grouped(void* stream, const float* x, const float* dy, con
         hipLaunchKernelGGL(galpha_groups_reduce_k, dim3(ngroups), dim3(256), 0, cg::S(stream), (const double*)gpart, nblk, gt, scale);
         CG_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+static int cat4_launch(void* stream, int n, float* const* parts, const int* C, float* whole, long M, bool split, const char* who) {
+    CG_REQUIRE(n >= 1 && n <= 4 && parts && C && whole && M > 0, "%s: 1..4 parts", who);
+    float* p[4] = {nullptr, nullptr, nullptr, nullptr};
+    int c4[4] = {0, 0, 0, 0};
+    long Ct = 0;
+    for (int i = 0; i < n; ++i) {
+        CG_REQUIRE(parts[i] && C[i] > 0 && C[i] % 4 == 0 && al16(parts[i]), "%s: part %d needs C %% 4 == 0 and 16-byte alignment", who, i);
+        p[i] = parts[i]; c4[i] = C[i] / 4; Ct += C[i];
+    }
+    CG_REQUIRE(al16(whole), "%s: unaligned tensor", who);
+    Cat4 b{p[0], p[1], p[2], p[3], c4[0], c4[1], c4[2], c4[3]};
+    const long total4 = M * (Ct / 4);
+    if (split) hipLaunchKernelGGL(concat4_v4k<true>, dim3(cg::ew_grid(total4)), dim3(256), 0, cg::S(stream), b, whole, total4, (int)(Ct / 4));
+    else hipLaunchKernelGGL(concat4_v4k<false>, dim3(cg::ew_grid(total4)), dim3(256), 0, cg::S(stream), b, whole, total4, (int)(Ct / 4));
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cg_concat_channels(void* stream, int n, const float* const* src, const int* C, float* dst, long M) {
+    return cat4_launch(stream, n, (float* const*)src, C, dst, M, false, "cg_concat_channels");
+}
+int cg_split_channels(void* stream, int n, const float* src, float* const* dst, const int* C, long M) {
+    return cat4_launch(stream, n, dst, C, (float*)src, M, true, "cg_split_channels");
+}
+int cg_sum_n(void* stream, int n, const float* const* src, float* out, long count) {
+    CG_REQUIRE(n >= 2 && n <= 4 && src && out && count > 0 && count % 4 == 0 && al16(out), "cg_sum_n: 2..4 aligned tensors of a multiple of 4 elements");
+    for (int i = 0; i < n; ++i) CG_REQUIRE(src[i] && al16(src[i]), "cg_sum_n: tensor %d", i);
+    hipLaunchKernelGGL(sum4_v4k, dim3(cg::ew_grid(count / 4)), dim3(256), 0, cg::S(stream), src[0], src[1], n > 2 ? src[2] : nullptr,
+                       n > 3 ? src[3] : nullptr, out, n, count / 4);
+    CG_LAUNCH_CHECK();
     return 0;
 }
 

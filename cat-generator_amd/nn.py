@@ -581,6 +581,9 @@ class ConcatTable(Sequential):
         return [m._sum([per_child[j][b] for j in range(len(per_child))]) for b, m in enumerate(mods)]
 
 
+_CAT_FUSE = os.environ.get("CG_CAT_FUSE", "1") != "0"   # single-launch concat / split / gradient sum
+
+
 class Concat(Sequential):
     """nn.Concat(2) (models.lua:688-692): branch outputs joined on channels."""
 
@@ -712,10 +715,15 @@ class Concat(Sequential):
         self._sizes = [o.shape[1] for o in outs]
         Ct = sum(self._sizes)
         out = self._get("out", (N, Ct, H, W), "nhwc")
-        off = 0
-        for o, c in zip(outs, self._sizes):
-            lib().copy_channels(stream(), o.ptr, out.ptr, N * H * W, c, 0, Ct, off, c)
-            off += c
+        if fusion and _CAT_FUSE and len(outs) <= 4 and all(c % 4 == 0 for c in self._sizes):   # one launch for all branches
+            import ctypes
+            lib().concat_channels(stream(), len(outs), _ptr_array([o.ptr for o in outs]), (ctypes.c_int * len(outs))(*self._sizes),
+                                  out.ptr, N * H * W)
+        else:
+            off = 0
+            for o, c in zip(outs, self._sizes):
+                lib().copy_channels(stream(), o.ptr, out.ptr, N * H * W, c, 0, Ct, off, c)
+                off += c
         self.output = out
         return out
 
@@ -731,14 +739,26 @@ class Concat(Sequential):
                     block = self._get(("gslice_block", idxs[0]), (len(idxs) * N, self._sizes[idxs[0]], H, W), "nhwc")
                     for i, sl in zip(idxs, _split(block, len(idxs))):
                         bufs[i] = sl
-        off = 0
-        for i, c in enumerate(self._sizes):
-            s = bufs[i] if bufs[i] is not None else self._get(("gslice", i), (N, c, H, W), "nhwc")
-            lib().copy_channels(stream(), g.ptr, s.ptr, N * H * W, Ct, off, c, 0, c)
-            off += c
-            yield self.modules[i], s
+        dst = [bufs[i] if bufs[i] is not None else self._get(("gslice", i), (N, c, H, W), "nhwc") for i, c in enumerate(self._sizes)]
+        if fusion and _CAT_FUSE and len(dst) <= 4 and all(c % 4 == 0 for c in self._sizes):
+            import ctypes
+            lib().split_channels(stream(), len(dst), g.ptr, _ptr_array([d.ptr for d in dst]), (ctypes.c_int * len(dst))(*self._sizes),
+                                 N * H * W)
+        else:
+            off = 0
+            for d, c in zip(dst, self._sizes):
+                lib().copy_channels(stream(), g.ptr, d.ptr, N * H * W, Ct, off, c, 0, c)
+                off += c
+        for i, d in enumerate(dst):
+            yield self.modules[i], d
 
     def _accumulate(self, grads):
+        gs = [as_nhwc(g) for g in grads]
+        if fusion and _CAT_FUSE and 2 <= len(gs) <= 4 and gs[0].phys_numel() % 4 == 0:   # copy + one add per further branch, in one launch
+            acc = self._get("gsum", gs[0].shape, "nhwc")
+            lib().sum_n(stream(), len(gs), _ptr_array([g.ptr for g in gs]), acc.ptr, acc.phys_numel())
+            self.gradInput = acc
+            return acc
         acc = None
         for k, g in enumerate(grads):
             g = as_nhwc(g)

@@ -332,6 +332,12 @@ int cg_nhwc_to_nchw(void* stream, const float* in, float* out, int N, int C, int
  * (models.lua:688-692). */
 int cg_copy_channels(void* stream, const float* src, float* dst, long M,
                      int Csrc, int src_off, int Cdst, int dst_off, int Ccopy);
+/* nn.Concat(2) over n <= 4 branches in one launch: dst[m][off_b + c] = src[b][m][c] (C[b] channels each, host array,
+ * all % 4); cg_split_channels is the reverse (the gradient slices handed to the branches); cg_sum_n: out = ((s0+s1)+s2)+s3,
+ * the accumulation order of nn.Concat's gradInput. */
+int cg_concat_channels(void* stream, int n, const float* const* src, const int* C, float* dst, long M);
+int cg_split_channels(void* stream, int n, const float* src, float* const* dst, const int* C, long M);
+int cg_sum_n(void* stream, int n, const float* const* src, float* out, long count);
 /* dst[i] = src[idx[i]] for rows of rowlen floats: D-batch assembly from the
  * real-image pool (adversarial.lua:225-230). */
 int cg_gather_rows(void* stream, const float* src, const int32_t* idx, float* dst,
