@@ -238,7 +238,7 @@ def main():
             step = cg.adversarial.GraphedIteration(S, data, N)
             launch = "hipGraph replay"
         except Exception as e:  # capture is an optimisation, not a requirement
-            launch = f"eager (graph capture failed: {type(e).__name__})"
+            launch = f"eager (graph capture failed: {type(e).__name__}: {str(e)[:160]})"
             step = lambda: cg.adversarial.iteration(S, data)
     for _ in range(args.warmup):
         step()
