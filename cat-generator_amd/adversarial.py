@@ -114,8 +114,10 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         f = S.CRITERION.forward(outputs, targets)
         df_do = S.CRITERION.backward(outputs, targets)
         nn.WGRAD_SIDE.begin()              # D's weight-gradient GEMMs on a side stream, under the rest of the backward chain
+        nn.WGRAD_DEFER.begin()             # their small split-K reductions queue up and run as one launch
         S.MODEL_D.backward(inputs, df_do)
         nn.WGRAD_SIDE.join()
+        nn.WGRAD_DEFER.end()
         if st.get("overlap"):  # start the xGMI all-reduce now, finish it after the G-step's generator forward
             st["pendingD"] = parallel.allreduce_mean_async(S.GRAD_PARAMETERS_D.t)
         else:
@@ -167,12 +169,15 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
             S.MODEL_D.updateGradInput(samples, df_samples)
         df_do = S.MODEL_D.modules[0].gradInput
         nn.WGRAD_SIDE.begin()
+        nn.WGRAD_DEFER.begin()
         if parallel.world_size() > 1 and OPT.get("overlap_comm", True) and _bucketable(S.MODEL_G):
             _backward_bucketed(S, st["noiseInputs"], df_do)
             nn.WGRAD_SIDE.join()
+            nn.WGRAD_DEFER.end()
         else:
             S.MODEL_G.backward(st["noiseInputs"], df_do)
             nn.WGRAD_SIDE.join()
+            nn.WGRAD_DEFER.end()
             parallel.allreduce_mean_(S.GRAD_PARAMETERS_G.t)
         if not OPT["fused_update"]:
             if OPT["G_L1"] != 0 or OPT["G_L2"] != 0:
@@ -289,6 +294,7 @@ def _backward_bucketed(S, noise, df_do):
                 if nn.WGRAD_SIDE.used:          # the bucket's weight gradients may still be on the side stream
                     nn.WGRAD_SIDE.join()
                     nn.WGRAD_SIDE.begin()
+                nn.WGRAD_DEFER.flush()          # ... or queued as deferred reductions
                 pending.append(parallel.allreduce_mean_async(flat[b[1]:b[1] + b[2]]))
         done[0] = i
 

@@ -29,7 +29,10 @@
 #include "common.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
+#include <vector>
 
 namespace {
 
@@ -832,18 +835,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
 struct RedPtrs { float* gw0; float* gw1; float* gw2; float* gw3; float* gb0; float* gb1; float* gb2; float* gb3; };
 
 template <bool UPS>
-__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* part, const float* bias_part, RedPtrs rp, int Cin,
-                                                                 int Cout, int k, int KK, int pad, int kp, int S, int P,
-                                                                 float scale, long sstride, long gstride, long bsstride,
-                                                                 int wblocks) {
-    __shared__ float sh[8][33];
+__device__ __forceinline__ void wgrad_reduce_small_body(float (*sh)[33], int bx, int group, const float* part, const float* bias_part,
+                                                        const RedPtrs& rp, int Cin, int Cout, int k, int KK, int pad, int kp, int S,
+                                                        int P, float scale, long sstride, long gstride, long bsstride, int wblocks) {
     const int ol = threadIdx.x & 31, ln = threadIdx.x >> 5;
-    const int group = blockIdx.y;
     float s = 0.f;
-    if ((int)blockIdx.x < wblocks) {
+    if (bx < wblocks) {
         const long total = (long)KK * Cin * Cout;
         const long plane = (long)(UPS ? kp * kp : KK) * Cin * Cout;
-        const long i = blockIdx.x * 32L + ol;
+        const long i = bx * 32L + ol;
         const float* pg = part + (long)group * gstride;
         int co = 0, ci = 0, tap = 0;
         if (i < total) {
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* pa
     } else {
         float* gb = sel4(group, rp.gb0, rp.gb1, rp.gb2, rp.gb3);
         if (!gb) return;
-        const int c = ((int)blockIdx.x - wblocks) * 32 + ol;
+        const int c = (bx - wblocks) * 32 + ol;
         const float* bp = bias_part + (long)group * P * Cout;
         if (c < Cout)
             for (int i = ln; i < S * P; i += 8) s += bp[(long)(i / P) * bsstride + (long)(i % P) * Cout + c];
@@ -889,6 +889,46 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* pa
             gb[c] += scale * t;
         }
     }
+}
+
+template <bool UPS>
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* part, const float* bias_part, RedPtrs rp, int Cin,
+                                                                 int Cout, int k, int KK, int pad, int kp, int S, int P,
+                                                                 float scale, long sstride, long gstride, long bsstride,
+                                                                 int wblocks) {
+    __shared__ float sh[8][33];
+    wgrad_reduce_small_body<UPS>(sh, (int)blockIdx.x, (int)blockIdx.y, part, bias_part, rp, Cin, Cout, k, KK, pad, kp, S, P, scale,
+                                 sstride, gstride, bsstride, wblocks);
+}
+
+// The same reduction for SEVERAL layers in one launch (cg_conv2d_wgrad_flush): the deferred form of cg_conv2d_wgrad* runs only
+// its GEMM and queues one RedJob; a dozen ~10 us reductions, each a short dependent chain, then overlap instead of queueing
+// up behind one another.  Workgroup b belongs to the job whose [block0, block0 + ngroups * (wblocks + bblocks)) holds b.
+struct RedJob {
+    const float* part; const float* bias_part;
+    RedPtrs rp;
+    long sstride, gstride, bsstride;
+    int Cin, Cout, k, KK, pad, kp, S, P, ups, wblocks, bblocks, block0;
+    float scale;
+};
+constexpr int kRedJobs = 20;
+struct RedJobTable { RedJob j[kRedJobs]; int n; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedJobTable t) {
+    __shared__ float sh[8][33];
+    const int b = (int)blockIdx.x;
+    int ji = 0;
+    for (int q = 1; q < t.n; ++q)
+        if (b >= t.j[q].block0) ji = q;
+    const RedJob& J = t.j[ji];
+    const int per = J.wblocks + J.bblocks;
+    const int group = (b - J.block0) / per, bx = (b - J.block0) - group * per;
+    if (J.ups)
+        wgrad_reduce_small_body<true>(sh, bx, group, J.part, J.bias_part, J.rp, J.Cin, J.Cout, J.k, J.KK, J.pad, J.kp, J.S, J.P, J.scale,
+                                      J.sstride, J.gstride, J.bsstride, J.wblocks);
+    else
+        wgrad_reduce_small_body<false>(sh, bx, group, J.part, J.bias_part, J.rp, J.Cin, J.Cout, J.k, J.KK, J.pad, J.kp, J.S, J.P, J.scale,
+                                       J.sstride, J.gstride, J.bsstride, J.wblocks);
 }
 
 // gb[c] += scale * sum_{s,p} bias_part[s*P+p][c]; 32 channels x 8 partial-sum lanes per workgroup
@@ -1596,9 +1636,84 @@ size_t cg_conv2d_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout,
     return cg_conv2d_wgrad_workspace_bytes_grouped(1, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups);
 }
 
+namespace {
+// reductions queued by the deferred entry points, per stream (one host thread per stream, but several streams may queue)
+std::mutex g_red_mu;
+std::unordered_map<hipStream_t, std::vector<RedJob>> g_red_queue;
+
+int small_reduce(hipStream_t st, bool defer, const RedJob& job, int ngroups) {
+    if (defer) {
+        std::lock_guard<std::mutex> lk(g_red_mu);
+        g_red_queue[st].push_back(job);
+        g_red_queue[st].back().block0 = ngroups;   // the group count rides here until the flush lays the blocks out
+        return 0;
+    }
+    dim3 sgrid(job.wblocks + job.bblocks, ngroups);
+    if (job.ups)
+        hipLaunchKernelGGL(wgrad_reduce_small_kernel<true>, sgrid, dim3(256), 0, st, job.part, job.bias_part, job.rp, job.Cin, job.Cout,
+                           job.k, job.KK, job.pad, job.kp, job.S, job.P, job.scale, job.sstride, job.gstride, job.bsstride, job.wblocks);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_small_kernel<false>, sgrid, dim3(256), 0, st, job.part, job.bias_part, job.rp, job.Cin, job.Cout,
+                           job.k, job.KK, job.pad, job.kp, job.S, job.P, job.scale, job.sstride, job.gstride, job.bsstride, job.wblocks);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* const* dy, float* const* gw, float* const* gb, int N,
+               int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes,
+               bool defer);
+}  // namespace
+
 int cg_conv2d_wgrad_grouped(void* stream, int ngroups, const float* const* x, const float* const* dy, float* const* gw,
                             float* const* gb, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW,
                             int ups, float scale, void* ws, size_t ws_bytes) {
+    return wgrad_impl(stream, ngroups, x, dy, gw, gb, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups, scale, ws, ws_bytes, false);
+}
+
+int cg_conv2d_wgrad_grouped_deferred(void* stream, int ngroups, const float* const* x, const float* const* dy, float* const* gw,
+                                     float* const* gb, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW,
+                                     int ups, float scale, void* ws, size_t ws_bytes) {
+    return wgrad_impl(stream, ngroups, x, dy, gw, gb, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups, scale, ws, ws_bytes, true);
+}
+
+int cg_conv2d_wgrad_pending(void* stream, int* njobs) {
+    CG_REQUIRE(njobs, "cg_conv2d_wgrad_pending: null pointer");
+    std::lock_guard<std::mutex> lk(g_red_mu);
+    auto it = g_red_queue.find(cg::S(stream));
+    *njobs = it == g_red_queue.end() ? 0 : (int)it->second.size();
+    return 0;
+}
+
+int cg_conv2d_wgrad_flush(void* stream) {
+    hipStream_t st = cg::S(stream);
+    std::vector<RedJob> jobs;
+    {
+        std::lock_guard<std::mutex> lk(g_red_mu);
+        auto it = g_red_queue.find(st);
+        if (it == g_red_queue.end() || it->second.empty()) return 0;
+        jobs.swap(it->second);
+    }
+    for (size_t j0 = 0; j0 < jobs.size(); j0 += kRedJobs) {
+        RedJobTable t;
+        memset(&t, 0, sizeof(t));
+        t.n = (int)std::min<size_t>(kRedJobs, jobs.size() - j0);
+        int blocks = 0;
+        for (int q = 0; q < t.n; ++q) {
+            t.j[q] = jobs[j0 + q];
+            const int ngroups = t.j[q].block0;
+            t.j[q].block0 = blocks;
+            blocks += ngroups * (t.j[q].wblocks + t.j[q].bblocks);
+        }
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, t);
+        CG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+namespace {
+int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* const* dy, float* const* gw, float* const* gb, int N,
+               int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes,
+               bool defer) {
     CG_REQUIRE(x && dy && gw, "cg_conv2d_wgrad: null pointer");
     CG_REQUIRE(ngroups >= 1 && ngroups <= MAXG, "cg_conv2d_wgrad: 1..%d groups per launch", MAXG);
     TNArgs a;
@@ -1617,15 +1732,14 @@ int cg_conv2d_wgrad_grouped(void* stream, int ngroups, const float* const* x, co
         if (Cout == 3) skinny_wgrad_launch<3>(st, x[0], dy[0], part, gb0 ? bpart : nullptr, N, Hp, Wp, Cin, blocks, ppb);
         else skinny_wgrad_launch<1>(st, x[0], dy[0], part, gb0 ? bpart : nullptr, N, Hp, Wp, Cin, blocks, ppb);
         CG_LAUNCH_CHECK();
-        RedPtrs rp;
-        memset(&rp, 0, sizeof(rp));
-        rp.gw0 = gw[0]; rp.gb0 = gb0;
-        const int wblocks = cg::cdiv(9L * Cin * Cout, 32), bblocks = gb0 ? cg::cdiv(Cout, 32) : 0;
-        hipLaunchKernelGGL(wgrad_reduce_small_kernel<false>, dim3(wblocks + bblocks, 1), dim3(256), 0, st, (const float*)part,
-                           (const float*)bpart, rp, Cin, Cout, 3, 9, 1, 0, blocks, 1, scale, 9L * Cin * Cout, 0L, (long)Cout,
-                           wblocks);
-        CG_LAUNCH_CHECK();
-        return 0;
+        RedJob job;
+        memset(&job, 0, sizeof(job));
+        job.part = part; job.bias_part = bpart;
+        job.rp.gw0 = gw[0]; job.rp.gb0 = gb0;
+        job.Cin = Cin; job.Cout = Cout; job.k = 3; job.KK = 9; job.pad = 1; job.S = blocks; job.P = 1; job.scale = scale;
+        job.sstride = 9L * Cin * Cout; job.gstride = 0; job.bsstride = Cout;
+        job.wblocks = cg::cdiv(9L * Cin * Cout, 32); job.bblocks = gb0 ? cg::cdiv(Cout, 32) : 0;
+        return small_reduce(st, defer, job, 1);
     }
     TNPlan p = plan_tn(g, ngroups);
     const size_t need = tn_ws_bytes(g, p, ngroups);
@@ -1664,24 +1778,19 @@ int cg_conv2d_wgrad_grouped(void* stream, int ngroups, const float* const* x, co
     const long sstride = (long)ZP * wplane;                 // floats between consecutive splits
     const int kp = ups ? phase_kp(kH, padH) : 0;
     if ((long)rgrid.x * rgrid.y < cg::kNumCU) {
-        RedPtrs rp;
+        RedJob job;
+        memset(&job, 0, sizeof(job));
         float* gws[MAXG] = {nullptr, nullptr, nullptr, nullptr};
         float* gbs[MAXG] = {nullptr, nullptr, nullptr, nullptr};
         for (int gi = 0; gi < ngroups; ++gi) { gws[gi] = gw[gi]; gbs[gi] = gb ? gb[gi] : nullptr; }
-        rp.gw0 = gws[0]; rp.gw1 = gws[1]; rp.gw2 = gws[2]; rp.gw3 = gws[3];
-        rp.gb0 = gbs[0]; rp.gb1 = gbs[1]; rp.gb2 = gbs[2]; rp.gb3 = gbs[3];
-        const int wblocks = cg::cdiv(relems, 32), bblocks = any_gb ? cg::cdiv(Cout, 32) : 0;
-        dim3 sgrid(wblocks + bblocks, ngroups);
-        if (ups)
-            hipLaunchKernelGGL(wgrad_reduce_small_kernel<true>, sgrid, dim3(256), 0, st, (const float*)ws,
-                               (const float*)a.bias_part, rp, Cin, Cout, kH, KK, padH, kp, p.splits, g.nphase, scale, sstride,
-                               (long)g.nphase * wplane, (long)ZP * Cout, wblocks);
-        else
-            hipLaunchKernelGGL(wgrad_reduce_small_kernel<false>, sgrid, dim3(256), 0, st, (const float*)ws,
-                               (const float*)a.bias_part, rp, Cin, Cout, kH, KK, padH, 0, p.splits, g.nphase, scale, sstride,
-                               (long)g.nphase * wplane, (long)ZP * Cout, wblocks);
-        CG_LAUNCH_CHECK();
-        return 0;
+        job.rp.gw0 = gws[0]; job.rp.gw1 = gws[1]; job.rp.gw2 = gws[2]; job.rp.gw3 = gws[3];
+        job.rp.gb0 = gbs[0]; job.rp.gb1 = gbs[1]; job.rp.gb2 = gbs[2]; job.rp.gb3 = gbs[3];
+        job.part = (const float*)ws; job.bias_part = a.bias_part;
+        job.Cin = Cin; job.Cout = Cout; job.k = kH; job.KK = KK; job.pad = padH; job.kp = ups ? kp : 0; job.S = p.splits; job.P = g.nphase;
+        job.ups = ups ? 1 : 0; job.scale = scale;
+        job.sstride = sstride; job.gstride = (long)g.nphase * wplane; job.bsstride = (long)ZP * Cout;
+        job.wblocks = cg::cdiv(relems, 32); job.bblocks = any_gb ? cg::cdiv(Cout, 32) : 0;
+        return small_reduce(st, defer, job, ngroups);
     }
     for (int gi = 0; gi < ngroups; ++gi) {
         const float* pg = (const float*)ws + (long)gi * g.nphase * wplane;
@@ -1701,6 +1810,8 @@ int cg_conv2d_wgrad_grouped(void* stream, int ngroups, const float* const* x, co
     }
     return 0;
 }
+
+}  // namespace
 
 int cg_conv2d_wgrad(void* stream, const float* x, const float* dy, float* gw, float* gb, int N, int Hp, int Wp, int Cin,
                     int Cout, int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes) {

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import parallel
-from .tensor import Tensor, WS, has_gpu, lib, rng, stream
+from .tensor import Tensor, WS, device, has_gpu, lib, rng, stream
 
 
 # ------------------------------------------------------------------ layout helpers
@@ -610,6 +610,7 @@ class Concat(Sequential):
             s.wait_event(self._fork_ev)
             with torch.cuda.stream(s):
                 out.append(f())
+                WGRAD_DEFER.flush()
                 ev.record(s)
         for s, ev in self._streams:
             main.wait_event(ev)
@@ -634,6 +635,7 @@ class Concat(Sequential):
             st_.wait_event(self._gfork)
             with torch.cuda.stream(st_):
                 out[k] = f()
+                WGRAD_DEFER.flush()
                 ev.record(st_)
         out[0] = thunks[0]()
         for (st_, ev), _ in zip(self._gstreams, thunks[1:]):
@@ -815,6 +817,8 @@ class _WgradSide:
     def join(self):
         """Every weight gradient started since begin() is visible to the current stream afterwards."""
         if self.used:
+            with torch.cuda.stream(self.stream):
+                WGRAD_DEFER.flush()
             self.ev_join.record(self.stream)
             torch.cuda.current_stream().wait_event(self.ev_join)
         self.used = False
@@ -822,6 +826,63 @@ class _WgradSide:
 
 
 WGRAD_SIDE = _WgradSide()
+
+
+class _WgradDefer:
+    """Deferred split-K reductions of the weight gradients (cg_conv2d_wgrad_grouped_deferred / cg_conv2d_wgrad_flush): between
+    begin() and end() a layer's accGradParameters launches only its GEMM (into a workspace the layer owns) and queues the
+    reduction; flush() reduces everything queued on the current stream in ONE launch.  ~20 reductions of ~10 us each, every
+    one a short dependent chain, then overlap instead of running back to back.  gradWeight / gradBias are complete after
+    the flush - adversarial.iteration() brackets MODEL_D:backward / MODEL_G:backward; stream joins flush first."""
+    enabled = os.environ.get("CG_WGRAD_DEFER", "1") != "0"
+
+    def __init__(self):
+        self.active = False
+        self.pending = []
+
+    def begin(self):
+        self.active = bool(self.enabled and fusion and has_gpu())
+
+    def workspace(self, owner, nbytes):
+        if getattr(owner, "_wg_pending", False):   # the same layer twice before a flush: its partials are still needed
+            self.flush_all()
+        t = getattr(owner, "_wg_ws", None)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(int(nbytes), 4096), dtype=torch.uint8, device=device())
+            owner._wg_ws = t
+        owner._wg_pending = True
+        self.pending.append((owner, stream()))
+        return t.data_ptr(), t.numel()
+
+    def flush(self):
+        """Reduce what is queued on the CURRENT stream."""
+        if not self.pending:
+            return
+        st = stream()
+        lib().conv2d_wgrad_flush(st)
+        keep = []
+        for owner, s_ in self.pending:
+            if s_ == st:
+                owner._wg_pending = False
+            else:
+                keep.append((owner, s_))
+        self.pending = keep
+
+    def flush_all(self):
+        for st in {s_ for _, s_ in self.pending}:   # ABI streams are raw handles: flush each queue on its own stream
+            lib().conv2d_wgrad_flush(st)
+        for owner, _ in self.pending:
+            owner._wg_pending = False
+        self.pending = []
+
+    def end(self):
+        self.flush()
+        if self.pending:
+            raise RuntimeError("weight-gradient reductions still queued on a side stream at the end of the backward pass")
+        self.active = False
+
+
+WGRAD_DEFER = _WgradDefer()
 
 
 class _GemmLayer(Module):
@@ -886,6 +947,11 @@ class _GemmLayer(Module):
 
     def accGradParameters(self, input, gradOutput, scale=1.0):
         x, dy, a = self._prep_acc(gradOutput)
+        if WGRAD_DEFER.active:
+            ws, wsb = WGRAD_DEFER.workspace(self, lib().conv2d_wgrad_workspace_bytes(*a))
+            lib().conv2d_wgrad_grouped_deferred(stream(), 1, _ptr_array([x.ptr]), _ptr_array([dy.ptr]), _ptr_array([self.gradWeight.ptr]),
+                                                _ptr_array([self.gradBias.ptr]), *a, float(scale), ws, wsb)
+            return
         ws, wsb = WS.get(lib().conv2d_wgrad_workspace_bytes(*a))
         lib().conv2d_wgrad(stream(), x.ptr, dy.ptr, self.gradWeight.ptr, self.gradBias.ptr, *a, float(scale), ws, wsb)
 
@@ -932,8 +998,10 @@ class _GemmLayer(Module):
             aa = accp[0][2]
 
             def wgrad():
-                ws, wsb = WS.get(lib().conv2d_wgrad_workspace_bytes_grouped(G, *aa))
-                lib().conv2d_wgrad_grouped(stream(), G, _ptr_array([p_[0].ptr for p_ in accp]), _ptr_array([p_[1].ptr for p_ in accp]),
+                need = lib().conv2d_wgrad_workspace_bytes_grouped(G, *aa)
+                ws, wsb = WGRAD_DEFER.workspace(mods[0], need) if WGRAD_DEFER.active else WS.get(need)
+                fn = lib().conv2d_wgrad_grouped_deferred if WGRAD_DEFER.active else lib().conv2d_wgrad_grouped
+                fn(stream(), G, _ptr_array([p_[0].ptr for p_ in accp]), _ptr_array([p_[1].ptr for p_ in accp]),
                                            _ptr_array([m.gradWeight.ptr for m in mods]), _ptr_array([m.gradBias.ptr for m in mods]),
                                            *aa, float(scale), ws, wsb)
             if WGRAD_SIDE.active:

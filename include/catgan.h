@@ -134,6 +134,15 @@ size_t cg_conv2d_wgrad_workspace_bytes_grouped(int ngroups, int N, int Hp, int W
 int cg_conv2d_wgrad_grouped(void* stream, int ngroups, const float* const* x, const float* const* dy,
                             float* const* gw_canonical, float* const* gb, int N, int Hp, int Wp, int Cin, int Cout,
                             int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes);
+/* Deferred form: runs the GEMM into `ws` and, for layers whose split reduction is a small kernel, QUEUES that reduction on the
+ * stream instead of launching it; cg_conv2d_wgrad_flush(stream) then reduces every queued layer in one launch (a dozen ~10 us
+ * kernels overlap instead of running back to back).  `ws` must not be reused before the flush - one workspace per layer - and
+ * gw / gb are incomplete until then.  Results are bit-identical to the immediate form.  cg_conv2d_wgrad_pending: queue length. */
+int cg_conv2d_wgrad_grouped_deferred(void* stream, int ngroups, const float* const* x, const float* const* dy,
+                            float* const* gw_canonical, float* const* gb, int N, int Hp, int Wp, int Cin, int Cout,
+                            int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes);
+int cg_conv2d_wgrad_flush(void* stream);
+int cg_conv2d_wgrad_pending(void* stream, int* njobs);
 
 /* gb[c] += scale * sum_m dy[m][c]   (gradBias of conv / linear).
  * ws: scratch of at least 8*C bytes (fp64 column sums). */

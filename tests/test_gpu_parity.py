@@ -717,6 +717,43 @@ def test_fusion_matches_separate_modules(cg, which):
     bulk_close(p1, p0, max_rel=1e-4, mean_rel=1e-6, what=f"{which} flat gradient fused vs separate")
 
 
+@pytest.mark.parametrize("which", ["G", "D"])
+def test_deferred_weight_gradient_reductions_are_bit_identical(cg, which):
+    """cg_conv2d_wgrad_grouped_deferred + cg_conv2d_wgrad_flush (one launch reducing every queued layer) against the immediate
+    form, on the real networks at batch 16: the flat gradient vectors must be equal bit for bit, nothing may stay queued,
+    and a layer hit twice before a flush must not lose its first partials."""
+    res = {}
+    for defer in (True, False):
+        P, _, _ = _pair(cg, 31, which)
+        pP, gP = P.getParameters()
+        rs = np.random.RandomState(9)
+        if which == "D":
+            x = rs.rand(16, 3, 32, 32).astype(f32); dy = rs.randn(16, 1).astype(f32)
+        else:
+            x = (rs.rand(16, 100) * 2 - 1).astype(f32); dy = (rs.randn(16, 3, 32, 32) * 0.1).astype(f32)
+        xin, dyt = cg.Tensor.from_numpy(x), cg.Tensor.from_numpy(dy)
+        P.forward(xin)
+        gP.zero()
+        if defer:
+            cg.nn.WGRAD_DEFER.begin()
+            assert cg.nn.WGRAD_DEFER.active
+        P.backward(xin, dyt)
+        if defer:
+            assert len(cg.nn.WGRAD_DEFER.pending) > 3          # several layers queued
+            import ctypes
+            n = ctypes.c_int(0)
+            cg.lib().conv2d_wgrad_pending(cg.tensor.stream(), ctypes.byref(n))
+            assert n.value > 0
+            P.backward(xin, dyt)                                 # every layer again: forces a flush of the first round
+            cg.nn.WGRAD_DEFER.end()
+            cg.lib().conv2d_wgrad_pending(cg.tensor.stream(), ctypes.byref(n))
+            assert n.value == 0 and not cg.nn.WGRAD_DEFER.pending
+        else:
+            P.backward(xin, dyt)
+        res[defer] = gP.numpy().copy()
+    np.testing.assert_array_equal(res[True], res[False])
+
+
 def test_collectives_through_the_c_abi_single_rank(cg):
     """csrc/comm.hip on the one GPU gpurun provides: RCCL bound at run time, a 1-rank communicator, all-reduce (sum, average,
     fp32 and fp64) and broadcast on the side stream with event fork/join against the compute stream.  With one rank every
