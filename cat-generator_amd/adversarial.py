@@ -228,11 +228,11 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         # Data-parallel overlap: D's gradient all-reduce travels over xGMI while the G-step's generator forward
         # (which reads no D parameter) runs; D's update is applied after the wait, before D sees those samples.
         st["overlap"] = (parallel.world_size() > 1 and OPT.get("overlap_comm", True) and OPT["fused_update"]
-                         and OPT["D_iterations"] == 1 and OPT["G_iterations"] == 1 and noise_G is None)
+                         and OPT["D_iterations"] == 1 and OPT["G_iterations"] == 1)
         if st["overlap"]:
             fD, gD = fevalD(S.PARAMETERS_D)
             if "samples_pre" not in st:
-                st["noiseInputs"] = nn_utils.createNoiseInputs(S, N)
+                st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.createNoiseInputs(S, N)
                 st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
             st.pop("pendingD").finish()
             getattr(optim, m)(lambda _x: (fD, gD), S.PARAMETERS_D, S.OPTSTATE[m]["D"], fused=fused)

@@ -72,3 +72,87 @@ def test_two_ranks_stay_replicas_and_overlap_is_result_neutral():
     for a, b in ((g_o, g_b), (d_o, d_b)):
         d = np.abs(a - b)
         assert d.max() <= 2 * 2.5e-3 and d.mean() <= 2e-5, (d.max(), d.mean())
+
+
+# ------------------------------------------------------------------ 2 ranks x N/2 == 1 rank x N on the HIP path
+def _shard_worker(rank, world, port, overlap, q):
+    """world == 1: the full batch in one process; world == 2: rank r takes rows [r*N/2R, (r+1)*N/2R) of the real / noise
+    draws (SURVEY.md 8e partitioning).  Dropout probabilities are set to 0 so that no mask depends on the position of a
+    sample in the counter stream - everything else (sync-BN, gradient buckets, overlap, fused penalty / clamp / Adam) is
+    the product's DP iteration on the HIP kernels."""
+    try:
+        sys.path.insert(0, ROOT)
+        torch.cuda.set_device(0)
+        if world > 1:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        cg = importlib.import_module("cat-generator_amd")
+        if world > 1:
+            cg.parallel.attach(world, rank)
+        cg.manual_seed(11)
+        G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
+        for net in (G, D):
+            for m in net.listModules():
+                if isinstance(m, (cg.nn.SpatialDropout, cg.nn.Dropout)):
+                    m.p = 0.0
+        N = 16
+        S = cg.adversarial.State(dict(batchSize=N // world, seed=1, overlap_comm=overlap), G, D)
+        S.keep_outputs = True
+        rs = np.random.RandomState(3)
+        pool = rs.rand(24, 3, 32, 32).astype(np.float32)
+        data = cg.adversarial.TrainData(pool)
+        out = []
+        for it in range(2):
+            idx = rs.randint(0, 24, size=N // 2)
+            zD = (rs.rand(N // 2, 100) * 2 - 1).astype(np.float32)
+            zG = (rs.rand(N, 100) * 2 - 1).astype(np.float32)
+            h, n = N // 2 // world, N // world
+            cg.adversarial.iteration(S, data, N // world, real_idx=idx[rank * h:(rank + 1) * h],
+                                     noise_D=zD[rank * h:(rank + 1) * h], noise_G=zG[rank * n:(rank + 1) * n])
+            out.append((S._last["gD"].numpy().copy(), S._last["gG"].numpy().copy()))
+        torch.cuda.synchronize()
+        q.put((rank, out, S.PARAMETERS_G.numpy(), S.PARAMETERS_D.numpy(), None))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, None, None, None, f"{type(e).__name__}: {e}\n{traceback.format_exc()[-1500:]}"))
+
+
+def _run_sharded(world, overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + os.getpid() % 40 + (5 if overlap else 0)
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, overlap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=400) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    errs = [r[4] for r in res if r[4]]
+    assert not errs, errs
+    return res
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_ranks_on_half_batches_equal_one_rank_on_the_full_batch(overlap):
+    """with the global batch split over two ranks (sync-BN statistics and the mean of the flat gradients
+    exchanged; `overlap`: D's all-reduce under the G-step's generator forward, G's in buckets under its backward) the
+    gradients handed to Adam and the parameters after two iterations equal the single-rank run on the full batch, up
+    to fp32 re-association of the batch reductions.  Both ranks run the HIP kernels on the one GPU of this box; the
+    transport is gloo (RCCL refuses two ranks on one device) - the collectives' placement and order are the product's."""
+    full = _run_sharded(1, overlap)[0]
+    r0, r1 = _run_sharded(2, overlap)
+    np.testing.assert_array_equal(r0[2], r1[2]); np.testing.assert_array_equal(r0[3], r1[3])   # replicas
+    for it in range(2):
+        for k, name in ((0, "D"), (1, "G")):
+            a, b = r0[1][it][k], full[1][it][k]
+            scale = np.abs(b).max()
+            d = np.abs(a - b)
+            assert d.max() <= (2e-4 if it == 0 else 5e-2) * scale and d.mean() <= (2e-6 if it == 0 else 1e-3) * scale, \
+                (it, name, d.max() / scale, d.mean() / scale)
+    for a, b, name in ((r0[2], full[2], "G"), (r0[3], full[3], "D")):
+        d = np.abs(a - b)   # Adam's first steps move every weight by ~lr * sign(g): weights whose gradient is ~0 may differ by 2 lr
+        assert d.max() <= 2.5e-3 and d.mean() <= 2e-5, (name, d.max(), d.mean())
