@@ -688,13 +688,15 @@ __device__ __forceinline__ BilinTaps bilin_taps(float yf, float xf, int Hi, int 
     t.in00 = yin0 && xin0; t.in01 = yin0 && xin1; t.in10 = yin1 && xin0; t.in11 = yin1 && xin1;
     return t;
 }
-__global__ void bilinear_fwd_k(const float* img, const float* grid, float* out, int N, int Hi, int Wi, int C, int Ho,
+// Nimg: the image batch; sample n of the grid / output batch reads image n % Nimg (cg_bilinear_sampler_*_shared: G sibling
+// transformers sampling the SAME images with their own grids, as one launch over G * Nimg samples)
+__global__ void bilinear_fwd_k(const float* img, const float* grid, float* out, int N, int Nimg, int Hi, int Wi, int C, int Ho,
                                int Wo) {
     const long total = (long)N * Ho * Wo * C;
     GRID_STRIDE(i, total) {
         const int c = (int)(i % C);
         const long pix = i / C;
-        const long n = pix / ((long)Ho * Wo);
+        const long n = (pix / ((long)Ho * Wo)) % Nimg;
         const BilinTaps t = bilin_taps(grid[pix * 2], grid[pix * 2 + 1], Hi, Wi);
         const float* b = img + (((n * Hi + t.y0) * (long)Wi + t.x0)) * C + c;
         float v = 0.f;
@@ -705,10 +707,33 @@ __global__ void bilinear_fwd_k(const float* img, const float* grid, float* out, 
         out[i] = v;
     }
 }
+// the same with one lane per channel QUAD (C % 4 == 0, 16-B aligned tensors): the taps are derived once per four outputs and
+// every access moves 16 B; per channel the operations and their order are those of the scalar kernel (bit-identical)
+__global__ __launch_bounds__(256) void bilinear_fwd_v4k(const float* __restrict__ img, const float* __restrict__ grid,
+                                                        float* __restrict__ out, int N, int Nimg, int Hi, int Wi, int C4, int Ho, int Wo) {
+    const long total = (long)N * Ho * Wo * C4;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C4);
+        const long pix = i / C4;
+        const long n = (pix / ((long)Ho * Wo)) % Nimg;
+        const float2 gyx = *reinterpret_cast<const float2*>(grid + pix * 2);
+        const BilinTaps t = bilin_taps(gyx.x, gyx.y, Hi, Wi);
+        const long b = (((n * Hi + t.y0) * (long)Wi + t.x0)) * C4 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto tap = [&](bool in, float w, long off) {
+            if (in) { const float4 q = ldv(img, b + off); v.x += w * q.x; v.y += w * q.y; v.z += w * q.z; v.w += w * q.w; }
+        };
+        tap(t.in00, t.wx0 * t.wy0, 0);
+        tap(t.in01, (1.f - t.wx0) * t.wy0, C4);
+        tap(t.in10, t.wx0 * (1.f - t.wy0), (long)Wi * C4);
+        tap(t.in11, (1.f - t.wx0) * (1.f - t.wy0), (long)Wi * C4 + C4);
+        stv(out, i, v);
+    }
+}
 // G lanes per output pixel (64/G pixels per wave), lanes stride the channels; G = smallest power of two >= min(C, 64)
 template <int G>
 __global__ __launch_bounds__(256) void bilinear_bwd_k(const float* img, const float* grid, const float* gout,
-                                                      float* gimg, float* ggrid, int N, int Hi, int Wi, int C, int Ho,
+                                                      float* gimg, float* ggrid, int N, int Nimg, int Hi, int Wi, int C, int Ho,
                                                       int Wo) {
     const long npix = (long)N * Ho * Wo;
     const int sub = threadIdx.x & (G - 1);
@@ -726,15 +751,16 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const float* img, const fl
             t = bilin_taps(grid[pix * 2], grid[pix * 2 + 1], Hi, Wi);
         }
         const long b = ((n * Hi + t.y0) * (long)Wi + t.x0) * C;
+        const float* im = img + ((n % Nimg) - n) * (long)Hi * Wi * C;   // the image this sample reads (its own unless shared)
         const long o01 = C, o10 = (long)Wi * C, o11 = (long)Wi * C + C;
         float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
         if (live)
             for (int c = sub; c < C; c += G) {
                 const float g = gout[pix * C + c];
-                if (t.in00) { d00 += img[b + c] * g;       atomicAdd(&gimg[b + c], t.wx0 * t.wy0 * g); }
-                if (t.in01) { d01 += img[b + o01 + c] * g; atomicAdd(&gimg[b + o01 + c], (1.f - t.wx0) * t.wy0 * g); }
-                if (t.in10) { d10 += img[b + o10 + c] * g; atomicAdd(&gimg[b + o10 + c], t.wx0 * (1.f - t.wy0) * g); }
-                if (t.in11) { d11 += img[b + o11 + c] * g; atomicAdd(&gimg[b + o11 + c], (1.f - t.wx0) * (1.f - t.wy0) * g); }
+                if (t.in00) { d00 += im[b + c] * g;       atomicAdd(&gimg[b + c], t.wx0 * t.wy0 * g); }
+                if (t.in01) { d01 += im[b + o01 + c] * g; atomicAdd(&gimg[b + o01 + c], (1.f - t.wx0) * t.wy0 * g); }
+                if (t.in10) { d10 += im[b + o10 + c] * g; atomicAdd(&gimg[b + o10 + c], t.wx0 * (1.f - t.wy0) * g); }
+                if (t.in11) { d11 += im[b + o11 + c] * g; atomicAdd(&gimg[b + o11 + c], (1.f - t.wx0) * (1.f - t.wy0) * g); }
             }
 #pragma unroll
         for (int off = G >> 1; off > 0; off >>= 1) {
@@ -761,7 +787,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const float* img, const fl
 template <int G, int CACC>
 __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restrict__ img, const float* __restrict__ grid,
                                                           const float* __restrict__ gout, float* __restrict__ gimg,
-                                                          float* __restrict__ ggrid, int Hi, int Wi, int C, int Ho, int Wo,
+                                                          float* __restrict__ ggrid, int Nimg, int Hi, int Wi, int C, int Ho, int Wo,
                                                           int nchunks, int S) {
     extern __shared__ float bl_sh[];
     const int P = Ho * Wo, Q = Hi * Wi;
@@ -821,7 +847,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restric
     }
     __syncthreads();
     const float* gsample = gout + n * (long)P * C;
-    const float* isample = img + n * (long)Q * C;
+    const float* isample = img + (n % Nimg) * (long)Q * C;
     const int sub = tid & (G - 1), grp = tid / G, ngrp = 256 / G;
     // ---- (A) grid gradient of this workgroup's output pixels (every lane of a wave runs the same trip count)
     for (int j0 = 0; j0 < S; j0 += ngrp) {
@@ -1324,15 +1350,19 @@ int cg_affine_grid_backward(void* stream, const float* ggrid, float* gT, int N, 
     hipLaunchKernelGGL(affine_grid_bwd_k, dim3(N), dim3(256), 0, cg::S(stream), ggrid, gT, N, H, W);
     CG_LAUNCH_CHECK(); return 0;
 }
-int cg_bilinear_sampler_forward(void* stream, const float* img, const float* grid, float* out, int N, int Hi, int Wi,
-                                int C, int Ho, int Wo) {
-    CG_REQUIRE(img && grid && out, "cg_bilinear_sampler_forward: null pointer");
+namespace {
+int sampler_forward(void* stream, const float* img, const float* grid, float* out, int N, int Nimg, int Hi, int Wi, int C, int Ho,
+                    int Wo) {
     const long total = (long)N * Ho * Wo * C;
-    EW_LAUNCH(bilinear_fwd_k, total, img, grid, out, N, Hi, Wi, C, Ho, Wo); return 0;
+    if (C % 4 == 0 && al16(img) && al16(out) && (uintptr_t)grid % 8 == 0) {
+        EW_LAUNCH(bilinear_fwd_v4k, total / 4, img, grid, out, N, Nimg, Hi, Wi, C / 4, Ho, Wo);
+        return 0;
+    }
+    EW_LAUNCH(bilinear_fwd_k, total, img, grid, out, N, Nimg, Hi, Wi, C, Ho, Wo); return 0;
 }
-int cg_bilinear_sampler_backward(void* stream, const float* img, const float* grid, const float* gout, float* gimg,
-                                 float* ggrid, int N, int Hi, int Wi, int C, int Ho, int Wo) {
-    CG_REQUIRE(img && grid && gout && gimg && ggrid, "cg_bilinear_sampler_backward: null pointer");
+
+int sampler_backward(void* stream, const float* img, const float* grid, const float* gout, float* gimg, float* ggrid, int N, int Nimg,
+                     int Hi, int Wi, int C, int Ho, int Wo) {
     const long P = (long)Ho * Wo, Q = (long)Hi * Wi;
     const size_t shb = ((size_t)5 * P + 2 * ((size_t)(Hi + 1) * (Wi + 1)) + 1) * 4;
     if (cg::opt(cg::OPT_SAMPLER_ATOMICS) == 0 && shb <= 150 * 1024 && C <= 256 && N > 0) {   // deterministic gather form
@@ -1342,7 +1372,7 @@ int cg_bilinear_sampler_backward(void* stream, const float* img, const float* gr
         const int S = std::max(std::max(32, 256 / G), cg::cdiv(std::max(P, Q), 16));
         const int nchunks = cg::cdiv(std::max(P, Q), S);
         const dim3 grd((unsigned)((long)N * nchunks)), blk(256);
-#define CG_BILIN_DET(GG, K) hipLaunchKernelGGL((bilinear_bwd_det_k<GG, K>), grd, blk, shb, cg::S(stream), img, grid, gout, gimg, ggrid, Hi, Wi, C, Ho, Wo, nchunks, S)
+#define CG_BILIN_DET(GG, K) hipLaunchKernelGGL((bilinear_bwd_det_k<GG, K>), grd, blk, shb, cg::S(stream), img, grid, gout, gimg, ggrid, Nimg, Hi, Wi, C, Ho, Wo, nchunks, S)
         if (G == 4) CG_BILIN_DET(4, 1);
         else if (G == 8) CG_BILIN_DET(8, 1);
         else if (G == 16) CG_BILIN_DET(16, 1);
@@ -1362,7 +1392,7 @@ int cg_bilinear_sampler_backward(void* stream, const float* img, const float* gr
     if (blocks > cg::kNumCU * 8) blocks = cg::kNumCU * 8;
     if (blocks < 1) blocks = 1;
     const dim3 grd((unsigned)blocks), blk(256);
-#define CG_BILIN_BWD(GG) hipLaunchKernelGGL(bilinear_bwd_k<GG>, grd, blk, 0, cg::S(stream), img, grid, gout, gimg, ggrid, N, Hi, Wi, C, Ho, Wo)
+#define CG_BILIN_BWD(GG) hipLaunchKernelGGL(bilinear_bwd_k<GG>, grd, blk, 0, cg::S(stream), img, grid, gout, gimg, ggrid, N, Nimg, Hi, Wi, C, Ho, Wo)
     switch (G) {
         case 4: CG_BILIN_BWD(4); break;
         case 8: CG_BILIN_BWD(8); break;
@@ -1372,6 +1402,28 @@ int cg_bilinear_sampler_backward(void* stream, const float* img, const float* gr
     }
 #undef CG_BILIN_BWD
     CG_LAUNCH_CHECK(); return 0;
+}
+}  // namespace
+
+int cg_bilinear_sampler_forward(void* stream, const float* img, const float* grid, float* out, int N, int Hi, int Wi,
+                                int C, int Ho, int Wo) {
+    CG_REQUIRE(img && grid && out && N > 0, "cg_bilinear_sampler_forward: null pointer");
+    return sampler_forward(stream, img, grid, out, N, N, Hi, Wi, C, Ho, Wo);
+}
+int cg_bilinear_sampler_backward(void* stream, const float* img, const float* grid, const float* gout, float* gimg,
+                                 float* ggrid, int N, int Hi, int Wi, int C, int Ho, int Wo) {
+    CG_REQUIRE(img && grid && gout && gimg && ggrid && N > 0, "cg_bilinear_sampler_backward: null pointer");
+    return sampler_backward(stream, img, grid, gout, gimg, ggrid, N, N, Hi, Wi, C, Ho, Wo);
+}
+int cg_bilinear_sampler_forward_shared(void* stream, int ngroups, const float* img, const float* grid, float* out, int N, int Hi,
+                                       int Wi, int C, int Ho, int Wo) {
+    CG_REQUIRE(img && grid && out && N > 0 && ngroups >= 1, "cg_bilinear_sampler_forward_shared: bad arguments");
+    return sampler_forward(stream, img, grid, out, ngroups * N, N, Hi, Wi, C, Ho, Wo);
+}
+int cg_bilinear_sampler_backward_shared(void* stream, int ngroups, const float* img, const float* grid, const float* gout,
+                                        float* gimg, float* ggrid, int N, int Hi, int Wi, int C, int Ho, int Wo) {
+    CG_REQUIRE(img && grid && gout && gimg && ggrid && N > 0 && ngroups >= 1, "cg_bilinear_sampler_backward_shared: bad arguments");
+    return sampler_backward(stream, img, grid, gout, gimg, ggrid, ngroups * N, N, Hi, Wi, C, Ho, Wo);
 }
 
 int cg_adam_step(void* stream, float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2,

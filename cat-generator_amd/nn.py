@@ -1826,15 +1826,49 @@ class BilinearSamplerBHWD(Module):
         self.gradInput = [gimg, ggrid]
         return self.gradInput
 
+    shared = os.environ.get("CG_SAMPLER_SHARED", "1") != "0"
+
     @staticmethod
     def _group_forward(mods, inputs, ctx):
+        """Sibling transformers sampling the SAME image tensor with stacked grids (D32_st3's branches): one launch over the
+        G * N samples (cg_bilinear_sampler_forward_shared); else one launch per branch into the slices of one block."""
+        m0, G = mods[0], len(mods)
+        m0._shared = None
         if _Stackable.stacking:
-            (N, _, _, C), (_, Ho, Wo, _) = inputs[0][0].shape, inputs[0][1].shape
+            (N, Hi, Wi, C), (_, Ho, Wo, _) = inputs[0][0].shape, inputs[0][1].shape
+            grids = _stacked([i_[1] for i_ in inputs])
+            img = inputs[0][0]
+            if (fusion and BilinearSamplerBHWD.shared and grids is not None and img.fmt == "plain" and grids.fmt == "plain"
+                    and all(i_[0].ptr == img.ptr and i_[0].shape == img.shape for i_ in inputs)):
+                out = m0._get(("out", "block"), (G * N, Ho, Wo, C))
+                lib().bilinear_sampler_forward_shared(stream(), G, img.ptr, grids.ptr, out.ptr, N, Hi, Wi, C, Ho, Wo)
+                ys = _split(out, G)
+                for m, y in zip(mods, ys):
+                    m.output = y
+                m0._shared = (out, grids)
+                return ys
             _seed_slices(mods, "out", (N, Ho, Wo, C), "plain")
         return Module._group_forward(mods, inputs, ctx)
 
     @staticmethod
     def _group_backward(mods, inputs, gouts, scale, acc, ctx):
+        m0, G = mods[0], len(mods)
+        sh = getattr(m0, "_shared", None)
+        if (sh is not None and isinstance(m0.output, Tensor) and m0.output.grp is not None and m0.output.grp[0] is sh[0].t
+                and all(g.fmt == "plain" for g in gouts)):
+            img, grids = inputs[0][0], sh[1]
+            (N, Hi, Wi, C), (_, Ho, Wo, _) = img.shape, inputs[0][1].shape
+            Gd = _stacked(gouts)
+            if Gd is None:
+                Gd = _restack(m0, gouts, gouts[0])
+            gimg = m0._get(("gimg", "block"), (G * N, Hi, Wi, C))
+            ggrid = m0._get(("ggrid", "block"), (G * N, Ho, Wo, 2))
+            lib().bilinear_sampler_backward_shared(stream(), G, img.ptr, grids.ptr, Gd.ptr, gimg.ptr, ggrid.ptr, N, Hi, Wi, C, Ho, Wo)
+            res = []
+            for m, gi, gg in zip(mods, _split(gimg, G), _split(ggrid, G)):
+                m.gradInput = [gi, gg]
+                res.append(m.gradInput)
+            return res
         if _Stackable.stacking:
             _seed_slices(mods, "ggrid", inputs[0][1].shape, "plain")
         return Module._group_backward(mods, inputs, gouts, scale, acc, ctx)

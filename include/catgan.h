@@ -383,6 +383,12 @@ int cg_bilinear_sampler_forward(void* stream, const float* img, const float* gri
 int cg_bilinear_sampler_backward(void* stream, const float* img, const float* grid, const float* gout,
                                  float* gimg, float* ggrid,
                                  int N, int Hi, int Wi, int C, int Ho, int Wo);
+/* `ngroups` sibling transformers sampling the SAME images [N,Hi,Wi,C] with their own grids (D32_st3's three branches,
+ * models.lua:655-686): grid / out / gout / gimg / ggrid are the branch-major stacks of ngroups * N samples, one launch. */
+int cg_bilinear_sampler_forward_shared(void* stream, int ngroups, const float* img, const float* grid, float* out,
+                                       int N, int Hi, int Wi, int C, int Ho, int Wo);
+int cg_bilinear_sampler_backward_shared(void* stream, int ngroups, const float* img, const float* grid, const float* gout,
+                                        float* gimg, float* ggrid, int N, int Hi, int Wi, int C, int Ho, int Wo);
 
 /* ---- collectives of the data-parallel step (csrc/comm.hip; RCCL over xGMI) ---------------------------------
  * The reference is single-GPU (train.lua:108-112).  The step shards on the batch: one process per GPU,

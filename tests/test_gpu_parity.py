@@ -250,6 +250,38 @@ def test_spatial_transformer_module(cg):
     close(P2.forward(cg.Tensor.from_numpy(x2)).numpy(), x2, tol=1e-6)
 
 
+@pytest.mark.parametrize("C,H", [(64, 16), (3, 32), (6, 8)])
+def test_shared_image_sampler_equals_one_launch_per_branch(cg, C, H):
+    """cg_bilinear_sampler_{forward,backward}_shared (G sibling transformers on the same images, one launch) against G plain
+    calls - bit for bit (the backward is the deterministic gather form) - and the plain forward against the oracle, for
+    the float4 (C % 4 == 0) and the scalar kernels; grids reach outside [-1, 1]."""
+    rs = np.random.RandomState(C)
+    N, G = 5, 3
+    img = rs.randn(N, H, H, C).astype(f32)
+    grid = (rs.rand(G * N, H, H, 2) * 2.6 - 1.3).astype(f32)
+    gout = rs.randn(G * N, H, H, C).astype(f32)
+    L, st = cg.lib(), cg.tensor.stream()
+    T = lambda a: cg.Tensor.from_numpy(a, "plain")
+    ti, tg, to = T(img), T(grid), T(gout)
+    out = cg.Tensor.empty((G * N, H, H, C)); gimg = cg.Tensor.empty((G * N, H, H, C)); ggrid = cg.Tensor.empty((G * N, H, H, 2))
+    L.bilinear_sampler_forward_shared(st, G, ti.ptr, tg.ptr, out.ptr, N, H, H, C, H, H)
+    L.bilinear_sampler_backward_shared(st, G, ti.ptr, tg.ptr, to.ptr, gimg.ptr, ggrid.ptr, N, H, H, C, H, H)
+    o_s, gi_s, gg_s = out.numpy(), gimg.numpy(), ggrid.numpy()
+    for b in range(G):
+        sl = slice(b * N, (b + 1) * N)
+        tgb, tob = T(grid[sl]), T(gout[sl])
+        o1 = cg.Tensor.empty((N, H, H, C)); gi1 = cg.Tensor.empty((N, H, H, C)); gg1 = cg.Tensor.empty((N, H, H, 2))
+        L.bilinear_sampler_forward(st, ti.ptr, tgb.ptr, o1.ptr, N, H, H, C, H, H)
+        L.bilinear_sampler_backward(st, ti.ptr, tgb.ptr, tob.ptr, gi1.ptr, gg1.ptr, N, H, H, C, H, H)
+        np.testing.assert_array_equal(o_s[sl], o1.numpy())
+        np.testing.assert_array_equal(gi_s[sl], gi1.numpy())
+        np.testing.assert_array_equal(gg_s[sl], gg1.numpy())
+        close(o1.numpy(), O.bilinear_forward(img, grid[sl]), tol=2e-6, what="sampler forward")
+        gi_o, gg_o = O.bilinear_backward(img, grid[sl], gout[sl])
+        close(gi1.numpy(), gi_o, K=16, tol=1e-5, what="sampler gradInput")
+        close(gg1.numpy(), gg_o, K=C, tol=2e-5, what="sampler gradGrid")
+
+
 def test_adam_and_fused_penalty_clamp(cg):
     rs = np.random.RandomState(6)
     n = 100003
