@@ -36,6 +36,37 @@ def test_dataset_loader(tmp_path):
     ds.colorSpace = "rgb"
 
 
+def test_image_grids_and_png_writer(tmp_path):
+    """nn_utils.lua:526-583: grid layout (row by row, 7 extra rows), the epoch digits at the bottom right (3 x 5 glyphs, last
+    digit rightmost, 6 px pitch), and the PNG on disk read back with PIL."""
+    from PIL import Image
+    U = importlib.import_module("cat-generator_amd.nn_utils")
+    rs = np.random.RandomState(0)
+    imgs = rs.rand(7, 3, 8, 8).astype(np.float32)
+    g = U.imagesToGridTensor(imgs, 2, 3, 407)
+    assert g.shape == (3, 2 * 8 + 7, 3 * 8)
+    np.testing.assert_array_equal(g[:, 0:8, 8:16], imgs[1])
+    np.testing.assert_array_equal(g[:, 8:16, 0:8], imgs[3])       # second row starts with the 4th image; the 7th is dropped
+    Hpx, Wpx = g.shape[1:]
+    seven = np.array([[1, 1, 1], [0, 0, 1], [0, 0, 1], [0, 0, 1], [0, 0, 1]], np.float32)
+    four = np.array([[1, 0, 1], [1, 0, 1], [1, 1, 1], [0, 0, 1], [0, 0, 1]], np.float32)
+    zero = np.array([[1, 1, 1], [1, 0, 1], [1, 0, 1], [1, 0, 1], [1, 1, 1]], np.float32)
+    for pos, glyph in ((1, seven), (2, zero), (3, four)):
+        x0 = Wpx - 1 - pos * 5 - pos - 1
+        np.testing.assert_array_equal(g[1, Hpx - 7:Hpx - 2, x0:x0 + 3], glyph)
+    assert g[:, Hpx - 2:, :].sum() == 0 and Hpx - 7 == 16              # digits start right below the images, two blank rows under them
+    path = tmp_path / "images" / "0_00407.png"
+    U.saveImagesAsGrid(str(path), imgs, 2, 3, 407)
+    back = np.asarray(Image.open(str(path)))
+    assert back.shape == (Hpx, Wpx, 3)
+    np.testing.assert_array_equal(back.transpose(2, 0, 1), np.rint(g * 255).astype(np.uint8))
+    y = U.toRgb(rs.rand(2, 1, 8, 8).astype(np.float32), "y")
+    assert y.shape == (2, 3, 8, 8) and np.array_equal(y[:, 0], y[:, 2])
+    gray = U._png_bytes(rs.rand(1, 5, 4).astype(np.float32))        # single-channel PNGs too
+    import io
+    assert np.asarray(Image.open(io.BytesIO(gray))).shape == (5, 4)
+
+
 @pytest.mark.gpu
 def test_train_cli_runs_epochs_and_resumes(tmp_path):
     _make_jpgs(str(tmp_path), n=40)

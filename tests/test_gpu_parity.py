@@ -8,6 +8,8 @@ tests/test_oracle_vs_torch.py) and are checked tight-on-the-bulk / loose-on-the-
 """
 import importlib
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -636,6 +638,36 @@ def test_sampling_in_evaluate_mode_and_ranking(cg):
     assert np.all(np.diff(preds) <= 0) and sorted_imgs.shape == (20, 3, 32, 32)
     cg.nn_utils.switchToTrainingMode(S)
     assert all(m.train for m in G.listModules())
+
+
+def test_visualize_progress_writes_the_three_grids_and_rates_with_v(cg, tmp_path):
+    """nn_utils.lua:130-186: fixed-noise images, D's best / worst 50 with the two planted sanity images,
+    the PNG grids with the epoch digits, V's ratings; the nets come back in training mode."""
+    from PIL import Image
+    cg.manual_seed(3)
+    G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
+    S = cg.adversarial.State(dict(batchSize=32), G, D)
+    S.EPOCH = 12
+    S.MODEL_V = cg.nn.Sequential().add(cg.nn.View(3 * 32 * 32)).add(cg.nn.Linear(3 * 32 * 32, 2)).add(cg.nn.Sigmoid())
+    rs = np.random.RandomState(1)
+    z = (rs.rand(100, 100) * 2 - 1).astype(f32)
+    train = rs.rand(60, 3, 32, 32).astype(f32)
+    plot = []
+    out = cg.nn_utils.visualizeProgress(S, z, train, str(tmp_path), start_time=7, plot_data=plot)
+    for sub, side in (("images", 10), ("images_good", 7), ("images_bad", 7)):
+        im = np.asarray(Image.open(out[sub]))
+        assert out[sub].endswith(os.path.join(sub, "7_00012.png")) and im.shape == (side * 32 + 7, side * 32, 3)
+        assert im[-7:-2, -8:-5].max() == 255            # the last digit ('2') is drawn
+    assert len(plot) == 1 and plot[0][0] == 12 and all(0.0 <= r <= 1.0 for r in plot[0][1:])
+    imgs = cg.nn_utils.createImagesFromNoise(S, z)       # V's rating of the fixed-noise images, recomputed by hand
+    cg.nn_utils.switchToEvaluationMode(S)
+    ev = cg.nn.as_nhwc(cg.nn_utils.createImagesFromNoise(S, z)).numpy()
+    cg.nn_utils.switchToTrainingMode(S)
+    w, b = S.MODEL_V.modules[1].weight.numpy(), S.MODEL_V.modules[1].bias.numpy()
+    p0 = 1.0 / (1.0 + np.exp(-(ev.reshape(100, -1) @ w[0] + b[0])))
+    assert abs((1.0 - p0.mean()) - out["ratings"][0]) < 1e-4
+    assert all(m.train for m in G.listModules()) and all(m.train for m in D.listModules())
+    del imgs
 
 
 # ------------------------------------------------------------------------------ fused chains (nn.fusion)
