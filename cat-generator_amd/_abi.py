@@ -16,7 +16,7 @@ _CTYPES = {
     "void*": C.c_void_p, "const void*": C.c_void_p, "void**": C.POINTER(C.c_void_p),
     "float*": C.c_void_p, "const float*": C.c_void_p,
     "const float* const*": C.c_void_p, "float* const*": C.c_void_p,
-    "double*": C.c_void_p, "const double*": C.c_void_p,
+    "double*": C.c_void_p, "const double*": C.c_void_p, "const unsigned char*": C.c_void_p,
     "int32_t*": C.c_void_p, "const int32_t*": C.c_void_p, "uint64_t*": C.c_void_p, "const uint64_t*": C.c_void_p,
     "int32_t": C.c_int32, "int*": C.POINTER(C.c_int), "long*": C.POINTER(C.c_long), "const int*": C.POINTER(C.c_int),
     "int": C.c_int, "long": C.c_long, "float": C.c_float, "double": C.c_double,

@@ -87,3 +87,62 @@ def load(path, S):
         else:
             st[k] = Tensor.from_numpy(v, fmt="plain")
     return S
+
+
+# ------------------------------------------------------------------ Torch7-format export / import
+def export_t7(path, S, plot_data=None, cuda=False, normalize_mean=None, normalize_std=None):
+    """saveAs (train.lua:252-261) in torch.save's own format: {D, G, opt, plot_data, epoch, normalize_mean, normalize_std},
+    the nets as nn / cudnn / stn objects with canonical parameter layouts.  Also writes `optstate` - the field the reference's
+    resume reads (train.lua:132) but its saveAs never wrote - with optim.adam's t / m / v over the flat vectors."""
+    from . import t7, t7_nn
+    opt = {k: v for k, v in S.OPT.items() if isinstance(v, (int, float, str, bool))}
+    optstate = {}
+    for method, per_net in S.OPTSTATE.items():
+        optstate[method] = {}
+        for net, st in per_net.items():
+            d = {}
+            for k, v in st.items():
+                if isinstance(v, Tensor):
+                    d[k] = np.ascontiguousarray(v.numpy(), dtype=np.float32)
+                elif isinstance(v, (int, float, bool)) and k != "device_step":
+                    d[k] = int(st["t_dev"].item()) if k == "t" and "t_dev" in st else v
+            optstate[method][net] = d
+    obj = {"D": t7_nn.to_t7(S.MODEL_D, cuda), "G": t7_nn.to_t7(S.MODEL_G, cuda), "opt": opt,
+           "plot_data": [list(r) for r in (plot_data or [])], "epoch": int(S.EPOCH), "optstate": optstate}
+    if normalize_mean is not None:
+        obj["normalize_mean"], obj["normalize_std"] = normalize_mean, normalize_std
+    return t7.save(path, obj)
+
+
+def import_t7(path):
+    """torch.load of a {D, G, opt, epoch, ...} file (train.lua:129-135, sample.lua:69-75): returns a dict with the nets
+    rebuilt as engine modules (G, D), and opt / epoch / plot_data / optstate as plain Python values."""
+    from . import t7, t7_nn
+    z = t7.load(path)
+    out = {k: v for k, v in z.items() if k not in ("D", "G")}
+    for k in ("D", "G"):
+        if z.get(k) is not None:
+            out[k] = t7_nn.from_t7(z[k])
+    if isinstance(out.get("plot_data"), dict):
+        out["plot_data"] = [t7.table_list(r) if isinstance(r, dict) else r for r in t7.table_list(out["plot_data"])]
+    return out
+
+
+def load_t7(path, S):
+    """--network with a torch.save file (train.lua:127-142): parameters and batch-norm statistics of D and G, epoch, and the
+    optimiser state when the file has one (the reference's own files do not: Adam then restarts, as it does upstream)."""
+    z = import_t7(path)
+    for net, flat in (("G", S.PARAMETERS_G), ("D", S.PARAMETERS_D)):
+        src, _ = z[net].getParameters()
+        if src.nElement() != flat.nElement():
+            raise ValueError(f"{path}: net {net} has {src.nElement()} parameters, the configured model {flat.nElement()}")
+        flat.copy(src.numpy())
+    for a, b in zip(_bn_modules(S.MODEL_G), _bn_modules(z["G"])):
+        a.running_mean.copy(b.running_mean.numpy()); a.running_var.copy(b.running_var.numpy())
+    S.EPOCH = int(z.get("epoch", 0)) + 1                    # train.lua:133
+    for method, per_net in (z.get("optstate") or {}).items():
+        for net, st in per_net.items():
+            dst = S.OPTSTATE.setdefault(method, {}).setdefault(net, {})
+            for k, v in st.items():
+                dst[k] = Tensor.from_numpy(v, fmt="plain") if isinstance(v, np.ndarray) else v
+    return S

@@ -50,6 +50,20 @@ using cg::wave_sum;
 #define GRID_STRIDE(i, n) \
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
+// ---------------------------------------------------------------- input pipeline
+// one lane per pixel; every operation correctly rounded on its own, like the numpy loader's
+__global__ void images_u8_to_f32_k(const unsigned char* __restrict__ src, float* __restrict__ dst, long npix, int cs) {
+#pragma clang fp contract(off)   // no fma: the same three products and two sums the numpy loader rounds one by one
+    GRID_STRIDE(i, npix) {
+        const float r = __fdiv_rn((float)src[3 * i], 255.f), g = __fdiv_rn((float)src[3 * i + 1], 255.f), b = __fdiv_rn((float)src[3 * i + 2], 255.f);
+        if (cs == 0) { dst[3 * i] = r; dst[3 * i + 1] = g; dst[3 * i + 2] = b; }
+        else {
+            const float t0 = 0.21f * r, t1 = 0.72f * g, t2 = 0.07f * b;   // plain operators: the pragma above governs them
+            dst[i] = (t0 + t1) + t2;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- activations
 // Memory-bound elementwise kernels move 16 B per lane (float4) when the buffers are 16-B aligned; `n4` counts
 // whole float4s, the (<4)-element tail is handled by the last lanes with scalar accesses.
@@ -1052,6 +1066,34 @@ int cg_stream_create(void** stream) {
 }
 int cg_stream_destroy(void* stream) { CG_HIP(hipStreamDestroy(cg::S(stream))); return 0; }
 int cg_stream_sync(void* stream) { CG_HIP(hipStreamSynchronize(cg::S(stream))); return 0; }
+
+int cg_host_alloc(void** hptr, size_t bytes) {
+    CG_REQUIRE(hptr && bytes > 0, "cg_host_alloc: bad arguments");
+    CG_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return 0;
+}
+int cg_host_free(void* hptr) { if (hptr) CG_HIP(hipHostFree(hptr)); return 0; }
+int cg_event_create(void** event) {
+    CG_REQUIRE(event, "cg_event_create: null pointer");
+    hipEvent_t e; CG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); *event = (void*)e; return 0;
+}
+int cg_event_destroy(void* event) { if (event) CG_HIP(hipEventDestroy((hipEvent_t)event)); return 0; }
+int cg_event_record(void* event, void* stream) {
+    CG_REQUIRE(event, "cg_event_record: null event");
+    CG_HIP(hipEventRecord((hipEvent_t)event, cg::S(stream))); return 0;
+}
+int cg_event_sync(void* event) {
+    CG_REQUIRE(event, "cg_event_sync: null event");
+    CG_HIP(hipEventSynchronize((hipEvent_t)event)); return 0;
+}
+int cg_stream_wait_event(void* stream, void* event) {
+    CG_REQUIRE(event, "cg_stream_wait_event: null event");
+    CG_HIP(hipStreamWaitEvent(cg::S(stream), (hipEvent_t)event, 0)); return 0;
+}
+int cg_images_u8_to_f32(void* stream, const unsigned char* src, float* dst, long npixels, int colorspace) {
+    CG_REQUIRE(src && dst && npixels > 0 && (colorspace == 0 || colorspace == 1), "cg_images_u8_to_f32: bad arguments");
+    EW_LAUNCH(images_u8_to_f32_k, npixels, src, dst, npixels, colorspace); return 0;
+}
 
 int cg_prelu_forward(void* stream, const float* x, const float* alpha, float* y, long n) {
     CG_REQUIRE(x && alpha && y, "cg_prelu_forward: null pointer");

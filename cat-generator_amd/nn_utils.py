@@ -192,7 +192,7 @@ def visualizeProgress(S, noiseInputs, trainImages, save_dir, start_time=0, plot_
     try:
         train = np.asarray(trainImages, dtype=np.float32)[:50]
         C, H, W = train.shape[1:]
-        sanity = S.random.uniform(0.0, 0.5, size=(C, H, W)).astype(np.float32)
+        sanity = np.random.RandomState(S.EPOCH).uniform(0.0, 0.5, size=(C, H, W)).astype(np.float32)   # not S.random: it draws the batches
         for i in range(1, H + 1):               # the reference walks OPT.scale (= the image side) in both directions
             for j in range(1, W + 1):
                 if i == j:

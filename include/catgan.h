@@ -62,6 +62,19 @@ int cg_memset_zero(void* stream, void* dst, size_t bytes);
 int cg_stream_create(void** stream);
 int cg_stream_destroy(void* stream);
 int cg_stream_sync(void* stream);
+/* Input pipeline (dataset.lua:123-170, adversarial.lua:225-230): page-locked host buffers, so that cg_memcpy_h2d on a copy
+ * stream really is asynchronous, and events to hand a finished upload over to the compute stream without a host sync. */
+int cg_host_alloc(void** hptr, size_t bytes);
+int cg_host_free(void* hptr);
+int cg_event_create(void** event);
+int cg_event_destroy(void* event);
+int cg_event_record(void* event, void* stream);
+int cg_event_sync(void* event);
+int cg_stream_wait_event(void* stream, void* event);
+/* Decoded images as the loader produces them (8-bit RGB, [N][H][W][3]) -> the engine's fp32 NHWC pool in [0,1]:
+ * colorspace 0 'rgb' (3 planes, v / 255), 1 'y' (1 plane, 0.21 R + 0.72 G + 0.07 B of the scaled values,
+ * nn_utils.lua:253-277).  Every operation is a single correctly rounded fp32 one, in the host loader's order. */
+int cg_images_u8_to_f32(void* stream, const unsigned char* src, float* dst, long npixels, int colorspace);
 
 /* ---- convolution / linear (implicit GEMM on fp32 MFMA) -------------------
  * Replaces cudnn.SpatialConvolution (models.lua:206,212,218,222),

@@ -68,6 +68,44 @@ def test_image_grids_and_png_writer(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cs", ["rgb", "y"])
+def test_async_loader_pools_equal_the_blocking_loader(tmp_path, cs):
+    """dataset.AsyncLoader (pinned 8-bit staging, copy stream, device-side conversion, two HBM pools) against
+    loadRandomImages + upload: the same images in the same order with the same bits, over four epochs (both pools reused),
+    with training-stream work reading the previous pool in between, and when fewer files exist than were asked for."""
+    import torch
+    cg = importlib.import_module("cat-generator_amd")
+    ds = importlib.import_module("cat-generator_amd.dataset")
+    _make_jpgs(str(tmp_path), n=9)
+    ds.setDirs([str(tmp_path)]); ds.setFileExtension("jpg"); ds.setHeight(32); ds.setWidth(32)
+    ds.colorSpace = cs
+    try:
+        ds.seed(5)
+        ref = [ds.loadRandomImages(6).scaled for _ in range(4)]
+        ds.seed(5)
+        ld = ds.AsyncLoader(6)
+        keep = []
+        for e in range(4):
+            pool = ld.next()
+            data = cg.adversarial.TrainData(pool)
+            assert data.size() == 6
+            np.testing.assert_array_equal(cg.nn.as_nhwc(pool).numpy(), ref[e])
+            keep.append(pool.t.sum())            # work on the training stream that reads this pool while the next one loads
+        torch.cuda.synchronize()
+        ld.close()
+        ds.seed(7)
+        few_ref = ds.loadRandomImages(20).scaled
+        ds.seed(7)
+        ld = ds.AsyncLoader(20)
+        few = ld.next()
+        assert few.shape[0] == 9
+        np.testing.assert_array_equal(cg.nn.as_nhwc(few).numpy(), few_ref)
+        ld.close()
+    finally:
+        ds.colorSpace = "rgb"
+
+
+@pytest.mark.gpu
 def test_train_cli_runs_epochs_and_resumes(tmp_path):
     _make_jpgs(str(tmp_path), n=40)
     cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--batchSize", "16", "--N_epoch", "32", "--epochs", "2",

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """train.lua on the engine: same flags (train.lua:15-49), same set-up order (:115-220: D, G,
 criterion, flat parameters, optimiser state) and the same endless epoch loop (:223-248) around adversarial.train.
-Not reproduced: the V network and plotting (`--noplot` is implied).
+Per epoch (unless --noplot): the image grids of NN_UTILS.visualizeProgress (PNG files; no display server).  The V network
+is not trained here (train_v.lua is out of scope): ratings appear only when a V is attached to the state.
 
     python train.py --batchSize 128 --N_epoch 1000 --epochs 3 --synthetic          # no dataset needed
     python train.py --dataDir dataset/out_aug_64x64 --colorSpace y --saveFreq 30
@@ -33,6 +34,8 @@ def parse():
     a("--seed", type=int, default=1); a("--colorSpace", default="rgb", choices=["rgb", "y"])
     a("--dataDir", default="dataset/out_aug_64x64"); a("--synthetic", action="store_true")
     a("--epochs", type=int, default=0, help="stop after this many epochs (0 = run forever, as train.lua does)")
+    a("--noplot", action="store_true", help="train.lua:33 - skip the per-epoch image grids (logs/images*/<start>_<epoch>.png)")
+    a("--blockingLoader", action="store_true", help="decode + upload each epoch's images on the training thread (dataset.loadRandomImages)")
     return ap.parse_args()
 
 
@@ -55,15 +58,26 @@ def main():
     ds.setDirs([o.dataDir]); ds.seed(o.seed)
     if o.network:   # after every generator was seeded: the checkpoint puts each of them back where the run stopped
         print(f"<trainer> reloading previously trained network: {o.network}")
-        cg.checkpoint.load(o.network, S)
+        (cg.checkpoint.load_t7 if o.network.endswith(".net") else cg.checkpoint.load)(o.network, S)
     n_pool = o.N_epoch if o.N_epoch > 0 else 10000
+    import time
+    START_TIME = int(time.time())                                  # train.lua:58
+    PLOT_DATA = []
+    # train.lua:216: the same 100 noise vectors every epoch (a generator of their own: the training streams do not move)
+    VIS_NOISE_INPUTS = np.random.RandomState(o.seed).uniform(-1, 1, (100, o.noiseDim)).astype(np.float32)
+    loader = None if (o.synthetic or o.blockingLoader) else ds.AsyncLoader(n_pool)   # the next epoch's pool loads while this one trains
     while True:                                                    # train.lua:223
         print("Loading new training data...")
         if o.synthetic:
             pool = np.random.RandomState(S.EPOCH).rand(n_pool, C, o.scale, o.scale).astype(np.float32)
+        elif loader is not None:
+            pool = loader.next()
         else:
             pool = ds.loadRandomImages(n_pool).scaled              # train.lua:225
         TRAIN_DATA = cg.adversarial.TrainData(pool)
+        if not o.noplot:                                           # train.lua:228-236
+            first = cg.nn.as_nhwc(TRAIN_DATA.pool.rows(1, min(50, TRAIN_DATA.size()))).numpy()
+            cg.nn_utils.visualizeProgress(S, VIS_NOISE_INPUTS, first, o.save, START_TIME, PLOT_DATA, verbose=True)
         cg.adversarial.train(S, TRAIN_DATA, o.D_maxAcc, max(20, min(1000 // o.batchSize, 250)))   # train.lua:238
         if (S.EPOCH - 1) % o.saveFreq == 0:                        # train.lua:241-244 (EPOCH was already advanced)
             os.makedirs(o.save, exist_ok=True)
@@ -72,6 +86,7 @@ def main():
                 os.replace(fn, fn + ".old")
             print(f"<trainer> saving network to {fn}")
             cg.checkpoint.save(fn, S)
+            cg.checkpoint.export_t7(os.path.join(o.save, "adversarial.net"), S, PLOT_DATA)   # torch.save's format, train.lua:252-261
         if o.epochs and S.EPOCH > o.epochs:
             break
 
