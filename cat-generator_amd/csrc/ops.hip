@@ -798,7 +798,27 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const float* img, const fl
 //   (B) for its S SOURCE pixels: gimg[q] = sum over the output pixels in the four buckets (y-1..y, x-1..x) that cover q,
 //       in bucket order - a gather: every gimg element is written exactly once (no memset), in a fixed summation order.
 // G = lanes per pixel (smallest power of two >= min(C, 64)); CACC = channels per lane.
-template <int G, int CACC>
+// VW = floats per lane access: 4 when C % 4 == 0 and the tensors are 16-B aligned (a wave then covers 64 / G pixels with G = C / 4
+// lanes each instead of one pixel per 64 channels), else 1.  A lane owns channels (sub + G * k) * VW .. + VW - 1.
+template <int VW> struct BVec;
+template <> struct BVec<1> {
+    typedef float T;
+    static __device__ __forceinline__ T zero() { return 0.f; }
+    static __device__ __forceinline__ T ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, T v) { *p = v; }
+    static __device__ __forceinline__ float dot(T a, T b) { return a * b; }
+    static __device__ __forceinline__ void fma(T& acc, float w, T g) { acc += w * g; }
+};
+template <> struct BVec<4> {
+    typedef float4 T;
+    static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ T ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ void st(float* p, T v) { *reinterpret_cast<float4*>(p) = v; }
+    static __device__ __forceinline__ float dot(T a, T b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+    static __device__ __forceinline__ void fma(T& acc, float w, T g) { acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w; }
+};
+
+template <int G, int CACC, int VW>
 __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restrict__ img, const float* __restrict__ grid,
                                                           const float* __restrict__ gout, float* __restrict__ gimg,
                                                           float* __restrict__ ggrid, int Nimg, int Hi, int Wi, int C, int Ho, int Wo,
@@ -825,16 +845,26 @@ __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restric
         if (t.y0 >= -1 && t.y0 <= Hi - 1 && t.x0 >= -1 && t.x0 <= Wi - 1) atomicAdd(&ccnt[(t.y0 + 1) * CW + t.x0 + 1], 1);
     }
     __syncthreads();
-    // exclusive scan of the bucket counts: per-thread chunk sums, serial scan of the 256 partials, chunk-local offsets
+    // exclusive scan of the bucket counts: per-thread chunk sums, wave-level prefix sums of the 256 partials (shuffles) plus
+    // the three wave totals, chunk-local offsets
     const int per = (NC + 255) / 256;
     int mine = 0;
     for (int c = tid * per; c < min(NC, (tid + 1) * per); ++c) mine += ccnt[c];
-    part[tid] = mine;
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
-        cstart[NC] = run;
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        __shared__ int wtot[4];
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wv; ++w) base += wtot[w];
+        part[tid] = base + incl - mine;
+        if (tid == 255) cstart[NC] = base + incl;
     }
     __syncthreads();
     {
@@ -878,12 +908,13 @@ __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restric
             const long o01 = C, o10 = (long)Wi * C, o11 = (long)Wi * C + C;
 #pragma unroll
             for (int k = 0; k < CACC; ++k) {
-                const int c = sub + G * k;
+                const int c = (sub + G * k) * VW;
                 if (c < C) {
-                    const float g = gsample[(long)p * C + c];
-                    const float i00 = (yin0 && xin0) ? isample[b + c] : 0.f, i01 = (yin0 && xin1) ? isample[b + o01 + c] : 0.f;
-                    const float i10 = (yin1 && xin0) ? isample[b + o10 + c] : 0.f, i11 = (yin1 && xin1) ? isample[b + o11 + c] : 0.f;
-                    d00 += i00 * g; d01 += i01 * g; d10 += i10 * g; d11 += i11 * g;
+                    typedef BVec<VW> V;
+                    const typename V::T g = V::ld(gsample + (long)p * C + c);
+                    const typename V::T i00 = (yin0 && xin0) ? V::ld(isample + b + c) : V::zero(), i01 = (yin0 && xin1) ? V::ld(isample + b + o01 + c) : V::zero();
+                    const typename V::T i10 = (yin1 && xin0) ? V::ld(isample + b + o10 + c) : V::zero(), i11 = (yin1 && xin1) ? V::ld(isample + b + o11 + c) : V::zero();
+                    d00 += V::dot(i00, g); d01 += V::dot(i01, g); d10 += V::dot(i10, g); d11 += V::dot(i11, g);
                 }
             }
         }
@@ -911,9 +942,10 @@ __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restric
         const int s2 = cstart[c00 + CW], n2 = ccnt[c00 + CW];
         const int s3 = cstart[c00 + CW + 1], n3 = ccnt[c00 + CW + 1];
         const int e1 = n0, e2 = n0 + n1, e3 = n0 + n1 + n2, total = e3 + n3;
-        float acc[CACC];
+        typedef BVec<VW> V;
+        typename V::T acc[CACC];
 #pragma unroll
-        for (int k = 0; k < CACC; ++k) acc[k] = 0.f;
+        for (int k = 0; k < CACC; ++k) acc[k] = V::zero();
         for (int i0 = 0; i0 < total; i0 += 4) {          // four gradient loads in flight, consumed in bucket order
             int ph[4];
             float w[4];
@@ -930,23 +962,23 @@ __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restric
                     ph[u] = ph[0]; w[u] = 0.f;            // padding: adds an exact +0
                 }
             }
-            float g[4][CACC];
+            typename V::T g[4][CACC];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int k = 0; k < CACC; ++k) {
-                    const int c = sub + G * k;
-                    g[u][k] = c < C ? gsample[(long)ph[u] * C + c] : 0.f;
+                    const int c = (sub + G * k) * VW;
+                    g[u][k] = c < C ? V::ld(gsample + (long)ph[u] * C + c) : V::zero();
                 }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int k = 0; k < CACC; ++k) acc[k] += w[u] * g[u][k];
+                for (int k = 0; k < CACC; ++k) V::fma(acc[k], w[u], g[u][k]);
         }
 #pragma unroll
         for (int k = 0; k < CACC; ++k) {
-            const int c = sub + G * k;
-            if (c < C) gimg[(n * Q + q) * C + c] = acc[k];
+            const int c = (sub + G * k) * VW;
+            if (c < C) V::st(gimg + (n * Q + q) * C + c, acc[k]);
         }
     }
 }
@@ -1408,20 +1440,30 @@ int sampler_backward(void* stream, const float* img, const float* grid, const fl
     const long P = (long)Ho * Wo, Q = (long)Hi * Wi;
     const size_t shb = ((size_t)5 * P + 2 * ((size_t)(Hi + 1) * (Wi + 1)) + 1) * 4;
     if (cg::opt(cg::OPT_SAMPLER_ATOMICS) == 0 && shb <= 150 * 1024 && C <= 256 && N > 0) {   // deterministic gather form
+        const bool v4 = C % 4 == 0 && al16(img) && al16(gout) && al16(gimg);
+        const int units = v4 ? C / 4 : C;                  // lane-sized channel units per pixel
         int G = 4;
-        while (G < 64 && G < C) G <<= 1;
-        // pixel slots per workgroup: at most 16 workgroups per sample (every workgroup stages and buckets all P taps again)
-        const int S = std::max(std::max(32, 256 / G), cg::cdiv(std::max(P, Q), 16));
+        while (G < 64 && G < units) G <<= 1;
+        // pixel slots per workgroup: at most 16 workgroups per sample (every workgroup stages and buckets all P taps again), and
+        // no more workgroups than keep the chip busy (~4 per CU) when the batch is large
+        const int want = std::max(1, std::min(16, (int)(cg::kNumCU * 4 / std::max(1, N))));
+        const int S = std::max(std::max(32, 256 / G), cg::cdiv(std::max(P, Q), want));
         const int nchunks = cg::cdiv(std::max(P, Q), S);
         const dim3 grd((unsigned)((long)N * nchunks)), blk(256);
-#define CG_BILIN_DET(GG, K) hipLaunchKernelGGL((bilinear_bwd_det_k<GG, K>), grd, blk, shb, cg::S(stream), img, grid, gout, gimg, ggrid, Nimg, Hi, Wi, C, Ho, Wo, nchunks, S)
-        if (G == 4) CG_BILIN_DET(4, 1);
-        else if (G == 8) CG_BILIN_DET(8, 1);
-        else if (G == 16) CG_BILIN_DET(16, 1);
-        else if (G == 32) CG_BILIN_DET(32, 1);
-        else if (C <= 64) CG_BILIN_DET(64, 1);
-        else if (C <= 128) CG_BILIN_DET(64, 2);
-        else CG_BILIN_DET(64, 4);
+#define CG_BILIN_DET(GG, K, VV) hipLaunchKernelGGL((bilinear_bwd_det_k<GG, K, VV>), grd, blk, shb, cg::S(stream), img, grid, gout, gimg, ggrid, Nimg, Hi, Wi, C, Ho, Wo, nchunks, S)
+        if (v4) {
+            if (G == 4) CG_BILIN_DET(4, 1, 4);
+            else if (G == 8) CG_BILIN_DET(8, 1, 4);
+            else if (G == 16) CG_BILIN_DET(16, 1, 4);
+            else if (G == 32) CG_BILIN_DET(32, 1, 4);
+            else CG_BILIN_DET(64, 1, 4);                   // C <= 256
+        } else if (G == 4) CG_BILIN_DET(4, 1, 1);
+        else if (G == 8) CG_BILIN_DET(8, 1, 1);
+        else if (G == 16) CG_BILIN_DET(16, 1, 1);
+        else if (G == 32) CG_BILIN_DET(32, 1, 1);
+        else if (C <= 64) CG_BILIN_DET(64, 1, 1);
+        else if (C <= 128) CG_BILIN_DET(64, 2, 1);
+        else CG_BILIN_DET(64, 4, 1);
 #undef CG_BILIN_DET
         CG_LAUNCH_CHECK();
         return 0;

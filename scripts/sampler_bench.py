@@ -19,7 +19,7 @@ def tk(fn, iters=30, warm=3):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-for N, C, H in ((128, 64, 16), (128, 3, 32), (64, 3, 64)):
+for N, C, H in ((128, 64, 16), (384, 64, 16), (128, 3, 32), (64, 3, 64)):
     img = torch.rand(N * H * H * C, device="cuda"); gout = torch.rand(N * H * H * C, device="cuda")
     th = (torch.rand(N, device="cuda") - 0.5) * 0.6
     ys = torch.linspace(-1, 1, H, device="cuda")
