@@ -1285,7 +1285,7 @@ static TileCfg pick_tile(long M, int Cout, int nphase) {
     int bm = 128;
     if (bn == 128 || bn == 64) {
         const long blocks128 = ((M + 127) / 128) * ((Cout + bn - 1) / bn) * nphase;
-        if (blocks128 < 2 * cg::kNumCU) bm = 64;
+        if (blocks128 < 2 * cg::kNumCU) bm = 64;   // swept 256 .. 2048 workgroups (r02): flat within 0.3 % from 384 up
     }
     return {bm, bn};
 }
@@ -1296,8 +1296,10 @@ static int pick_splits(long tiles, long kiters) {
     const int target = (int)cg::opt(cg::OPT_SPLIT_TARGET), mink = (int)cg::opt(cg::OPT_SPLIT_MINK);
     const int forced = (int)cg::opt(cg::OPT_NN_SPLITS);
     if (forced > 0) return (int)std::min<long>(forced, std::max<long>(1, kiters / 2));
+    // CG_SPLIT_TARGET < 16: workgroups per CU; larger values: the workgroup count itself
+    const long want = target < 16 ? (long)target * cg::kNumCU : (long)target;
     int s = 1;
-    while (tiles * s < (long)target * cg::kNumCU && kiters / (s * 2) >= mink && s < 64) s *= 2;
+    while (tiles * s < want && kiters / (s * 2) >= mink && s < 64) s *= 2;
     return s;
 }
 
