@@ -153,6 +153,7 @@ struct WinoArgs {
     int so;              // 2: output pixel (2i+a, 2j+b) of phase (a,b) = blockIdx.z; 1: pixel (i, j)
     int Ho, Wo;
     float* stats;        // != null: column sums of y and y^2 per (phase, tile block, wave row): [rows][2][Nc] (see gemm.hip)
+    int xcd;             // XCD-aware placement of the workgroups that share a V block (CG_XCD_SWIZZLE)
 };
 
 // NW waves per workgroup: 4 (wave tile 32x64) or 8 (wave tile 32x32: twice the waves per tile for latency hiding); BK = K step
@@ -170,9 +171,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(Win
     const int l31 = lane & 31, h = lane >> 5;
     const int wm0 = (wave & 1) * 32, wn0 = (wave >> 1) * (32 * NI);
     const int ntn = a.Nc / BN;
-    const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
+    // The ntn * P workgroups that read the same 64-tile block of V (all column blocks, all phases) are placed on ONE XCD in
+    // consecutive dispatch slots, so that V comes out of that XCD's L2 after the first of them has fetched it (workgroup L of
+    // the dispatch order runs on XCD L % 8).  Needs a multiple of 8 tile blocks; else the plain (x, z) order.
+    int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn, phase = blockIdx.z;
+    const int tiles_m = gridDim.x / ntn;
+    if (a.xcd && (tiles_m & 7) == 0) {
+        const int share = ntn * (int)gridDim.z;
+        const int L = (int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x;
+        const int slot = L >> 3, member = slot % share;
+        tm = (slot / share) * 8 + (L & 7);
+        phase = member / ntn;
+        tn = member - phase * ntn;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int phase = blockIdx.z;
     const int KT = a.K / BK;
 
     // staging: A one float4 per thread (row a_r, k quad a_kv); B two float4 per thread
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(Win
         }
     }
     if (a.stats) {
-        const int srow = ((int)blockIdx.z * (int)((a.T + BM - 1) / BM) + tm) * 2 + (wave & 1);
+        const int srow = (phase * (int)((a.T + BM - 1) / BM) + tm) * 2 + (wave & 1);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const float t1 = st1[j] + __shfl_xor(st1[j], 32, 64), t2 = st2[j] + __shfl_xor(st2[j], 32, 64);
@@ -450,6 +462,7 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
     const int T = N * (Hp / 2) * (Wp / 2);
     WinoArgs a;
     a.V = v; a.U = u; a.bias = bias; a.y = y; a.T = T; a.tH = Hp / 2; a.tW = Wp / 2; a.stats = stats;
+    a.xcd = (int)cg::opt(cg::OPT_XCD_SWIZZLE);
     CG_REQUIRE(!stats || (!dgrad && cg::opt(cg::OPT_WINO_WAVES) != 4), "wino_gemm: statistics only on the 8-wave forward launch");
     if (dgrad) { a.K = 4 * Cout; a.Nc = Cin; a.so = 1; a.Ho = Hp; a.Wo = Wp; }
     else { a.K = Cin; a.Nc = Cout; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp; }
