@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, backend, overlap, q):
+def _worker(rank, world, port, backend, overlap, q, max_acc=1.01):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -31,9 +31,12 @@ def _worker(rank, world, port, backend, overlap, q):
         cg.tensor.rng().offset += rank << 40
         pool = np.random.RandomState(100 + rank).rand(32, 3, 32, 32).astype(np.float32)
         data = cg.adversarial.TrainData(pool)
+        d_before = S.PARAMETERS_D.numpy().copy()
         for _ in range(2):
-            cg.adversarial.iteration(S, data)
+            cg.adversarial.iteration(S, data, maxAccuracyD=max_acc)
         torch.cuda.synchronize()
+        if max_acc <= 0.0:   # the gate held D back on every rank, G trained on
+            assert np.array_equal(S.PARAMETERS_D.numpy(), d_before), "D moved although the accuracy gate was closed"
         q.put((rank, S.PARAMETERS_G.numpy(), S.PARAMETERS_D.numpy(), None))
         dist.barrier()
         dist.destroy_process_group()
@@ -41,11 +44,11 @@ def _worker(rank, world, port, backend, overlap, q):
         q.put((rank, None, None, f"{type(e).__name__}: {e}"))
 
 
-def _run(backend, overlap):
+def _run(backend, overlap, max_acc=1.01):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + os.getpid() % 200 + (50 if overlap else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, backend, overlap, q)) for r in range(2)]
+    port = 29700 + os.getpid() % 200 + (50 if overlap else 0) + (25 if max_acc <= 1 else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, backend, overlap, q, max_acc)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=400) for _ in procs], key=lambda r: r[0])
@@ -72,6 +75,15 @@ def test_two_ranks_stay_replicas_and_overlap_is_result_neutral():
     for a, b in ((g_o, g_b), (d_o, d_b)):
         d = np.abs(a - b)
         assert d.max() <= 2 * 2.5e-3 and d.mean() <= 2e-5, (d.max(), d.mean())
+
+
+@pytest.mark.timeout(900)
+def test_closed_accuracy_gate_under_overlapped_collectives():
+    """adversarial.lua:150-166 under DP: with the gate closed (D_maxAcc = 0) fevalD returns false, false AFTER the
+    overlapped all-reduce of D's gradient was started - every rank must take the same decision (global-batch accuracy),
+    finish the collective, leave D untouched and keep training G; the replicas stay bit-equal."""
+    g, d = _run("gloo", True, max_acc=0.0)
+    assert np.isfinite(g).all() and np.isfinite(d).all()
 
 
 # ------------------------------------------------------------------ 2 ranks x N/2 == 1 rank x N on the HIP path
