@@ -119,9 +119,12 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         df_do = S.CRITERION.backward(outputs, targets)
         nn.WGRAD_SIDE.begin()              # D's weight-gradient GEMMs on a side stream, under the rest of the backward chain
         nn.WGRAD_DEFER.begin()             # their small split-K reductions queue up and run as one launch
-        S.MODEL_D.backward(inputs, df_do)
-        nn.WGRAD_SIDE.join()
-        nn.WGRAD_DEFER.end()
+        try:
+            S.MODEL_D.backward(inputs, df_do)
+            nn.WGRAD_SIDE.join()
+            nn.WGRAD_DEFER.end()
+        finally:
+            nn.WGRAD_DEFER.active = nn.WGRAD_SIDE.active = False   # a failed pass must not leave later backward() calls deferring
         if st.get("overlap"):  # start the xGMI all-reduce now, finish it after the G-step's generator forward
             st["pendingD"] = parallel.allreduce_mean_async(S.GRAD_PARAMETERS_D.t)
         else:
@@ -174,15 +177,18 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         df_do = S.MODEL_D.modules[0].gradInput
         nn.WGRAD_SIDE.begin()
         nn.WGRAD_DEFER.begin()
-        if parallel.world_size() > 1 and OPT.get("overlap_comm", True) and _bucketable(S.MODEL_G):
-            _backward_bucketed(S, st["noiseInputs"], df_do)
-            nn.WGRAD_SIDE.join()
-            nn.WGRAD_DEFER.end()
-        else:
-            S.MODEL_G.backward(st["noiseInputs"], df_do)
-            nn.WGRAD_SIDE.join()
-            nn.WGRAD_DEFER.end()
-            parallel.allreduce_mean_(S.GRAD_PARAMETERS_G.t)
+        try:
+            if parallel.world_size() > 1 and OPT.get("overlap_comm", True) and _bucketable(S.MODEL_G):
+                _backward_bucketed(S, st["noiseInputs"], df_do)
+                nn.WGRAD_SIDE.join()
+                nn.WGRAD_DEFER.end()
+            else:
+                S.MODEL_G.backward(st["noiseInputs"], df_do)
+                nn.WGRAD_SIDE.join()
+                nn.WGRAD_DEFER.end()
+                parallel.allreduce_mean_(S.GRAD_PARAMETERS_G.t)
+        finally:
+            nn.WGRAD_DEFER.active = nn.WGRAD_SIDE.active = False
         if not OPT["fused_update"]:
             if OPT["G_L1"] != 0 or OPT["G_L2"] != 0:
                 f = float(f) + OPT["G_L1"] * S.PARAMETERS_G.norm(1) + OPT["G_L2"] * S.PARAMETERS_G.norm(2) ** 2 / 2

@@ -259,12 +259,13 @@ def _grad_report(tag, a, b):
     return q / scale, d.max() / scale
 
 
-@pytest.mark.parametrize("N", [8, 128])
-def test_training_steps_gradients_and_adam_state(cg, N):
+@pytest.mark.parametrize("cfg,N", [("c2", 8), ("c2", 128), ("c3", 256)])
+def test_training_steps_gradients_and_adam_state(cg, cfg, N):
     """adversarial.lua:51-275 x3 against the oracle Trainer on identical batches / noise / masks, comparing what a
     wrong gradient cannot hide in: the flat gradient optim.adam receives (after penalty and clamp, :92-112) and Adam's
     m / v after the update, for D and for G, at EVERY step, tight on the bulk of the entries and per parameter tensor.
-    N = 128 is BASELINE configs[1] itself (the oracle needs ~20 s per step there).
+    c2 / N = 128 is BASELINE configs[1] itself (the oracle needs ~20 s per step there); c3 / N = 256 is configs[2]: G32up on
+    one grey plane at batch 256 (one step).
 
     Why not exact: engine and oracle are both fp32 with different summation orders, so activations differ by ~1e-6
     relative; an activation within that distance of a PReLU / max-pool / clamp kink takes the other branch, which moves
@@ -272,8 +273,12 @@ def test_training_steps_gradients_and_adam_state(cg, N):
     themselves differ by +-2 lr on the few weights whose step-0 gradient was ~0 (Adam's first update is lr*sign(g))."""
     seed = 31
     cg.manual_seed(seed); rng = O.RNG(seed)
-    G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
-    Go, Do = O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng)
+    C = 3 if cfg == "c2" else 1
+    if cfg == "c2":
+        G, Go = cg.models.create_G((C, 32, 32), 100), O.create_G32up_c(C, 100, rng)
+    else:
+        G, Go = cg.models.create_G_decoder_upsampling32((C, 32, 32), 100), O.create_G32up(C, 100, rng)
+    D, Do = cg.models.create_D((C, 32, 32)), O.create_D32_st3(C, 32, rng)
     S = cg.adversarial.State(dict(batchSize=N), G, D)
     S.keep_outputs = True
     T = O.Trainer(Go, Do)
@@ -281,9 +286,9 @@ def test_training_steps_gradients_and_adam_state(cg, N):
     np.testing.assert_array_equal(S.PARAMETERS_G.numpy(), T.pG)
     rs = np.random.RandomState(9)
     P = 2 * N
-    pool = rs.rand(P, 3, 32, 32).astype(f32)
+    pool = rs.rand(P, C, 32, 32).astype(f32)
     data = cg.adversarial.TrainData(pool)
-    steps = 3 if N <= 16 else 2
+    steps = 3 if N <= 16 else (2 if N <= 128 else 1)
     slices = {"D": [], "G": []}
     for key, net in (("D", Do), ("G", Go)):
         off = 0
