@@ -223,3 +223,38 @@ def visualizeProgress(S, noiseInputs, trainImages, save_dir, start_time=0, plot_
         return out
     finally:
         switchToTrainingMode(S)
+
+
+# ------------------------------------------------------------------ sample.lua's helpers
+def toDisplayTensor(images, nrow, padding=0):
+    """image.toDisplayTensor{input=images, nrow=nrow} as sample.lua:166-168 uses it: `nrow` images PER ROW on a black canvas,
+    the whole grid rescaled to [0,1] by its global minimum / maximum (the package's default min-max normalisation; recalled
+    upstream behaviour - the image rock is not vendored).  images [n,C,H,W]; returns [C, rows*H, nrow*W]."""
+    images = np.asarray(images, dtype=np.float32)
+    n, C, H, W = images.shape
+    rows = -(-n // nrow)
+    grid = np.zeros((C, rows * (H + padding), nrow * (W + padding)), np.float32)
+    for i in range(n):
+        y, x = divmod(i, nrow)
+        grid[:, y * (H + padding):y * (H + padding) + H, x * (W + padding):x * (W + padding) + W] = images[i]
+    lo, hi = float(grid.min()), float(grid.max())
+    return (grid - lo) / (hi - lo) if hi > lo else np.zeros_like(grid)
+
+
+def selectRandomImagesFrom(images, n, rs):
+    """sample.lua:199-207: the first n entries of a random permutation (torch.randperm -> the given generator)."""
+    images = np.asarray(images)
+    shuffle = rs.permutation(images.shape[0])
+    return images[shuffle[:min(n, images.shape[0])]]
+
+
+def findClosestNeighboursOf(images, trainingSet):
+    """sample.lua:131-151: for every image its nearest training image in the 2-norm; [(image, neighbour, distance)]."""
+    train = np.asarray(trainingSet, dtype=np.float32)
+    flat = train.reshape(train.shape[0], -1)
+    out = []
+    for img in np.asarray(images, dtype=np.float32):
+        d = np.sqrt(((flat - img.reshape(1, -1)) ** 2).sum(axis=1))
+        j = int(np.argmin(d))
+        out.append((img, train[j].copy(), float(d[j])))
+    return out
