@@ -260,7 +260,8 @@ def test_full_G_matches_torch_autograd():
             assert np.abs(a - b).mean() <= 2e-3 * scale
 
 
-def test_whole_step_gradients_match_torch_autograd():
+@pytest.mark.parametrize("cfg", ["G32up-c rgb", "G32up y"])
+def test_whole_step_gradients_match_torch_autograd(cfg):
     """The oracle's D-step and G-step gradients (adversarial.lua:72-112, 171-215: D32_st3 with three spatial transformers,
     G32up-c with training-mode batch-norm, BCE, L2 penalty, clamps) against PyTorch-CPU autograd evaluating the same module
     trees on the same parameters and dropout masks (oracle/torch_ref.py).  With no reference fixtures to pin the oracle
@@ -268,12 +269,14 @@ def test_whole_step_gradients_match_torch_autograd():
     chain rule through the whole graph."""
     from oracle import torch_ref as TR
     rng = O.RNG(5)
-    G, D = O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng)
+    C = 3 if cfg.endswith("rgb") else 1                    # BASELINE configs[1] / configs[2]
+    G = O.create_G32up_c(C, 100, rng) if C == 3 else O.create_G32up(C, 100, rng)
+    D = O.create_D32_st3(C, 32, rng)
     T = O.Trainer(G, D)
     rs = np.random.RandomState(1)
     T.pD += (rs.randn(T.pD.size) * 0.01).astype(f32)       # move the transformers off their identity initialisation
     N = 4
-    real = rs.rand(N // 2, 3, 32, 32).astype(f32)
+    real = rs.rand(N // 2, C, 32, 32).astype(f32)
     nd = (rs.rand(N // 2, 100) * 2 - 1).astype(f32); ng = (rs.rand(N, 100) * 2 - 1).astype(f32)
     fake = G.forward(nd)
     inputs = np.concatenate([real, fake]).astype(f32)
