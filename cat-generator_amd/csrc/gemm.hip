@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
     // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (each XCD has its own L2), so hand every XCD a CONTIGUOUS
     // range of tiles - neighbours then share their A rows / B columns through one L2 instead of eight
     int bid = blockIdx.x;
-    if (a.xcd_swizzle && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    if ((a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int tn = bid % ntn, tm = bid / ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
@@ -530,11 +530,19 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
     const int wn0 = (wave % WN) * (BN / WN);
 
     const int ntn = (g.Cout + BN - 1) / BN;
-    int bid = blockIdx.x;
-    if (a.xcd_swizzle && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // see igemm_nn_kernel
+    int bid = blockIdx.x, split = blockIdx.y;
+    if ((a.xcd_swizzle & 2) && (gridDim.y & 7) == 0) {
+        // XCD = pixel chunk: workgroup L of the dispatch order (x fastest, then y) runs on XCD L % 8; give every XCD the splits
+        // congruent to its number, for all tiles - it then reads one eighth of x and dy (each pixel chunk is wanted by every
+        // tile), instead of every XCD reading all of dy for its few tiles
+        const int L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, s8 = (int)gridDim.y >> 3;
+        split = (L & 7) + 8 * ((L >> 3) % s8);
+        bid = (L >> 3) / s8;
+    } else if ((a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) {
+        bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // see igemm_nn_kernel
+    }
     const int tn = bid % ntn, tm = bid / ntn;
     const int m0 = tm * BM, n0 = tn * BN;  // m0: row of dW (tap,ci)
-    const int split = blockIdx.y;
     const int zz = blockIdx.z;
     const int group = zz / g.nphase;
     const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
