@@ -106,6 +106,7 @@ template <typename T>
 __device__ __forceinline__ T sel4(int i, T a, T b, T c, T d) { return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d)); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // NOTE: cast the WHOLE vector.  Extracting the four dwords one by one (bit_cast(float, v.x) ...) makes LLVM's
@@ -161,9 +162,21 @@ __device__ __forceinline__ int a_swizzle(int kv) { return BKT == 32 ? ((kv & 7) 
 // ---------------------------------------------------------------------------
 // NN: Y[m][n] = sum_k A(m,k) * W[k][n]
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool FAST, bool VECB, int BK>
-__global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs a) {
+//
+// QUAD (FAST && VECB only): the LDS tiles hold k QUADS - As[k/4][m][4], Bs[k/4][n][4] - so that one ds_read_b128 hands a
+// lane its operand values of FOUR MFMA steps (the kernel above reads one ds_read_b32 per operand per step and waits for
+// it: the ISA showed `ds_read2_b32 ; s_waitcnt lgkmcnt(0) ; 2 x v_mfma` sixteen times per K tile, i.e. the LDS latency
+// exposed once per 128 MFMA cycles).  Within a group of 8 k the half-wave h = lane / 32 takes quad h, MFMA step s
+// multiplies A[m][8g + 4h + s] with B[8g + 4h + s][n] - a permutation of the k order, the same for both operands.
+//   A: the gathered float4 (4 consecutive channels of a pixel) IS a quad: one ds_write_b128 instead of four transposed
+//      ds_write_b32; slot (kq, m ^ swz(kq)) keeps the 8 lanes of a store group (8 quads of one pixel, or 4 quads of two)
+//      on 8 distinct 16-byte bank slots, and a fragment read (16 lanes = 16 rows at fixed kq) a permutation of all 16.
+//   B: a thread loads the 4 x 4 block (rows 4kq..4kq+3, columns n..n+3) and stores its register transpose as four
+//      quads; slot (kq, n ^ ((n >> 3) & 3)) does the same for the weights.
+template <int BM, int BN, int WM, int WN, bool FAST, bool VECB, int BK, bool QUAD = false>
+__global__ __launch_bounds__(256, (BK == 16 && !QUAD) ? 4 : 2) void igemm_nn_kernel(NNArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(!QUAD || (FAST && VECB), "the quad layout exists for the buffer-load path only");
     constexpr int MI = BM / WM / 32;
     constexpr int NI = BN / WN / 32;
     static_assert(MI >= 1 && NI >= 1, "wave tile >= 32x32");
@@ -178,7 +191,9 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
     static_assert(BM % ARPP == 0 && AROWS >= 1, "BM multiple of rows-per-pass");
     constexpr int NVEC = BN / 4;
     constexpr int BRPP = 256 / NVEC;  // B rows per pass
-    constexpr int BPASS = (BK + BRPP - 1) / BRPP;
+    constexpr int BPASS = QUAD ? 4 : (BK + BRPP - 1) / BRPP;
+    constexpr int NBLK = KV * NVEC;   // QUAD: 4 x 4 blocks of the B tile, one per thread of the first NBLK threads
+    static_assert(!QUAD || NBLK <= 256, "one B block per thread");
 
     __shared__ __attribute__((aligned(16))) float smem[2 * A_TILE + 2 * B_TILE];
     float* As = smem;
@@ -223,7 +238,8 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
         r_oy[p] = oy; r_ox[p] = ox;
         rowb[p] = ((n * g.Hs + oy * g.td.ss) * g.Ws + ox * g.td.ss) * g.Cin;
     }
-    const int b_nv = tid % NVEC, b_kr = tid / NVEC;
+    const int b_nv = tid % NVEC, b_kr = tid / NVEC;   // QUAD: b_kr is the k quad of the thread's 4 x 4 block
+    const bool b_on = !QUAD || tid < NBLK;
 
     float4 areg[AROWS];
     float4 breg[BPASS];
@@ -277,9 +293,9 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
         rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wph, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int q = 0; q < BPASS; ++q) {
-            const int kr = b_kr + q * BRPP;
+            const int kr = QUAD ? 4 * b_kr + q : b_kr + q * BRPP;
             const int n = n0 + 4 * b_nv;
-            bvoff[q] = (kr < BK && n < g.Cout) ? (unsigned)(kr * g.Cout + n) * 4u : OOB;
+            bvoff[q] = (b_on && kr < BK && n < g.Cout) ? (unsigned)(kr * g.Cout + n) * 4u : OOB;
         }
     }
 
@@ -354,10 +370,48 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
 
     // the LDS double-buffer index is a compile-time constant everywhere (the K loop is unrolled by two), so that every
     // ds_read / ds_write address is a loop-invariant register plus an immediate offset - no address VALU in the loop
+    // QUAD: loop-invariant slot indices (16-byte units) of the stores and of the fragment reads
+    int qa_st[AROWS], qb_st[4], qa_rd[KV / 2 > 0 ? KV / 2 : 1], qb_rd = 0;
+    if (QUAD) {
+        constexpr int SH = KV == 8 ? 0 : 1;   // 8 quads of one pixel per store group, or 4 quads of two pixels
+#pragma unroll
+        for (int p = 0; p < AROWS; ++p) qa_st[p] = a_kv * BM + ((a_r + ARPP * p) ^ ((a_kv & 7) << SH));
+        const int sb = (b_nv >> 1) & 3;       // ((4 b_nv + i) >> 3) & 3
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qb_st[i] = b_kr * BN + 4 * b_nv + (i ^ sb);
+#pragma unroll
+        for (int gq = 0; gq < KV / 2; ++gq) {
+            const int kq = 2 * gq + h;
+            qa_rd[gq] = kq * BM + wm0 + (l31 ^ ((kq & 7) << SH));
+        }
+        qb_rd = h * BN + wn0 + (l31 ^ ((l31 >> 3) & 3));
+    }
+
     auto store_tile = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         float* A = As + buf * A_TILE;
         float* B = Bs + buf * B_TILE;
+        if (QUAD) {
+            float4* A4 = reinterpret_cast<float4*>(A);
+            float4* B4 = reinterpret_cast<float4*>(B);
+#pragma unroll
+            for (int p = 0; p < AROWS; ++p) A4[qa_st[p]] = areg[p];
+            // pin the 16 loaded values HERE: without it the register coalescer builds the transposed quads with moves
+            // right behind the buffer loads, i.e. waits for the global loads before the tile's MFMAs instead of after
+            float4 tb4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tb4[q] = breg[q];
+                asm volatile("" : "+v"(tb4[q].x), "+v"(tb4[q].y), "+v"(tb4[q].z), "+v"(tb4[q].w));
+            }
+            if (NBLK == 256 || b_on) {
+                B4[qb_st[0]] = make_float4(tb4[0].x, tb4[1].x, tb4[2].x, tb4[3].x);
+                B4[qb_st[1]] = make_float4(tb4[0].y, tb4[1].y, tb4[2].y, tb4[3].y);
+                B4[qb_st[2]] = make_float4(tb4[0].z, tb4[1].z, tb4[2].z, tb4[3].z);
+                B4[qb_st[3]] = make_float4(tb4[0].w, tb4[1].w, tb4[2].w, tb4[3].w);
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < AROWS; ++p) {
             const int rs = (a_r + ARPP * p) ^ a_swizzle<BK>(a_kv);
@@ -390,6 +444,41 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
     auto k_tile = [&](auto bufc, int t) {
         constexpr int buf = decltype(bufc)::value;
         if (t + 1 < T) load_tile(ks + (t + 1) * BK);
+        if (QUAD) {
+            const float4* A4 = reinterpret_cast<const float4*>(As + buf * A_TILE);
+            const float4* B4 = reinterpret_cast<const float4*>(Bs + buf * B_TILE);
+            constexpr int G2 = KV / 2;
+            // hand-placed schedule (sched_barrier(0) = nothing crosses): the fragments of group g + 2 are requested before
+            // the 4 MI NI MFMAs of group g are issued, so a wave waits for the LDS once per K tile (for groups 0 / 1 behind
+            // the barrier) instead of once per MFMA pair; the transposing moves of the B store stay behind the MFMAs
+            float4 af[G2][MI], bf[G2][NI];
+            auto frag = [&](int gq) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[gq][i] = A4[qa_rd[gq] + i * 32];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bf[gq][j] = B4[qb_rd + gq * 2 * BN + j * 32];
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            frag(0);
+            if (G2 > 1) frag(1);
+#pragma unroll
+            for (int gq = 0; gq < G2; ++gq) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (gq + 2 < G2) frag(gq + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af[gq][i], sidx), f4c(bf[gq][j], sidx), acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < T) store_tile(std::integral_constant<int, buf ^ 1>{});
+            __syncthreads();
+            return;
+        }
         const float* A = As + buf * A_TILE + wm0;
         const float* B = Bs + buf * B_TILE + wn0 + l31;
 #pragma unroll
@@ -768,6 +857,246 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 256 / BVEC; ++r) t += red[r * BN + tid];
+            a.bias_part[(long)(split * (a.ngroups * g.nphase) + zz) * g.Cout + n0 + tid] = t;
+        }
+    }
+    float* pout = a.part + (long)(split * (a.ngroups * g.nphase) + zz) * g.Ktot * g.Cout;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        if (n >= g.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < g.Ktot) pout[(long)m * g.Cout + n] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// TN with quad LDS tiles (see the QUAD note above igemm_nn_kernel): the reduction index is the pixel, so a quad is
+// 4 consecutive PIXELS of one column - As[p/4][k][4], Bs[p/4][n][4].  A thread loads a 4 x 4 block (4 pixel rows x one
+// float4 of channels) per operand and stores its register transpose as four ds_write_b128; a fragment read is one
+// ds_read_b128 per operand per FOUR MFMA steps.  Only the lean addressing of igemm_tn_kernel is implemented (the host
+// checks): 16-byte aligned channel quads, a source tensor with the grid's geometry, a reduction range of whole K tiles,
+// and either a power-of-two grid with HWg >= BKT (a K tile never straddles two images) or a 1 x 1 kernel without padding
+// (`flat`: every row is valid and rows are simply consecutive - the linear layers and the Winograd-domain GEMMs).
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int BKT>
+__global__ __launch_bounds__(256, 2) void igemm_tnq_kernel(TNArgs a, int flat) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int MI = BM / WM / 32;
+    constexpr int NI = BN / WN / 32;
+    constexpr int PQ = BKT / 4, G2 = PQ / 2;
+    constexpr int AVEC = BM / 4, BVEC = BN / 4;
+    constexpr int NA = PQ * AVEC, NB = PQ * BVEC;     // 4 x 4 blocks per operand tile
+    static_assert(NA <= 256 && NB <= 256, "one block per thread and operand");
+    constexpr bool SPLIT_THREADS = NA + NB <= 256;    // disjoint thread ranges stage A and B
+    constexpr int A_TILE = BKT * BM, B_TILE = BKT * BN;
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_TILE + 2 * B_TILE];
+    float* As = smem;
+    float* Bs = smem + 2 * A_TILE;
+
+    const Geom& g = a.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm0 = (wave / WN) * (BM / WM);
+    const int wn0 = (wave % WN) * (BN / WN);
+
+    const int ntn = (g.Cout + BN - 1) / BN;
+    int bid = blockIdx.x, split = blockIdx.y;
+    if ((a.xcd_swizzle & 2) && (gridDim.y & 7) == 0) {   // XCD = pixel chunk, see igemm_tn_kernel
+        const int L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, s8 = (int)gridDim.y >> 3;
+        split = (L & 7) + 8 * ((L >> 3) % s8);
+        bid = (L >> 3) / s8;
+    } else if ((a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) {
+        bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    }
+    const int tn = bid % ntn, tm = bid / ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int zz = blockIdx.z;
+    const int group = zz / g.nphase;
+    const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
+    const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
+    const float* gdy = sel4(group, a.d0, a.d1, a.d2, a.d3);
+    const int ps = split * a.pchunk;
+    const int pend = min(g.M, ps + a.pchunk);
+    const int T = (pend - ps) / BKT;
+
+    // ---- staging: thread -> (pixel quad, column quad) of each operand
+    const bool a_on = tid < NA;
+    const int tb = SPLIT_THREADS ? tid - NA : tid;
+    const bool b_on = tb >= 0 && tb < NB;
+    const int a_cq = tid % AVEC, a_pq = tid / AVEC;
+    const int b_cq = (b_on ? tb : 0) % BVEC, b_pq = (b_on ? tb : 0) / BVEC;
+    const bool lin_out = g.so == 1 && g.nphase == 1;
+    const int HWg = g.Hg * g.Wg;
+
+    int l_minoff = 0, c_ty = 0, c_tx = 0, c_off = 0;
+    bool c_ok;
+    {
+        const int mm = m0 + 4 * a_cq;
+        c_ok = a_on && mm < g.Ktot;
+        const int mc = c_ok ? mm : 0;
+        const int tap = mc / g.Cin;
+        int off;
+        tap_decode(g, tap, pa, pb, c_ty, c_tx, off);
+        c_off = off + (mc - tap * g.Cin);
+        for (int t = 0; t < g.ntaps; ++t) {
+            int ty, tx, o2;
+            tap_decode(g, t, pa, pb, ty, tx, o2);
+            l_minoff = min(l_minoff, o2);
+        }
+    }
+    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(gx + l_minoff), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)gdy, 0, 0x7fffffff, 0x00020000);
+    const bool b_nok = b_on && n0 + 4 * b_cq < g.Cout;
+    int l_ay[4], l_ax[4];
+    unsigned l_avoff[4], l_bvoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int kra = 4 * a_pq + q, krb = 4 * b_pq + q;
+        const bool wide = flat || g.Wg >= BKT;
+        const int kyo = wide ? 0 : (kra >> g.lgW), kxo = flat ? 0 : (wide ? kra : (kra & (g.Wg - 1)));
+        l_ay[q] = kyo + c_ty;
+        l_ax[q] = kxo + c_tx;
+        l_avoff[q] = c_ok ? (unsigned)(kra * g.Cin + c_off - l_minoff) * 4u : OOB;
+        const int byo = wide ? 0 : (krb >> g.lgW), bxo = wide ? krb : (krb & (g.Wg - 1));
+        const int rel = lin_out ? krb * g.Cout : (byo * g.so * g.Wout + bxo * g.so) * g.Cout;
+        l_bvoff[q] = b_nok ? (unsigned)(rel + n0 + 4 * b_cq) * 4u : OOB;
+    }
+
+    float4 areg[4], breg[4];
+    const bool do_bias = a.bias_part != nullptr && tm == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto load_tile = [&](int p0) {
+        const int r0 = flat ? 0 : (p0 & (HWg - 1));
+        const int oyb = flat ? 0 : (r0 >> g.lgW), oxb = flat ? 0 : (r0 & (g.Wg - 1));
+        const int soa = p0 * g.Cin * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = (unsigned)(oyb + l_ay[q]) < (unsigned)g.Hv && (unsigned)(oxb + l_ax[q]) < (unsigned)g.Wv;
+            areg[q] = bufld4(rsx, ok ? l_avoff[q] : OOB, soa);
+        }
+        int sob;
+        if (lin_out) sob = p0 * g.Cout * 4;
+        else {
+            const int nimg = p0 >> g.lgHW;
+            sob = (((nimg * g.Hout + oyb * g.so + pa) * g.Wout + oxb * g.so + pb) * g.Cout) * 4;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) breg[q] = bufld4(rsd, l_bvoff[q], sob);
+    };
+
+    // loop-invariant slot indices (16-byte units): column c of pixel quad pq lives at pq * LD + (c ^ ((c >> 3) & 3))
+    int qa_st[4], qb_st[4];
+    {
+        const int sa = (a_cq >> 1) & 3, sb = (b_cq >> 1) & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qa_st[i] = a_pq * BM + 4 * a_cq + (i ^ sa);
+            qb_st[i] = b_pq * BN + 4 * b_cq + (i ^ sb);
+        }
+    }
+    const int lsw = l31 ^ ((l31 >> 3) & 3);
+    const int qa_rd = h * BM + wm0 + lsw, qb_rd = h * BN + wn0 + lsw;
+
+    auto store_tile = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        float4* A4 = reinterpret_cast<float4*>(As + buf * A_TILE);
+        float4* B4 = reinterpret_cast<float4*>(Bs + buf * B_TILE);
+        // pin the loaded values here (see igemm_nn_kernel): the transposing moves must not drag the wait for the global loads
+        // in front of the MFMAs
+        float4 ta[4], tb4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ta[q] = areg[q]; tb4[q] = breg[q];
+            asm volatile("" : "+v"(ta[q].x), "+v"(ta[q].y), "+v"(ta[q].z), "+v"(ta[q].w));
+            asm volatile("" : "+v"(tb4[q].x), "+v"(tb4[q].y), "+v"(tb4[q].z), "+v"(tb4[q].w));
+        }
+        if (NA == 256 || a_on) {
+            A4[qa_st[0]] = make_float4(ta[0].x, ta[1].x, ta[2].x, ta[3].x);
+            A4[qa_st[1]] = make_float4(ta[0].y, ta[1].y, ta[2].y, ta[3].y);
+            A4[qa_st[2]] = make_float4(ta[0].z, ta[1].z, ta[2].z, ta[3].z);
+            A4[qa_st[3]] = make_float4(ta[0].w, ta[1].w, ta[2].w, ta[3].w);
+        }
+        if (NB == 256 || b_on) {
+            B4[qb_st[0]] = make_float4(tb4[0].x, tb4[1].x, tb4[2].x, tb4[3].x);
+            B4[qb_st[1]] = make_float4(tb4[0].y, tb4[1].y, tb4[2].y, tb4[3].y);
+            B4[qb_st[2]] = make_float4(tb4[0].z, tb4[1].z, tb4[2].z, tb4[3].z);
+            B4[qb_st[3]] = make_float4(tb4[0].w, tb4[1].w, tb4[2].w, tb4[3].w);
+            if (do_bias) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { bsum.x += tb4[q].x; bsum.y += tb4[q].y; bsum.z += tb4[q].z; bsum.w += tb4[q].w; }
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (T > 0) {
+        load_tile(ps);
+        store_tile(std::integral_constant<int, 0>{});
+    }
+    __syncthreads();
+
+    auto k_tile = [&](auto bufc, int t) {
+        constexpr int buf = decltype(bufc)::value;
+        if (t + 1 < T) load_tile(ps + (t + 1) * BKT);
+        const float4* A4 = reinterpret_cast<const float4*>(As + buf * A_TILE);
+        const float4* B4 = reinterpret_cast<const float4*>(Bs + buf * B_TILE);
+        float4 af[G2][MI], bf[G2][NI];
+        auto frag = [&](int gq) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[gq][i] = A4[qa_rd + gq * 2 * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[gq][j] = B4[qb_rd + gq * 2 * BN + j * 32];
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        frag(0);
+        if (G2 > 1) frag(1);
+#pragma unroll
+        for (int gq = 0; gq < G2; ++gq) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (gq + 2 < G2) frag(gq + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af[gq][i], sidx), f4c(bf[gq][j], sidx), acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < T) store_tile(std::integral_constant<int, buf ^ 1>{});
+        __syncthreads();
+    };
+    for (int t = 0; t < T; t += 2) {
+        k_tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < T) k_tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+
+    if (do_bias) {  // all waves are past the loop's final barrier: reuse the A tile as scratch
+        float* red = smem;
+        if (b_on) *reinterpret_cast<float4*>(red + b_pq * BN + 4 * b_cq) = bsum;
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < PQ; ++r) t += red[r * BN + tid];
             a.bias_part[(long)(split * (a.ngroups * g.nphase) + zz) * g.Cout + n0 + tid] = t;
         }
     }
@@ -1314,6 +1643,12 @@ static int pick_splits(long tiles, long kiters) {
 template <int BM, int BN, int WM, int WN>
 static void launch_nn(const NNArgs& a, dim3 grid, hipStream_t st, bool fast, bool vecb, bool bk32) {
     if (fast && vecb) {
+        const long quad = cg::opt(cg::OPT_NN_QUAD);   // 0 off, 1 on with the K steps of the b32 kernels, 2 K step 32 wherever it divides
+        if (quad) {
+            if (bk32 && (BM == 64 || quad >= 2)) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, 32, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, 16, true>), grid, dim3(256), 0, st, a);
+            return;
+        }
         // 64-row tiles do only 8-16 MFMAs per wave per K step of 16: give them 32 so the per-tile work
         // (address VALU, LDS stores, barrier) is amortised like in the 128x128 tile
         if (BM == 64 && bk32) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, (BM == 64 ? 32 : 16)>), grid, dim3(256), 0, st, a);
@@ -1330,6 +1665,30 @@ static void launch_tn(const TNArgs& a, dim3 grid, hipStream_t st, bool veca, boo
     else if (veca) hipLaunchKernelGGL((igemm_tn_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, a);
     else if (vecb) hipLaunchKernelGGL((igemm_tn_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((igemm_tn_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, a);
+}
+
+// quad-tile weight-gradient kernel (igemm_tnq_kernel): 0 = not eligible, else the K step (pixels per tile)
+static int tnq_kstep(const Geom& g, int pchunk, bool veca, bool vecb) {
+    const long mode = cg::opt(cg::OPT_TN_QUAD);
+    if (!mode || !veca || !vecb) return 0;
+    const bool lin_src = g.td.ss == 1 && g.Hs == g.Hg && g.Ws == g.Wg;
+    const bool lin_out = g.so == 1 && g.nphase == 1;
+    if (!lin_src) return 0;
+    const bool flat = g.ntaps == 1 && g.td.r0y0 == 0 && g.td.r0x0 == 0 && lin_out;
+    const int HWg = g.Hg * g.Wg;
+    for (int bkt = (mode >= 2 ? 32 : 16); bkt >= 16; bkt >>= 1) {
+        if (g.M % bkt || pchunk % bkt) continue;
+        if (flat || (g.lgW >= 0 && g.lgHW >= 0 && HWg >= bkt && (lin_out || g.so == 2))) return bkt;
+    }
+    return 0;
+}
+static bool tnq_flat(const Geom& g) { return g.ntaps == 1 && g.td.r0y0 == 0 && g.td.r0x0 == 0 && g.so == 1 && g.nphase == 1; }
+
+template <int BM, int BN, int WM, int WN>
+static void launch_tnq(const TNArgs& a, dim3 grid, hipStream_t st, int bkt) {
+    const int flat = tnq_flat(a.g) ? 1 : 0;
+    if (bkt == 32) hipLaunchKernelGGL((igemm_tnq_kernel<BM, BN, WM, WN, 32>), grid, dim3(256), 0, st, a, flat);
+    else hipLaunchKernelGGL((igemm_tnq_kernel<BM, BN, WM, WN, 16>), grid, dim3(256), 0, st, a, flat);
 }
 
 static int ilog2_exact(int v) {
@@ -1441,6 +1800,7 @@ static TNPlan plan_tn(const Geom& g, int ngroups) {
     else
     while (tiles * s < (long)tgt * cg::kNumCU && piters / (s * 2) >= 8 && s < smax) s *= 2;
     p.pchunk = cg::cdiv(piters, s) * BK;
+    if (cg::opt(cg::OPT_TN_QUAD) >= 2) p.pchunk = cg::cdiv(p.pchunk, 32) * 32;   // whole K tiles of 32 pixels
     p.splits = cg::cdiv(g.M, p.pchunk);
     return p;
 }
@@ -1773,7 +2133,15 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
     a.bias_part = any_gb ? (float*)ws + (size_t)p.splits * ZP * wplane : nullptr;
     hipStream_t st = cg::S(stream);
     dim3 grid(cg::cdiv(g.Ktot, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, ZP);
-    if (p.tc.bm == 128 && p.tc.bn == 128) launch_tn<128, 128, 2, 2>(a, grid, st, veca, vecb);
+    const int bkt = tnq_kstep(g, p.pchunk, veca, vecb);
+    if (bkt) {
+        if (p.tc.bm == 128 && p.tc.bn == 128) launch_tnq<128, 128, 2, 2>(a, grid, st, bkt);
+        else if (p.tc.bm == 64 && p.tc.bn == 128) launch_tnq<64, 128, 2, 2>(a, grid, st, bkt);
+        else if (p.tc.bm == 128 && p.tc.bn == 64) launch_tnq<128, 64, 2, 2>(a, grid, st, bkt);
+        else if (p.tc.bm == 64 && p.tc.bn == 64) launch_tnq<64, 64, 2, 2>(a, grid, st, bkt);
+        else launch_tnq<128, 32, 4, 1>(a, grid, st, bkt);
+    }
+    else if (p.tc.bm == 128 && p.tc.bn == 128) launch_tn<128, 128, 2, 2>(a, grid, st, veca, vecb);
     else if (p.tc.bm == 64 && p.tc.bn == 128) launch_tn<64, 128, 2, 2>(a, grid, st, veca, vecb);
     else if (p.tc.bm == 128 && p.tc.bn == 64) launch_tn<128, 64, 2, 2>(a, grid, st, veca, vecb);
     else if (p.tc.bm == 64 && p.tc.bn == 64) launch_tn<64, 64, 2, 2>(a, grid, st, veca, vecb);

@@ -26,6 +26,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float wf4c(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
@@ -157,12 +158,17 @@ struct WinoArgs {
 };
 
 // NW waves per workgroup: 4 (wave tile 32x64) or 8 (wave tile 32x32: twice the waves per tile for latency hiding); BK = K step
-template <int NW, int BK>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(WinoArgs a) {
+// QUAD: k-quad LDS tiles read with ds_read_b128, one read per operand per four MFMA steps (see igemm_nn_kernel in gemm.hip:
+// same slots, swizzles and hand-placed schedule; V rows are stored as they are loaded, U goes in as register-transposed
+// 4 x 4 blocks held by the first KV * 32 threads).
+template <int NW, int BK, bool QUAD = false>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ((QUAD && BK == 32) ? 2 : 4) : 2) void wino_gemm_kernel(WinoArgs a) {
     constexpr int BM = 64, BN = 128, NI = 8 / NW, NT = 64 * NW;
     constexpr int KV = BK / 4;                 // float4 per A row per K tile
     constexpr int BQ = BK * 32 / NT;           // B float4 per thread (1 or 2), NT/32 rows apart
-    static_assert(BM * KV <= NT && (BQ == 1 || BQ == 2), "staging layout");
+    static_assert(BM * KV <= NT && (QUAD || BQ == 1 || BQ == 2), "staging layout");
+    constexpr int NBLK = KV * 32;              // QUAD: 4 x 4 blocks of the B tile
+    static_assert(!QUAD || NBLK <= NT, "one B block per thread");
     constexpr int A_TILE = BK * BM, B_TILE = BK * BN;
     __shared__ __attribute__((aligned(16))) float smem[2 * A_TILE + 2 * B_TILE];
     float* As = smem;
@@ -197,22 +203,66 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(Win
     const long a_xi = (long)a.T * a.K;            // V stride between xi
     const long b_half = (long)(NT / 32) * a.Nc;   // second B float4: k row + NT/32
     float4 areg, breg0, breg1;
+    // QUAD staging of B: thread -> block (k quad tid >> 5, column quad tid & 31), rows 4 * (tid >> 5) + q
+    const bool bq_on = QUAD && tid < NBLK;
+    const float* Bq = a.U + (long)phase * 16 * a.K * a.Nc + (long)(4 * (bq_on ? b_kr : 0)) * a.Nc + n0 + 4 * b_nv;
+    float4 bq[4];
     // running operand pointers: U is contiguous over (xi, k), V jumps to the next xi plane after the last K tile
     const float* Ac = Ap;
     const float* Bc = Bp;
     const long b_step = (long)BK * a.Nc;
     const long a_jump = a_xi - a.K + BK;
+    auto load_b_quad = [&]() {
+        if (NBLK == NT || bq_on) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = ld4(Bq + (long)q * a.Nc);
+        }
+    };
     auto load_next = [&](bool last_kt) {
         Ac += last_kt ? a_jump : (long)BK;
         Bc += b_step;
         if (BM * KV == NT || a_thr) areg = ld4(Ac);
+        if (QUAD) { Bq += b_step; load_b_quad(); return; }
         breg0 = ld4(Bc);
         if (BQ == 2) breg1 = ld4(Bc + b_half);
     };
+    // QUAD slot indices (16-byte units), all loop invariants
+    constexpr int SH = KV == 8 ? 0 : 1;
+    const int qa_st = a_kv * BM + (a_r ^ ((a_kv & 7) << SH));
+    int qb_st[4], qa_rd[KV / 2];
+    {
+        const int sb = (b_nv >> 1) & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qb_st[i] = b_kr * BN + 4 * b_nv + (i ^ sb);
+#pragma unroll
+        for (int gq = 0; gq < KV / 2; ++gq) {
+            const int kq = 2 * gq + h;
+            qa_rd[gq] = kq * BM + wm0 + (l31 ^ ((kq & 7) << SH));
+        }
+    }
+    const int qb_rd = h * BN + wn0 + (l31 ^ ((l31 >> 3) & 3));
     const int a_so = a_r ^ (BK == 32 ? ((a_kv & 7) << 2) : ((a_kv & 3) << 3));   // see a_swizzle in gemm.hip
     auto store_tile = [&](int buf) {
         float* A = As + buf * A_TILE;
         float* B = Bs + buf * B_TILE;
+        if (QUAD) {
+            float4* A4 = reinterpret_cast<float4*>(A);
+            float4* B4 = reinterpret_cast<float4*>(B);
+            if (BM * KV == NT || a_thr) A4[qa_st] = areg;
+            float4 tb4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {   // pinned here so that the transposing moves stay behind the MFMAs
+                tb4[q] = bq[q];
+                asm volatile("" : "+v"(tb4[q].x), "+v"(tb4[q].y), "+v"(tb4[q].z), "+v"(tb4[q].w));
+            }
+            if (NBLK == NT || bq_on) {
+                B4[qb_st[0]] = make_float4(tb4[0].x, tb4[1].x, tb4[2].x, tb4[3].x);
+                B4[qb_st[1]] = make_float4(tb4[0].y, tb4[1].y, tb4[2].y, tb4[3].y);
+                B4[qb_st[2]] = make_float4(tb4[0].z, tb4[1].z, tb4[2].z, tb4[3].z);
+                B4[qb_st[3]] = make_float4(tb4[0].w, tb4[1].w, tb4[2].w, tb4[3].w);
+            }
+            return;
+        }
         if (BM * KV == NT || a_thr) {
             A[(4 * a_kv + 0) * BM + a_so] = areg.x;
             A[(4 * a_kv + 1) * BM + a_so] = areg.y;
@@ -234,14 +284,49 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void wino_gemm_kernel(Win
         }
 
     areg = ld4(Ac);
-    breg0 = ld4(Bc);
-    breg1 = ld4(Bc + b_half);
+    if (QUAD) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        load_b_quad();
+    } else {
+        breg0 = ld4(Bc);
+        breg1 = ld4(Bc + b_half);
+    }
     store_tile(0);
     __syncthreads();
     // one K tile from LDS buffer BUF (compile-time, so every ds_read offset is an immediate)
     auto k_tile = [&](auto bufc, bool more, bool last_kt) {
         constexpr int BUF = decltype(bufc)::value;
         if (more) load_next(last_kt);
+        if (QUAD) {
+            constexpr int G2 = KV / 2;
+            const float4* A4 = reinterpret_cast<const float4*>(As + BUF * A_TILE);
+            const float4* B4 = reinterpret_cast<const float4*>(Bs + BUF * B_TILE);
+            float4 af[G2], bf[G2][NI];
+            auto frag = [&](int gq) {
+                af[gq] = A4[qa_rd[gq]];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bf[gq][j] = B4[qb_rd + gq * 2 * BN + j * 32];
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            frag(0);
+            if (G2 > 1) frag(1);
+#pragma unroll
+            for (int gq = 0; gq < G2; ++gq) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (gq + 2 < G2) frag(gq + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        accM[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf4c(af[gq], sidx), wf4c(bf[gq][j], sidx), accM[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) store_tile(BUF ^ 1);
+            __syncthreads();
+            return;
+        }
         const float* A = As + BUF * A_TILE + wm0;
         const float* B = Bs + BUF * B_TILE + wn0 + l31;
 #pragma unroll
@@ -471,7 +556,10 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
     // K step 32 (half the barriers per MFMA) pays when the launch is at most ~one workgroup per CU - the data-gradient
     // geometry at batch 128 (0.53 -> 0.41 ms) - and costs 6 % when two workgroups per CU already hide each other's barriers
     const bool k32 = bk == 32 || (bk == 0 && (long)grid.x * grid.z <= cg::kNumCU * 3 / 2);
-    if (nw == 4) hipLaunchKernelGGL((wino_gemm_kernel<4, 16>), grid, dim3(256), 0, cg::S(stream), a);
+    const bool quad = cg::opt(cg::OPT_WINO_QUAD) != 0 && nw != 4;
+    if (quad && k32 && a.K % 64 == 0) hipLaunchKernelGGL((wino_gemm_kernel<8, 32, true>), grid, dim3(512), 0, cg::S(stream), a);
+    else if (quad) hipLaunchKernelGGL((wino_gemm_kernel<8, 16, true>), grid, dim3(512), 0, cg::S(stream), a);
+    else if (nw == 4) hipLaunchKernelGGL((wino_gemm_kernel<4, 16>), grid, dim3(256), 0, cg::S(stream), a);
     else if (k32 && a.K % 64 == 0) hipLaunchKernelGGL((wino_gemm_kernel<8, 32>), grid, dim3(512), 0, cg::S(stream), a);
     else hipLaunchKernelGGL((wino_gemm_kernel<8, 16>), grid, dim3(512), 0, cg::S(stream), a);
     CG_LAUNCH_CHECK();

@@ -199,24 +199,46 @@ NN_TILES = [128128, 64128, 128064, 64064, 128032]
 @pytest.mark.parametrize("tile", NN_TILES)
 @pytest.mark.parametrize("bk32", [0, 1])
 @pytest.mark.parametrize("splits", [0, 3])
-def test_forced_nn_tile_variants(cg, tile, bk32, splits):
-    """igemm_nn_kernel<BM,BN,...,BK> for every block tile, K step 16 / 32, with and without split-K (+ reduce kernel),
-    on plain, upsample-folded (4 phases) and folded data-gradient (4 tap groups) geometries; ragged M and Cout."""
-    with options(cg, CG_NN_TILE=tile, CG_GEMM_BK32=bk32, CG_NN_SPLITS=splits, CG_SKINNY=0):
+@pytest.mark.parametrize("quad", [pytest.param(0, id="b32"), pytest.param(2, id="quad")])
+def test_forced_nn_tile_variants(cg, tile, bk32, splits, quad):
+    """igemm_nn_kernel<BM,BN,...,BK,QUAD> for every block tile, K step 16 / 32, with and without split-K (+ reduce kernel),
+    on plain, upsample-folded (4 phases) and folded data-gradient (4 tap groups) geometries; ragged M and Cout.
+    quad = 0: the ds_read_b32 kernels; quad = 2: the k-quad LDS layout (ds_read_b128 fragments), K step 32 for every tile
+    when bk32 (quad = 1, the default, takes K step 32 for the 64-row tiles only - a subset of these instances)."""
+    with options(cg, CG_NN_TILE=tile, CG_GEMM_BK32=bk32, CG_NN_SPLITS=splits, CG_SKINNY=0, CG_NN_QUAD=quad):
         run_conv(cg, 3, 64, 10, 6, 72, 3, 0, seed=tile % 97)          # ragged M = 180, Cout = 72
         run_conv(cg, 2, 32, 8, 8, 128, 3, 1, seed=tile % 89, wino=False)
         run_conv(cg, 2, 64, 4, 4, 32, 5, 1, seed=tile % 83, wino=False)
 
 
+def run_linear(cg, N, i, o, seed=0):
+    rs = np.random.RandomState(seed)
+    m = cg.nn.Linear(i, o)
+    w = (rs.randn(o, i) / np.sqrt(i)).astype(f32); b = rs.randn(o).astype(f32)
+    m.weight.copy(w); m.bias.copy(b)
+    x = rs.randn(N, i).astype(f32); dy = rs.randn(N, o).astype(f32)
+    close(m.forward(cg.Tensor.from_numpy(x)).numpy(), O.linear_forward(x, w, b), K=i, what="forward")
+    m.gradWeight.zero(); m.gradBias.zero()
+    gi = m.backward(cg.Tensor.from_numpy(x), cg.Tensor.from_numpy(dy)).numpy()
+    close(gi, O.linear_backward_data(dy, w), K=o, what="gradInput")
+    gw, gb = np.zeros_like(w), np.zeros_like(b)
+    O.linear_backward_weight(x, dy, gw, gb)
+    close(m.gradWeight.numpy(), gw, K=N, what="gradWeight"); close(m.gradBias.numpy(), gb, K=N, what="gradBias")
+
+
 @pytest.mark.parametrize("tile", NN_TILES)
 @pytest.mark.parametrize("splits", [0, 5])
-def test_forced_tn_tile_variants(cg, tile, splits):
-    """igemm_tn_kernel<BM,BN> (weight gradient) for every block tile, default and forced pixel splits; the lean
-    power-of-two addressing (16x16 grid) and the generic one (10x6 grid)."""
-    with options(cg, CG_TN_TILE=tile, CG_TN_SPLITS=splits, CG_SKINNY=0):
+@pytest.mark.parametrize("quad", [pytest.param(0, id="b32"), pytest.param(1, id="quad16"), pytest.param(2, id="quad32")])
+def test_forced_tn_tile_variants(cg, tile, splits, quad):
+    """igemm_tn_kernel<BM,BN> / igemm_tnq_kernel<BM,BN,BKT> (weight gradient) for every block tile, default and forced pixel
+    splits; the lean power-of-two addressing (16x16 grid, and the 4 phases of a folded upsampling), the generic one (10x6
+    grid: always the b32 kernel) and the flat rows of a linear layer.  quad = 1 / 2: the pixel-quad LDS layout with K
+    steps of 16 / 32 pixels."""
+    with options(cg, CG_TN_TILE=tile, CG_TN_SPLITS=splits, CG_SKINNY=0, CG_TN_QUAD=quad):
         run_conv(cg, 3, 64, 10, 6, 72, 3, 0, seed=tile % 97, check_dgrad=False)
         run_conv(cg, 2, 64, 16, 16, 64, 3, 0, seed=tile % 89, check_dgrad=False)
         run_conv(cg, 2, 32, 8, 8, 128, 3, 1, seed=tile % 83, wino=False, check_dgrad=False)
+        run_linear(cg, 96, 136, 72, seed=tile % 79)
 
 
 def test_generic_gather_variants(cg):
@@ -228,13 +250,15 @@ def test_generic_gather_variants(cg):
         run_conv(cg, 2, 64, 8, 8, 64, 3, 0, seed=3)
 
 
-@pytest.mark.parametrize("waves,bk", [(8, 16), (8, 32), (4, 16)])
-def test_forced_winograd_variants(cg, waves, bk):
-    """wino_gemm_kernel<8,16>, <8,32>, <4,16> on the F(2x2,3x3) path of upsample2 -> conv5x5 (models.lua:217-218),
-    forward + data gradient + weight gradient, ragged tile count."""
+@pytest.mark.parametrize("waves,bk,quad", [(8, 16, 0), (8, 32, 0), (4, 16, 0), pytest.param(8, 16, 1, id="8-16-quad"),
+                                           pytest.param(8, 32, 1, id="8-32-quad")])
+def test_forced_winograd_variants(cg, waves, bk, quad):
+    """wino_gemm_kernel<8,16>, <8,32>, <4,16> and the k-quad instances <8,16,true>, <8,32,true> on the F(2x2,3x3) path of
+    upsample2 -> conv5x5 (models.lua:217-218), forward + data gradient + weight gradient (the Winograd-domain weight
+    gradient runs on the TN kernels: quad there too), ragged tile count."""
     cg.nn.SpatialConvolution.winograd_min_tiles = 0
     try:
-        with options(cg, CG_WINO_WAVES=waves, CG_WINO_BK=bk):
+        with options(cg, CG_WINO_WAVES=waves, CG_WINO_BK=bk, CG_WINO_QUAD=quad, CG_TN_QUAD=2 * quad):
             m = run_conv(cg, 3, 128, 6, 4, 128, 5, 1, seed=waves + bk)
             assert getattr(m, "_wino", False)
             m = run_conv(cg, 2, 256, 8, 8, 128, 5, 1, seed=waves * bk)
