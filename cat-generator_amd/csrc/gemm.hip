@@ -40,7 +40,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;
-constexpr unsigned OOB = 0x80000000u;  // >= num_records of every descriptor below: the load returns 0
+// Ablation builds (scripts/build_exp.sh, timing only - results are garbage): -DCG_EXP=<bits> removes from the K loop of
+// igemm_nn_kernel 1 = the global loads, 2 = the LDS stores, 4 = the barriers, 8 = the MFMAs.
+#ifndef CG_EXP
+#define CG_EXP 0
+#endif
+constexpr unsigned OOB = 0x80000000u;
+// -DCG_TRACE (scripts/build_exp.sh trace): every igemm_nn_kernel workgroup records 100 MHz timestamps at its start, behind
+// the prologue (first tile in LDS), behind the K loop and at its end, plus the hardware id of the CU it ran on, into the
+// buffer handed to cg_debug_set_trace - scripts/wg_trace.py turns that into the dispatch balance and the phase times.
+#ifdef CG_TRACE
+__device__ unsigned long long* g_trace;
+#define CG_STAMP(slot)                                                                                                  \
+    do {                                                                                                                \
+        if (threadIdx.x == 0 && g_trace) {                                                                              \
+            const long wg = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);                  \
+            g_trace[wg * 8 + (slot)] = wall_clock64();                                                                  \
+            if ((slot) == 0) {                                                                                          \
+                g_trace[wg * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  /* HW_REG_HW_ID */                     \
+                g_trace[wg * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); /* HW_REG_XCC_ID */                    \
+            }                                                                                                           \
+        }                                                                                                               \
+    } while (0)
+#else
+#define CG_STAMP(slot) do { } while (0)
+#endif  // >= num_records of every descriptor below: the load returns 0
 
 // tap t of a launch -> (ty, tx, element offset):  group = t / kk, (ry,rx) = (t % kk) / kw, % kw
 //   phase bits (a,b) = launch phase (nphase == 4)  or  group bits (ngroups == 4)  or  0
@@ -85,6 +109,9 @@ struct NNArgs {
     // of the layer behind this convolution, models.lua:206-207; single group, unsplit launches only)
     float* stats;
     int xcd_swizzle;
+    // > 0: waves in an odd wave slot of their SIMD (the second workgroup on a CU) sleep stagger x 128 clocks before they start,
+    // so that two co-resident workgroups do not run their load / store / barrier phases at the same time (CG_NN_STAGGER)
+    int stagger;
 };
 
 __device__ __forceinline__ float apply_act(int act, float v, float a) {
@@ -115,6 +142,14 @@ __device__ __forceinline__ float4 bufld4(__amdgpu_buffer_rsrc_t r, unsigned voff
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     const f32x4 f = __builtin_bit_cast(f32x4, v);
     return make_float4(f.x, f.y, f.z, f.w);
+}
+
+// buffer_load_dwordx4 ... lds: lane l's 16 bytes go to lds + 16 l (lds wave-uniform), zeros for an out-of-range voff.
+// The builtin exists in the device pass only (the host pass would silently drop the kernel's launch stub).
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, float* lds, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ void tap_decode(const Geom& g, int t, int pa, int pb, int& ty, int& tx, int& off) {
@@ -173,8 +208,13 @@ __device__ __forceinline__ int a_swizzle(int kv) { return BKT == 32 ? ((kv & 7) 
 //      on 8 distinct 16-byte bank slots, and a fragment read (16 lanes = 16 rows at fixed kq) a permutation of all 16.
 //   B: a thread loads the 4 x 4 block (rows 4kq..4kq+3, columns n..n+3) and stores its register transpose as four
 //      quads; slot (kq, n ^ ((n >> 3) & 3)) does the same for the weights.
-template <int BM, int BN, int WM, int WN, bool FAST, bool VECB, int BK, bool QUAD = false>
-__global__ __launch_bounds__(256, (BK == 16 && !QUAD) ? 4 : 2) void igemm_nn_kernel(NNArgs a) {
+//
+// PF = 2: the global loads run TWO K tiles ahead of the MFMAs (two sets of staging registers; tile t + 2 is requested at the
+// start of tile t and stored to LDS at the end of tile t + 1).  The per-workgroup timeline (scripts/wg_trace.py) showed the K
+// loop at 74 % of its MFMA time with two workgroups per CU and 58 % with one: a K tile's MFMAs last 0.85 us, less than a
+// load that misses the XCD's L2, so with a distance of one tile every wave waited for its loads once per tile.
+template <int BM, int BN, int WM, int WN, bool FAST, bool VECB, int BK, bool QUAD = false, int PF = 1>
+__global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void igemm_nn_kernel(NNArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(!QUAD || (FAST && VECB), "the quad layout exists for the buffer-load path only");
     constexpr int MI = BM / WM / 32;
@@ -199,6 +239,10 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD) ? 4 : 2) void igemm_nn_ker
     float* As = smem;
     float* Bs = smem + 2 * A_TILE;
 
+    CG_STAMP(0);
+    if (a.stagger > 0 && (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1)) {   // HW_REG_HW_ID bits 3:0 = wave slot
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(2);
+    }
     const Geom& g = a.g;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -241,8 +285,8 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD) ? 4 : 2) void igemm_nn_ker
     const int b_nv = tid % NVEC, b_kr = tid / NVEC;   // QUAD: b_kr is the k quad of the thread's 4 x 4 block
     const bool b_on = !QUAD || tid < NBLK;
 
-    float4 areg[AROWS];
-    float4 breg[BPASS];
+    float4 aregs[PF][AROWS];
+    float4 bregs[PF][BPASS];
 
     // ---- FAST-path state -------------------------------------------------------------------------------
     unsigned long long cur[AROWS];     // tap-validity mask of each row, shifted so bit 0 = next tile's tap
@@ -299,19 +343,24 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD) ? 4 : 2) void igemm_nn_ker
         }
     }
 
-    auto load_tile = [&](int k0) {
+    // live == false (PF == 2 only: a tile behind the last one): the loads are still issued, at the out-of-range offset that
+    // returns 0 - the K loop then has no branch around its loads and the compiler's vmcnt bookkeeping stays exact (with a
+    // conditional load it waited for the newest tile's loads before storing the older one, which undid the prefetch)
+    auto load_tile = [&](int k0, auto setc, bool live = true) {
+        float4 (&areg)[AROWS] = aregs[decltype(setc)::value];
+        float4 (&breg)[BPASS] = bregs[decltype(setc)::value];
         if (FAST) {
             // (tapi, ci0, toff) describe this tile; all SGPR arithmetic
-            const int soff = (toff - minoff + ci0) * 4;
+            const int soff = live ? (toff - minoff + ci0) * 4 : 0;
 #pragma unroll
             for (int p = 0; p < AROWS; ++p) {
-                const unsigned voff = ((unsigned)cur[p] & 1u) ? rowbytes[p] : OOB;
+                const unsigned voff = (live && ((unsigned)cur[p] & 1u)) ? rowbytes[p] : OOB;
                 areg[p] = bufld4(rsx, voff, soff);
             }
             if (VECB) {
-                const int sb = k0 * g.Cout * 4;
+                const int sb = live ? k0 * g.Cout * 4 : 0;
 #pragma unroll
-                for (int q = 0; q < BPASS; ++q) breg[q] = bufld4(rsw, bvoff[q], sb);
+                for (int q = 0; q < BPASS; ++q) breg[q] = bufld4(rsw, live ? bvoff[q] : OOB, sb);
             }
             ci0 += BK;
             if (ci0 >= g.Cin) {
@@ -387,8 +436,10 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD) ? 4 : 2) void igemm_nn_ker
         qb_rd = h * BN + wn0 + (l31 ^ ((l31 >> 3) & 3));
     }
 
-    auto store_tile = [&](auto bufc) {
+    auto store_tile = [&](auto bufc, auto setc) {
         constexpr int buf = decltype(bufc)::value;
+        float4 (&areg)[AROWS] = aregs[decltype(setc)::value];
+        float4 (&breg)[BPASS] = bregs[decltype(setc)::value];
         float* A = As + buf * A_TILE;
         float* B = Bs + buf * B_TILE;
         if (QUAD) {
@@ -435,15 +486,23 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD) ? 4 : 2) void igemm_nn_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    using Set0 = std::integral_constant<int, 0>;
     if (T > 0) {
-        load_tile(ks);
-        store_tile(std::integral_constant<int, 0>{});
+        load_tile(ks, Set0{});
+        store_tile(std::integral_constant<int, 0>{}, Set0{});
+        if (PF == 2) load_tile(ks + BK, std::integral_constant<int, PF - 1>{}, T > 1);
     }
     __syncthreads();
+    CG_STAMP(1);
 
     auto k_tile = [&](auto bufc, int t) {
         constexpr int buf = decltype(bufc)::value;
-        if (t + 1 < T) load_tile(ks + (t + 1) * BK);
+        // PF == 1: request tile t + 1 into the only register set; PF == 2: request tile t + 2 into set `buf` (its previous
+        // content, tile t, went to LDS one tile ago) - tile t + 1 waits in set buf ^ 1 for the store at the end of this tile
+        using LoadSet = std::integral_constant<int, PF == 2 ? buf : 0>;
+        using StoreSet = std::integral_constant<int, PF == 2 ? (buf ^ 1) : 0>;
+        if (PF == 2) load_tile(ks + (t + PF) * BK, LoadSet{}, t + PF < T);
+        else if (!(CG_EXP & 1) && t + PF < T) load_tile(ks + (t + PF) * BK, LoadSet{});
         if (QUAD) {
             const float4* A4 = reinterpret_cast<const float4*>(As + buf * A_TILE);
             const float4* B4 = reinterpret_cast<const float4*>(Bs + buf * B_TILE);
@@ -475,7 +534,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD) ? 4 : 2) void igemm_nn_ker
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af[gq][i], sidx), f4c(bf[gq][j], sidx), acc[i][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < T) store_tile(std::integral_constant<int, buf ^ 1>{});
+            if (t + 1 < T) store_tile(std::integral_constant<int, buf ^ 1>{}, StoreSet{});
             __syncthreads();
             return;
         }
@@ -491,17 +550,29 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD) ? 4 : 2) void igemm_nn_ker
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
+                for (int j = 0; j < NI; ++j) {
+                    if (CG_EXP & 8) { asm volatile("" :: "v"(av[i]), "v"(bv[j])); continue; }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
         }
-        if (t + 1 < T) store_tile(std::integral_constant<int, buf ^ 1>{});
-        __syncthreads();
+        if (!(CG_EXP & 2) && t + 1 < T) store_tile(std::integral_constant<int, buf ^ 1>{}, StoreSet{});
+        if (!(CG_EXP & 4)) __syncthreads();
+        else asm volatile("" ::: "memory");
     };
+    if (PF == 2) {   // whole pairs first, then the odd tile: no branch between the two halves of the loop body
+        int t = 0;
+        for (; t + 1 < T; t += 2) {
+            k_tile(std::integral_constant<int, 0>{}, t);
+            k_tile(std::integral_constant<int, 1>{}, t + 1);
+        }
+        if (t < T) k_tile(std::integral_constant<int, 0>{}, t);
+    } else
     for (int t = 0; t < T; t += 2) {
         k_tile(std::integral_constant<int, 0>{}, t);
         if (t + 1 < T) k_tile(std::integral_constant<int, 1>{}, t + 1);
     }
 
+    CG_STAMP(2);
     // ---- epilogue: D[i][j], i = (r&3) + 8*(r>>2) + 4*h (pixel), j = l31 (channel)
     const bool partial = a.nsplit > 1;
     const bool add_bias = (gbias != nullptr) && !partial;
@@ -549,6 +620,268 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD) ? 4 : 2) void igemm_nn_ker
             }
         }
     }
+    CG_STAMP(3);
+}
+
+// ---------------------------------------------------------------------------
+// NN with LDS-direct loads (buffer_load_dwordx4 ... lds, gfx950): the tiles go from global memory straight into LDS - no
+// staging registers, no ds_write, no wait for a load in front of a store.  (Ablation of igemm_nn_kernel, CG_EXP builds: the
+// K loop of the 512 -> 256 data gradient runs 0.318 ms; without its LDS stores and the loads feeding them 0.271 ms.)
+// A lane's 16 bytes land at M0 + 16 * lane, so a wave instruction fills 1 KB of consecutive LDS and the tile layouts follow
+// from which global quad every lane asks for:
+//   A: row-major [m][BK] (a pixel's BK consecutive channels = 8 or 4 quads); the lane at position (m, j) loads quad
+//      j ^ swz(m), swz(m) = (m >> 1) & 7 (BK 32) / (m >> 2) & 3 (BK 16), so that a ds_read_b128 fragment read (16 lanes = 16
+//      rows, one quad each) covers all 16 bank slots while 8 (4) neighbouring lanes still fetch one pixel's 128 (64)
+//      consecutive bytes.  A lane whose tap falls into the padding asks for the out-of-range offset and its quad is
+//      written as zeros (checked on the hardware: tools/glds_test.hip).
+//   B: [k][n] as in igemm_nn_kernel (a wave instruction = 64 / (BN/4) consecutive weight rows), ds_read_b32 fragments.
+// MFMA step (g, s) multiplies A[m][8g + 4h + s] with B[8g + 4h + s][n] (h = lane / 32), the k order of the QUAD kernels.
+// FAST && VECB geometries only (Cin % BK == 0, 16-byte aligned operands, Cout % 4 == 0); prologue and epilogue as above.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int BK>
+__global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int MI = BM / WM / 32;
+    constexpr int NI = BN / WN / 32;
+    constexpr int A_TILE = BK * BM, B_TILE = BK * BN;
+    constexpr int KV = BK / 4;        // quads per A row
+    constexpr int RPW = 64 / KV;      // A rows per wave instruction
+    constexpr int ARPP = 256 / KV;    // A rows per pass of the workgroup
+    constexpr int AROWS = BM / ARPP;
+    static_assert(BM % ARPP == 0 && AROWS >= 1, "BM multiple of rows-per-pass");
+    constexpr int NVEC = BN / 4;
+    constexpr int BRPW = 64 / NVEC;   // B rows per wave instruction
+    constexpr int BRPP = 256 / NVEC;  // B rows per pass
+    constexpr int BPASS = (BK + BRPP - 1) / BRPP;
+    constexpr int G2 = KV / 2;
+
+    // separate arrays per buffer: the compiler can then tell the buffer the DMA writes from the one the fragments are read from
+    __shared__ __attribute__((aligned(16))) float As0[A_TILE];
+    __shared__ __attribute__((aligned(16))) float As1[A_TILE];
+    __shared__ __attribute__((aligned(16))) float Bs0[B_TILE];
+    __shared__ __attribute__((aligned(16))) float Bs1[B_TILE];
+
+    CG_STAMP(0);
+    const Geom& g = a.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm0 = (wave / WN) * (BM / WM);
+    const int wn0 = (wave % WN) * (BN / WN);
+
+    const int ntn = (g.Cout + BN - 1) / BN;
+    int bid = blockIdx.x;
+    if ((a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int tn = bid % ntn, tm = bid / ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y;
+    const int zz = blockIdx.z;
+    const int group = zz / g.nphase;
+    const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
+    const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
+    const float* gbias = sel4(group, a.b0, a.b1, a.b2, a.b3);
+    float* gy = sel4(group, a.y0, a.y1, a.y2, a.y3);
+    const int ks = split * a.kchunk;
+    const int kend = min(g.Ktot, ks + a.kchunk);
+    const int T = (kend - ks + BK - 1) / BK;
+    const float* wph = sel4(group, a.w0, a.w1, a.w2, a.w3) + (long)phase * g.Ktot * g.Cout;
+
+    // ---- A: lane -> (row a_r + ARPP p, LDS quad position a_kv); the quad it loads is a_kv ^ swz(row)
+    const int a_kv = tid % KV, a_r = tid / KV;
+    const int a_sw = KV == 8 ? ((a_r >> 1) & 7) : ((a_r >> 2) & 3);   // ARPP is a multiple of 16: the same for every pass
+    int rowb[AROWS], r_oy[AROWS], r_ox[AROWS];
+    bool r_ok[AROWS];
+#pragma unroll
+    for (int p = 0; p < AROWS; ++p) {
+        const int m = m0 + a_r + ARPP * p;
+        r_ok[p] = m < g.M;
+        int n, oy, ox;
+        pix_decode(g, r_ok[p] ? m : 0, n, oy, ox);
+        r_oy[p] = oy; r_ox[p] = ox;
+        rowb[p] = ((n * g.Hs + oy * g.td.ss) * g.Ws + ox * g.td.ss) * g.Cin;
+    }
+    const int b_nv = tid % NVEC, b_kr = tid / NVEC;
+
+    unsigned long long cur[AROWS];     // tap-validity mask of each row, shifted so bit 0 = next tile's tap
+    unsigned rowbytes[AROWS];
+    unsigned bvoff[BPASS];
+    int tapi = 0, ci0 = 0, toff = 0, minoff = 0;
+    {
+        const TapDesc& d = g.td;
+        const int kh = d.kk / d.kw;
+#pragma unroll
+        for (int p = 0; p < AROWS; ++p) cur[p] = 0ull;
+        for (int grp = 0; grp < d.ngroups; ++grp) {
+            int ga = pa, gb = pb;
+            if (d.ngroups > 1) { ga = grp >> 1; gb = grp & 1; }
+            unsigned xb[AROWS];
+#pragma unroll
+            for (int p = 0; p < AROWS; ++p) xb[p] = 0u;
+            for (int rx = 0; rx < d.kw; ++rx) {
+                const int tx = d.sgn * ((gb ? d.r0x1 : d.r0x0) + rx);
+#pragma unroll
+                for (int p = 0; p < AROWS; ++p)
+                    xb[p] |= ((unsigned)(r_ox[p] + tx) < (unsigned)g.Wv ? 1u : 0u) << rx;
+            }
+            for (int ry = 0; ry < kh; ++ry) {
+                const int ty = d.sgn * ((ga ? d.r0y1 : d.r0y0) + ry);
+                const int sh = grp * d.kk + ry * d.kw;
+#pragma unroll
+                for (int p = 0; p < AROWS; ++p)
+                    if (r_ok[p] && (unsigned)(r_oy[p] + ty) < (unsigned)g.Hv) cur[p] |= (unsigned long long)xb[p] << sh;
+            }
+        }
+        for (int t = 0; t < g.ntaps; ++t) {
+            int ty, tx, off;
+            tap_decode(g, t, pa, pb, ty, tx, off);
+            minoff = min(minoff, off);
+        }
+        tapi = ks / g.Cin;
+        ci0 = ks - tapi * g.Cin;
+        { int ty, tx; tap_decode(g, tapi, pa, pb, ty, tx, toff); }
+#pragma unroll
+        for (int p = 0; p < AROWS; ++p) {
+            cur[p] >>= tapi;
+            rowbytes[p] = (unsigned)(rowb[p] + 4 * (a_kv ^ a_sw)) * 4u;
+        }
+#pragma unroll
+        for (int q = 0; q < BPASS; ++q) {
+            const int kr = b_kr + q * BRPP;
+            const int n = n0 + 4 * b_nv;
+            bvoff[q] = (kr < BK && n < g.Cout) ? (unsigned)(kr * g.Cout + n) * 4u : OOB;
+        }
+    }
+    // base shifted down by the most negative tap offset so that the SGPR offset stays non-negative
+    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(gx + minoff), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wph, 0, 0x7fffffff, 0x00020000);
+
+    // request tile k0 (the FAST-path state describes it) into buffer `buf`; the wave's own 1 KB pieces
+    auto dma_tile = [&](int k0, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        float* A = buf ? As1 : As0;
+        float* B = buf ? Bs1 : Bs0;
+        const int soff = (toff - minoff + ci0) * 4;
+#pragma unroll
+        for (int p = 0; p < AROWS; ++p) {
+            const unsigned voff = ((unsigned)cur[p] & 1u) ? rowbytes[p] : OOB;
+            glds16(rsx, A + (ARPP * p + wave * RPW) * BK, voff, soff);
+        }
+        const int sb = k0 * g.Cout * 4;
+#pragma unroll
+        for (int q = 0; q < BPASS; ++q) {
+            const int row0 = q * BRPP + wave * BRPW;   // wave-uniform
+            if (BPASS * BRPP == BK || row0 < BK)
+                glds16(rsw, B + row0 * BN, bvoff[q], sb);
+        }
+        ci0 += BK;
+        if (ci0 >= g.Cin) {
+            ci0 = 0;
+            ++tapi;
+#pragma unroll
+            for (int p = 0; p < AROWS; ++p) cur[p] >>= 1;
+            if (tapi < g.ntaps) { int ty, tx; tap_decode(g, tapi, pa, pb, ty, tx, toff); }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (T > 0) dma_tile(ks, std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    CG_STAMP(1);
+
+    // fragment addresses: A quad (row, kq) at float4 index row * KV + (kq ^ swz(row)); swz depends on l31 only
+    const int f_sw = KV == 8 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
+    int qa_rd[G2];
+#pragma unroll
+    for (int gq = 0; gq < G2; ++gq) qa_rd[gq] = (wm0 + l31) * KV + ((2 * gq + h) ^ f_sw);
+    const int qb_rd = 4 * h * BN + wn0 + l31;
+
+    auto k_tile = [&](auto bufc, int t) {
+        constexpr int buf = decltype(bufc)::value;
+        if (t + 1 < T) dma_tile(ks + (t + 1) * BK, std::integral_constant<int, buf ^ 1>{});
+        const float4* A4 = reinterpret_cast<const float4*>(buf ? As1 : As0);
+        const float* B = (buf ? Bs1 : Bs0) + qb_rd;
+#pragma unroll
+        for (int gq = 0; gq < G2; ++gq) {
+            float4 af[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = A4[qa_rd[gq] + i * 32 * KV];
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                float bv[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bv[j] = B[(8 * gq + sidx) * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af[i], sidx), bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t + 1 are in LDS
+        __syncthreads();
+    };
+    for (int t = 0; t < T; t += 2) {
+        k_tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < T) k_tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+
+    CG_STAMP(2);
+    // ---- epilogue (as igemm_nn_kernel): D[i][j], i = (r&3) + 8*(r>>2) + 4*h (pixel), j = l31 (channel)
+    const bool partial = a.nsplit > 1;
+    const bool add_bias = (gbias != nullptr) && !partial;
+    float* yout = partial ? a.part : gy;
+    const int act = partial ? 0 : a.act;
+    float* zout = act ? sel4(group, a.z0, a.z1, a.z2, a.z3) : nullptr;
+    float aslope = a.slope;
+    if (act == 1) aslope = *sel4(group, a.al0, a.al1, a.al2, a.al3);
+    const bool stats = a.stats != nullptr && !partial;
+    float bj[NI], s1[NI], s2[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        bj[j] = (add_bias && n < g.Cout) ? gbias[n] : 0.f;
+        s1[j] = 0.f; s2[j] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= g.M) continue;
+            const long ro = partial ? ((long)(split * (a.ngroups * g.nphase) + zz) * g.M + m) * g.Cout : out_row(g, m, pa, pb);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn0 + j * 32 + l31;
+                if (n < g.Cout) {
+                    const float v = acc[i][j][r] + bj[j];
+                    yout[ro + n] = v;
+                    if (act) zout[ro + n] = apply_act(act, v, aslope);
+                    if (stats) { s1[j] += v; s2[j] += v * v; }
+                }
+            }
+        }
+    }
+    if (stats) {   // the two half-waves hold the two row halves of the same columns
+        const int srow = (zz * (int)((g.M + BM - 1) / BM) + tm) * WM + wave / WN;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64), t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+            const int n = n0 + wn0 + j * 32 + l31;
+            if (h == 0 && n < g.Cout) {
+                a.stats[((long)srow * 2 + 0) * g.Cout + n] = t1;
+                a.stats[((long)srow * 2 + 1) * g.Cout + n] = t2;
+            }
+        }
+    }
+    CG_STAMP(3);
 }
 
 // split-K reduce for NN: y_group[out_row(m)][n] = bias_group[n] + sum_s part[s][group*nphase+phase][m][n]
@@ -1116,6 +1449,187 @@ __global__ __launch_bounds__(256, 2) void igemm_tnq_kernel(TNArgs a, int flat) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// TN with LDS-direct loads (see igemm_nng_kernel): both operands are pixel rows of consecutive channels, i.e. already the
+// K-major [pixel][column] tiles the MFMA fragments are read from, so a wave instruction simply drops 64 / (BM / 4) pixel
+// rows of 4 BM bytes into place (no swizzle, ds_read_b32 fragments exactly as in igemm_tn_kernel).  Lean addressing only
+// (the host checks, tnq_kstep): power-of-two grid with HWg >= 16 or the flat rows of a 1 x 1 kernel, whole K tiles.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int flat) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int MI = BM / WM / 32;
+    constexpr int NI = BN / WN / 32;
+    constexpr int LDA = BM, LDB = BN;
+    constexpr int A_TILE = BK * LDA, B_TILE = BK * LDB;
+    constexpr int AVEC = BM / 4, ARPP = 256 / AVEC, APASS = (BK + ARPP - 1) / ARPP, ARPW = 64 / AVEC;
+    constexpr int BVEC = BN / 4, BRPP = 256 / BVEC, BPASS = (BK + BRPP - 1) / BRPP, BRPW = 64 / BVEC;
+
+    __shared__ __attribute__((aligned(16))) float As0[A_TILE];
+    __shared__ __attribute__((aligned(16))) float As1[A_TILE];
+    __shared__ __attribute__((aligned(16))) float Bs0[B_TILE];
+    __shared__ __attribute__((aligned(16))) float Bs1[B_TILE];
+
+    const Geom& g = a.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm0 = (wave / WN) * (BM / WM);
+    const int wn0 = (wave % WN) * (BN / WN);
+
+    const int ntn = (g.Cout + BN - 1) / BN;
+    int bid = blockIdx.x, split = blockIdx.y;
+    if ((a.xcd_swizzle & 2) && (gridDim.y & 7) == 0) {   // XCD = pixel chunk, see igemm_tn_kernel
+        const int L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, s8 = (int)gridDim.y >> 3;
+        split = (L & 7) + 8 * ((L >> 3) % s8);
+        bid = (L >> 3) / s8;
+    } else if ((a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) {
+        bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    }
+    const int tn = bid % ntn, tm = bid / ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int zz = blockIdx.z;
+    const int group = zz / g.nphase;
+    const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
+    const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
+    const float* gdy = sel4(group, a.d0, a.d1, a.d2, a.d3);
+    const int ps = split * a.pchunk;
+    const int pend = min(g.M, ps + a.pchunk);
+    const int T = (pend - ps) / BK;
+
+    const int a_mv = tid % AVEC, a_kr = tid / AVEC;
+    const int b_nv = tid % BVEC, b_kr = tid / BVEC;
+    const bool lin_out = g.so == 1 && g.nphase == 1;
+    const int HWg = g.Hg * g.Wg;
+    int l_minoff = 0, c_ty = 0, c_tx = 0, c_off = 0;
+    bool c_ok;
+    {
+        const int mm = m0 + 4 * a_mv;
+        c_ok = mm < g.Ktot;
+        const int mc = c_ok ? mm : 0;
+        const int tap = mc / g.Cin;
+        int off;
+        tap_decode(g, tap, pa, pb, c_ty, c_tx, off);
+        c_off = off + (mc - tap * g.Cin);
+        for (int t = 0; t < g.ntaps; ++t) {
+            int ty, tx, o2;
+            tap_decode(g, t, pa, pb, ty, tx, o2);
+            l_minoff = min(l_minoff, o2);
+        }
+    }
+    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(gx + l_minoff), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)gdy, 0, 0x7fffffff, 0x00020000);
+    const bool b_nok = n0 + 4 * b_nv < g.Cout;
+    int l_ay[APASS], l_ax[APASS];
+    unsigned l_avoff[APASS], l_bvoff[BPASS];
+    const bool wide = flat || g.Wg >= BK;
+#pragma unroll
+    for (int q = 0; q < APASS; ++q) {
+        const int kr = a_kr + q * ARPP;
+        const int kyo = wide ? 0 : (kr >> g.lgW), kxo = flat ? 0 : (wide ? kr : (kr & (g.Wg - 1)));
+        l_ay[q] = kyo + c_ty;
+        l_ax[q] = kxo + c_tx;
+        l_avoff[q] = (c_ok && kr < BK) ? (unsigned)(kr * g.Cin + c_off - l_minoff) * 4u : OOB;
+    }
+#pragma unroll
+    for (int q = 0; q < BPASS; ++q) {
+        const int kr = b_kr + q * BRPP;
+        const int byo = wide ? 0 : (kr >> g.lgW), bxo = wide ? kr : (kr & (g.Wg - 1));
+        const int rel = lin_out ? kr * g.Cout : (byo * g.so * g.Wout + bxo * g.so) * g.Cout;
+        l_bvoff[q] = (b_nok && kr < BK) ? (unsigned)(rel + n0 + 4 * b_nv) * 4u : OOB;
+    }
+    // gradBias rides along on the row-tile 0 workgroups: column sums of the dy rows, read back from the LDS tile
+    const bool do_bias = a.bias_part != nullptr && tm == 0;
+    float bsum = 0.f;
+
+    auto dma_tile = [&](int p0, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        float* A = buf ? As1 : As0;
+        float* B = buf ? Bs1 : Bs0;
+        const int r0 = flat ? 0 : (p0 & (HWg - 1));
+        const int oyb = flat ? 0 : (r0 >> g.lgW), oxb = flat ? 0 : (r0 & (g.Wg - 1));
+        const int soa = p0 * g.Cin * 4;
+#pragma unroll
+        for (int q = 0; q < APASS; ++q) {
+            const int row0 = q * ARPP + wave * ARPW;   // wave-uniform
+            if (APASS * ARPP == BK || row0 < BK) {
+                const bool ok = (unsigned)(oyb + l_ay[q]) < (unsigned)g.Hv && (unsigned)(oxb + l_ax[q]) < (unsigned)g.Wv;
+                glds16(rsx, A + row0 * LDA, ok ? l_avoff[q] : OOB, soa);
+            }
+        }
+        int sob;
+        if (lin_out) sob = p0 * g.Cout * 4;
+        else {
+            const int nimg = p0 >> g.lgHW;
+            sob = (((nimg * g.Hout + oyb * g.so + pa) * g.Wout + oxb * g.so + pb) * g.Cout) * 4;
+        }
+#pragma unroll
+        for (int q = 0; q < BPASS; ++q) {
+            const int row0 = q * BRPP + wave * BRPW;
+            if (BPASS * BRPP == BK || row0 < BK) glds16(rsd, B + row0 * LDB, l_bvoff[q], sob);
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (T > 0) dma_tile(ps, std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto k_tile = [&](auto bufc, int t) {
+        constexpr int buf = decltype(bufc)::value;
+        if (t + 1 < T) dma_tile(ps + (t + 1) * BK, std::integral_constant<int, buf ^ 1>{});
+        const float* A = (buf ? As1 : As0) + wm0 + l31;
+        const float* B = (buf ? Bs1 : Bs0) + wn0 + l31;
+        if (do_bias && tid < BN) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) bsum += (buf ? Bs1 : Bs0)[kk * LDB + tid];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[MI], bv[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) av[i] = A[(kk + h) * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bv[j] = B[(kk + h) * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    for (int t = 0; t < T; t += 2) {
+        k_tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < T) k_tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+
+    if (do_bias && tid < BN && n0 + tid < g.Cout)
+        a.bias_part[(long)(split * (a.ngroups * g.nphase) + zz) * g.Cout + n0 + tid] = bsum;
+    float* pout = a.part + (long)(split * (a.ngroups * g.nphase) + zz) * g.Ktot * g.Cout;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        if (n >= g.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < g.Ktot) pout[(long)m * g.Cout + n] = acc[i][j][r];
+            }
+        }
+    }
+}
+
 // canonical tap d of a k-tap kernel (pad p) seen from output phase a -> index of the low-res tap it folds into
 __device__ __host__ __forceinline__ int phase_map(int a, int d, int pad) { return ((a + d - pad) >> 1) - ((a - pad) >> 1); }
 
@@ -1649,6 +2163,23 @@ static void launch_nn(const NNArgs& a, dim3 grid, hipStream_t st, bool fast, boo
             else hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, 16, true>), grid, dim3(256), 0, st, a);
             return;
         }
+        // LDS-direct loads (igemm_nng_kernel).  CG_NN_GLDS = 1: the 64-row tiles at K step 32 (a pixel's 128 consecutive
+        // bytes per 8 lanes; measured inside the replayed step 2.43 -> 1.91 ms for the 64x128 tile), 2: K step 32 for every
+        // tile whose Cin allows it, 3: K step 16 as well (64-byte runs per pixel: slower than the register path in the step)
+        const long glds = cg::opt(cg::OPT_NN_GLDS);
+        if (glds && bk32 && (BM == 64 || glds >= 2)) {
+            hipLaunchKernelGGL((igemm_nng_kernel<BM, BN, WM, WN, 32>), grid, dim3(256), 0, st, a);
+            return;
+        }
+        if (glds >= 3) {
+            hipLaunchKernelGGL((igemm_nng_kernel<BM, BN, WM, WN, 16>), grid, dim3(256), 0, st, a);
+            return;
+        }
+        if (cg::opt(cg::OPT_NN_PF) >= 2) {   // global loads two K tiles ahead
+            if (BM == 64 && bk32) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, (BM == 64 ? 32 : 16), false, 2>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, 16, false, 2>), grid, dim3(256), 0, st, a);
+            return;
+        }
         // 64-row tiles do only 8-16 MFMAs per wave per K step of 16: give them 32 so the per-tile work
         // (address VALU, LDS stores, barrier) is amortised like in the 128x128 tile
         if (BM == 64 && bk32) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, (BM == 64 ? 32 : 16)>), grid, dim3(256), 0, st, a);
@@ -1669,7 +2200,9 @@ static void launch_tn(const TNArgs& a, dim3 grid, hipStream_t st, bool veca, boo
 
 // quad-tile weight-gradient kernel (igemm_tnq_kernel): 0 = not eligible, else the K step (pixels per tile)
 static int tnq_kstep(const Geom& g, int pchunk, bool veca, bool vecb) {
-    const long mode = cg::opt(cg::OPT_TN_QUAD);
+    long mode = cg::opt(cg::OPT_TN_QUAD);
+    const bool glds = cg::opt(cg::OPT_TN_GLDS) != 0;   // igemm_tng_kernel: same eligibility at K step 16; returns -16
+    if (glds) mode = 1;
     if (!mode || !veca || !vecb) return 0;
     const bool lin_src = g.td.ss == 1 && g.Hs == g.Hg && g.Ws == g.Wg;
     const bool lin_out = g.so == 1 && g.nphase == 1;
@@ -1678,7 +2211,7 @@ static int tnq_kstep(const Geom& g, int pchunk, bool veca, bool vecb) {
     const int HWg = g.Hg * g.Wg;
     for (int bkt = (mode >= 2 ? 32 : 16); bkt >= 16; bkt >>= 1) {
         if (g.M % bkt || pchunk % bkt) continue;
-        if (flat || (g.lgW >= 0 && g.lgHW >= 0 && HWg >= bkt && (lin_out || g.so == 2))) return bkt;
+        if (flat || (g.lgW >= 0 && g.lgHW >= 0 && HWg >= bkt && (lin_out || g.so == 2))) return glds ? -bkt : bkt;
     }
     return 0;
 }
@@ -1687,6 +2220,10 @@ static bool tnq_flat(const Geom& g) { return g.ntaps == 1 && g.td.r0y0 == 0 && g
 template <int BM, int BN, int WM, int WN>
 static void launch_tnq(const TNArgs& a, dim3 grid, hipStream_t st, int bkt) {
     const int flat = tnq_flat(a.g) ? 1 : 0;
+    if (bkt < 0) {   // LDS-direct loads, K step 16
+        hipLaunchKernelGGL((igemm_tng_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, a, flat);
+        return;
+    }
     if (bkt == 32) hipLaunchKernelGGL((igemm_tnq_kernel<BM, BN, WM, WN, 32>), grid, dim3(256), 0, st, a, flat);
     else hipLaunchKernelGGL((igemm_tnq_kernel<BM, BN, WM, WN, 16>), grid, dim3(256), 0, st, a, flat);
 }
@@ -1866,6 +2403,7 @@ static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const
     a.part = (float*)ws; a.ngroups = ngroups; a.g = g;
     a.kchunk = p.kchunk; a.nsplit = p.splits;
     a.xcd_swizzle = (int)cg::opt(cg::OPT_XCD_SWIZZLE);
+    a.stagger = (int)cg::opt(cg::OPT_NN_STAGGER);
     if (ep && ep->act) {
         CG_REQUIRE(ep->act == 1 || ep->act == 2, "%s: unknown activation %d", who, ep->act);
         CG_REQUIRE(ep->y_act, "%s: fused activation needs y_act", who);
@@ -1914,6 +2452,13 @@ static int conv_geom(Geom& g, int N, int Hp, int Wp, int Cin, int Cout, int kH, 
 }
 
 }  // namespace
+
+#ifdef CG_TRACE
+extern "C" int cg_debug_set_trace(void* p) {
+    unsigned long long* q = (unsigned long long*)p;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &q, sizeof(q)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" {
 

@@ -199,13 +199,17 @@ NN_TILES = [128128, 64128, 128064, 64064, 128032]
 @pytest.mark.parametrize("tile", NN_TILES)
 @pytest.mark.parametrize("bk32", [0, 1])
 @pytest.mark.parametrize("splits", [0, 3])
-@pytest.mark.parametrize("quad", [pytest.param(0, id="b32"), pytest.param(2, id="quad")])
-def test_forced_nn_tile_variants(cg, tile, bk32, splits, quad):
-    """igemm_nn_kernel<BM,BN,...,BK,QUAD> for every block tile, K step 16 / 32, with and without split-K (+ reduce kernel),
-    on plain, upsample-folded (4 phases) and folded data-gradient (4 tap groups) geometries; ragged M and Cout.
-    quad = 0: the ds_read_b32 kernels; quad = 2: the k-quad LDS layout (ds_read_b128 fragments), K step 32 for every tile
-    when bk32 (quad = 1, the default, takes K step 32 for the 64-row tiles only - a subset of these instances)."""
-    with options(cg, CG_NN_TILE=tile, CG_GEMM_BK32=bk32, CG_NN_SPLITS=splits, CG_SKINNY=0, CG_NN_QUAD=quad):
+@pytest.mark.parametrize("stage", ["b32", "quad", "pf2", "glds"])
+def test_forced_nn_tile_variants(cg, tile, bk32, splits, stage):
+    """igemm_nn_kernel<BM,BN,...,BK,QUAD,PF> / igemm_nng_kernel<BM,BN,..,BK> for every block tile, K step 16 / 32, with and
+    without split-K (+ reduce kernel), on plain, upsample-folded (4 phases) and folded data-gradient (4 tap groups)
+    geometries; ragged M and Cout.  How a K tile reaches the MFMAs: b32 = registers -> transposed LDS tile -> ds_read_b32
+    fragments; quad = k-quad LDS layout with ds_read_b128 fragments (CG_NN_QUAD=2: K step 32 for every tile when bk32; 1
+    takes it for the 64-row tiles only - a subset of these instances); pf2 = b32 with the global loads two tiles ahead;
+    glds = LDS-direct loads (buffer_load ... lds)."""
+    how = {"b32": dict(CG_NN_GLDS=0), "quad": dict(CG_NN_GLDS=0, CG_NN_QUAD=2), "pf2": dict(CG_NN_GLDS=0, CG_NN_PF=2),
+           "glds": dict(CG_NN_GLDS=3)}[stage]
+    with options(cg, CG_NN_TILE=tile, CG_GEMM_BK32=bk32, CG_NN_SPLITS=splits, CG_SKINNY=0, **how):
         run_conv(cg, 3, 64, 10, 6, 72, 3, 0, seed=tile % 97)          # ragged M = 180, Cout = 72
         run_conv(cg, 2, 32, 8, 8, 128, 3, 1, seed=tile % 89, wino=False)
         run_conv(cg, 2, 64, 4, 4, 32, 5, 1, seed=tile % 83, wino=False)
@@ -228,13 +232,15 @@ def run_linear(cg, N, i, o, seed=0):
 
 @pytest.mark.parametrize("tile", NN_TILES)
 @pytest.mark.parametrize("splits", [0, 5])
-@pytest.mark.parametrize("quad", [pytest.param(0, id="b32"), pytest.param(1, id="quad16"), pytest.param(2, id="quad32")])
-def test_forced_tn_tile_variants(cg, tile, splits, quad):
-    """igemm_tn_kernel<BM,BN> / igemm_tnq_kernel<BM,BN,BKT> (weight gradient) for every block tile, default and forced pixel
-    splits; the lean power-of-two addressing (16x16 grid, and the 4 phases of a folded upsampling), the generic one (10x6
-    grid: always the b32 kernel) and the flat rows of a linear layer.  quad = 1 / 2: the pixel-quad LDS layout with K
-    steps of 16 / 32 pixels."""
-    with options(cg, CG_TN_TILE=tile, CG_TN_SPLITS=splits, CG_SKINNY=0, CG_TN_QUAD=quad):
+@pytest.mark.parametrize("stage", ["b32", "quad16", "quad32", "glds"])
+def test_forced_tn_tile_variants(cg, tile, splits, stage):
+    """igemm_tn_kernel<BM,BN> / igemm_tnq_kernel<BM,BN,BKT> / igemm_tng_kernel<BM,BN> (weight gradient) for every block tile,
+    default and forced pixel splits; the lean power-of-two addressing (16x16 grid, and the 4 phases of a folded upsampling),
+    the generic one (10x6 grid: always the b32 kernel) and the flat rows of a linear layer.  quad16 / quad32: the pixel-quad
+    LDS layout with K steps of 16 / 32 pixels; glds: LDS-direct loads."""
+    how = {"b32": dict(CG_TN_GLDS=0), "quad16": dict(CG_TN_GLDS=0, CG_TN_QUAD=1), "quad32": dict(CG_TN_GLDS=0, CG_TN_QUAD=2),
+           "glds": dict(CG_TN_GLDS=1)}[stage]
+    with options(cg, CG_TN_TILE=tile, CG_TN_SPLITS=splits, CG_SKINNY=0, **how):
         run_conv(cg, 3, 64, 10, 6, 72, 3, 0, seed=tile % 97, check_dgrad=False)
         run_conv(cg, 2, 64, 16, 16, 64, 3, 0, seed=tile % 89, check_dgrad=False)
         run_conv(cg, 2, 32, 8, 8, 128, 3, 1, seed=tile % 83, wino=False, check_dgrad=False)
