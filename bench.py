@@ -86,13 +86,13 @@ def time_kernel(fn, iters=20, warm=3):
 def kernel_rooflines(cg, N):
     """The kernels that carry the step (time shares from profiles/r02*_per_step_breakdown.txt), each timed in isolation with
     HIP events on the launch stream at the benchmarked batch, EXECUTED MFMA FLOPs per launch / duration against the fp32 MFMA
-    peak.  `traffic` / MFMA-pipe utilisation come from the committed PMC pass of the same launches (profiles/r02_pmc_kernels.json,
+    peak.  `traffic` / MFMA-pipe utilisation come from the committed PMC pass of the same launches (profiles/r02b_pmc_kernels.json,
     scripts/pmc_kernels.sh; bench.py cannot run rocprofv3 on itself) and carry their source."""
     lib, stream = cg.tensor.lib(), cg.tensor.stream()
     out = []
     pmc = {}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02b_pmc_kernels.json")))
     except Exception:
         pass
 
@@ -109,7 +109,7 @@ def kernel_rooflines(cg, N):
             e["traffic"] = p_.get("hbm_bytes_per_launch_corrected")
             e["mfma_pipe_util_pmc"] = p_.get("mfma_pipe_util")
             e["valu_per_mfma_pmc"] = p_.get("valu_per_mfma")
-            e["pmc_source"] = p_.get("source", "profiles/r02_pmc_kernels.json")
+            e["pmc_source"] = p_.get("source", "profiles/r02b_pmc_kernels.json")
         if extra:
             e.update(extra)
         out.append(e)
@@ -123,17 +123,17 @@ def kernel_rooflines(cg, N):
         m.forward(xin)
         return m, xin, dy
 
-    # (1) igemm_nn_kernel<64,128,2,2,FAST,VECB,32>: largest launch = data gradient of G's 512->256 3x3 layer behind the 2x
+    # (1) igemm_nng_kernel<64,128,2,2,32> (LDS-direct loads): largest launch = data gradient of G's 512->256 3x3 layer behind the 2x
     #     upsampling (models.lua:211-212), one GEMM over the 4 phases' taps: M = N*8*8, K = 16 taps * 256, Cout = 512
     m, xin, dy = conv(512, 256, 3, 8, N, 1)
     t = time_kernel(lambda: m.updateGradInput(xin, dy))
     direct = 2.0 * N * 16 * 16 * 256 * 512 * 9
-    entry("nn64x128", "igemm_nn_kernel<64,128,2,2,true,true,32> (gemm.hip)",
+    entry("nn64x128", "igemm_nng_kernel<64,128,2,2,32> (gemm.hip; LDS-direct loads)",
           f"updateGradInput of upsample2 -> conv3x3 512->256 @8->16, batch {N}: one implicit GEMM, M={N * 64} K=4096 N=512",
           2.0 * N * 64 * 4096 * 512, t, direct, "19 % of the step's kernel time (16 launches)")
-    # (2) igemm_tn_kernel<128,128>: weight gradient of the same layer (4 phases, split over pixels) + its reduce kernels
+    # (2) igemm_tng_kernel<128,128> (LDS-direct loads): weight gradient of the same layer (4 phases, split over pixels) + its reduce kernels
     t = time_kernel(lambda: m.accGradParameters(xin, dy))
-    entry("tn128x128", "igemm_tn_kernel<128,128,2,2,true,true> + wgrad_reduce_kernel<true> + bias_part_reduce_kernel (gemm.hip)",
+    entry("tn128x128", "igemm_tng_kernel<128,128,2,2> + wgrad_reduce_kernel<true> + bias_part_reduce_kernel (gemm.hip)",
           f"accGradParameters of the same layer, batch {N}: launch GROUP (TN GEMM + deterministic split reduce)",
           2.0 * N * 64 * 4 * 2048 * 256, t, direct, "12 % (10 launches)", {"timed": "launch group, not the GEMM kernel alone"})
     # (3) igemm_nn_kernel<128,64,...,16>: D's 64->64 3x3 convolution at 32x32 (models.lua:648)

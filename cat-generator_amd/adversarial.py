@@ -32,6 +32,7 @@ DEFAULT_OPT = dict(  # train.lua:15-49
     # the G-step's generator forward on a side stream beside the D update (single rank): 7.52 -> 7.45 ms/step (round 1: no gain -
     # the D update's tail was still long enough to fill the chip on its own)
     concurrent_g_forward=os.environ.get("CG_CONCURRENT_G", "1") != "0",
+    g_forward_fork=os.environ.get("CG_G_FORK", "early"),   # "late": fork it behind D's forward pass instead of in front of it
 )
 
 
@@ -115,6 +116,8 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         S.GRAD_PARAMETERS_D.zero()
         targets = buf["targets_D"]
         outputs = S.MODEL_D.forward(inputs)
+        if st.get("fork_late"):            # CG_G_FORK=late: the G-step's generator forward beside D's BACKWARD pass only
+            st.pop("fork_late")()
         f = S.CRITERION.forward(outputs, targets)
         df_do = S.CRITERION.backward(outputs, targets)
         nn.WGRAD_SIDE.begin()              # D's weight-gradient GEMMs on a side stream, under the rest of the backward chain
@@ -225,13 +228,20 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
             if S._side is None:
                 S._side = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
             side, ev_fork, ev_join = S._side
-            ev_fork.record()
-            side.wait_event(ev_fork)
-            with torch.cuda.stream(side):
-                st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.createNoiseInputs(S, N)
-                st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
-                ev_join.record()
-            st["join"] = ev_join
+
+            def fork():
+                ev_fork.record()
+                side.wait_event(ev_fork)
+                with torch.cuda.stream(side):
+                    st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.createNoiseInputs(S, N)
+                    st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
+                    ev_join.record()
+                st["join"] = ev_join
+
+            if OPT.get("g_forward_fork", "early") == "late":
+                st["fork_late"] = fork
+            else:
+                fork()
         fused = dict(l1=OPT["D_L1"], l2=OPT["D_L2"], clamp=OPT["D_clamp"]) if OPT["fused_update"] else None
         m = OPT["D_optmethod"]  # adversarial.lua:240-248
         assert m in ("sgd", "adagrad", "adam"), "[Warning] Unknown optimizer method chosen for D."
