@@ -142,14 +142,16 @@ def kernel_rooflines(cg, N):
     f2 = 2.0 * N * 32 * 32 * 64 * 64 * 9
     entry("nn128x64", "igemm_nn_kernel<128,64,2,2,true,true,16> (gemm.hip)",
           f"updateOutput of conv3x3 64->64 @32x32, batch {N}: M={N * 1024} K=576 N=64", f2, t, f2, "9 % (8 launches)")
-    # (4) wino_gemm_kernel<8,16>: the 16 Winograd-domain GEMMs + in-register output transform of G's upsample2 -> conv5x5
+    # (4) wino_gemm_g_kernel<16>: the 16 Winograd-domain GEMMs + in-register output transform of G's upsample2 -> conv5x5
     m3, x3, dy3 = conv(256, 128, 5, 16, N, 1)
     if getattr(m3, "_wino", False):
         y = m3.output
         v = m3._get("wino_v", (lib.conv2d_ups2_wino_v_floats(N, 16, 16, 256),))
         t = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(stream, v.ptr, m3._u_fwd.data_ptr(), m3.bias.ptr, y.ptr, N, 16, 16, 256, 128, 0))
         d3 = 2.0 * N * 32 * 32 * 128 * 256 * 25
-        entry("wino8x16", "wino_gemm_kernel<8,16> (winograd.hip)",
+        # the LDS-direct-load kernel became the default after the last PMC pass of this round (profiles/r02b_pmc_kernels.json
+        # holds wino_gemm_kernel<8,16>): no counter figures are attached to this entry until it is re-profiled
+        entry("wino_g16", "wino_gemm_g_kernel<16> (winograd.hip; LDS-direct loads)",
               f"forward of upsample2 -> conv5x5 256->128 @16->32 (models.lua:217-218), batch {N}: 4 phases x 16 GEMMs [tiles x 256].[256 x 128]",
               d3 * 36 / 100 * 16 / 36, t, d3, "9 % (3 launches of the two wino_gemm variants)",
               {"layer_ms": {"fwd": 1e3 * time_kernel(lambda: m3.updateOutput(x3)), "dgrad": 1e3 * time_kernel(lambda: m3.updateGradInput(x3, dy3)),

@@ -399,6 +399,158 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((QUAD && BK == 32) ? 2 : 4) : 2
 }
 
 // ---------------------------------------------------------------------------
+// The same 16 GEMMs + output transform with LDS-direct loads (buffer_load_dwordx4 ... lds; igemm_nng_kernel in gemm.hip has
+// the layouts and the reasoning): 8 waves, wave tile 32 x 32.  A = 64 rows of V (a tile's BK consecutive k = 8 or 4 quads,
+// row-major, quad index XOR-ed with swz(row) so that the ds_read_b128 fragment reads are conflict-free), B = BK rows of U
+// ([k][n], ds_read_b32 fragments).  A wave instruction fills 1 KB: BK 32 -> every wave brings 8 rows of V and 2 x 2 rows
+// of U per K tile; BK 16 -> waves 0..3 bring 16 rows of V each, every wave 2 rows of U.  Rows past the last tile are
+// clamped to it (their results are never stored), as in wino_gemm_kernel.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wino_glds16(__amdgpu_buffer_rsrc_t r, float* lds, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass would drop the kernel's launch stub (see gemm.hip)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+#endif
+}
+
+template <int BK>
+__global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
+    constexpr int BM = 64, BN = 128;
+    constexpr int KV = BK / 4, RPW = 64 / KV, G2 = KV / 2;
+    constexpr int A_TILE = BK * BM, B_TILE = BK * BN;
+    constexpr int AW = BM / RPW;          // waves that bring A rows (8 at BK 32, 4 at BK 16)
+    constexpr int BQ = BK / 16;           // B instructions per wave per K tile (16 rows per pass of the 8 waves)
+    __shared__ __attribute__((aligned(16))) float As0[A_TILE];
+    __shared__ __attribute__((aligned(16))) float As1[A_TILE];
+    __shared__ __attribute__((aligned(16))) float Bs0[B_TILE];
+    __shared__ __attribute__((aligned(16))) float Bs1[B_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm0 = (wave & 1) * 32, wn0 = (wave >> 1) * 32;
+    const int ntn = a.Nc / BN;
+    int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn, phase = blockIdx.z;
+    const int tiles_m = gridDim.x / ntn;
+    if (a.xcd && (tiles_m & 7) == 0) {   // the workgroups sharing a V block on one XCD, see wino_gemm_kernel
+        const int share = ntn * (int)gridDim.z;
+        const int L = (int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x;
+        const int slot = L >> 3, member = slot % share;
+        tm = (slot / share) * 8 + (L & 7);
+        phase = member / ntn;
+        tn = member - phase * ntn;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int KT = a.K / BK;
+
+    // ---- staging: lane -> (row, LDS quad position) of A, (k row, column quad) of B
+    const int a_row_l = (wave % AW) * RPW + lane / KV;            // row of the tile block this lane brings (waves >= AW: unused)
+    const int a_pos = lane % KV;
+    const int a_sw = KV == 8 ? ((a_row_l >> 1) & 7) : ((a_row_l >> 2) & 3);
+    const int a_row = min(m0 + a_row_l, a.T - 1);
+    const unsigned a_voff = (unsigned)(a_row * a.K + 4 * (a_pos ^ a_sw)) * 4u;
+    const int b_kr = wave * 2 + (lane >> 5);                      // + 16 q
+    const unsigned b_voff = (unsigned)(b_kr * a.Nc + n0 + 4 * (lane & 31)) * 4u;
+    const float* Up = a.U + (long)phase * 16 * a.K * a.Nc;
+    __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc((void*)Up, 0, 0x7fffffff, 0x00020000);
+    const long a_plane = (long)a.T * a.K;                         // V stride between xi (one plane < 2 GB: host check)
+
+    // the next tile to request: (xi, k0), advanced by every dma_tile
+    int nxi = 0, nk0 = 0;
+    auto dma_tile = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        float* A = buf ? As1 : As0;
+        float* B = buf ? Bs1 : Bs0;
+        if (AW == 8 || wave < AW) {
+            __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)(a.V + nxi * a_plane), 0, 0x7fffffff, 0x00020000);
+            wino_glds16(rsv, A + (wave % AW) * RPW * BK, a_voff, nk0 * 4);
+        }
+        const int sb = (nxi * a.K + nk0) * a.Nc * 4;
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) wino_glds16(rsu, B + (16 * q + wave * 2) * BN, b_voff + (unsigned)(16 * q * a.Nc) * 4u, sb);
+        nk0 += BK;
+        if (nk0 >= a.K) { nk0 = 0; ++nxi; }
+    };
+
+    f32x16 accM, accY[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        accM[r] = 0.f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) accY[o][r] = 0.f;
+    }
+
+    dma_tile(std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int f_sw = KV == 8 ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
+    int qa_rd[G2];
+#pragma unroll
+    for (int gq = 0; gq < G2; ++gq) qa_rd[gq] = (wm0 + l31) * KV + ((2 * gq + h) ^ f_sw);
+    const int qb_rd = 4 * h * BN + wn0 + l31;
+
+    auto k_tile = [&](auto bufc, bool more) {
+        constexpr int BUF = decltype(bufc)::value;
+        if (more) dma_tile(std::integral_constant<int, BUF ^ 1>{});
+        const float4* A4 = reinterpret_cast<const float4*>(BUF ? As1 : As0);
+        const float* B = (BUF ? Bs1 : Bs0) + qb_rd;
+#pragma unroll
+        for (int gq = 0; gq < G2; ++gq) {
+            const float4 af = A4[qa_rd[gq]];
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+                accM = __builtin_amdgcn_mfma_f32_32x32x2f32(wf4c(af, sidx), B[(8 * gq + sidx) * BN], accM, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    for (int xi = 0; xi < 16; ++xi) {
+        for (int kt = 0; kt < KT; kt += 2) {   // KT is even (host checks K % (2 BK) == 0)
+            k_tile(std::integral_constant<int, 0>{}, true);
+            k_tile(std::integral_constant<int, 1>{}, !(kt + 2 == KT && xi == 15));
+        }
+        // M_xi complete: fold it into the four outputs, A^T = [1 1 1 0; 0 1 -1 -1]
+        const int xy = xi >> 2, xx = xi & 3;
+        const float cy0 = xy < 3 ? 1.f : 0.f, cy1 = xy == 0 ? 0.f : (xy == 1 ? 1.f : -1.f);
+        const float cx0 = xx < 3 ? 1.f : 0.f, cx1 = xx == 0 ? 0.f : (xx == 1 ? 1.f : -1.f);
+        const float c00 = cy0 * cx0, c01 = cy0 * cx1, c10 = cy1 * cx0, c11 = cy1 * cx1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m = accM[r];
+            accY[0][r] += c00 * m; accY[1][r] += c01 * m;
+            accY[2][r] += c10 * m; accY[3][r] += c11 * m;
+            accM[r] = 0.f;
+        }
+    }
+
+    // ---- epilogue (as wino_gemm_kernel, NI = 1): D[i][j], i = (r&3) + 8*(r>>2) + 4*h (tile), j = l31 (column)
+    const int pa = a.so == 2 ? (phase >> 1) : 0, pb = a.so == 2 ? (phase & 1) : 0;
+    float st1 = 0.f, st2 = 0.f;
+    const float bcol = a.bias ? a.bias[n0 + wn0 + l31] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= a.T) continue;
+        const int tj = m % a.tW;
+        const int ti = (m / a.tW) % a.tH;
+        const long n = m / (a.tW * a.tH);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int oy = (2 * ti + (o >> 1)) * a.so + pa, ox = (2 * tj + (o & 1)) * a.so + pb;
+            const float v = accY[o][r] + bcol;
+            a.y[((n * a.Ho + oy) * (long)a.Wo + ox) * a.Nc + n0 + wn0 + l31] = v;
+            if (a.stats) { st1 += v; st2 += v * v; }
+        }
+    }
+    if (a.stats) {
+        const int srow = (phase * (int)((a.T + BM - 1) / BM) + tm) * 2 + (wave & 1);
+        const float t1 = st1 + __shfl_xor(st1, 32, 64), t2 = st2 + __shfl_xor(st2, 32, 64);
+        if (h == 0) {
+            a.stats[((long)srow * 2 + 0) * a.Nc + n0 + wn0 + l31] = t1;
+            a.stats[((long)srow * 2 + 1) * a.Nc + n0 + wn0 + l31] = t2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Weight gradient, Winograd domain.  dM = A dY_p A^T per tile and phase (A = [1 0; 1 1; 1 -1; 0 -1]):
 //   Mdy[xi][tile][p*Cout+co]; then dU_xi = V_xi^T Mdy_xi (plain TN GEMMs), and G^T dU G maps back to the 3x3 phase
 //   kernels, whose taps are scattered onto the canonical 5x5 taps exactly like the direct path's reduce.
@@ -556,6 +708,11 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
     // K step 32 (half the barriers per MFMA) pays when the launch is at most ~one workgroup per CU - the data-gradient
     // geometry at batch 128 (0.53 -> 0.41 ms) - and costs 6 % when two workgroups per CU already hide each other's barriers
     const bool k32 = bk == 32 || (bk == 0 && (long)grid.x * grid.z <= cg::kNumCU * 3 / 2);
+    // LDS-direct loads (CG_WINO_GLDS): 8-wave geometry only; one xi plane of V must stay below the 2 GB a buffer offset reaches
+    const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && nw != 4 && (long)T * a.K * 4L < 0x7fffffffL &&
+                      16L * a.K * a.Nc * 4L < 0x7fffffffL;
+    if (glds && k32 && a.K % 64 == 0) { hipLaunchKernelGGL((wino_gemm_g_kernel<32>), grid, dim3(512), 0, cg::S(stream), a); CG_LAUNCH_CHECK(); return 0; }
+    if (glds) { hipLaunchKernelGGL((wino_gemm_g_kernel<16>), grid, dim3(512), 0, cg::S(stream), a); CG_LAUNCH_CHECK(); return 0; }
     const bool quad = cg::opt(cg::OPT_WINO_QUAD) != 0 && nw != 4;
     if (quad && k32 && a.K % 64 == 0) hipLaunchKernelGGL((wino_gemm_kernel<8, 32, true>), grid, dim3(512), 0, cg::S(stream), a);
     else if (quad) hipLaunchKernelGGL((wino_gemm_kernel<8, 16, true>), grid, dim3(512), 0, cg::S(stream), a);

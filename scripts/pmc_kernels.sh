@@ -13,7 +13,7 @@ root, src = sys.argv[1], sys.argv[2]
 want = {"nn64x128": ("k_conv2", "igemm_nng_kernel<64, 128, 2, 2, 32>"),
         "tn128x128": ("k_conv2", "igemm_tng_kernel<128, 128, 2, 2>"),
         "nn128x64": ("k_dconv2", "igemm_nn_kernel<128, 64, 2, 2, true, true, 16"),
-        "wino8x16": ("k_conv3", "wino_gemm_kernel<8, 16")}
+        "wino_g16": ("k_conv3", "wino_gemm_g_kernel<16>")}
 out = {}
 for key, (tag, pat) in want.items():
     j = json.loads(subprocess.check_output([sys.executable, f"{root}/scripts/pmc_json.py", f"{root}/gpurun_out/pmc", tag, pat]))

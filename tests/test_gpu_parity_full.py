@@ -256,15 +256,17 @@ def test_generic_gather_variants(cg):
         run_conv(cg, 2, 64, 8, 8, 64, 3, 0, seed=3)
 
 
-@pytest.mark.parametrize("waves,bk,quad", [(8, 16, 0), (8, 32, 0), (4, 16, 0), pytest.param(8, 16, 1, id="8-16-quad"),
-                                           pytest.param(8, 32, 1, id="8-32-quad")])
-def test_forced_winograd_variants(cg, waves, bk, quad):
-    """wino_gemm_kernel<8,16>, <8,32>, <4,16> and the k-quad instances <8,16,true>, <8,32,true> on the F(2x2,3x3) path of
-    upsample2 -> conv5x5 (models.lua:217-218), forward + data gradient + weight gradient (the Winograd-domain weight
-    gradient runs on the TN kernels: quad there too), ragged tile count."""
+@pytest.mark.parametrize("waves,bk,stage", [(8, 16, "b32"), (8, 32, "b32"), (4, 16, "b32"), (8, 16, "quad"), (8, 32, "quad"),
+                                            (8, 16, "glds"), (8, 32, "glds")])
+def test_forced_winograd_variants(cg, waves, bk, stage):
+    """wino_gemm_kernel<8,16>, <8,32>, <4,16>, the k-quad instances <8,16,true>, <8,32,true> and the LDS-direct-load kernels
+    wino_gemm_g_kernel<16>, <32> on the F(2x2,3x3) path of upsample2 -> conv5x5 (models.lua:217-218), forward + data gradient
+    + weight gradient (the Winograd-domain weight gradient runs on the TN kernels: quad / glds there too), ragged tile count."""
+    how = {"b32": dict(CG_WINO_GLDS=0, CG_TN_GLDS=0), "quad": dict(CG_WINO_GLDS=0, CG_TN_GLDS=0, CG_WINO_QUAD=1, CG_TN_QUAD=2),
+           "glds": dict(CG_WINO_GLDS=1, CG_TN_GLDS=1)}[stage]
     cg.nn.SpatialConvolution.winograd_min_tiles = 0
     try:
-        with options(cg, CG_WINO_WAVES=waves, CG_WINO_BK=bk, CG_WINO_QUAD=quad, CG_TN_QUAD=2 * quad):
+        with options(cg, CG_WINO_WAVES=waves, CG_WINO_BK=bk, **how):
             m = run_conv(cg, 3, 128, 6, 4, 128, 5, 1, seed=waves + bk)
             assert getattr(m, "_wino", False)
             m = run_conv(cg, 2, 256, 8, 8, 128, 5, 1, seed=waves * bk)
