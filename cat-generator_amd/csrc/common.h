@@ -42,7 +42,7 @@ constexpr int kNumCU = 256;  // MI355X: 8 XCDs x 32 CUs
 enum Opt {
     OPT_SPLIT_TARGET, OPT_SPLIT_MINK, OPT_TN_SMAX, OPT_TN_TARGET, OPT_SKINNY, OPT_GEMM_SLOW, OPT_GEMM_BK32,
     OPT_COLREDUCE_WGS_PER_CU, OPT_WINO_WAVES, OPT_WINO_BK, OPT_NN_TILE, OPT_TN_TILE, OPT_NN_SPLITS, OPT_TN_SPLITS,
-    OPT_EPILOGUE_STATS, OPT_SAMPLER_ATOMICS, OPT_XCD_SWIZZLE, OPT_NN_QUAD, OPT_TN_QUAD, OPT_WINO_QUAD, OPT_NN_PF, OPT_NN_STAGGER, OPT_NN_GLDS, OPT_TN_GLDS, OPT_WINO_GLDS, OPT_COUNT
+    OPT_EPILOGUE_STATS, OPT_SAMPLER_ATOMICS, OPT_XCD_SWIZZLE, OPT_NN_QUAD, OPT_TN_QUAD, OPT_WINO_QUAD, OPT_NN_PF, OPT_NN_GLDS, OPT_TN_GLDS, OPT_WINO_GLDS, OPT_COUNT
 };
 long opt(Opt o);
 

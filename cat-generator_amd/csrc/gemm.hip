@@ -109,9 +109,6 @@ struct NNArgs {
     // of the layer behind this convolution, models.lua:206-207; single group, unsplit launches only)
     float* stats;
     int xcd_swizzle;
-    // > 0: waves in an odd wave slot of their SIMD (the second workgroup on a CU) sleep stagger x 128 clocks before they start,
-    // so that two co-resident workgroups do not run their load / store / barrier phases at the same time (CG_NN_STAGGER)
-    int stagger;
 };
 
 __device__ __forceinline__ float apply_act(int act, float v, float a) {
@@ -240,9 +237,6 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void i
     float* Bs = smem + 2 * A_TILE;
 
     CG_STAMP(0);
-    if (a.stagger > 0 && (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1)) {   // HW_REG_HW_ID bits 3:0 = wave slot
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(2);
-    }
     const Geom& g = a.g;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -2403,7 +2397,6 @@ static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const
     a.part = (float*)ws; a.ngroups = ngroups; a.g = g;
     a.kchunk = p.kchunk; a.nsplit = p.splits;
     a.xcd_swizzle = (int)cg::opt(cg::OPT_XCD_SWIZZLE);
-    a.stagger = (int)cg::opt(cg::OPT_NN_STAGGER);
     if (ep && ep->act) {
         CG_REQUIRE(ep->act == 1 || ep->act == 2, "%s: unknown activation %d", who, ep->act);
         CG_REQUIRE(ep->y_act, "%s: fused activation needs y_act", who);

@@ -49,7 +49,7 @@ const char* cg_last_error(void);
  * CG_WINO_BK; CG_WINO_WAVES; CG_SKINNY; CG_GEMM_SLOW; CG_SPLIT_TARGET; CG_SPLIT_MINK; CG_TN_SMAX; CG_TN_TARGET;
  * CG_COLREDUCE_WGS_PER_CU; CG_EPILOGUE_STATS; CG_SAMPLER_ATOMICS; CG_XCD_SWIZZLE; how a K tile reaches the MFMAs in the GEMM
  * kernels: CG_NN_GLDS (0..3) / CG_TN_GLDS / CG_WINO_GLDS = LDS-direct loads, CG_NN_QUAD / CG_TN_QUAD / CG_WINO_QUAD = k-quad LDS layout with
- * ds_read_b128 fragments, CG_NN_PF = 2 loads two K tiles ahead, CG_NN_STAGGER = start delay of a CU's second workgroup).
+ * ds_read_b128 fragments, CG_NN_PF = 2 loads two K tiles ahead).
  * value == -1 restores the default.  Results never depend on them beyond
  * fp32 re-association; the parity tests use them to run every compiled kernel variant against the oracle. */
 int cg_set_option(const char* name, long value);
