@@ -85,6 +85,21 @@ def build_tools(hipcc, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    # stand-alone micro-benchmarks (tools/*.hip, run by scripts/gpu_peak.sh): MFMA ceiling, LDS -> MFMA loop, LDS-direct-load semantics
+    tools = os.path.join(root, "tools")
+    jobs = [("mfma_peak.hip", "mfma_peak", []), ("lds_mfma.hip", "lds_mfma", []), ("lds_mfma.hip", "lds_mfma_agpr", ["-DACC_AGPR"]),
+            ("glds_test.hip", "glds_test", [])]
+
+    def one(job):
+        src, out, extra = (os.path.join(tools, job[0]), os.path.join(tools, job[1]), job[2])
+        if os.path.exists(src) and _newer(out, [src]):
+            c = [hipcc, f"--offload-arch={ARCH}", "-O3", "-Wno-unused-result", "-Wno-unused-value", *extra, src, "-o", out]
+            if verbose:
+                print(" ".join(c))
+            subprocess.check_call(c, stderr=subprocess.DEVNULL)
+
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        list(ex.map(one, jobs))
 
 
 if __name__ == "__main__":
