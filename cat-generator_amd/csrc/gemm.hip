@@ -21,11 +21,14 @@
 // lean: tap bookkeeping lives in SGPRs, per-row validity is a precomputed 64-bit tap mask, and loads are
 // buffer_load_dwordx4 whose out-of-range offset returns 0 (no branches, no zero-fills).
 //
-// Tiling (wave64, 4 waves / workgroup): block tile BM x BN, K step 16, each wave owns MI x NI MFMA 32x32
-// accumulators.  Both operands sit K-major in LDS ([k][m] XOR-swizzled, [k][n]) so a fragment read is one
-// conflict-free ds_read_b32 per operand per MFMA; global->register->LDS staging is double buffered (one
-// barrier per K tile) with the next tile's loads issued before the current tile's MFMAs.  32 KiB LDS and
-// <= 128 registers per workgroup -> 4 workgroups per CU.
+// Tiling (wave64, 4 waves / workgroup): block tile BM x BN, K step 16 or 32, each wave owns MI x NI MFMA 32x32
+// accumulators; LDS tiles are double buffered, one barrier per K tile.  How a K tile gets into LDS:
+//   * igemm_nn_kernel / igemm_tn_kernel (register staging): both operands K-major in LDS ([k][m] XOR-swizzled, [k][n]),
+//     a fragment read is one conflict-free ds_read_b32 per operand per MFMA; the next tile's global loads are issued
+//     before the current tile's MFMAs and stored to LDS behind them.  Variants kept for A/B: QUAD (k-quad tiles,
+//     ds_read_b128 fragments), PF = 2 (loads two tiles ahead).
+//   * igemm_nng_kernel / igemm_tng_kernel (LDS-direct loads, buffer_load_dwordx4 ... lds): the default where the
+//     geometry allows (round 2: the ablation builds below located the loop's loss in the register -> LDS staging).
 #include "common.h"
 #include <stdlib.h>
 #include <algorithm>
