@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA = 157.3e12               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM = 8.0e12                       # HBM3E spec (6.29 TB/s measured with a float4 copy)
+PMC_FILE = "r03_pmc_kernels.json"       # counter passes of the roofline launches (scripts/pmc_kernels.sh), newest round first
+if not os.path.exists(os.path.join(ROOT, "profiles", PMC_FILE)):
+    PMC_FILE = "r02b_pmc_kernels.json"
 
 CONFIGS = {   # BASELINE.json configs (index + 1)
     2: dict(name="BASELINE configs[1]: G32up-c + D32_st3, 32x32 RGB, batch 128 per GPU", gen="G32up-c", ch=3, size=32, batch=128,
@@ -70,29 +73,37 @@ def step_work(cfg, N):
 
 
 def time_kernel(fn, iters=20, warm=3):
-    """Average duration (s) of one launch group, HIP events on the stream the kernels are launched on."""
+    """Average duration (s) of one launch group: `iters` launches captured into ONE hipGraph on the launch stream and the replay
+    bracketed by HIP events on that stream.  (Round 2 timed eager launches from Python: the host gap between two dependent launches
+    - 20-25 us of interpreter + dispatch per call - sat inside the bracket, 8 % of a 0.29 ms kernel; the replay leaves the ~2 us
+    dependent-launch floor, so the figure follows the rocprofv3 per-grid duration in profiles/r03_roofline_launch_durations.txt.)"""
     for _ in range(warm):
         fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(iters):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
 def kernel_rooflines(cg, N):
-    """The kernels that carry the step (time shares from profiles/r02*_per_step_breakdown.txt), each timed in isolation with
+    """The kernels that carry the step (time shares from profiles/r03_per_step_breakdown.txt), each timed in isolation with
     HIP events on the launch stream at the benchmarked batch, EXECUTED MFMA FLOPs per launch / duration against the fp32 MFMA
-    peak.  `traffic` / MFMA-pipe utilisation come from the committed PMC pass of the same launches (profiles/r02b_pmc_kernels.json,
+    peak.  `traffic` / MFMA-pipe utilisation come from the committed PMC pass of the same launches (profiles/r03_pmc_kernels.json,
     scripts/pmc_kernels.sh; bench.py cannot run rocprofv3 on itself) and carry their source."""
     lib, stream = cg.tensor.lib(), cg.tensor.stream()
     out = []
     pmc = {}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02b_pmc_kernels.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
     except Exception:
         pass
 
@@ -109,7 +120,7 @@ def kernel_rooflines(cg, N):
             e["traffic"] = p_.get("hbm_bytes_per_launch_corrected")
             e["mfma_pipe_util_pmc"] = p_.get("mfma_pipe_util")
             e["valu_per_mfma_pmc"] = p_.get("valu_per_mfma")
-            e["pmc_source"] = p_.get("source", "profiles/r02b_pmc_kernels.json")
+            e["pmc_source"] = p_.get("source", "profiles/" + PMC_FILE)
         if extra:
             e.update(extra)
         out.append(e)
@@ -149,8 +160,6 @@ def kernel_rooflines(cg, N):
         v = m3._get("wino_v", (lib.conv2d_ups2_wino_v_floats(N, 16, 16, 256),))
         t = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(stream, v.ptr, m3._u_fwd.data_ptr(), m3.bias.ptr, y.ptr, N, 16, 16, 256, 128, 0))
         d3 = 2.0 * N * 32 * 32 * 128 * 256 * 25
-        # the LDS-direct-load kernel became the default after the last PMC pass of this round (profiles/r02b_pmc_kernels.json
-        # holds wino_gemm_kernel<8,16>): no counter figures are attached to this entry until it is re-profiled
         entry("wino_g16", "wino_gemm_g_kernel<16> (winograd.hip; LDS-direct loads)",
               f"forward of upsample2 -> conv5x5 256->128 @16->32 (models.lua:217-218), batch {N}: 4 phases x 16 GEMMs [tiles x 256].[256 x 128]",
               d3 * 36 / 100 * 16 / 36, t, d3, "9 % (3 launches of the two wino_gemm variants)",

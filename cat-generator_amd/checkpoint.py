@@ -17,7 +17,7 @@ from .tensor import Tensor, rng
 
 
 def _pack_rs(prefix, rs, out):
-    kind, keys, pos, has_gauss, cached = rs.get_state()
+    kind, keys, pos, has_gauss, cached = rs if isinstance(rs, tuple) else rs.get_state()
     out[prefix + "_keys"] = np.asarray(keys, dtype=np.uint32)
     out[prefix + "_meta"] = np.array([pos, has_gauss, cached], dtype=np.float64)
 
@@ -25,7 +25,8 @@ def _pack_rs(prefix, rs, out):
 def _unpack_rs(prefix, z, rs):
     if prefix + "_keys" in z.files:
         pos, has_gauss, cached = z[prefix + "_meta"]
-        rs.set_state(("MT19937", z[prefix + "_keys"], int(pos), int(has_gauss), float(cached)))
+        state = ("MT19937", z[prefix + "_keys"], int(pos), int(has_gauss), float(cached))
+        rs(state) if callable(rs) else rs.set_state(state)
 
 
 def _bn_modules(net):
@@ -40,7 +41,7 @@ def save(path, S):
     if rng().dev_base is not None:   # hipGraph replay mode: the stream position is offset + *dev_base
         out["rng_dev_base"] = rng().dev_base.cpu().numpy().astype(np.int64)
     _pack_rs("host_random", S.random, out)
-    _pack_rs("dataset_random", dataset._rs, out)
+    _pack_rs("dataset_random", dataset.checkpoint_state(), out)   # before a pending AsyncLoader prefetch
     for i, m in enumerate(_bn_modules(S.MODEL_G)):
         out[f"bnG{i}_mean"], out[f"bnG{i}_var"] = m.running_mean.numpy(), m.running_var.numpy()
     for method, per_net in S.OPTSTATE.items():
@@ -70,7 +71,7 @@ def load(path, S):
     if "rng_dev_base" in z.files:
         r.enable_device_base().copy_(torch.from_numpy(z["rng_dev_base"]))
     _unpack_rs("host_random", z, S.random)
-    _unpack_rs("dataset_random", z, dataset._rs)
+    _unpack_rs("dataset_random", z, dataset.restore_state)
     for i, m in enumerate(_bn_modules(S.MODEL_G)):
         m.running_mean.copy(z[f"bnG{i}_mean"])
         m.running_var.copy(z[f"bnG{i}_var"])

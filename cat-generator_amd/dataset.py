@@ -20,6 +20,7 @@ width = 32
 colorSpace = "rgb"
 paths = None
 _rs = np.random.RandomState(1)
+_prefetch_state = None   # AsyncLoader: the generator's state BEFORE the pick of the prefetch that has not been consumed yet
 
 
 def setDirs(d):
@@ -43,8 +44,22 @@ def setWidth(w):
 
 
 def seed(s):
-    global _rs
+    global _rs, _prefetch_state
     _rs = np.random.RandomState(s)
+    _prefetch_state = None
+
+
+def checkpoint_state():
+    """What a checkpoint must store so that a resumed run loads the pools an uninterrupted one would: AsyncLoader has already
+    drawn the NEXT epoch's permutation when an epoch ends, and a resumed loader draws again on construction - so the state to
+    restore is the one from before that not-yet-consumed pick (the blocking loader has no pick in flight)."""
+    return _prefetch_state if _prefetch_state is not None else _rs.get_state()
+
+
+def restore_state(state):
+    global _prefetch_state
+    _rs.set_state(state)
+    _prefetch_state = None
 
 
 def loadPaths():
@@ -98,6 +113,14 @@ def _pick(count):
     return [paths[shuffle[i]] for i in range(min(len(paths), count))]
 
 
+def _prefetch_pick(count):
+    """_pick for a load that is consumed one epoch later (AsyncLoader): remembers the generator's state from before the pick,
+    which is what a checkpoint taken in between must restore (checkpoint_state)."""
+    global _prefetch_state
+    _prefetch_state = _rs.get_state()
+    return _pick(count)
+
+
 def _decode(path):
     """One file as 8-bit RGB [height, width, 3] (image.load + image.scale, dataset.lua:129-131)."""
     from PIL import Image
@@ -143,7 +166,7 @@ class AsyncLoader:
         self._start(self.slots[0])
 
     def _start(self, slot):
-        files = _pick(self.count)          # on the caller's thread: the generator's draws stay in program order
+        files = _prefetch_pick(self.count)   # on the caller's thread: the generator's draws stay in program order
         slot["n"] = len(files)
         if slot["used"]:
             self.L.event_sync(slot["ready"])   # its previous upload has left the pinned buffer (long ago; costs nothing)
@@ -183,6 +206,8 @@ class AsyncLoader:
         return pool if slot["n"] == self.count else pool.rows(1, slot["n"])
 
     def close(self):
+        global _prefetch_state
+        _prefetch_state = None             # the pending pick dies with the loader
         if self._thread is not None:
             self._thread.join()
         self.L.stream_sync(self.copy_stream)

@@ -38,31 +38,61 @@ def init_from_env(backend=None):
 
 def _init_abi_comms(world, rank):
     """Two RCCL communicators through the C ABI (gradients / sync-BN sums).  Rank 0 creates the unique ids, the process
-    group ships them (host objects over gloo).  On any failure the torch.distributed backend stays in charge."""
+    group ships them (host objects over gloo).  The decision is COLLECTIVE: every step that can fail on one rank only
+    (device count, dlopen of librccl, communicator init) is followed by an agreement over the host channel, so either every
+    rank ends up on cg_comm_* or every rank stays on torch.distributed - a split would deadlock the next all-reduce."""
     from .tensor import lib
+
+    def agree(ok):   # logical AND over ranks (gloo, host tensor)
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    if local_world > torch.cuda.device_count():
-        return   # ranks share a GPU (functional tests on a 1-GPU box): RCCL refuses duplicate devices
+    # ranks sharing a GPU (functional tests on a 1-GPU box): RCCL refuses duplicate devices.  CG_COMM=abi1 keeps the ABI path
+    # alive there with one single-rank communicator pair per process (collectives degenerate to copies; the transport of the
+    # cross-rank sum is then torch.distributed) so that buckets, _PendingAbi and both communicators execute - see parallel tests.
+    err, L = None, None
     try:
         L = lib()
         ok = ctypes.c_int(0)
         L.comm_available(ctypes.byref(ok))
         if not ok.value:
-            raise RuntimeError("librccl.so.1 not loadable")
-        ids = [None, None]
-        if rank == 0:
-            for k in range(2):
-                buf = ctypes.create_string_buffer(128)
-                L.comm_unique_id(buf, 128)
-                ids[k] = buf.raw
-        dist.broadcast_object_list(ids, src=0, device=torch.device("cpu"))
-        for k, name in enumerate(("comm_grad", "comm_bn")):
-            h = ctypes.c_void_p()
+            err = "librccl.so.1 not loadable"
+        elif local_world > torch.cuda.device_count():
+            err = "ranks share a GPU"
+    except Exception as e:
+        err = str(e)
+    if not agree(err is None):
+        if err not in (None, "ranks share a GPU"):
+            warnings.warn(f"cg_comm_* unavailable ({err}); device collectives fall back to torch.distributed on every rank")
+        return
+    ids = [None, None]
+    if rank == 0:
+        for k in range(2):
+            buf = ctypes.create_string_buffer(128)
+            L.comm_unique_id(buf, 128)
+            ids[k] = buf.raw
+    dist.broadcast_object_list(ids, src=0, device=torch.device("cpu"))
+    made = []
+    for k in range(2):   # one agreement per communicator: a rank whose init failed must not leave the others inside ncclCommInitRank's peers' next call
+        h = ctypes.c_void_p()
+        try:
             L.comm_init(ctypes.byref(h), world, rank, ids[k], 128)
-            _S[name] = h
-    except Exception as e:   # keep training possible: torch.distributed's nccl backend carries the tensors instead
-        warnings.warn(f"cg_comm_* unavailable ({e}); device collectives fall back to torch.distributed")
-        _S["comm_grad"] = _S["comm_bn"] = None
+            made.append(h)
+            good = True
+        except Exception as e:
+            err, good = str(e), False
+        if not agree(good):
+            for h_ in made:
+                try:
+                    L.comm_destroy(h_)
+                except Exception:
+                    pass
+            warnings.warn(f"cg_comm_init failed on some rank ({err or 'another rank'}); device collectives fall back to "
+                          "torch.distributed on every rank")
+            return
+    _S["comm_grad"], _S["comm_bn"] = made
 
 
 def comm_backend():

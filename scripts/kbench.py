@@ -77,7 +77,8 @@ def main():
              "b4": lambda: conv_case("D.b4 7x7 128->128 @8^2", N, 128, 8, 128, 7, 0),
              "conv1": lambda: conv_case("G.conv1 3x3 512->512 @4^2 ups", N, 512, 4, 512, 3, 1),
              "conv2": lambda: conv_case("G.conv2 3x3 512->256 @8^2 ups", N, 512, 8, 256, 3, 1),
-             "dconv2": lambda: conv_case("D.conv2 3x3 64->64 @32^2", N, 64, 32, 64, 3, 0)}
+             "dconv2": lambda: conv_case("D.conv2 3x3 64->64 @32^2", N, 64, 32, 64, 3, 0),
+             "loc": lambda: conv_case("D.loc 3x3 64->16 @8^2 (3 branches stacked)", 3 * N, 64, 8, 16, 3, 0)}
     if only:
         cases = [named[o] for o in only.split(",")]
     print(f"{'layer':34s} {'GFLOP':>8s}  " + "  ".join(f"{p:>16s}" for p in ("fwd ms / TF", "dgrad ms / TF", "wgrad ms / TF")))

@@ -1,9 +1,9 @@
 #!/bin/bash
-# PMC passes (separate from tracing) of the four kernels bench.py's `roofline_top` times -> gpurun_out/pmc/<tag>_pmc_kernels.json
+# PMC passes (separate from tracing) of the kernels bench.py's `roofline_top` times -> gpurun_out/pmc/<tag>_pmc_kernels.json
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"; ROOTD=$PWD
-SRC=${1:-r02b}
-for k in conv2 dconv2 conv3; do
+SRC=${1:-r03}
+for k in conv2 dconv2 conv3 loc; do
   bash scripts/pmc.sh k_$k python $ROOTD/scripts/kbench.py 128 --only $k > gpurun_out/pmc_k_$k.txt 2>&1
   tail -3 gpurun_out/pmc_k_$k.txt
 done
@@ -13,7 +13,9 @@ root, src = sys.argv[1], sys.argv[2]
 want = {"nn64x128": ("k_conv2", "igemm_nng_kernel<64, 128, 2, 2, 32>"),
         "tn128x128": ("k_conv2", "igemm_tng_kernel<128, 128, 2, 2>"),
         "nn128x64": ("k_dconv2", "igemm_nn_kernel<128, 64, 2, 2, true, true, 16"),
-        "wino_g16": ("k_conv3", "wino_gemm_g_kernel<16>")}
+        "wino_g16": ("k_conv3", "wino_gemm_g_kernel<16>"),
+        "wino_g32": ("k_conv3", "wino_gemm_g_kernel<32>"),
+        "nn128x32": ("k_loc", "igemm_nn_kernel<128, 32, 4, 1")}
 out = {}
 for key, (tag, pat) in want.items():
     j = json.loads(subprocess.check_output([sys.executable, f"{root}/scripts/pmc_json.py", f"{root}/gpurun_out/pmc", tag, pat]))

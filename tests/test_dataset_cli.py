@@ -36,6 +36,34 @@ def test_dataset_loader(tmp_path):
     ds.colorSpace = "rgb"
 
 
+def test_checkpoint_during_a_pending_prefetch_resumes_on_the_same_pools(tmp_path):
+    """ADVICE round 2 (train.py:68): AsyncLoader has already drawn epoch E+1's permutation when epoch E ends and a resumed loader
+    draws again on construction.  checkpoint.save stores dataset.checkpoint_state() - the generator's state from BEFORE the pending
+    pick - so the resumed run trains E+1, E+2 ... on exactly the pools the uninterrupted (or blocking-loader) run uses."""
+    ds = importlib.import_module("cat-generator_amd.dataset")
+    ck = importlib.import_module("cat-generator_amd.checkpoint")
+    _make_jpgs(str(tmp_path), n=9)
+    ds.setDirs([str(tmp_path)]); ds.setFileExtension("jpg"); ds.seed(3)
+    blocking = [ds._pick(5) for _ in range(4)]                     # epochs 1..4 with --blockingLoader
+    ds.seed(3)
+    pending = ds._prefetch_pick(5)                                 # AsyncLoader.__init__: epoch 1's pool starts loading
+    assert pending == blocking[0]
+    consumed, pending = pending, ds._prefetch_pick(5)              # next(): epoch 1 trains, epoch 2 prefetches
+    out = {}
+    ck._pack_rs("dataset_random", ds.checkpoint_state(), out)      # checkpoint.save after epoch 1
+    np.savez(tmp_path / "c.npz", **out)
+    ds.seed(77)                                                    # a new process: train.py seeds, then loads
+    ck._unpack_rs("dataset_random", np.load(tmp_path / "c.npz"), ds.restore_state)
+    assert ds._prefetch_pick(5) == blocking[1]                     # the resumed loader's first pool is epoch 2's
+    assert ds._prefetch_pick(5) == blocking[2]
+    ds.seed(3)                                                     # blocking loader: nothing pending, the current state is stored
+    ds._pick(5)
+    st = ds.checkpoint_state()
+    ds.seed(78); ds.restore_state(st)
+    assert ds._pick(5) == blocking[1]
+    ds.seed(1)
+
+
 def test_image_grids_and_png_writer(tmp_path):
     """nn_utils.lua:526-583: grid layout (row by row, 7 extra rows), the epoch digits at the bottom right (3 x 5 glyphs, last
     digit rightmost, 6 px pitch), and the PNG on disk read back with PIL."""
