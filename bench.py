@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA = 157.3e12               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM = 8.0e12                       # HBM3E spec (6.29 TB/s measured with a float4 copy)
-PMC_FILE = "r03_pmc_kernels.json"       # counter passes of the roofline launches (scripts/pmc_kernels.sh), newest round first
+PMC_FILE = "r03a_pmc_kernels.json"       # counter passes of the roofline launches (scripts/pmc_kernels.sh), newest round first
 if not os.path.exists(os.path.join(ROOT, "profiles", PMC_FILE)):
     PMC_FILE = "r02b_pmc_kernels.json"
 
@@ -158,7 +158,7 @@ def kernel_rooflines(cg, N):
     if getattr(m3, "_wino", False):
         y = m3.output
         v = m3._get("wino_v", (lib.conv2d_ups2_wino_v_floats(N, 16, 16, 256),))
-        t = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(stream, v.ptr, m3._u_fwd.data_ptr(), m3.bias.ptr, y.ptr, N, 16, 16, 256, 128, 0))
+        t = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(cg.tensor.stream(), v.ptr, m3._u_fwd.data_ptr(), m3.bias.ptr, y.ptr, N, 16, 16, 256, 128, 0))
         d3 = 2.0 * N * 32 * 32 * 128 * 256 * 25
         entry("wino_g16", "wino_gemm_g_kernel<16> (winograd.hip; LDS-direct loads)",
               f"forward of upsample2 -> conv5x5 256->128 @16->32 (models.lua:217-218), batch {N}: 4 phases x 16 GEMMs [tiles x 256].[256 x 128]",

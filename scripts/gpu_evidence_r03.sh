@@ -7,7 +7,7 @@ TAG=${TAG:-r03}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/${TAG}_pytest.log 2>&1; echo "rc=$?"; tail -5 gpurun_out/${TAG}_pytest.log
+  echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q -rP -p no:cacheprovider > gpurun_out/${TAG}_pytest.log 2>&1; echo "rc=$?"; tail -5 gpurun_out/${TAG}_pytest.log
   grep -h "^\[grad\]\|^\[adam\]" gpurun_out/${TAG}_pytest.log > gpurun_out/${TAG}_step_gradients_vs_oracle.txt 2>/dev/null
 fi
 echo "== PMC"; bash scripts/pmc_kernels.sh $TAG 2>&1 | tail -10
