@@ -21,7 +21,11 @@ _CTYPES = {
     "int32_t": C.c_int32, "int*": C.POINTER(C.c_int), "long*": C.POINTER(C.c_long), "const int*": C.POINTER(C.c_int),
     "int": C.c_int, "long": C.c_long, "float": C.c_float, "double": C.c_double,
     "size_t": C.c_size_t, "uint64_t": C.c_uint64, "const char*": C.c_char_p, "void": None,
+    "const long*": C.POINTER(C.c_long), "float**": C.POINTER(C.c_void_p), "char*": C.c_void_p, "size_t*": C.POINTER(C.c_size_t),
+    "cg_alloc_fn": C.c_void_p, "cg_hook_fn": C.c_void_p,
 }
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)                                          # cg_alloc_fn
+HOOK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)    # cg_hook_fn
 
 
 class CatganError(RuntimeError):

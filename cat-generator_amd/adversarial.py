@@ -32,7 +32,6 @@ DEFAULT_OPT = dict(  # train.lua:15-49
     # the G-step's generator forward on a side stream beside the D update (single rank): 7.52 -> 7.45 ms/step (round 1: no gain -
     # the D update's tail was still long enough to fill the chip on its own)
     concurrent_g_forward=os.environ.get("CG_CONCURRENT_G", "1") != "0",
-    g_forward_fork=os.environ.get("CG_G_FORK", "early"),   # "late": fork it behind D's forward pass instead of in front of it
 )
 
 
@@ -108,6 +107,8 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
     inputs, half = buf["inputs"], N // 2
     rowlen = int(np.prod(dims))
     st = {"doTrainD": True}
+    # data parallelism: G's gradient travels in per-layer buckets started from inside the planned backward
+    S.MODEL_G._bucket_overlap = bool(parallel.world_size() > 1 and OPT.get("overlap_comm", True) and _bucketable(S.MODEL_G) and nn.planned)
 
     # ------------------------------------------------------------------ fevalD (adversarial.lua:72-167)
     def fevalD(x):
@@ -116,18 +117,9 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         S.GRAD_PARAMETERS_D.zero()
         targets = buf["targets_D"]
         outputs = S.MODEL_D.forward(inputs)
-        if st.get("fork_late"):            # CG_G_FORK=late: the G-step's generator forward beside D's BACKWARD pass only
-            st.pop("fork_late")()
         f = S.CRITERION.forward(outputs, targets)
         df_do = S.CRITERION.backward(outputs, targets)
-        nn.WGRAD_SIDE.begin()              # D's weight-gradient GEMMs on a side stream, under the rest of the backward chain
-        nn.WGRAD_DEFER.begin()             # their small split-K reductions queue up and run as one launch
-        try:
-            S.MODEL_D.backward(inputs, df_do)
-            nn.WGRAD_SIDE.join()
-            nn.WGRAD_DEFER.end()
-        finally:
-            nn.WGRAD_DEFER.active = nn.WGRAD_SIDE.active = False   # a failed pass must not leave later backward() calls deferring
+        S.MODEL_D.backward(inputs, df_do)   # planned: weight-gradient reductions deferred and flushed inside cg_net_backward
         if st.get("overlap"):  # start the xGMI all-reduce now, finish it after the G-step's generator forward
             st["pendingD"] = parallel.allreduce_mean_async(S.GRAD_PARAMETERS_D.t)
         else:
@@ -169,7 +161,6 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
             torch.cuda.current_stream().wait_event(st.pop("join"))
         if samples is None:
             samples = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
-        nn.repack(S.MODEL_D)   # D's parameters moved in this step's D update
         outputs = S.MODEL_D.forward(samples)
         f = S.CRITERION.forward(outputs, targets)
         df_samples = S.CRITERION.backward(outputs, targets)
@@ -178,20 +169,15 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         else:
             S.MODEL_D.updateGradInput(samples, df_samples)
         df_do = S.MODEL_D.modules[0].gradInput
-        nn.WGRAD_SIDE.begin()
-        nn.WGRAD_DEFER.begin()
-        try:
-            if parallel.world_size() > 1 and OPT.get("overlap_comm", True) and _bucketable(S.MODEL_G):
-                _backward_bucketed(S, st["noiseInputs"], df_do)
-                nn.WGRAD_SIDE.join()
-                nn.WGRAD_DEFER.end()
-            else:
-                S.MODEL_G.backward(st["noiseInputs"], df_do)
-                nn.WGRAD_SIDE.join()
-                nn.WGRAD_DEFER.end()
+        if getattr(S.MODEL_G, "_bucket_overlap", False) and S.MODEL_G._planned_last:
+            # the plan starts each gradient bucket's all-reduce as soon as its backward is complete (cg_net_set_dp): all but the
+            # last bucket (Linear 100 -> 8192) travel under the remaining backward; nothing is ever one step stale
+            S.MODEL_G.backward(st["noiseInputs"], df_do)
+            if not S.MODEL_G._pnet[1].finish_buckets():       # no contiguous buckets: the whole vector at once
                 parallel.allreduce_mean_(S.GRAD_PARAMETERS_G.t)
-        finally:
-            nn.WGRAD_DEFER.active = nn.WGRAD_SIDE.active = False
+        else:
+            S.MODEL_G.backward(st["noiseInputs"], df_do)
+            parallel.allreduce_mean_(S.GRAD_PARAMETERS_G.t)
         if not OPT["fused_update"]:
             if OPT["G_L1"] != 0 or OPT["G_L2"] != 0:
                 f = float(f) + OPT["G_L1"] * S.PARAMETERS_G.norm(1) + OPT["G_L2"] * S.PARAMETERS_G.norm(2) ** 2 / 2
@@ -215,7 +201,6 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
             buf["idx"].copy_(torch.from_numpy(np.asarray(idx, dtype=np.int32)), non_blocking=True)
         lib().gather_rows(stream(), trainData.pool.ptr, buf["idx"].data_ptr(), inputs.ptr, half, rowlen)
         # (1.2) sampled data
-        nn.repack(S.MODEL_G)   # G's parameters moved in the previous step's Adam: one launch re-packs all its plain layers
         noise = nn.to_device(noise_D) if noise_D is not None else nn_utils.createNoiseInputs(S, half)
         samples = nn.as_nhwc(nn_utils.createImagesFromNoise(S, noise, False))
         lib().memcpy_d2d(stream(), inputs.ptr + half * rowlen * 4, samples.ptr, half * rowlen * 4)
@@ -238,10 +223,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
                     ev_join.record()
                 st["join"] = ev_join
 
-            if OPT.get("g_forward_fork", "early") == "late":
-                st["fork_late"] = fork
-            else:
-                fork()
+            fork()
         fused = dict(l1=OPT["D_L1"], l2=OPT["D_L2"], clamp=OPT["D_clamp"]) if OPT["fused_update"] else None
         m = OPT["D_optmethod"]  # adversarial.lua:240-248
         assert m in ("sgd", "adagrad", "adam"), "[Warning] Unknown optimizer method chosen for D."
@@ -280,57 +262,17 @@ def _bucketable(G):
     return isinstance(G, nn.Sequential) and type(G) is nn.Sequential and len(G.modules) > 1
 
 
-def _g_buckets(S):
-    """Contiguous ranges of G's flat gradient, one per convolution / linear layer together with the parameters of the
-    modules up to the next one (BN, PReLU): [(first module index, offset, count)], in forward order."""
-    if getattr(S, "_gbuckets", None) is None:
-        G = S.MODEL_G
-        starts, off = [], 0
-        for i, m in enumerate(G.modules):
-            n = sum(getattr(mm, p).nElement() for mm, p, _ in m.param_refs())
-            if isinstance(m, nn._GemmLayer) or not starts:
-                starts.append([i, off, 0])
-            starts[-1][2] += n
-            off += n
-        assert off == S.GRAD_PARAMETERS_G.nElement()
-        S._gbuckets = [tuple(b) for b in starts if b[2] > 0]
-    return S._gbuckets
-
-
-def _backward_bucketed(S, noise, df_do):
-    """G:backward module by module (same order as nn.Sequential:backward); as soon as a bucket's gradients are complete
-    its slice of the flat vector starts its all-reduce on RCCL's stream, under the backward of the layers before it
-    (G's all-reduce is otherwise on the critical path - the next fake generation needs the updated G)."""
-    G = S.MODEL_G
-    flat = S.GRAD_PARAMETERS_G.t
-    first = {b[0]: b for b in _g_buckets(S)}
-    pending = []
-    done = [len(G.modules)]
-
-    def on_done(i):   # every parameter gradient of G.modules[i:] is on the stream: start the buckets that begin in [i, done)
-        for k in range(done[0] - 1, i - 1, -1):
-            b = first.get(k)
-            if b is not None:
-                if nn.WGRAD_SIDE.used:          # the bucket's weight gradients may still be on the side stream
-                    nn.WGRAD_SIDE.join()
-                    nn.WGRAD_SIDE.begin()
-                nn.WGRAD_DEFER.flush()          # ... or queued as deferred reductions
-                pending.append(parallel.allreduce_mean_async(flat[b[1]:b[1] + b[2]]))
-        done[0] = i
-
-    G._walk_back(noise, df_do, 1.0, True, on_done)   # nn.Sequential:backward, segment by segment (fused chains stay fused)
-    for p_ in pending:
-        p_.finish()
-
-
 class GraphedIteration:
-    """The whole D+G iteration captured once in a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm) and replayed:
-    ~730 launches per step stop costing host time and inter-kernel gaps.  Everything that varies per step lives in
-    device memory: the counter-stream position of every mask / noise / index draw (SplitMix.dev_base, advanced by
-    `stride` draws per replay) and Adam's step counts (optim.adam device_step).  Only the inert-by-default accuracy
-    gate (D_maxAcc <= 1) needs the host, so it is not available here."""
+    """The whole D+G iteration captured once into a hipGraph through the C ABI (cg_graph_begin / _end: every launch this host
+    code makes between the two calls - on the capture stream and on the streams forked from it by events - is recorded) and
+    replayed with cg_graph_launch: ~300 launches per step stop costing host time and inter-kernel gaps.  Everything that varies per
+    step lives in device memory: the counter-stream position of every mask / noise / index draw (SplitMix.dev_base, advanced by
+    `stride` draws per replay) and Adam's step counts (optim.adam device_step).  Only the inert-by-default accuracy gate
+    (D_maxAcc <= 1) needs the host, so it is not available here.  Nothing may allocate during the capture: the eager warm-up
+    passes compile every plan (cg_net_*: all buffers are allocated when a shape is first seen) and create every host-side buffer."""
 
     def __init__(self, S, trainData, thisBatchSize=None, warmup=2):
+        import ctypes
         assert torch.cuda.is_available()
         self.S, self.data, self.N = S, trainData, thisBatchSize or S.OPT["batchSize"]
         S.device_rng = True
@@ -343,10 +285,15 @@ class GraphedIteration:
         for _ in range(max(1, warmup)):  # eager passes: allocate every buffer, pack weights, learn the stride
             self._eager()
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
         ts = {k: S.OPTSTATE["adam"][k]["t"] for k in ("D", "G")}
-        with torch.cuda.graph(self.graph):
-            self._body()
+        self.stream = torch.cuda.Stream()
+        self.exec = ctypes.c_void_p()
+        with torch.cuda.stream(self.stream):
+            lib().graph_begin(stream())
+            try:
+                self._body()
+            finally:
+                lib().graph_end(stream(), ctypes.byref(self.exec))
         for k in ("D", "G"):   # capture launched nothing: the host step count must not move (it is what a checkpoint stores)
             S.OPTSTATE["adam"][k]["t"] = ts[k]
         self.replays = 0
@@ -363,10 +310,16 @@ class GraphedIteration:
         self._body()
 
     def __call__(self):
-        self.graph.replay()
+        lib().graph_launch(self.exec, stream())
         self.replays += 1
         for k in ("D", "G"):
             self.S.OPTSTATE["adam"][k]["t"] += 1
+
+    def __del__(self):
+        try:
+            lib().graph_destroy(self.exec)
+        except Exception:
+            pass
 
 
 def train(S, trainData, maxAccuracyD=1.01, accsInterval=20, verbose=True):

@@ -16,14 +16,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libcatgan_hip.so")
-SOURCES = ["gemm.hip", "winograd.hip", "ops.hip", "fused.hip", "comm.hip"]
+SOURCES = ["gemm.hip", "winograd.hip", "ops.hip", "fused.hip", "comm.hip", "net.hip"]
 ARCH = "gfx950"
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
 
 
 def _headers():
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "catgan.h")]
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "catgan.h")]   # net_ktable.inc is regenerated from catgan.h
 
 
 def _newer(target, deps):
@@ -43,6 +43,7 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
     os.makedirs(OBJ_DIR, exist_ok=True)
+    _generate("gen_net_ktable.py", os.path.join(CSRC, "net_ktable.inc"))   # the launch table net.hip dispatches through
     hdrs = _headers()
     jobs = []
     for s in SOURCES:
@@ -70,6 +71,14 @@ def build(force=False, verbose=False):
     subprocess.check_call(link)
     build_tools(hipcc, verbose)
     return LIB_PATH
+
+
+def _generate(script, out_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(script[:-3], os.path.join(HERE, "..", "scripts", script))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    return gen.main(out_path)
 
 
 def build_tools(hipcc, verbose=False):

@@ -33,6 +33,7 @@ long g_opt_val[OPT_COUNT];
 int g_opt_state[OPT_COUNT];   // 0 = not read yet, 1 = default / environment, 2 = set through the ABI
 }  // namespace
 
+unsigned long g_opt_epoch = 1;   // bumped by cg_set_option: compiled plans (net.hip) re-derive workspace sizes / dispatch-dependent rows
 long opt(Opt o) {
     if (g_opt_state[o] == 0) {
         const char* e = getenv(kOptDefs[o].name);
@@ -1061,6 +1062,7 @@ int cg_set_option(const char* name, long value) {
     CG_REQUIRE(name, "cg_set_option: null name");
     for (int i = 0; i < cg::OPT_COUNT; ++i)
         if (strcmp(name, cg::kOptDefs[i].name) == 0) {
+            ++cg::g_opt_epoch;
             if (value == -1) { cg::g_opt_state[i] = 0; return 0; }   // back to the environment / built-in default
             cg::g_opt_val[i] = value; cg::g_opt_state[i] = 2;
             return 0;

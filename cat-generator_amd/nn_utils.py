@@ -13,8 +13,13 @@ from .tensor import Tensor, lib, rng, stream
 
 
 def createNoiseInputs(S, N):
-    """U(-1,1) noise [N, noiseDim], generated on the device from the engine's counter stream."""
-    t = Tensor.empty((N, S.OPT["noiseDim"]))
+    """U(-1,1) noise [N, noiseDim], generated on the device from the engine's counter stream.  One persistent buffer per N (the
+    D-step's half batch and the G-step's full batch never share one): a captured iteration (cg_graph_*) must find its noise at
+    the same address on every replay, and nothing on the path keeps a noise tensor across two calls."""
+    cache = S.__dict__.setdefault("_noise_bufs", {})
+    t = cache.get(N)
+    if t is None:
+        t = cache[N] = Tensor.empty((N, S.OPT["noiseDim"]))
     r = rng()
     lib().rng_uniform_dev(stream(), t.ptr, t.nElement(), -1.0, 1.0, r.seed, r.take(t.nElement()), r.base_ptr())
     return t

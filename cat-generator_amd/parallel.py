@@ -100,6 +100,11 @@ def comm_backend():
     return "abi" if _S["comm_grad"] is not None else "torch"
 
 
+def comm_handle(name):
+    """The cg_comm_* communicator ('comm_grad' / 'comm_bn') as the C ABI takes it, or None (torch.distributed carries the exchange)."""
+    return _S.get(name)
+
+
 def attach(world, rank):
     """Use an already initialised process group (tests)."""
     _S["world"], _S["rank"] = world, rank

@@ -111,10 +111,9 @@ def rng():
 
 
 class Tensor:
-    __slots__ = ("t", "shape", "fmt", "ups", "epoch", "grp")
+    __slots__ = ("t", "shape", "fmt", "ups", "epoch")
 
-    def __init__(self, t, shape=None, fmt="plain", ups=0, epoch=None, grp=None):
-        self.grp = grp   # (block torch tensor, index, count) when this tensor is one of `count` equal slices of a block
+    def __init__(self, t, shape=None, fmt="plain", ups=0, epoch=None):
         self.t = t
         self.shape = tuple(int(s) for s in (shape if shape is not None else t.shape))
         self.fmt = fmt

@@ -432,6 +432,85 @@ int cg_comm_broadcast(void* comm, void* compute_stream, void* buf, size_t count,
 int cg_comm_wait(void* comm, void* compute_stream);
 int cg_comm_sync(void* comm);
 
+/* ---- planned executor (csrc/net.hip) ----------------------------------------------------------------------------
+ * Where the reference calls MODEL_X:forward / :backward / :updateGradInput on a whole network (adversarial.lua:84-89,
+ * 182-197; utils/nn_utils.lua:52,95) the host calls cg_net_forward / cg_net_backward on a `net` it described once, module by
+ * module, with the constructor calls of models.lua (:138-160, 196-228, 640-711, 814-906).  The library plans the pass:
+ * fused segments of nn.Sequential (conv|linear -> PReLU|LeakyReLU in the GEMM epilogue; activation -> 2x2 pooling ->
+ * SpatialDropout in one pass; conv -> SpatialBatchNormalization (training) -> PReLU with the statistics in the GEMM epilogue;
+ * nn.View -> nn.Linear on the NHWC map), lockstep execution of identical nn.Concat branches (grouped GEMM launches, stacked
+ * parameter-free layers, shared pooling / sampling), the other branch group on a side stream, deferred + batched weight-
+ * gradient reductions, one batched weight re-pack per parameter update, sync-BN and gradient-bucket collectives in place.
+ * Per-element arithmetic is that of the per-module entry points above; every buffer is allocated when a (net, input shape)
+ * pair is first compiled, so later passes only launch (and can be captured, cg_graph_*).
+ *
+ * cg_net_add: `kind` and its arguments (iargs / fargs), mirroring the reference constructors:
+ *   0 nn.Sequential()                      1 nn.Concat(dim): iargs {2}               2 nn.ConcatTable()
+ *   3 nn.Linear(in, out): {in, out}        4 nn|cudnn.SpatialConvolution(nIn,nOut,kW,kH,dW,dH,padW,padH): {nIn,nOut,kW,kH,padW,padH,dW,dH}
+ *   5 nn.PReLU()                           6 nn.LeakyReLU(s): fargs {s}              7 nn.Sigmoid()
+ *   8 nn.SpatialBatchNormalization(n): {n}, fargs {eps, momentum}                    9 nn.View(sizes...): {sizes} (1 or 3)
+ *  10 nn.Copy (identity on the device)    11 nn.Transpose: {0} NCHW->BHWD (models.lua:870), {1} BHWD->NCHW (:903)
+ *  12 nn.SpatialUpSamplingNearest(2)      13 nn.SpatialAveragePooling(2,2,2,2)      14 nn.SpatialMaxPooling(2,2)
+ *  15 nn.SpatialDropout(p): fargs {p}     16 nn.Dropout(p): fargs {p}
+ *  17 nn.AffineTransformMatrixGenerator(rot,scale,trans): {rot,scale,trans}          18 nn.AffineGridGeneratorBHWD(H,W): {H,W}
+ *  19 nn.BilinearSamplerBHWD()
+ * parent: id of the container the module is :add()-ed to; the first module (parent -1) is the root.  *id: the new module.
+ * cg_net_bind: the device tensors Module:getParameters() (train.lua:184-185) left in the module - slot 0 weight / gradWeight,
+ *   1 bias / gradBias, 2 running_mean / running_var of a batch-norm.  Call again whenever the host re-points them.
+ * cg_net_params_changed: the parameters moved (optimiser step, checkpoint load): re-pack before the next pass.
+ * cg_net_set_training: module:training() / :evaluate() (utils/nn_utils.lua:334-349); id -1 = every module.
+ * cg_net_set_option: "overlap_groups", "defer_wgrad", "winograd", "winograd_min_tiles", "share_pool", "sampler_shared",
+ *   "view_fuse", "cat_fuse", "stacking", "grouped", "fusion" (0/1: ablation switches, results unchanged up to fp32
+ *   re-association); "trace" 1 (before the first pass): launches go to recording stubs instead of the GPU, cg_net_trace_take
+ *   returns the text (one `call|<entry point>|<args>` line per launch; pointers as r<region>+<offset>, regions = the plan's
+ *   allocations in order plus what cg_net_trace_region registered) - how the planner is tested without a GPU.
+ * cg_net_set_allocator: device memory for the plan's buffers from the host's allocator (must return zeroed memory, owned by
+ *   the host); default cg_malloc-style memory owned by the net.
+ * cg_net_set_dp: data parallelism: world size, sync-BN on/off, the two cg_comm_* communicators (sync-BN sums /
+ *   gradient buckets; NULL: the host hook carries the exchange), bucket_overlap != 0: cg_net_backward starts the all-reduce
+ *   (average) of each gradient bucket of the root nn.Sequential as soon as its backward is complete (join: cg_comm_wait).
+ * cg_net_set_hook: host transport for those exchanges when no communicator is set: hook(user, what, buf, count, dtype, stream),
+ *   what 0 = in-place SUM of `count` elements (dtype as cg_comm_allreduce) ordered on `stream`, 1 = start the averaging
+ *   all-reduce of a gradient bucket (the host finishes them after cg_net_backward).
+ *
+ * cg_net_forward: x = the input ([dims], fmt 0 row-major / 1 NHWC); rng_seed / rng_offset / rng_base: position of the counter
+ *   stream (cg_rng_*_dev semantics) the pass's dropout masks are drawn from, in module order; *draws = how many it consumed.
+ *   Returns the output tensor (owned by the net, valid until the next pass at this shape).
+ * cg_net_backward: continues the most recent forward.  gy = gradOutput in layout gy_fmt; acc != 0: Module:backward (gradInput +
+ *   accGradParameters with `scale`), acc == 0: Module:updateGradInput only (fevalG_on_D's pass through D, adversarial.lua:192-193).
+ *   gfmt: 0 row-major, 1 NHWC.
+ * cg_net_module_state: .output (which 0) / .gradInput (1) / dropout mask (2) of one module after a pass (NULL when fused away). */
+int cg_net_create(void** net);
+int cg_net_destroy(void* net);
+int cg_net_set_option(void* net, const char* name, long value);
+typedef void* (*cg_alloc_fn)(void* user, size_t bytes);
+typedef int (*cg_hook_fn)(void* user, int what, void* buf, size_t count, int dtype, void* stream);
+int cg_net_set_allocator(void* net, cg_alloc_fn alloc, void* user);
+int cg_net_set_hook(void* net, cg_hook_fn hook, void* user);
+int cg_net_set_dp(void* net, int world, int sync_bn, void* comm_bn, void* comm_grad, int bucket_overlap);
+int cg_net_add(void* net, int parent, int kind, const long* iargs, int niargs, const float* fargs, int nfargs, int* id);
+int cg_net_bind(void* net, int id, int slot, float* param, float* grad);
+int cg_net_set_training(void* net, int id, int train);
+int cg_net_params_changed(void* net);
+int cg_net_forward(void* net, void* stream, const float* x, int nd, const long* dims, int fmt, uint64_t rng_seed, uint64_t rng_offset,
+                   const uint64_t* rng_base, uint64_t* draws, float** y, int* ynd, long* ydims, int* yfmt);
+int cg_net_backward(void* net, void* stream, const float* x, const float* gy, int gy_fmt, int acc, float scale, float** gx, int* gnd,
+                    long* gdims, int* gfmt);
+int cg_net_buckets(void* net, int* nbuckets);
+int cg_net_module_state(void* net, int id, int which, float** ptr, int* nd, long* dims, int* fmt);
+int cg_net_stats(void* net, long* nprograms, long* nlaunch_fwd, long* nlaunch_bwd, size_t* bytes);
+int cg_net_trace_region(void* net, const void* base, size_t bytes);
+int cg_net_trace_take(void* net, char* out, size_t cap, size_t* len);
+
+/* Whole-iteration replay (the reference pays ~10^3 Lua -> C dispatches per iteration; adversarial.lua:51-275): between
+ * cg_graph_begin and cg_graph_end every launch the host makes on `stream` (and on streams forked from it through events:
+ * cg_net_* side streams, cg_stream_wait_event) is recorded into a hipGraph instead of executed; cg_graph_launch replays it.
+ * Everything that varies per step must live in device memory (cg_rng_*_dev's base counter, cg_adam_step_dev's step count). */
+int cg_graph_begin(void* stream);
+int cg_graph_end(void* stream, void** graph_exec);
+int cg_graph_launch(void* graph_exec, void* stream);
+int cg_graph_destroy(void* graph_exec);
+
 /* ---- optimiser ----------------------------------------------------------
  * Fuses adversarial.lua:92-98 (L1/L2 penalty on the gradient), :110-112
  * (clamp) and optim.adam (adversarial.lua:245,262; Torch7 form: eps is added

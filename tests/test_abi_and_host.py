@@ -108,31 +108,3 @@ def test_host_rng_is_the_oracle_stream(cg):
     np.testing.assert_array_equal(r.u01(17), O.u01(17, 77, 1000))
 
 
-def test_branch_grouping_helpers(cg):
-    """Host logic of the lockstep / stacked execution of D32_st3's identical branches (nn.Concat, models.lua:653-692):
-    equal branches share a structure signature, slices of one block are recognised as stackable in order only, and
-    seeding gives sibling modules the slices of one block."""
-    nn = cg.nn
-    D = cg.models.create_D((3, 32, 32))
-    concat = [m for m in D.listModules() if type(m).__name__ == "Concat"][0]
-    sigs = [nn.structure_signature(b) for b in concat.modules]
-    assert sigs[0] == sigs[1] == sigs[2] and sigs[3] != sigs[0]
-    assert concat._branch_groups() == [[0, 1, 2], [3]]
-    # stacking: [3*N, ...] block <-> three [N, ...] slices
-    block = cg.Tensor.zeros((6, 4, 2, 2), "nhwc")
-    parts = nn._split(block, 3)
-    assert [p.shape for p in parts] == [(2, 4, 2, 2)] * 3 and all(p.grp[0] is block.t for p in parts)
-    st = nn._stacked(parts)
-    assert st is not None and st.shape == (6, 4, 2, 2) and st.t is block.t
-    assert nn._stacked(parts[::-1]) is None            # order matters
-    assert nn._stacked(parts[:2]) is None              # all of the block or nothing
-    assert nn._stacked([cg.Tensor.zeros((2, 4, 2, 2), "nhwc") for _ in range(3)]) is None
-    parts[1].t[:] = 7.0                                 # slices alias the block
-    assert float(block.t.view(3, -1)[1].min()) == 7.0
-    # seeding: the 'out' buffers of sibling modules become the slices of one block owned by the first
-    mods = [nn.PReLU() for _ in range(3)]
-    nn._seed_slices(mods, "out", (2, 4, 2, 2), "nhwc")
-    outs = [m._get("out", (2, 4, 2, 2), "nhwc") for m in mods]
-    assert nn._stacked(outs) is not None
-    nn._seed_slices(mods, "out", (2, 4, 2, 2), "nhwc")   # idempotent
-    assert all(a is b for a, b in zip(outs, [m._get("out", (2, 4, 2, 2), "nhwc") for m in mods]))

@@ -3,10 +3,14 @@ C-ABI calls and replayed by tools/abi_replay - a plain C++ program that owns its
 (cg_stream_create) and dispatches every call by name through a table generated from include/catgan.h.  No interpreter,
 no PyTorch in that process.
 
-The recorded host is the module layer with every fast path off (nn.fusion = False, no grouped / stacked branches, one
-stream): one C call per nn.Module method - the call sequence lua/catgan/nn.lua issues, class for class (the LuaJIT layer
-cannot run in this image; scripts/check_lua_binding.py checks its C calls against the header statically).  The replay must
-reproduce the Python host's parameter vectors exactly."""
+Two recordings:
+  * the PLANNED step at the benchmarked batch (128): the description of G32up-c and D32_st3 (cg_net_create / _add / _bind), then one
+    cg_net_forward / cg_net_backward per pass with the batch assembly, criterion and optimiser calls between them - the path
+    bench.py times, as a LuaJIT host issues it (lua/catgan/net.lua);
+  * the per-module walk at a small batch: one C call per nn.Module method, the sequence the per-module classes of
+    lua/catgan/nn.lua issue (the LuaJIT layer cannot run in this image; scripts/check_lua_binding.py checks its C calls against
+    the header statically).
+Either replay must reproduce the Python host's parameter vectors exactly."""
 import importlib
 import os
 import subprocess
@@ -20,48 +24,81 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 f32 = np.float32
 
+_CHILD = r"""
+import importlib, os, sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tools"))
+from abi_record import Recorder
+cg = importlib.import_module("cat-generator_amd")
+cg.nn.planned = {planned}
+N = {N}
+cg.manual_seed(91)
+G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
+S = cg.adversarial.State(dict(batchSize=N), G, D)
+S.device_rng = True      # real-batch indices from the device generator: nothing but ABI calls touches the device
+data = cg.adversarial.TrainData(np.random.RandomState(4).rand(2 * N, 3, 32, 32).astype(np.float32))
+cg.adversarial.iteration(S, data, N)      # warm-up: every buffer exists, weights are packed, plans are compiled
+torch.cuda.synchronize()
+rec = Recorder(cg)
+rec.start()
+cg.adversarial.iteration(S, data, N)      # the recorded update
+torch.cuda.synchronize()
+pD, pG = S.PARAMETERS_D, S.PARAMETERS_G
+out = {out!r}
+ncalls = rec.stop({{os.path.join(out, "pD.bin"): (pD.ptr, pD.nElement() * 4), os.path.join(out, "pG.bin"): (pG.ptr, pG.nElement() * 4)}},
+                  os.path.join(out, "step.trace"), os.path.join(out, "step.blob"))
+pD.numpy().tofile(os.path.join(out, "pD.ref")); pG.numpy().tofile(os.path.join(out, "pG.ref"))
+print("NCALLS", ncalls)
+"""
 
-@pytest.mark.gpu
-def test_whole_step_replayed_through_the_c_abi_without_python(tmp_path):
-    from abi_record import Recorder
-    cg = importlib.import_module("cat-generator_amd")
+
+def _record_and_replay(tmp_path, planned, N):
+    """Record in a fresh process (its device memory image is the blob: nothing of this test session is in it), replay, compare."""
     exe = os.path.join(ROOT, "tools", "abi_replay")
     assert os.path.exists(exe), "tools/abi_replay is built by __graft_entry__.build()"
-    nn = cg.nn
-    saved = (nn.fusion, nn.Concat.grouped, nn.Concat.overlap_groups, nn._Stackable.stacking)
-    nn.fusion, nn.Concat.grouped, nn.Concat.overlap_groups, nn._Stackable.stacking = False, False, False, False
-    try:
-        cg.manual_seed(91)
-        G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
-        S = cg.adversarial.State(dict(batchSize=8), G, D)
-        S.device_rng = True      # real-batch indices from the device generator: nothing but ABI calls touches the device
-        data = cg.adversarial.TrainData(np.random.RandomState(4).rand(32, 3, 32, 32).astype(f32))
-        cg.adversarial.iteration(S, data, 8)      # warm-up: every buffer exists, weights are packed
-        rec = Recorder(cg)
-        rec.start()
-        cg.adversarial.iteration(S, data, 8)      # the recorded update
-        torch.cuda.synchronize()
-        pD, pG = S.PARAMETERS_D, S.PARAMETERS_G
-        trace, blob = str(tmp_path / "step.trace"), str(tmp_path / "step.blob")
-        ncalls = rec.stop({str(tmp_path / "pD.bin"): (pD.ptr, pD.nElement() * 4), str(tmp_path / "pG.bin"): (pG.ptr, pG.nElement() * 4)},
-                          trace, blob)
-        assert ncalls > 300, ncalls
-        names = {l.split("|")[1] for l in open(trace) if l.startswith("call|")}
-        for must in ("cg_conv2d_forward", "cg_conv2d_wgrad", "cg_conv2d_dgrad_ups2", "cg_prelu_backward", "cg_bn_forward", "cg_bn_backward",
-                     "cg_bilinear_sampler_backward", "cg_adam_step", "cg_pack_conv_weight", "cg_rng_bernoulli_dev", "cg_bce_backward"):
-            assert must in names, f"{must} missing from the recorded step"
-        assert not any("grouped" in n or n in ("cg_conv2d_forward_ex", "cg_act_pool2_mask_forward", "cg_bn_act_forward") for n in names), \
-            "the recorded host must be the plain one-call-per-module layer"
-        env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "cat-generator_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
-        r = subprocess.run([exe, trace, blob], capture_output=True, text=True, env=env, timeout=600)
-        assert r.returncode == 0, r.stdout + r.stderr
-        assert f"{ncalls} calls replayed" in r.stdout, r.stdout
-        rD = np.fromfile(str(tmp_path / "pD.bin"), dtype=f32); rG = np.fromfile(str(tmp_path / "pG.bin"), dtype=f32)
-        np.testing.assert_array_equal(rD, pD.numpy())       # D: no atomics of any kind on the path
-        dG = np.abs(rG - pG.numpy())                        # G: batch-norm column sums use fp64 atomics (order-dependent in the last bit)
-        assert dG.max() <= 2.5e-3 and np.mean(dG > 0) < 1e-3, (dG.max(), np.mean(dG > 0))
-    finally:
-        nn.fusion, nn.Concat.grouped, nn.Concat.overlap_groups, nn._Stackable.stacking = saved
+    env = dict(os.environ, CG_NET_ALLOC="lib")     # plan buffers from the library's own allocator, as in a LuaJIT host
+    r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT, planned=planned, N=N, out=str(tmp_path))], capture_output=True,
+                       text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ncalls = int(r.stdout.split("NCALLS")[1].split()[0])
+    trace, blob = str(tmp_path / "step.trace"), str(tmp_path / "step.blob")
+    names = [l.split("|")[1] for l in open(trace) if l.startswith("call|")]
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "cat-generator_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, trace, blob], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"{ncalls} calls replayed" in r.stdout, r.stdout
+    out = {}
+    for k in ("pD", "pG"):
+        out[k] = (np.fromfile(str(tmp_path / f"{k}.bin"), dtype=f32), np.fromfile(str(tmp_path / f"{k}.ref"), dtype=f32))
+    return names, out
+
+
+@pytest.mark.gpu
+def test_planned_step_at_the_benchmarked_batch_replayed_without_python(tmp_path):
+    names, out = _record_and_replay(tmp_path, True, 128)
+    assert names.count("cg_net_create") == 2 and names.count("cg_net_add") > 120            # G32up-c (17 modules) + D32_st3
+    # 3 forwards of G?  no: fake generation (N/2) + the G-step's forward (N); D: the D-step's and the G-step's forward
+    assert names.count("cg_net_forward") == 4 and names.count("cg_net_backward") == 3        # D backward, D updateGradInput, G backward
+    per_module = [n for n in names if n.startswith(("cg_conv2d", "cg_prelu", "cg_bn_", "cg_act_pool", "cg_bilinear", "cg_affine", "cg_avgpool",
+                                                    "cg_maxpool", "cg_mask_mul", "cg_sigmoid", "cg_leakyrelu", "cg_pack_"))]
+    assert not per_module, f"the planned step issues no per-module launch through the host: {per_module[:5]}"
+    for must in ("cg_gather_rows", "cg_rng_uniform_dev", "cg_bce_forward", "cg_bce_backward", "cg_adam_step", "cg_confusion_update"):
+        assert must in names, f"{must} missing from the recorded step"
+    assert len(names) < 400                                                                   # builders included
+    np.testing.assert_array_equal(out["pD"][0], out["pD"][1])
+    np.testing.assert_array_equal(out["pG"][0], out["pG"][1])
+
+
+@pytest.mark.gpu
+def test_per_module_step_replayed_without_python(tmp_path):
+    names, out = _record_and_replay(tmp_path, False, 8)
+    assert len(names) > 300 and not any(n.startswith("cg_net_") for n in names)
+    for must in ("cg_conv2d_forward", "cg_conv2d_wgrad", "cg_conv2d_dgrad_ups2", "cg_prelu_backward", "cg_bn_forward", "cg_bn_backward",
+                 "cg_bilinear_sampler_backward", "cg_adam_step", "cg_pack_conv_weight", "cg_rng_bernoulli_dev", "cg_bce_backward"):
+        assert must in names, f"{must} missing from the recorded step"
+    assert not any("grouped" in n or n in ("cg_conv2d_forward_ex", "cg_act_pool2_mask_forward", "cg_bn_act_forward") for n in names), \
+        "the recorded host must be the plain one-call-per-module layer"
+    np.testing.assert_array_equal(out["pD"][0], out["pD"][1])
+    np.testing.assert_array_equal(out["pG"][0], out["pG"][1])
 
 
 def test_lua_binding_calls_match_the_header():
@@ -81,7 +118,9 @@ def test_replayer_dispatch_covers_every_compute_entry_point():
     host_only = {"cg_comm_available", "cg_comm_init", "cg_comm_size", "cg_device_count", "cg_get_option", "cg_malloc", "cg_set_option",
                  "cg_stream_create", "cg_abi_version", "cg_pack_conv_weight_batch", "cg_concat_channels",
                  "cg_split_channels",   # the last three: host int arrays (fused hosts only)
-                 "cg_conv2d_wgrad_pending", "cg_host_alloc", "cg_event_create"}
+                 "cg_conv2d_wgrad_pending", "cg_host_alloc", "cg_event_create",
+                 # the planned executor's host-only services: callbacks, tracing, introspection
+                 "cg_net_set_allocator", "cg_net_set_hook", "cg_net_trace_region", "cg_net_trace_take", "cg_net_module_state", "cg_net_stats"}
     for name, (ret, _) in protos.items():
         if ret == "int" and name not in host_only:
             assert f'"{name}"' in inc, f"{name} has no dispatch entry (re-run scripts/gen_abi_dispatch.py)"

@@ -670,7 +670,7 @@ def test_visualize_progress_writes_the_three_grids_and_rates_with_v(cg, tmp_path
     del imgs
 
 
-# ------------------------------------------------------------------------------ fused chains (nn.fusion)
+# ------------------------------------------------------------------------------ fused chains / planned passes
 def test_fused_chain_entry_points_against_oracle_modules(cg):
     """csrc/fused.hip through the C ABI, against the oracle's separate modules: activation -> 2x2 pooling -> spatial dropout
     (models.lua:649-651, 656-658) for three stacked groups with their own PReLU slopes, and batch-norm -> PReLU
@@ -748,12 +748,13 @@ def test_fused_chain_entry_points_against_oracle_modules(cg):
 
 
 @pytest.mark.parametrize("which", ["G", "D"])
-def test_fusion_matches_separate_modules(cg, which):
-    """nn.fusion on vs off on the real networks (training mode, batch 6): same outputs (bit-equal where no batch statistics
-    are involved), same gradients up to the summation order of the slope / statistics reductions."""
+def test_planned_pass_matches_the_per_module_walk(cg, which):
+    """The planned executor (cg_net_*: fused segments, lockstep branches, side stream, deferred reductions) against the plain
+    nn.Module walk - one C call per module method - on the real networks (training mode, batch 6): same outputs (bit-equal where
+    no batch statistics are involved), same gradients up to the summation order of the slope / statistics reductions."""
     res = {}
-    for fused in (True, False):
-        cg.nn.fusion = fused
+    for planned in (True, False):
+        cg.nn.planned = planned
         try:
             P, _, _ = _pair(cg, 77, which)
             pP, gP = P.getParameters()
@@ -765,57 +766,61 @@ def test_fusion_matches_separate_modules(cg, which):
                 x = (rs.rand(6, 100) * 2 - 1).astype(f32); dy = (rs.randn(6, 3, 32, 32) * 0.1).astype(f32)
             xin = cg.Tensor.from_numpy(x)
             out = P.forward(xin).numpy()
+            assert P._planned_last == planned
             gi = cg.nn.as_plain(P.backward(xin, cg.Tensor.from_numpy(dy))).numpy() if which == "D" else None
-            kinds = {k for m in P.listModules() if isinstance(m, cg.nn.Sequential) and type(m) is cg.nn.Sequential
-                     for k, _, _ in (getattr(m, "_ran", None) or [])}
-            assert (kinds - {"one"} != set()) == fused, kinds
-            res[fused] = (out, gi, gP.numpy().copy())
+            if planned:
+                st = P._pnet[1].stats()
+                assert st["programs"] == 1 and 0 < st["launches_forward"] < (20 if which == "G" else 50), st
+                # module state is served by the plan: the first module's gradInput (adversarial.lua:193), fused-away outputs are None
+                assert P.modules[0].gradInput is not None
+                fused_away = [m for m in P.listModules() if isinstance(m, cg.nn.SpatialBatchNormalization)]
+                assert all(P.module_state(m, "output") is None for m in fused_away)
+            res[planned] = (out, gi, gP.numpy().copy())
         finally:
-            cg.nn.fusion = True
+            cg.nn.planned = True
     (o1, g1, p1), (o0, g0, p0) = res[True], res[False]
     if which == "D":
         np.testing.assert_array_equal(o1, o0)
-        close(g1, g0, tol=1e-6, what="D gradInput fused vs separate")
+        close(g1, g0, tol=1e-6, what="D gradInput planned vs per-module")
     else:
-        close(o1, o0, tol=2e-6, what="G output fused vs separate")
-    bulk_close(p1, p0, max_rel=1e-4, mean_rel=1e-6, what=f"{which} flat gradient fused vs separate")
+        close(o1, o0, tol=2e-6, what="G output planned vs per-module")
+    bulk_close(p1, p0, max_rel=1e-4, mean_rel=1e-6, what=f"{which} flat gradient planned vs per-module")
 
 
 @pytest.mark.parametrize("which", ["G", "D"])
-def test_deferred_weight_gradient_reductions_are_bit_identical(cg, which):
-    """cg_conv2d_wgrad_grouped_deferred + cg_conv2d_wgrad_flush (one launch reducing every queued layer) against the immediate
-    form, on the real networks at batch 16: the flat gradient vectors must be equal bit for bit, nothing may stay queued,
-    and a layer hit twice before a flush must not lose its first partials."""
+def test_plan_options_are_result_neutral(cg, which):
+    """cg_net_set_option's ablation switches on the real networks at batch 16: deferred + batched weight-gradient reductions
+    (cg_conv2d_wgrad_grouped_deferred + one cg_conv2d_wgrad_flush) against the immediate form, the side stream for the second
+    branch group against one stream, shared pooling / shared-image sampling against one launch per branch: the flat gradient
+    vectors must be equal bit for bit, and nothing may stay queued."""
+    import ctypes
     res = {}
-    for defer in (True, False):
+    for name, opts in (("default", {}), ("immediate", {"defer_wgrad": 0}), ("one stream", {"overlap_groups": 0}),
+                       ("unshared", {"share_pool": 0, "sampler_shared": 0})):
         P, _, _ = _pair(cg, 31, which)
         pP, gP = P.getParameters()
         rs = np.random.RandomState(9)
         if which == "D":
+            pP.copy(pP.numpy() + (rs.randn(pP.nElement()) * 0.01).astype(f32))
             x = rs.rand(16, 3, 32, 32).astype(f32); dy = rs.randn(16, 1).astype(f32)
         else:
             x = (rs.rand(16, 100) * 2 - 1).astype(f32); dy = (rs.randn(16, 3, 32, 32) * 0.1).astype(f32)
         xin, dyt = cg.Tensor.from_numpy(x), cg.Tensor.from_numpy(dy)
+        net = P._planned_net()
+        for k, v in opts.items():
+            cg.lib().net_set_option(net.h, k.encode(), v)
+        cg.manual_seed(5)                     # same dropout masks in every variant
         P.forward(xin)
         gP.zero()
-        if defer:
-            cg.nn.WGRAD_DEFER.begin()
-            assert cg.nn.WGRAD_DEFER.active
         P.backward(xin, dyt)
-        if defer:
-            assert len(cg.nn.WGRAD_DEFER.pending) > 3          # several layers queued
-            import ctypes
-            n = ctypes.c_int(0)
-            cg.lib().conv2d_wgrad_pending(cg.tensor.stream(), ctypes.byref(n))
-            assert n.value > 0
-            P.backward(xin, dyt)                                 # every layer again: forces a flush of the first round
-            cg.nn.WGRAD_DEFER.end()
-            cg.lib().conv2d_wgrad_pending(cg.tensor.stream(), ctypes.byref(n))
-            assert n.value == 0 and not cg.nn.WGRAD_DEFER.pending
-        else:
-            P.backward(xin, dyt)
-        res[defer] = gP.numpy().copy()
-    np.testing.assert_array_equal(res[True], res[False])
+        P.backward(xin, dyt)                  # accumulate semantics: every layer a second time
+        n = ctypes.c_int(-1)
+        cg.lib().conv2d_wgrad_pending(cg.tensor.stream(), ctypes.byref(n))
+        assert n.value == 0, f"{name}: weight-gradient reductions still queued after cg_net_backward"
+        res[name] = gP.numpy().copy()
+        assert np.abs(res[name]).max() > 0
+    for name in ("immediate", "one stream", "unshared"):
+        np.testing.assert_array_equal(res[name], res["default"], err_msg=name)
 
 
 def test_collectives_through_the_c_abi_single_rank(cg):

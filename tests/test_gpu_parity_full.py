@@ -189,28 +189,38 @@ def test_linear_layer_at_benchmarked_batch(cg, name, N, i, o):
 
 
 def test_grouped_branch_convs_at_benchmarked_batch(cg):
-    """D32_st3's three identical transformer branches (models.lua:653-678) run their convolutions as ONE grouped
-    launch (blockIdx.z = branch): forward, data gradient and weight gradient of the group at batch 128."""
+    """D32_st3's three identical transformer branches (models.lua:653-678) run their convolutions as ONE grouped launch
+    (blockIdx.z = branch) inside the planned pass: an nn.Concat of three structurally identical conv -> PReLU branches at batch
+    128 - forward (grouped GEMM with the activation in its epilogue), data gradient and weight gradient of the group."""
     rs = np.random.RandomState(12)
     N, C, H = 128, 64, 16
-    mods, ws, bs, xs, dys = [], [], [], [], []
+    net = cg.nn.Sequential()
+    cat = cg.nn.Concat(2)
+    convs, ws, bs = [], [], []
     for g in range(3):
         m = cg.nn.SpatialConvolution(C, C, 3, 3, 1, 1, 1)
         w = (rs.randn(C, C, 3, 3) / 24).astype(f32); b = rs.randn(C).astype(f32)
         m.weight.copy(w); m.bias.copy(b); m.gradWeight.zero(); m.gradBias.zero()
-        mods.append(m); ws.append(w); bs.append(b)
-        xs.append(rs.randn(N, C, H, H).astype(f32)); dys.append(rs.randn(N, C, H, H).astype(f32))
-    xin = [cg.nn.as_nhwc(cg.Tensor.from_numpy(x)) for x in xs]
-    ctx = cg.nn._GroupCtx([0, 0, 0])
-    outs = cg.nn.group_forward(mods, xin, ctx)
-    gins = cg.nn.group_backward(mods, xin, [cg.nn.as_nhwc(cg.Tensor.from_numpy(d)) for d in dys], 1.0, True, ctx)
+        cat.add(cg.nn.Sequential().add(m).add(cg.nn.PReLU()))
+        convs.append(m); ws.append(w); bs.append(b)
+    net.add(cat)
+    x = rs.randn(N, C, H, H).astype(f32); dy = rs.randn(N, 3 * C, H, H).astype(f32)
+    xin = cg.nn.as_nhwc(cg.Tensor.from_numpy(x))
+    out = net.forward(xin).numpy()
+    assert net._planned_last
+    gin = cg.nn.as_nhwc(net.backward(xin, cg.nn.as_nhwc(cg.Tensor.from_numpy(dy)))).numpy()
+    gref = np.zeros_like(x)
     for g in range(3):
-        close(outs[g].numpy(), O.conv2d_forward(xs[g], ws[g], bs[g], 1), K=C * 9, what=f"branch {g} output")
-        close(gins[g].numpy(), O.conv2d_backward_data(dys[g], ws[g], xs[g].shape, 1), K=C * 9, what=f"branch {g} gradInput")
+        y = O.conv2d_forward(x, ws[g], bs[g], 1)
+        A = O.PReLU()
+        close(out[:, g * C:(g + 1) * C], A.forward(y), K=C * 9, what=f"branch {g} output")
+        dyg = A.backward(np.ascontiguousarray(dy[:, g * C:(g + 1) * C]))
+        gref = gref + O.conv2d_backward_data(dyg, ws[g], x.shape, 1)
         gw, gb = np.zeros_like(ws[g]), np.zeros_like(bs[g])
-        O.conv2d_backward_weight(xs[g], dys[g], gw, gb, 1)
-        close(mods[g].gradWeight.numpy(), gw, K=N * H * H, tol=4e-5, what=f"branch {g} gradWeight")
-        close(mods[g].gradBias.numpy(), gb, K=N * H * H, tol=4e-5, what=f"branch {g} gradBias")
+        O.conv2d_backward_weight(x, dyg, gw, gb, 1)
+        close(convs[g].gradWeight.numpy(), gw, K=N * H * H, tol=4e-5, what=f"branch {g} gradWeight")
+        close(convs[g].gradBias.numpy(), gb, K=N * H * H, tol=4e-5, what=f"branch {g} gradBias")
+    close(gin, gref, K=3 * C * 9, what="gradInput (sum over the branches)")
 
 
 # ------------------------------------------------------------------ every compiled variant, forced

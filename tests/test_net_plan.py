@@ -1,0 +1,214 @@
+"""The planner below the C ABI (csrc/net.hip, cg_net_*), tested WITHOUT a GPU: in trace mode every launch goes to a recording
+stub generated from include/catgan.h, so a whole forward / backward of G32up-c / G32up / D32_st3 (models.lua:138-160,196-228,
+640-711,814-906) leaves its launch sequence as text.  What is pinned here:
+  * the sequence itself (tests/golden/net_plan_*.txt: entry points, geometry, data flow, counter-stream offsets) - the fixtures
+    were checked launch for launch against the round-2 Python executor before it was deleted (make_net_plan_golden.py);
+  * the structure of the plan: fused segments, grouped / stacked / shared launches of D's three identical branches, the other
+    branch group on a side stream between fork / join events, deferred reductions flushed once;
+  * data flow: nothing reads a buffer no earlier launch (or the host) wrote;
+  * the dropout draws follow the oracle's module-after-module order;
+  * data parallelism: sync-BN sums exchanged between statistics and normalisation, gradient buckets started as their layers finish.
+The arithmetic of every launch is the GPU suite's business (tests/test_gpu_parity*.py run the same plans on the MI355X)."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import plan_trace as T  # noqa: E402
+from make_net_plan_golden import CASES, text  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+@pytest.mark.parametrize("which,N", CASES, ids=[f"{w}-N{n}" for w, n in CASES])
+def test_plan_equals_the_golden_launch_sequence(which, N):
+    fn = os.path.join(HERE, "golden", "net_plan_%s_N%d.txt" % (which.replace("@", "_at_"), N))
+    want = open(fn).read().split("\n")
+    got = text(which, N).split("\n")
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a == b, f"{which} N={N}: line {i} differs\n  plan  : {a[:300]}\n  golden: {b[:300]}"
+    assert len(got) == len(want)
+
+
+def test_segments_and_lockstep_branches_of_the_discriminator():
+    r = T.trace("D32_st3", 128)
+    f = r["forward"]
+    names = [c[0] for c in T.calls(f)]
+    # three identical transformer branches: their localisation nets pool the trunk's output ONCE, convolutions run grouped
+    # (ngroups 3) with the activation in the epilogue, one shared-image sampler launch, one stacked launch per parameter-free layer
+    ex = T.calls(f, "cg_conv2d_forward_ex")
+    assert sum(1 for _, a in ex if a["ngroups"] == "i:3") == 3      # loc conv1+LeakyReLU, loc View+Linear+LeakyReLU, branch conv2+PReLU
+    grouped = T.calls(f, "cg_conv2d_forward_grouped")
+    assert len(grouped) == 3 and all(a["ngroups"] == "i:3" for _, a in grouped)       # loc conv2, loc classifier, branch conv1
+    assert len(T.calls(f, "cg_bilinear_sampler_forward_shared")) == 1 and len(T.calls(f, "cg_bilinear_sampler_forward")) == 1
+    assert names.count("cg_avgpool2_forward") == 2       # ST0's localisation net + ONE shared by the three branch nets
+    pools = T.calls(f, "cg_act_pool2_mask_forward")
+    assert sorted(a["ngroups"] for _, a in pools) == ["i:1", "i:1", "i:1", "i:3", "i:3"]
+    assert names.count("cg_concat_channels") == 1 and "cg_copy_channels" not in names
+    # nn.View -> nn.Linear on the NHWC map: no layout pass in front of the 20480 -> 256 layer or the localisation nets' linears
+    assert "cg_nhwc_to_nchw" not in names
+    # side stream: the two-convolution branch runs on s1 between fork and join
+    s1 = [c for c in T.calls(f) if c[1]["stream"] == "s1"]
+    assert {c[0] for c in s1} == {"cg_conv2d_forward", "cg_act_pool2_mask_forward", "cg_rng_bernoulli_dev", "cg_conv2d_forward_ex"}
+    ev = [l for l in f if l.startswith("event|")]
+    assert ev == ["event|record|fork|s0", "event|wait|fork|s1", "event|record|join1|s1", "event|wait|join1|s0"]
+    assert f.index("event|wait|join1|s0") < next(i for i, l in enumerate(f) if "cg_concat_channels" in l)
+    # backward: weight-gradient reductions deferred, one flush per stream, grads of the three branches in grouped launches
+    b = r["backward"]
+    assert len(T.calls(b, "cg_conv2d_wgrad_flush")) == 2 and not T.calls(b, "cg_conv2d_wgrad")
+    assert {a["stream"] for _, a in T.calls(b, "cg_conv2d_wgrad_flush")} == {"s0", "s1"}
+    assert b[-1].startswith("call|cg_conv2d_wgrad_flush|s0")
+    assert len(T.calls(b, "cg_bilinear_sampler_backward_shared")) == 1
+    assert len(T.calls(b, "cg_prelu_backward_grouped")) == 1      # the PReLUs behind the branches' second convolutions (the first ones are inside act_pool)
+    # updateGradInput only (fevalG_on_D's pass through D, adversarial.lua:192-193): no weight gradient of any kind
+    u = r["updateGradInput"]
+    assert not [c for c in T.calls(u) if "wgrad" in c[0]]
+    assert r["stats"]["launches_forward"] < 45 and r["stats"]["launches_backward"] < 70
+
+
+def test_generator_plan_uses_epilogue_statistics_and_winograd_at_the_benchmarked_batch():
+    r = T.trace("G32up-c", 128)
+    f = [c[0] for c in T.calls(r["forward"])]
+    # conv -> BN -> PReLU: statistics partials from the GEMM epilogue (no separate pass over the convolution output)
+    assert f.count("cg_bn_stats_finalize") == 3 and "cg_bn_stats" not in f and f.count("cg_bn_act_forward") == 3
+    assert f.count("cg_conv2d_ups2_wino_forward_stats") == 1      # the 5x5 layer's phases in Winograd F(2x2,3x3)
+    assert "cg_upsample2x_forward" not in f and "cg_prelu_forward" not in f
+    b = [c[0] for c in T.calls(r["backward"])]
+    assert b.count("cg_conv2d_ups2_wino_dgrad") == 1 and b.count("cg_conv2d_ups2_wino_wgrad") == 1
+    assert b.count("cg_conv2d_dgrad_ups2") == 2 and b.count("cg_bn_act_backward") == 3 and b[-1] == "cg_conv2d_wgrad_flush"
+    small = [c[0] for c in T.calls(T.trace("G32up-c", 8)["forward"])]
+    assert "cg_conv2d_ups2_wino_forward_stats" not in small        # below 2048 tiles the direct phase kernels run
+
+
+PTR_ARG = {"void*", "const void*", "float*", "const float*", "double*", "const double*", "int32_t*", "const int32_t*", "uint64_t*",
+           "const uint64_t*"}
+
+
+@pytest.mark.parametrize("which,N", [("D32_st3", 16), ("G32up-c", 16), ("G32up", 8)])
+def test_no_launch_reads_what_nothing_wrote(which, N):
+    """Data-flow check over forward + backward: a `const T*` argument is an input; every input region must have been written by an
+    earlier launch (a non-const pointer argument) or belong to the host (parameters, input, gradOutput)."""
+    r = T.trace(which, N)
+    P = T.protos()
+    pn = r["net"]
+    host_regions = set()
+    # regions registered by the host come after the plan's own allocations in the list: find them through a marker call
+    lines = r["first_forward"] + r["backward"]      # the first pass includes the weight packing
+    written = set()
+
+    def reg(tok):
+        m = re.match(r"r(\d+)\+", tok)
+        return m.group(1) if m else None
+
+    # the plan's scratch is allocated zeroed, the statistics buffers start as zeros: reading zero-initialised sums is legal;
+    # everything else must follow a write.  Collect the host-owned regions from the parameter / input pointers.
+    for l in lines:
+        f = l.split("|")
+        if f[0] != "call":
+            continue
+        for (t, an), v in zip(P[f[1]][1], f[2:]):
+            if an in ("wpk", "bias", "gamma", "beta", "alpha", "w_canonical", "gw_canonical", "gb", "ggamma", "gbeta", "galpha", "running_mean",
+                      "running_var") and v not in ("n",):
+                for tok in (v.split(":", 2)[2].split(",") if v.startswith("a:") else [v]):
+                    if reg(tok):
+                        host_regions.add(reg(tok))
+    first = r["forward"][0].split("|")
+    bad = []
+    inputs_seen = set()
+    for l in lines:
+        f = l.split("|")
+        if f[0] != "call":
+            continue
+        for (t, an), v in zip(P[f[1]][1], f[2:]):
+            if t in ("const float* const*", "float* const*"):
+                toks, const = ([] if v == "n" else v.split(":", 2)[2].split(",")), t.startswith("const")
+            elif t in PTR_ARG and an != "stream":
+                toks, const = [v], t.startswith("const")
+            else:
+                continue
+            for tok in toks:
+                k = reg(tok)
+                if k is None or an in ("ws", "base"):
+                    continue
+                if const:
+                    if k not in written and k not in host_regions:
+                        inputs_seen.add(k)
+                        bad.append((f[1], an, tok))
+                else:
+                    written.add(k)
+    # the only never-written inputs are the caller's x and gradOutput (two regions)
+    assert len({reg(b[2]) for b in bad}) <= 2, bad[:5]
+
+
+def test_dropout_draws_follow_the_oracle_order():
+    """The masks of a planned pass sit at the counter-stream offsets a module-after-module walk draws them at (the oracle's order):
+    same total, and the per-launch offsets partition [offset, offset + draws) without gaps or overlaps."""
+    N = 8
+    r = T.trace("D32_st3", N, rng_offset=5000)
+    rng = O.RNG(3)
+    Do = O.create_D32_st3(3, 32, rng)
+    o0 = rng.offset
+    Do.forward(np.zeros((N, 3, 32, 32), np.float32))
+    assert r["draws"] == rng.offset - o0
+    spans = []
+    for name, a in T.calls(r["forward"]):
+        if name == "cg_rng_bernoulli_dev":
+            spans.append((int(a["offset"][2:]), int(a["n"][2:])))
+        elif name == "cg_rng_bernoulli_dev_grouped":
+            n, G = int(a["n_per_group"][2:]), int(a["ngroups"][2:])
+            spans += [(int(a[f"off{g}"][2:]), n) for g in range(G)]
+    spans.sort()
+    pos = 5000
+    for off, n in spans:
+        assert off == pos, (off, pos)
+        pos += n
+    assert pos == 5000 + r["draws"]
+    # the three branches' first masks (SpatialDropout(0.2) behind the max pool) are 64 channels x N samples each, in branch order
+    g = [a for n_, a in T.calls(r["forward"], "cg_rng_bernoulli_dev_grouped")][0]
+    offs = [int(g[f"off{i}"][2:]) for i in range(3)]
+    assert offs[1] - offs[0] == offs[2] - offs[1] == N * 64          # each branch draws one [N,64] mask (models.lua:658)
+
+
+def test_data_parallel_exchanges_sit_inside_the_plan():
+    """world 2 (trace mode: the exchanges appear as hook lines): sync-BN sums between statistics and normalisation, forward and
+    backward; G's flat gradient in five buckets (one per convolution / linear layer, with the BN / PReLU parameters behind it), each
+    started right after its layer's weight gradient, the deferred reductions flushed first."""
+    r = T.trace("G32up-c", 128, dp=dict(world=2, buckets=True))
+    f = r["forward"]
+    hooks = [i for i, l in enumerate(f) if l.startswith("hook|allreduce_sum")]
+    assert len(hooks) == 3
+    for i in hooks:
+        assert "cg_bn_stats_finalize" in f[i - 1] and "cg_bn_act_forward" in f[i + 1]
+        cnt = [a for n_, a in T.calls([f[i + 1]])][0]["count"]
+        assert float.fromhex(cnt[2:]) in (2.0 * 128 * 64, 2.0 * 128 * 256, 2.0 * 128 * 1024)      # global-batch count
+    b = r["backward"]
+    assert sum(1 for l in b if l.startswith("hook|allreduce_sum")) == 3
+    buckets = [(i, l.split("|")) for i, l in enumerate(b) if l.startswith("hook|bucket_start")]
+    assert len(buckets) == 5
+    counts = [int(t[3]) for _, t in buckets]
+    lin = 100 * 8192 + 8192 + 1
+    c1 = 512 * 512 * 9 + 512 + 2 * 512 + 1
+    c2 = 512 * 256 * 9 + 256 + 2 * 256 + 1
+    c3 = 256 * 128 * 25 + 128 + 2 * 128 + 1
+    c4 = 128 * 3 * 9 + 3
+    assert counts == [c4, c3, c2, c1, lin] and sum(counts) == 5191687        # reverse layer order, the whole vector
+    offs = [int(t[2].split("+")[1]) // 4 for _, t in buckets]
+    assert offs == [lin + c1 + c2 + c3, lin + c1 + c2, lin + c1, lin, 0]
+    for i, _ in buckets[:-1]:
+        # complete gradients: the deferred reductions flushed, or the layer's own immediate (Winograd-domain) weight gradient
+        assert "cg_conv2d_wgrad_flush" in b[i - 1] or "cg_conv2d_ups2_wino_wgrad" in b[i - 1] or b[i - 1].startswith("hook|")
+    for (i0, _), (i1, _) in zip(buckets, buckets[1:]):                                   # the next layer's backward runs under the bucket
+        assert sum(1 for l in b[i0:i1] if l.startswith("call|")) >= 3
+
+
+def test_per_module_walk_is_still_the_protocol():
+    """nn.planned = False (or a module used on its own): updateOutput / updateGradInput / accGradParameters module by module."""
+    cg = T.cg_pkg()
+    net, _, _ = T.build("G32up-c")
+    assert type(net) is cg.nn.Sequential and not net._planned_last
+    assert [type(m).__name__ for m in net.modules[:3]] == ["Linear", "PReLU", "View"]
+    assert cg.nn.planned is True

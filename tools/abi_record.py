@@ -8,12 +8,14 @@
 Device pointers are translated into (allocator segment, byte offset), so the replayer can rebuild the same memory image
 with cg_malloc and needs neither PyTorch nor the original addresses.  Test tooling: nothing in the product imports it."""
 import ctypes
+import importlib
 
 import torch
 
 PTR_TYPES = {"void*", "const void*", "float*", "const float*", "double*", "const double*", "int32_t*", "const int32_t*",
              "uint64_t*", "const uint64_t*"}
 PARR_TYPES = {"const float* const*", "float* const*"}
+NET_OUT = {"id", "draws", "y", "ynd", "ydims", "yfmt", "gx", "gnd", "gdims", "gfmt", "nbuckets"}   # scripts/gen_abi_dispatch.py
 
 
 class Recorder:
@@ -22,6 +24,8 @@ class Recorder:
         self.segs = []        # (address, size, has_initial_contents)
         self.blob = bytearray()
         self.blob_off = []
+        self.vals = []        # (call index, address, bytes): tensors returned by cg_net_forward / cg_net_backward
+        self.handles = {}     # cg_net handle value -> index
 
     def _segments(self):
         return sorted((s["address"], s["total_size"]) for s in torch.cuda.memory_snapshot())
@@ -39,6 +43,9 @@ class Recorder:
         self.lib.trace = []
 
     def _seg_of(self, p):
+        for k, addr, size in self.vals:      # a tensor a planned pass returned: reached through that call in the replay
+            if addr <= p < addr + size:
+                return f"v:{k}:{p - addr}"
         for i, (addr, size, _) in enumerate(self.segs):
             if addr <= p < addr + size:
                 return f"p:{i}:{p - addr}"
@@ -53,6 +60,44 @@ class Recorder:
                 return "n"
         return self._seg_of(int(v))
 
+    def _handle(self, v):
+        v = v.value if hasattr(v, "value") else int(v)
+        if v not in self.handles:
+            self.handles[v] = len(self.handles)
+        return self.handles[v]
+
+    def _net_args(self, name, args, index):
+        """Argument tokens of a cg_net_* / cg_graph_* call (handles, host arrays, out-parameters by name)."""
+        out = []
+        protos = self.lib.protos[name][1]
+        for (typ, an), v in zip(protos, args):
+            if an in ("net", "graph_exec"):
+                out.append(f"h:{self._handle(v)}")
+            elif an == "stream":
+                out.append("s")
+            elif an in NET_OUT and typ.endswith("*"):
+                out.append("o")
+            elif typ == "const long*":
+                out.append("L:" + ",".join(str(int(e)) for e in v))
+            elif typ == "const char*":
+                out.append("c:" + (v.decode() if isinstance(v, bytes) else str(v)))
+            elif typ in PTR_TYPES:
+                out.append(self._ptr(v))
+            elif typ in ("float", "double"):
+                out.append("f:" + float(v).hex())
+            elif typ in ("size_t", "uint64_t"):
+                out.append(f"u:{int(v)}")
+            else:
+                out.append(f"i:{int(v)}")
+        if name in ("cg_net_forward", "cg_net_backward"):   # the tensor this call returned
+            yi, ni, di = (10, 11, 12) if name == "cg_net_forward" else (7, 8, 9)
+            ptr, nd, dims = args[yi]._obj.value, args[ni]._obj.value, args[di]
+            n = 1
+            for k in range(nd):
+                n *= int(dims[k])
+            self.vals.append((index, ptr, n * 4))
+        return out
+
     def stop(self, dumps, trace_path, blob_path):
         torch.cuda.synchronize()
         calls, self.lib.trace = self.lib.trace, None
@@ -63,7 +108,25 @@ class Recorder:
                 self.blob_off.append(-1)
         lines = [f"seg|{i}|{size}|{self.blob_off[i]}" for i, (_, size, _) in enumerate(self.segs)]
         protos = self.lib.protos
+        # nets built before the recording started: their description first (planned.PlannedNet.prologue)
+        P = importlib.import_module(self.cg.__name__ + ".planned")
+        used = {(a[0].value if hasattr(a[0], "value") else int(a[0])) for n_, a in calls if n_.startswith("cg_net_")}
+        ncall = 0
+        for net in sorted(P.LIVE, key=lambda n_: n_.h.value):
+            if net.h.value not in used:
+                continue
+            hk = self._handle(net.h)
+            for name, toks in net.prologue():
+                toks = [f"H:{hk}" if t == "H" else f"h:{hk}" if t == "h" else self._ptr(t[1]) if isinstance(t, tuple) else t for t in toks]
+                lines.append("|".join(["call", name] + toks))
+                ncall += 1
+        self.prologue_calls = ncall
         for name, args in calls:
+            if name.startswith(("cg_net_", "cg_graph_")):
+                lines.append("|".join(["call", name] + self._net_args(name, args, ncall)))
+                ncall += 1
+                continue
+            ncall += 1
             out = ["call", name]
             for (typ, argname), v in zip(protos[name][1], args):
                 if typ == "void*" and argname == "stream":
@@ -85,4 +148,4 @@ class Recorder:
             lines.append(f"dump|{self._seg_of(int(ptr))}|{int(nbytes)}|{fname}")
         open(trace_path, "w").write("\n".join(lines) + "\n")
         open(blob_path, "wb").write(self.blob)
-        return len(calls)
+        return ncall

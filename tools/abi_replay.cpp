@@ -1,14 +1,19 @@
 // abi_replay — runs a recorded sequence of C-ABI calls (include/catgan.h) with NO interpreter and NO PyTorch in the
 // process: device memory from cg_malloc, one stream from cg_stream_create, every call dispatched by name through
 // tools/abi_dispatch.inc (generated from the header).  It stands in for the LuaJIT host the build image cannot run:
-// tests/test_abi_step.py records one whole D+G update (adversarial.lua:51-275) of the UNFUSED, ungrouped module layer -
-// one C call per nn.Module method, the sequence lua/catgan/nn.lua issues - replays it here and requires the resulting
-// parameter vectors to equal the Python host's bit for bit.
+// tests/test_abi_step.py records one whole D+G update (adversarial.lua:51-275) at the benchmarked batch - the description of the
+// two networks (cg_net_create / _add / _bind ...), then per pass ONE cg_net_forward / cg_net_backward call with the criterion,
+// batch assembly and optimiser calls between them, i.e. the PLANNED (fused) path the bench times - replays it here and requires
+// the resulting parameter vectors to equal the Python host's bit for bit.  The same test replays the per-module walk
+// (one C call per nn.Module method, the sequence the per-module Lua classes issue) at a small batch.
 //
 // Trace format (text, one record per line, fields separated by '|'):
 //   seg|<index>|<bytes>|<offset of its initial contents in the blob file, or -1: start zeroed>
 //   call|<entry point>|<arg>|<arg>...     arg = s (the stream) | n (NULL) | p:<seg>:<byte offset> | i:<int> | u:<uint> |
 //                                               f:<hex float> | a:<k>:<p or n>,<p or n>,... (array of k device pointers)
+//                                               cg_net_* / cg_graph_* (the planned executor): h:<k> handle k | H:<k> create handle k | o out-parameter |
+//                                               L:<int>,<int>.. host long array | F:<hexfloat>,.. host float array | c:<text> |
+//                                               v:<call index>:<byte offset> = inside the tensor that call returned
 //   dump|p:<seg>:<offset>|<bytes>|<output file>
 // usage: abi_replay <trace file> <blob file>
 #include <stdint.h>
@@ -27,11 +32,19 @@ namespace {
 
 std::vector<char*> g_seg;      // device base of every segment
 void* g_stream = nullptr;
+std::vector<void*> g_handles;  // cg_net / graph handles by index
+std::vector<char*> g_vals;     // tensor address returned by call <index> (cg_net_forward / cg_net_backward)
 
 [[noreturn]] void die(const std::string& m) { fprintf(stderr, "abi_replay: %s\n", m.c_str()); exit(2); }
 
 void* resolve(const std::string& tok) {   // "n" | "p:<seg>:<off>"
     if (tok == "n") return nullptr;
+    if (tok.size() >= 3 && tok[0] == 'v') {
+        const size_t c = tok.find(':', 2);
+        const size_t k = strtoull(tok.substr(2, c - 2).c_str(), nullptr, 10);
+        if (k >= g_vals.size() || !g_vals[k]) die("value of a call that returned no tensor: " + tok);
+        return g_vals[k] + atoll(tok.substr(c + 1).c_str());
+    }
     if (tok.size() < 3 || tok[0] != 'p') die("bad pointer token '" + tok + "'");
     const size_t c = tok.find(':', 2);
     const long seg = atol(tok.substr(2, c - 2).c_str());
@@ -48,6 +61,14 @@ struct Arg {
     unsigned long long u() const { return strtoull(tok.c_str() + 2, nullptr, 10); }
     double f() const { return strtod(tok.c_str() + 2, nullptr); }   // hex float: exact
     void* const* parr() const { return tok == "n" ? nullptr : arr.data(); }
+    // planned-executor arguments
+    mutable std::vector<long> la; mutable std::vector<float> fa; mutable long long scratch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void* handle() const { const size_t k = strtoull(tok.c_str() + 2, nullptr, 10); if (k >= g_handles.size()) die("unknown handle " + tok); return g_handles[k]; }
+    void** newh() const { const size_t k = strtoull(tok.c_str() + 2, nullptr, 10); if (g_handles.size() <= k) g_handles.resize(k + 1, nullptr); return &g_handles[k]; }
+    void* out() const { return (void*)scratch; }
+    const long* larr() const { la.clear(); std::stringstream ss(tok.substr(2)); std::string it; while (std::getline(ss, it, ',')) if (!it.empty()) la.push_back(atol(it.c_str())); la.push_back(0); return la.data(); }
+    const float* farr() const { fa.clear(); std::stringstream ss(tok.substr(2)); std::string it; while (std::getline(ss, it, ',')) if (!it.empty()) fa.push_back((float)strtod(it.c_str(), nullptr)); fa.push_back(0.f); return fa.data(); }
+    const char* str() const { return tok.c_str() + 2; }
 };
 
 void need(const std::vector<Arg>& A, size_t n, const char* name) {
@@ -113,6 +134,11 @@ int main(int argc, char** argv) {
                 }
             }
             ck(dispatch(f[1], A), f[1]);
+            if (f[1] == "cg_net_forward" || f[1] == "cg_net_backward") {   // keep the returned tensor's address under this call's index
+                const size_t yi = f[1] == "cg_net_forward" ? 10 : 7;
+                if ((size_t)ncalls >= g_vals.size()) g_vals.resize(ncalls + 1, nullptr);
+                g_vals[ncalls] = *(char**)A[yi].out();
+            }
             ++ncalls;
         } else if (f[0] == "dump") {
             ck(cg_stream_sync(g_stream), "cg_stream_sync");
