@@ -1,6 +1,10 @@
+#!/bin/bash
+# GPU check of the planned executor: parity suite, then the bench in its launch modes (same box)
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -x --deselect tests/test_abi_step.py > gpurun_out/planned_pytest.log 2>&1; echo "rc=$?"; tail -40 gpurun_out/planned_pytest.log
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline > gpurun_out/planned_bench.json 2> gpurun_out/planned_bench.err; echo "bench rc=$?"; cut -c1-400 gpurun_out/planned_bench.json; tail -5 gpurun_out/planned_bench.err
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline --no-graph > gpurun_out/planned_bench_eager.json 2>> gpurun_out/planned_bench.err; cut -c1-300 gpurun_out/planned_bench_eager.json
-CG_PLANNED=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline > gpurun_out/legacy_bench.json 2>> gpurun_out/planned_bench.err; cut -c1-300 gpurun_out/legacy_bench.json
+timeout 1700 python -m pytest tests -m gpu -q -p no:cacheprovider ${PYTEST_ARGS:-} > gpurun_out/planned_pytest.log 2>&1; echo "rc=$?"; tail -60 gpurun_out/planned_pytest.log
+for mode in "" "--no-graph"; do
+  timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-roofline $mode 2>> gpurun_out/planned_bench.err | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); print(j['config']['launch'], j['ms_per_step'], j['value'])"
+done

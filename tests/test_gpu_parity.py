@@ -767,7 +767,7 @@ def test_planned_pass_matches_the_per_module_walk(cg, which):
             xin = cg.Tensor.from_numpy(x)
             out = P.forward(xin).numpy()
             assert P._planned_last == planned
-            gi = cg.nn.as_plain(P.backward(xin, cg.Tensor.from_numpy(dy))).numpy() if which == "D" else None
+            gi = cg.nn.as_plain(P.backward(xin, cg.Tensor.from_numpy(dy))).numpy()
             if planned:
                 st = P._pnet[1].stats()
                 assert st["programs"] == 1 and 0 < st["launches_forward"] < (20 if which == "G" else 50), st
@@ -784,6 +784,7 @@ def test_planned_pass_matches_the_per_module_walk(cg, which):
         close(g1, g0, tol=1e-6, what="D gradInput planned vs per-module")
     else:
         close(o1, o0, tol=2e-6, what="G output planned vs per-module")
+        close(g1, g0, tol=1e-5, what="G gradInput (w.r.t. the noise) planned vs per-module")
     bulk_close(p1, p0, max_rel=1e-4, mean_rel=1e-6, what=f"{which} flat gradient planned vs per-module")
 
 
