@@ -13,7 +13,17 @@
 // library loads - and every non-collective entry point works - on a machine without RCCL.
 #include "common.h"
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+#include <stdlib.h>
+
+// The handful of RCCL declarations this file needs, stated here so that the library BUILDS on a machine without the RCCL
+// headers too (values as in rccl.h / nccl.h 2.x; the functions themselves are bound with dlsym below).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+}
 
 namespace {
 
@@ -73,6 +83,22 @@ struct Comm {
     bool pending = false;
 };
 
+// Collectives of DIFFERENT communicators on one device are ordered on the device: the side stream of the communicator that
+// launches next waits for the join event of the one that launched last.  Two RCCL kernels of different communicators can
+// otherwise be in flight together (D's gradient all-reduce under the G-step's generator forward, whose sync-BN sums travel on
+// the other communicator), which NCCL / RCCL documents as deadlock-prone when ranks schedule them in different orders.  The
+// cost is that a sync-BN exchange may wait for a gradient bucket in flight (~0.3 ms at 8 GPUs); CG_COMM_SERIAL=0 lifts it.
+Comm* g_last_comm = nullptr;
+bool serial_comms() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CG_COMM_SERIAL"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    return v != 0;
+}
+int order_after_other_comm(Comm* c) {
+    if (serial_comms() && g_last_comm && g_last_comm != c) CG_HIP(hipStreamWaitEvent(c->side, g_last_comm->join, 0));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -117,6 +143,7 @@ int cg_comm_init(void** comm, int nranks, int rank, const void* unique_id, size_
 int cg_comm_destroy(void* comm) {
     if (!comm) return 0;
     Comm* c = static_cast<Comm*>(comm);
+    if (g_last_comm == c) g_last_comm = nullptr;
     (void)hipStreamSynchronize(c->side);
     if (c->nccl) g_rccl.CommDestroy(c->nccl);
     if (c->fork) (void)hipEventDestroy(c->fork);
@@ -145,9 +172,11 @@ int cg_comm_allreduce(void* comm, void* compute_stream, void* buf, size_t count,
     hipStream_t cs = cg::S(compute_stream);
     CG_HIP(hipEventRecord(c->fork, cs));
     CG_HIP(hipStreamWaitEvent(c->side, c->fork, 0));
+    if (order_after_other_comm(c)) return 1;
     CG_NCCL(g_rccl.AllReduce(buf, buf, count, dtype == 0 ? ncclFloat32 : ncclFloat64, op == 0 ? ncclSum : ncclAvg, c->nccl, c->side));
     CG_HIP(hipEventRecord(c->join, c->side));
     c->pending = true;
+    g_last_comm = c;
     return 0;
 }
 
@@ -161,9 +190,11 @@ int cg_comm_broadcast(void* comm, void* compute_stream, void* buf, size_t count,
     hipStream_t cs = cg::S(compute_stream);
     CG_HIP(hipEventRecord(c->fork, cs));
     CG_HIP(hipStreamWaitEvent(c->side, c->fork, 0));
+    if (order_after_other_comm(c)) return 1;
     CG_NCCL(g_rccl.Broadcast(buf, buf, count, dtype == 0 ? ncclFloat32 : ncclFloat64, root, c->nccl, c->side));
     CG_HIP(hipEventRecord(c->join, c->side));
     c->pending = true;
+    g_last_comm = c;
     return 0;
 }
 

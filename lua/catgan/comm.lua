@@ -3,7 +3,9 @@ HIP stream with event fork / join).  One LuaJIT process per GPU (SURVEY.md 8e); 
 (train.lua:108-112).
 
    local comm = require 'catgan.comm'
-   comm.init(rank, nranks, '/shared/path/uid')      -- rank 0 writes the two RCCL unique ids, the others read them
+   comm.init(rank, nranks, '/shared/path/uid')      -- rank 0 writes the two RCCL unique ids, the others read them; the launcher's
+                                                    -- CATGAN_RUN_ID (any string unique to this launch) becomes part of the file name, so
+                                                    -- a file a previous run left behind is never read
    -- in fevalD / fevalG_on_D, right after MODEL_X:backward and BEFORE the penalty / clamp lines (adversarial.lua:89-112):
    comm.allreduce_mean(GRAD_PARAMETERS_D)           -- or comm.allreduce_mean_async(...) ... comm.wait()
 installs nn.sync_bn so that nn.SpatialBatchNormalization all-reduces its fp64 sums (sync-BN). ]]
@@ -29,7 +31,9 @@ function comm.init(rank, nranks, uid_path, device)
    local ok = ffi.new('int[1]'); check(C.cg_comm_available(ok))
    assert(ok[0] == 1, 'librccl.so.1 not loadable')
    local ids
+   uid_path = uid_path .. '.' .. (os.getenv('CATGAN_RUN_ID') or os.getenv('MASTER_PORT') or '0')
    if rank == 0 then
+      os.remove(uid_path)                                 -- never let a reader see the previous launch's ids
       local a, b = ffi.new('char[128]'), ffi.new('char[128]')
       check(C.cg_comm_unique_id(a, 128)); check(C.cg_comm_unique_id(b, 128))
       ids = ffi.string(a, 128) .. ffi.string(b, 128)
@@ -44,6 +48,7 @@ function comm.init(rank, nranks, uid_path, device)
       return ffi.gc(h[0], function(p) C.cg_comm_destroy(p) end)
    end
    comm.grad, comm.bn, comm.nranks, comm.rank = mk(0), mk(128), nranks, rank
+   if rank == 0 then os.remove(uid_path) end              -- ncclCommInitRank is collective: every rank has read the ids by now
    -- sync-BN hook of catgan.nn: all-reduce(sum) of `count` doubles, returns the global element count
    require('catgan.nn').nn.sync_bn = function(sums, count, M)
       check(C.cg_comm_allreduce(comm.bn, T.stream, sums, count, 1, 0)); check(C.cg_comm_wait(comm.bn, T.stream))

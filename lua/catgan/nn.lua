@@ -8,10 +8,15 @@ updateOutput / updateGradInput / accGradParameters, forward / backward, .weight 
     torch = require 'catgan'.torch ; nn = require 'catgan'.nn ; cudnn = require 'catgan'.cudnn
 in place of the Torch7 rocks, models.lua:138-160 / :196-228 / :640-711 / :814-906 build as written.
 
-One C-ABI call (or a short fixed sequence) per module method; the executable twin is cat-generator_amd/nn.py, whose
-UNFUSED path (nn.fusion = False) issues these same calls in the same order - tools/abi_step.cpp replays that sequence
-without any interpreter in the process.  Feature maps stay NHWC between modules; nn.View / nn.Transpose / nn.Copy
-are where the logical Torch7 layout is (re)established.
+Two ways through a network, as in the executable twin cat-generator_amd/nn.py:
+  * the nn.Module protocol module by module - one C-ABI call (or a short fixed sequence) per module method: what a module used
+    on its own gets;
+  * planned passes: nn.Sequential:forward / :backward / :updateGradInput on a whole network (what adversarial.lua:84-89,182-197
+    calls on MODEL_D / MODEL_G) describe the tree to the library once and run as ONE cg_net_forward / cg_net_backward call
+    (catgan.net; csrc/net.hip plans fusion, lockstep branches, streams, re-packing below the C ABI).  nn.planned = false keeps
+    the per-module walk.
+tools/abi_replay replays both call sequences without any interpreter in the process (tests/test_abi_step.py).  Feature maps stay
+NHWC between modules; nn.View / nn.Transpose / nn.Copy are where the logical Torch7 layout is (re)established.
 ]]
 local ffi = require 'ffi'
 local abi = require 'catgan.ffi'
@@ -20,6 +25,7 @@ local C, check = abi.C, abi.check
 local Device, Host, prod, copy_shape = T.Device, T.Host, T.prod, T.copy_shape
 
 local nn, cudnn = {}, {}
+nn.planned = os.getenv('CG_PLANNED') ~= '0'
 local function S() return T.stream end
 
 -- counter-based generator shared with the engine's kernels (cg_rng_*): seed + running offset
@@ -166,7 +172,36 @@ function Sequential:listModules()
    for _, m in ipairs(self.modules) do for _, c in ipairs(m:listModules()) do out[#out + 1] = c end end
    return out
 end
+-- planned passes (catgan.net): the calls adversarial.lua makes on a whole network
+local function planned_net(self)
+   if not nn.planned or self.__typename ~= 'nn.Sequential' then return nil end
+   if self._pnet == nil or self._pnet_n ~= #self:listModules() then
+      self._pnet = require('catgan.net').Net.new(self) or false
+      self._pnet_n = #self:listModules()
+   end
+   return self._pnet or nil
+end
+function Sequential:forward(input)
+   local net = planned_net(self)
+   if not net then return self:updateOutput(input) end
+   local x = to_device(input):materialise()
+   local out = net:forward(x, rng, nil)
+   self._planned_last = true
+   local last = self.modules[#self.modules]
+   if last and last.__typename == 'nn.Copy' and not last.outtype:find('Cuda') then out = out:float() end   -- models.lua:704
+   self.output = out
+   return out
+end
+local function planned_backward(self, gradOutput, scale, acc)
+   local gi = self._pnet:backward(to_device(gradOutput):materialise(), acc, scale)
+   local first = self.modules[1]
+   if first then first.gradInput = gi end                     -- adversarial.lua:193 reads MODEL_D.modules[1].gradInput
+   if first and first.__typename == 'nn.Copy' and not first.intype:find('Cuda') then gi = gi:float() end
+   self.gradInput = gi
+   return gi
+end
 function Sequential:updateOutput(input)
+   self._planned_last = false
    local cur = input
    for _, m in ipairs(self.modules) do cur = m:updateOutput(cur) end
    self.output = cur
@@ -180,6 +215,7 @@ local function walk_back(self, input, gradOutput, fn)
    return cur
 end
 function Sequential:updateGradInput(input, gradOutput)
+   if self._planned_last then return planned_backward(self, gradOutput, 1, false) end
    return walk_back(self, input, gradOutput, function(m, i, g) return m:updateGradInput(i, g) end)
 end
 function Sequential:accGradParameters(input, gradOutput, scale)
@@ -192,6 +228,7 @@ function Sequential:accGradParameters(input, gradOutput, scale)
 end
 function Sequential:backward(input, gradOutput, scale)
    scale = scale or 1
+   if self._planned_last then return planned_backward(self, gradOutput, scale, true) end
    return walk_back(self, input, gradOutput, function(m, i, g) return m:backward(i, g, scale) end)
 end
 function Sequential:__repr()
@@ -205,6 +242,7 @@ nn.Sequential = Sequential
 -- nn.ConcatTable(): every branch sees the input; output = table of branch outputs; backward sums the gradInputs
 local ConcatTable = class('nn.ConcatTable', Sequential)
 function ConcatTable:updateOutput(input)
+   self._planned_last = false
    self.output = {}
    for i, m in ipairs(self.modules) do self.output[i] = m:updateOutput(input) end
    return self.output
@@ -244,6 +282,7 @@ function Concat:__init(dimension)
    Sequential.__init(self); assert(dimension == 2, 'only channel concatenation is on the path'); self.dimension = dimension
 end
 function Concat:updateOutput(input)
+   self._planned_last = false
    local outs, Ct = {}, 0
    self._sizes = {}
    for i, m in ipairs(self.modules) do
