@@ -98,6 +98,54 @@ def check_blocks(path, src):
     return errs
 
 
+def check_net_builder():
+    """4. the planned executor's builder: lua/catgan/net.lua describes a module with the same (kind, iargs, fargs) as the executable
+    twin cat-generator_amd/planned.py, and both use the kind numbers of csrc/net.hip's enum (the header documents them)."""
+    errs = []
+    hip = open(os.path.join(ROOT, "cat-generator_amd", "csrc", "net.hip")).read()
+    enum = dict((n, int(v)) for n, v in re.findall(r"K_([A-Z]+) = (\d+)", hip))
+    names = {"SEQ": "Sequential", "CONCAT": "Concat", "CONCATTABLE": "ConcatTable", "LINEAR": "Linear", "CONV": "SpatialConvolution", "PRELU": "PReLU",
+             "LRELU": "LeakyReLU", "SIGMOID": "Sigmoid", "BN": "SpatialBatchNormalization", "VIEW": "View", "COPY": "Copy", "TRANSPOSE": "Transpose",
+             "UPS": "SpatialUpSamplingNearest", "AVGPOOL": "SpatialAveragePooling", "MAXPOOL": "SpatialMaxPooling", "SDROP": "SpatialDropout",
+             "DROP": "Dropout", "AFFMAT": "AffineTransformMatrixGenerator", "AFFGRID": "AffineGridGeneratorBHWD", "SAMPLER": "BilinearSamplerBHWD"}
+    want = {names[k]: v for k, v in enum.items() if k in names}
+    py = open(os.path.join(ROOT, "cat-generator_amd", "planned.py")).read()
+    py_kind = dict((n, int(v)) for n, v in re.findall(r"(\w+)=(\d+)", py[py.index("KIND = dict("):py.index(")", py.index("KIND = dict("))]))
+    lua = open(os.path.join(ROOT, "lua", "catgan", "net.lua")).read()
+    lua_kind = dict((n.split(".")[1], int(v)) for n, v in re.findall(r"\['((?:nn|cudnn)\.\w+)'\] = (\d+)", lua))
+    hdr = open(os.path.join(ROOT, "include", "catgan.h")).read()
+    for cls, k in want.items():
+        if py_kind.get(cls) != k:
+            errs.append(f"planned.py: KIND[{cls}] = {py_kind.get(cls)}, csrc/net.hip says {k}")
+        if lua_kind.get(cls) != k:
+            errs.append(f"lua/catgan/net.lua: KIND[nn.{cls}] = {lua_kind.get(cls)}, csrc/net.hip says {k}")
+        if not re.search(r"\b%d (?:nn|nn\|cudnn)\.%s" % (k, cls), hdr):
+            errs.append(f"include/catgan.h: cg_net_add's comment does not list kind {k} as {cls}")
+    # argument lists: the fields each describe() reads, per kind, must be the same fields in the same order
+    def fields(src, lang):
+        out = {}
+        if lang == "py":
+            for m in re.finditer(r'if n == "(\w+)":\n\s+return k, \[([^\]]*)\], \[([^\]]*)\]', src):
+                out[KINDNUM(py_kind, m.group(1))] = (re.findall(r"m\.(\w+)", m.group(2)), re.findall(r"m\.(\w+)", m.group(3)))
+        else:
+            for m in re.finditer(r"if k == (\d+) then return k, \{([^}]*)\}, \{([^}]*)\} end", src):
+                out[int(m.group(1))] = (re.findall(r"m\.(\w+)", m.group(2)), re.findall(r"m\.(\w+)", m.group(3)))
+        return out
+    def KINDNUM(tab, name):
+        return tab[name]
+    fp, fl = fields(py, "py"), fields(lua, "lua")
+    canon = lambda f: [x for x in f if x not in ("shape",)]
+    for k in sorted(set(fp) & set(fl)):
+        a, b = fp[k], fl[k]
+        if k == 3:
+            continue   # nn.Linear: weight.shape[1], weight.shape[0] (0-based) vs weight.shape[2], weight.shape[1] (1-based)
+        if (canon(a[0]), canon(a[1])) != (canon(b[0]), canon(b[1])):
+            errs.append(f"net builders disagree on kind {k}: planned.py reads {a}, net.lua reads {b}")
+    if len(set(fp) & set(fl)) < 7:
+        errs.append(f"net builders: only {len(set(fp) & set(fl))} kinds could be compared (parser out of date?)")
+    return errs
+
+
 def main():
     P = protos()
     errs, ncalls, files = [], 0, []
@@ -138,6 +186,7 @@ def main():
     for c in needed:
         if c not in defined and not re.search(r"name\s*=\s*'%s'|pool_class\('%s'" % (re.escape(c), re.escape(c)), src_all):
             errs.append(f"lua/: class or function {c} is not defined")
+    errs += check_net_builder()
     for e in errs:
         print(e)
     print(f"{len(files)} Lua files, {ncalls} C-ABI calls checked against {len(P)} prototypes, {len(errs)} problems")
