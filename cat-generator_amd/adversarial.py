@@ -282,11 +282,13 @@ class GraphedIteration:
         self.base = r.enable_device_base()
         self.off0 = r.offset
         self.stride = None
-        for _ in range(max(1, warmup)):  # eager passes: allocate every buffer, pack weights, learn the stride
-            self._eager()
+        self.stream = torch.cuda.Stream()     # warm-up AND capture run here: per-stream scratch (column reductions, split-K
+        self.stream.wait_stream(torch.cuda.current_stream())   # workspaces) must exist before the capture starts
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(1, warmup)):  # eager passes: allocate every buffer, pack weights, learn the stride
+                self._eager()
         torch.cuda.synchronize()
         ts = {k: S.OPTSTATE["adam"][k]["t"] for k in ("D", "G")}
-        self.stream = torch.cuda.Stream()
         self.exec = ctypes.c_void_p()
         with torch.cuda.stream(self.stream):
             lib().graph_begin(stream())
@@ -310,7 +312,7 @@ class GraphedIteration:
         self._body()
 
     def __call__(self):
-        lib().graph_launch(self.exec, stream())
+        lib().graph_launch(self.exec, stream())   # on the caller's current stream
         self.replays += 1
         for k in ("D", "G"):
             self.S.OPTSTATE["adam"][k]["t"] += 1

@@ -48,6 +48,14 @@ long opt(Opt o);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Per-stream scratch of the deterministic column reductions (batch-norm statistics / backward sums, bias gradients): every
+// workgroup writes its per-channel partials here, the LAST one to arrive (a ticket counter, kept at the front of the block and
+// left at zero again) adds them up in a fixed order - no floating-point atomics, so a batch-norm layer gives the same bits on
+// every run (the property the reference protects by pinning stn's sampler to the CPU, models.lua:889-899).  One block per
+// stream, allocated on the stream's first use (which therefore must not happen inside a graph capture: warm up first).
+constexpr size_t kColScratchBytes = 8u << 20;
+void* col_scratch(hipStream_t stream);   // nullptr + cg::fail() on error
+
 // grid for memory-bound grid-stride kernels: enough blocks to fill 256 CUs x 8
 static inline int ew_grid(long n, int per_block = 256) {
     long b = (n + per_block - 1) / per_block;
@@ -66,6 +74,22 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
+}
+
+// true in exactly one workgroup of the grid: the last one to arrive at this point (everything the others wrote before their
+// arrival is visible to it).  counter must be zero before the launch; the last workgroup leaves it at zero again.
+__device__ __forceinline__ bool last_block_arrives(unsigned* counter, unsigned total) {
+    __shared__ int last_flag;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(counter, 1u);
+        last_flag = (t == total - 1) ? 1 : 0;
+        if (last_flag) *counter = 0u;
+    }
+    __syncthreads();
+    if (last_flag) __threadfence();
+    return last_flag != 0;
 }
 
 // block-wide sum for 256-thread blocks; result valid in thread 0

@@ -279,14 +279,16 @@ __global__ __launch_bounds__(256) void bn_act_fwd_v4k(const float* __restrict__ 
 
 // backward statistics of PReLU(BN(x)) from x and the gradient dy w.r.t. the PReLU output:
 //   u = (x - mean) * invstd * gamma + beta (recomputed, bit-equal to the forward);  d = u > 0 ? dy : alpha * dy
-//   sums[c] = sum d, sums[C + c] = sum d * xhat, sums[2C] = sum_{u <= 0} u * dy   (fp64, all channels of one block
-//   folded before the atomics; block = QB channel quads x RL row lanes as colreduce4_k)
+//   sums[c] = sum d, sums[C + c] = sum d * xhat, sums[2C] = sum_{u <= 0} u * dy   (fp64; block = QB channel quads x RL row
+//   lanes as colreduce4_k; per-workgroup partials go to the stream's scratch and the last workgroup to arrive adds them up in a
+//   fixed order: no floating-point atomics, the same bits on every run)
 template <int QB>
 __global__ __launch_bounds__(256) void bn_act_bwd_stats_k(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* alpha, long M, int C, long rows_per_block,
-                                                          double* __restrict__ sums) {
+                                                          double* __restrict__ sums, unsigned* counter, double* part,
+                                                          double* part_alpha) {
     constexpr int RL = 256 / QB;
     __shared__ double sh[2][RL][QB * 4 + 2];
     __shared__ double shg[4];
@@ -334,11 +336,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stats_k(const float* __restric
         double t = 0.0;
 #pragma unroll
         for (int r = 0; r < RL; ++r) t += sh[which][r][cl];
-        atomicAdd(&sums[which * C + c], t);
+        part[(size_t)blockIdx.y * (2 * C) + which * C + c] = t;
     }
-    if (alpha) {
-        const double t = block_sum_256(ga, shg);
-        if (threadIdx.x == 0) atomicAdd(&sums[2 * C], t);
+    {
+        const double t = alpha ? block_sum_256(ga, shg) : 0.0;
+        if (threadIdx.x == 0) part_alpha[blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+    if (cg::last_block_arrives(counter, gridDim.x * gridDim.y)) {
+        const int chunks = (int)gridDim.y;
+        for (int k = threadIdx.x; k < 2 * C; k += 256) {
+            double t = 0.0;
+            for (int y = 0; y < chunks; ++y) t += part[(size_t)y * (2 * C) + k];
+            sums[k] = t;
+        }
+        double a = 0.0;
+        for (int i = threadIdx.x; i < (int)(gridDim.x * gridDim.y); i += 256) a += part_alpha[i];
+        a = block_sum_256(a, shg);
+        if (threadIdx.x == 0) sums[2 * C] = a;
     }
 }
 
@@ -591,7 +605,6 @@ int cg_bn_act_backward_stats(void* stream, const float* x, const float* dy, cons
                              const float* gamma, const float* beta, const float* alpha, long M, int C, double* sums) {
     CG_REQUIRE(x && dy && save_mean && save_invstd && gamma && beta && sums && C > 0 && M > 0, "cg_bn_act_backward_stats: bad args");
     CG_REQUIRE(C % 4 == 0 && al16(x) && al16(dy), "cg_bn_act_backward_stats: needs C %% 4 == 0 and 16-byte aligned tensors");
-    CG_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (2 * (size_t)C + 1), cg::S(stream)));
     const int qb = C >= 128 ? 32 : 16;
     const int cblocks = cg::cdiv(C / 4, qb);
     const int cmul = (int)cg::opt(cg::OPT_COLREDUCE_WGS_PER_CU);
@@ -599,12 +612,19 @@ int cg_bn_act_backward_stats(void* stream, const float* x, const float* dy, cons
     const long rows_per_block = ((M + chunks - 1) / chunks + 3) / 4 * 4;
     chunks = (M + rows_per_block - 1) / rows_per_block;
     const dim3 grid(cblocks, (unsigned)chunks);
+    char* scr = (char*)cg::col_scratch(cg::S(stream));
+    if (!scr) return 1;
+    const size_t np = (size_t)chunks * 2 * C, na = (size_t)chunks * cblocks;
+    CG_REQUIRE(256 + sizeof(double) * (np + na) <= cg::kColScratchBytes, "cg_bn_act_backward_stats: partials exceed the scratch");
+    unsigned* counter = (unsigned*)scr;
+    double* part = (double*)(scr + 256);
+    double* part_alpha = part + np;
     if (qb == 32)
         hipLaunchKernelGGL(bn_act_bwd_stats_k<32>, grid, dim3(256), 0, cg::S(stream), x, dy, save_mean, save_invstd, gamma, beta, alpha,
-                           M, C, rows_per_block, sums);
+                           M, C, rows_per_block, sums, counter, part, part_alpha);
     else
         hipLaunchKernelGGL(bn_act_bwd_stats_k<16>, grid, dim3(256), 0, cg::S(stream), x, dy, save_mean, save_invstd, gamma, beta, alpha,
-                           M, C, rows_per_block, sums);
+                           M, C, rows_per_block, sums, counter, part, part_alpha);
     CG_LAUNCH_CHECK();
     return 0;
 }

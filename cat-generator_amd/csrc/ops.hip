@@ -33,6 +33,29 @@ long g_opt_val[OPT_COUNT];
 int g_opt_state[OPT_COUNT];   // 0 = not read yet, 1 = default / environment, 2 = set through the ABI
 }  // namespace
 
+}  // namespace cg
+#include <mutex>
+#include <unordered_map>
+namespace cg {
+void* col_scratch(hipStream_t stream) {
+    static std::unordered_map<hipStream_t, void*> blocks;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = blocks.find(stream);
+    if (it != blocks.end()) return it->second;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+        cg::fail("column reduce: first use of this stream inside a graph capture (run one pass on it before cg_graph_begin)");
+        return nullptr;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, kColScratchBytes) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) {
+        cg::fail("column reduce: cannot allocate %zu bytes of scratch", kColScratchBytes);
+        return nullptr;
+    }
+    blocks[stream] = p;
+    return p;
+}
 unsigned long g_opt_epoch = 1;   // bumped by cg_set_option: compiled plans (net.hip) re-derive workspace sizes / dispatch-dependent rows
 long opt(Opt o) {
     if (g_opt_state[o] == 0) {
@@ -46,6 +69,7 @@ long opt(Opt o) {
 
 namespace {
 using cg::block_sum_256;
+using cg::last_block_arrives;
 using cg::wave_sum;
 
 #define GRID_STRIDE(i, n) \
@@ -253,10 +277,20 @@ __global__ void bce_bwd_k(const float* p, const float* t, float* dp, long n) {
 // ------------------------------------------------------------- column reduces
 // x: [M][C].  grid = (ceil(C/64), row chunks); block = 64 channels x 4 row lanes.
 // MODE 0: (x, x^2)   MODE 1: (dy, dy*xhat)   MODE 2: (dy, 0)
+// Second stage of the column reductions, run by the last workgroup to arrive: sums[k] = part[0][k] + part[1][k] + ... in chunk
+// order (nk = number of sums; part rows are nk doubles).
+__device__ __forceinline__ void colreduce_finish(const double* part, int chunks, int nk, double* sums) {
+    for (int k = threadIdx.x; k < nk; k += blockDim.x) {
+        double t = 0.0;
+        for (int y = 0; y < chunks; ++y) t += part[(size_t)y * nk + k];
+        sums[k] = t;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_k(const float* x, const float* dy, const float* mean,
                                                    const float* invstd, long M, int C, long rows_per_block,
-                                                   double* sums) {
+                                                   double* sums, unsigned* counter, double* part) {
     __shared__ double sh1[4][64], sh2[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -290,9 +324,11 @@ __global__ __launch_bounds__(256) void colreduce_k(const float* x, const float* 
     if (rl == 0 && c < C) {
         const double t1 = sh1[0][cl] + sh1[1][cl] + sh1[2][cl] + sh1[3][cl];
         const double t2 = sh2[0][cl] + sh2[1][cl] + sh2[2][cl] + sh2[3][cl];
-        atomicAdd(&sums[c], t1);
-        if (MODE != 2) atomicAdd(&sums[C + c], t2);
+        const int nk = (MODE == 2 ? 1 : 2) * C;
+        part[(size_t)blockIdx.y * nk + c] = t1;
+        if (MODE != 2) part[(size_t)blockIdx.y * nk + C + c] = t2;
     }
+    if (last_block_arrives(counter, gridDim.x * gridDim.y)) colreduce_finish(part, (int)gridDim.y, (MODE == 2 ? 1 : 2) * C, sums);
 }
 
 // float4 form (C % 4 == 0, 16-byte aligned rows): block = QB channel quads x RL row lanes (QB*RL = 256), four
@@ -300,7 +336,7 @@ __global__ __launch_bounds__(256) void colreduce_k(const float* x, const float* 
 template <int MODE, int QB>
 __global__ __launch_bounds__(256) void colreduce4_k(const float* x, const float* dy, const float* mean,
                                                     const float* invstd, long M, int C, long rows_per_block,
-                                                    double* sums) {
+                                                    double* sums, unsigned* counter, double* part) {
     constexpr int RL = 256 / QB;
     __shared__ double sh[2][RL][QB * 4 + 2];
     const int ql = threadIdx.x % QB, rl = threadIdx.x / QB;
@@ -347,8 +383,9 @@ __global__ __launch_bounds__(256) void colreduce4_k(const float* x, const float*
         double t = 0.0;
 #pragma unroll
         for (int r = 0; r < RL; ++r) t += sh[which][r][cl];
-        atomicAdd(&sums[which * C + c], t);
+        part[(size_t)blockIdx.y * ((MODE == 2 ? 1 : 2) * C) + which * C + c] = t;
     }
+    if (last_block_arrives(counter, gridDim.x * gridDim.y)) colreduce_finish(part, (int)gridDim.y, (MODE == 2 ? 1 : 2) * C, sums);
 }
 
 __global__ void bias_grad_finish_k(const double* sums, float* gb, int C, float scale) {
@@ -1185,8 +1222,7 @@ int cg_bce_backward(void* stream, const float* p, const float* t, float* dp, lon
 
 static int colreduce_launch(void* stream, int mode, const float* x, const float* dy, const float* mean,
                             const float* invstd, long M, int C, double* sums, int nsums) {
-    CG_HIP(hipMemsetAsync(sums, 0, sizeof(double) * nsums * C, cg::S(stream)));
-    if (M <= 0) return 0;
+    if (M <= 0) { CG_HIP(hipMemsetAsync(sums, 0, sizeof(double) * nsums * C, cg::S(stream))); return 0; }
     const bool v4 = C % 4 == 0 && (!x || al16(x)) && (!dy || al16(dy));
     const int qb = C >= 128 ? 32 : 16;   // channel quads per block in the float4 form
     const int cblocks = v4 ? cg::cdiv(C / 4, qb) : cg::cdiv(C, 64);
@@ -1197,7 +1233,13 @@ static int colreduce_launch(void* stream, int mode, const float* x, const float*
     const long rows_per_block = ((M + chunks - 1) / chunks + 3) / 4 * 4;
     chunks = (M + rows_per_block - 1) / rows_per_block;
     dim3 grid(cblocks, (unsigned)chunks);
-#define CG_COLRED(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, cg::S(stream), x, dy, mean, invstd, M, C, rows_per_block, sums)
+    // deterministic two-stage sum inside one launch: partials in the stream's scratch, the last workgroup adds them in order
+    char* scr = (char*)cg::col_scratch(cg::S(stream));
+    if (!scr) return 1;
+    CG_REQUIRE(256 + sizeof(double) * (size_t)chunks * nsums * C <= cg::kColScratchBytes, "column reduce: %ld chunks x %d sums exceed the scratch", chunks, nsums * C);
+    unsigned* counter = (unsigned*)scr;
+    double* part = (double*)(scr + 256);
+#define CG_COLRED(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, cg::S(stream), x, dy, mean, invstd, M, C, rows_per_block, sums, counter, part)
     if (v4 && qb == 32) {
         if (mode == 0) CG_COLRED((colreduce4_k<0, 32>)); else if (mode == 1) CG_COLRED((colreduce4_k<1, 32>)); else CG_COLRED((colreduce4_k<2, 32>));
     } else if (v4) {

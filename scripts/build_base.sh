@@ -8,7 +8,7 @@ T=$(mktemp -d)
 git -C "$ROOTD" archive "$REV" cat-generator_amd/csrc include | tar -x -C "$T"
 OBJS=""
 for f in "$T"/cat-generator_amd/csrc/*.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I/opt/rocm/include -c "$f" -o "$f.o" &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I/opt/rocm/include -c "$f" -o "$f.o" &
   OBJS="$OBJS $f.o"
 done
 wait

@@ -788,6 +788,33 @@ def test_planned_pass_matches_the_per_module_walk(cg, which):
     bulk_close(p1, p0, max_rel=1e-4, mean_rel=1e-6, what=f"{which} flat gradient planned vs per-module")
 
 
+def test_generator_and_discriminator_passes_are_bit_reproducible(cg):
+    """No floating-point atomics anywhere on the path: batch-norm statistics, their backward sums, bias / slope gradients and the
+    sampler's image gradient are all summed in a fixed order (two-stage sums whose last workgroup adds the partials in order), so
+    running the same forward + backward twice gives the same bits - for G (three batch-norm layers) as for D.  The reference buys
+    this property for its sampler by pinning it to the CPU (models.lua:889-899)."""
+    for which, N in (("G", 64), ("D", 32)):
+        P, _, _ = _pair(cg, 13, which)
+        pP, gP = P.getParameters()
+        rs = np.random.RandomState(2)
+        if which == "D":
+            pP.copy(pP.numpy() + (rs.randn(pP.nElement()) * 0.01).astype(f32))
+            x = rs.rand(N, 3, 32, 32).astype(f32); dy = rs.randn(N, 1).astype(f32)
+        else:
+            x = (rs.rand(N, 100) * 2 - 1).astype(f32); dy = (rs.randn(N, 3, 32, 32) * 0.1).astype(f32)
+        xin, dyt = cg.Tensor.from_numpy(x), cg.Tensor.from_numpy(dy)
+        runs = []
+        for _ in range(3):
+            cg.manual_seed(7)
+            out = P.forward(xin).numpy()
+            gP.zero()
+            gi = cg.nn.as_plain(P.backward(xin, dyt)).numpy()
+            runs.append((out, gi, gP.numpy().copy()))
+        for r in runs[1:]:
+            for a, b, what in zip(r, runs[0], ("output", "gradInput", "flat gradient")):
+                np.testing.assert_array_equal(a, b, err_msg=f"{which}: {what} differs between two identical passes")
+
+
 @pytest.mark.parametrize("which", ["G", "D"])
 def test_plan_options_are_result_neutral(cg, which):
     """cg_net_set_option's ablation switches on the real networks at batch 16: deferred + batched weight-gradient reductions
