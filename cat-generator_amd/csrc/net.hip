@@ -173,6 +173,8 @@ struct MS {
     vector<Seg> ran;             // nn.Sequential: the plan its forward ran
     bool ran_set = false;
     void* wg_ws = nullptr; size_t wg_ws_bytes = 0; bool wg_pending = false;   // deferred weight-gradient workspace
+    bool loc_fused = false; int locG = 0; long locN = 0;                      // [locnet, AffMat, AffGrid] ran as cg_locnet_forward
+    void* loc_ws[4] = {nullptr, nullptr, nullptr, nullptr}; size_t loc_ws_bytes[4] = {0, 0, 0, 0};
     std::map<std::string, Val> bufs;
 };
 
@@ -213,7 +215,7 @@ struct Net {
     bool params_dirty = true;
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
-        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1;
+        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1;
     long wino_min_tiles = 2048;
     std::string trace_log;
     const KTable* K = &kRealTable;
@@ -592,7 +594,12 @@ struct Compiler {
         const KTable* k = K();
         MS& s = S(m);
         switch (m.kind) {
-        case K_SEQ: return fwd_seq(m, in);
+        case K_SEQ: {
+            LocDesc ld;
+            if (match_loc(m, in, ld)) return fwd_loc({&m}, in, ld)[0];
+            S(m).loc_fused = false;
+            return fwd_seq(m, in);
+        }
         case K_CONCATTABLE: {
             Val t; t.is_tab = true; t.none = false;
             for (int c : m.kids) t.tab.push_back(fwd(M(c), in));
@@ -805,7 +812,19 @@ struct Compiler {
         const KTable* k = K();
         const int G = (int)mods.size();
         switch (m0.kind) {
-        case K_SEQ: return gfwd_seq(mods, ins, ctx);
+        case K_SEQ: {
+            // sibling localisation branches on the SAME input (D32_st3's three transformers): one fused launch for the group
+            LocDesc ld;
+            bool same = G <= 4 && match_loc(m0, ins[0], ld);
+            for (int b = 1; same && b < G; ++b) {
+                LocDesc lb;
+                same = ins[b].key() == ins[0].key() && ins[b].same_shape(ins[0]) && match_loc(*mods[b], ins[b], lb) && lb.S == ld.S && lb.Cin == ld.Cin &&
+                       lb.P == ld.P && lb.ur == ld.ur && lb.us == ld.us && lb.ut == ld.ut && lb.slope == ld.slope;
+            }
+            if (same) return fwd_loc(mods, ins[0], ld);
+            for (Mod* m : mods) S(*m).loc_fused = false;
+            return gfwd_seq(mods, ins, ctx);
+        }
         case K_CONCATTABLE: {
             const size_t nch = m0.kids.size();
             vector<vector<Val>> per_child;
@@ -1193,6 +1212,123 @@ struct Compiler {
         return y;
     }
 
+    // ---------------------------------------------------------------------------------------- fused localisation branch
+    // nn.Sequential{ localisation net (models.lua:842-855), AffineTransformMatrixGenerator, AffineGridGeneratorBHWD } (:874-879) as
+    // cg_locnet_forward / cg_locnet_backward: one launch each way instead of ~10 / ~12, off the GEMM path (csrc/locnet.hip).
+    struct LocDesc { Mod *conv1, *conv2, *lin1, *lin2; int S, Cin, P, ur, us, ut, Hg, Wg; float slope; };
+    bool match_loc(Mod& q, const Val& in, LocDesc& d) {
+        if (!net->fuse_locnet || !net->fusion || q.kind != K_SEQ || q.kids.size() != 3) return false;
+        Mod& L = M(q.kids[0]);
+        static const int want[10] = {K_AVGPOOL, K_CONV, K_LRELU, K_CONV, K_LRELU, K_AVGPOOL, K_VIEW, K_LINEAR, K_LRELU, K_LINEAR};
+        if (L.kind != K_SEQ || L.kids.size() != 10 || M(q.kids[1]).kind != K_AFFMAT || M(q.kids[2]).kind != K_AFFGRID) return false;
+        for (int i = 0; i < 10; ++i) if (M(L.kids[i]).kind != want[i]) return false;
+        if (in.is_tab || in.none || in.nd != 4 || in.fmt != NHWC || in.ups || in.d[2] != in.d[3] || in.d[2] % 4) return false;
+        d.conv1 = &M(L.kids[1]); d.conv2 = &M(L.kids[3]); d.lin1 = &M(L.kids[7]); d.lin2 = &M(L.kids[9]);
+        d.S = (int)(in.d[2] / 2); d.Cin = (int)in.d[1]; d.P = (int)d.lin2->ia[1];
+        auto conv_ok = [](const Mod& c, long ci) { return c.ia[0] == ci && c.ia[1] == 16 && c.kW() == 3 && c.kH() == 3 && c.padW() == 1 && c.padH() == 1; };
+        if (!conv_ok(*d.conv1, d.Cin) || !conv_ok(*d.conv2, 16)) return false;
+        const long K3 = 16L * (d.S / 2) * (d.S / 2);
+        if (M(L.kids[6]).ia[7] != 1 || M(L.kids[6]).ia[0] != K3 || d.lin1->ia[0] != K3 || d.lin1->ia[1] != 64 || d.lin2->ia[0] != 64) return false;
+        d.slope = M(L.kids[2]).fa[0];
+        if (M(L.kids[4]).fa[0] != d.slope || M(L.kids[8]).fa[0] != d.slope) return false;
+        const Mod &am = M(q.kids[1]), &ag = M(q.kids[2]);
+        d.ur = (int)am.ia[0]; d.us = (int)am.ia[1]; d.ut = (int)am.ia[2]; d.Hg = (int)ag.ia[0]; d.Wg = (int)ag.ia[1];
+        if (d.P != d.ur + d.us + 2 * d.ut) return false;
+        return cg_locnet_supported(d.S, d.Cin, d.P) != 0;
+    }
+    static void loc_weights(const vector<Mod*>& qs, Net* n, const float* w[32]) {
+        for (size_t b = 0; b < qs.size(); ++b) {
+            const Mod& L = *n->mods[qs[b]->kids[0]];
+            const Mod *c1 = n->mods[L.kids[1]].get(), *c2 = n->mods[L.kids[3]].get(), *l1 = n->mods[L.kids[7]].get(), *l2 = n->mods[L.kids[9]].get();
+            const float* v[8] = {c1->w, c1->b, c2->w, c2->b, l1->w, l1->b, l2->w, l2->b};
+            for (int k = 0; k < 8; ++k) w[8 * b + k] = v[k];
+        }
+    }
+    vector<Val> fwd_loc(const vector<Mod*>& qs, const Val& in, const LocDesc& d) {
+        const KTable* k = K();
+        const int G = (int)qs.size();
+        Mod& q0 = *qs[0];
+        const long N = in.d[0], S_ = d.S, Cin = d.Cin, K3 = 16L * (S_ / 2) * (S_ / 2);
+        Val pooled = buf(q0, "loc.pooled", {G * N, Cin, S_, S_}, NHWC), h1 = buf(q0, "loc.h1", {G * N, 16, S_, S_}, NHWC),
+            m2 = buf(q0, "loc.m2", {G * N, 16, S_, S_}, NHWC), h2 = buf(q0, "loc.h2", {G * N, K3}), h3 = buf(q0, "loc.h3", {G * N, 64}),
+            prm = buf(q0, "loc.params", {G * N, d.P}), grid = buf(q0, "loc.grid", {G * N, d.Hg, d.Wg, 2});
+        Net* n_ = net; vector<Mod*> qv = qs; const LocDesc dd = d; Val x = in;
+        emit([=](Run& c) {
+            const float* w[32];
+            loc_weights(qv, n_, w);
+            return k->locnet_forward(c.CS(), G, (int)N, c.P(x), 1, w, dd.S, dd.Cin, dd.P, dd.ur, dd.us, dd.ut, dd.slope, dd.Hg, dd.Wg, c.P(pooled), c.P(h1),
+                                     c.P(m2), c.P(h2), c.P(h3), c.P(prm), c.P(grid));
+        });
+        vector<Val> outs = G == 1 ? vector<Val>{grid} : split(grid, G);
+        for (int b = 0; b < G; ++b) {
+            MS& s = S(*qs[b]);
+            s.out = outs[b]; s.loc_fused = true; s.locG = G; s.locN = N;
+            s.ran_set = false;
+        }
+        MS& s0 = S(q0);
+        s0.x = in;
+        return outs;
+    }
+    vector<Val> bwd_loc(const vector<Mod*>& qs, const vector<Val>& gouts, bool acc) {
+        const KTable* k = K();
+        const int G = (int)qs.size();
+        Mod& q0 = *qs[0];
+        MS& s0 = S(q0);
+        LocDesc d;
+        if (!match_loc(q0, s0.x, d)) { err("cg_net: fused localisation branch lost its shape"); return gouts; }
+        const long N = s0.locN, S_ = d.S, Cin = d.Cin, K3 = 16L * (S_ / 2) * (S_ / 2);
+        Val GG;
+        if (G == 1) GG = gouts[0];
+        else if (!stacked(gouts, &GG)) GG = restack(q0, gouts, gouts[0]);
+        Val pooled = buf(q0, "loc.pooled", {G * N, Cin, S_, S_}, NHWC), h1 = buf(q0, "loc.h1", {G * N, 16, S_, S_}, NHWC),
+            m2 = buf(q0, "loc.m2", {G * N, 16, S_, S_}, NHWC), h2 = buf(q0, "loc.h2", {G * N, K3}), h3 = buf(q0, "loc.h3", {G * N, 64}),
+            prm = buf(q0, "loc.params", {G * N, d.P});
+        Val ga1 = buf(q0, "loc.ga1", {G * N, 16, S_, S_}, NHWC), ga2 = buf(q0, "loc.ga2", {G * N, 16, S_, S_}, NHWC), g3 = buf(q0, "loc.g3", {G * N, 64}),
+            g4 = buf(q0, "loc.g4", {G * N, d.P}), gx = buf(q0, "loc.gx", {G * N, Cin, 2 * S_, 2 * S_}, NHWC);
+        Net* n_ = net; vector<Mod*> qv = qs; const LocDesc dd = d;
+        emit([=](Run& c) {
+            const float* w[32];
+            loc_weights(qv, n_, w);
+            return k->locnet_backward(c.CS(), G, (int)N, w, dd.S, dd.Cin, dd.P, dd.ur, dd.us, dd.ut, dd.slope, dd.Hg, dd.Wg, c.P(h1), c.P(m2), c.P(h3), c.P(prm),
+                                      c.P(GG), c.P(ga1), c.P(ga2), c.P(g3), c.P(g4), c.P(gx));
+        });
+        if (acc) {
+            // weight gradients of the four layers on the GEMM path (grouped over the sibling branches), reductions deferred
+            struct W { int li; Val x, dy; Geo g; };
+            const W ws_[4] = {
+                {1, pooled, ga1, Geo{(int)N, (int)S_, (int)S_, (int)Cin, 16, 3, 3, 1, 1, 0}},
+                {3, h1, ga2, Geo{(int)N, (int)S_, (int)S_, 16, 16, 3, 3, 1, 1, 0}},
+                {7, h2, g3, Geo{(int)N, 1, 1, (int)K3, 64, 1, 1, 0, 0, 0}},
+                {9, h3, g4, Geo{(int)N, 1, 1, 64, d.P, 1, 1, 0, 0, 0}}};
+            for (int wi = 0; wi < 4; ++wi) {
+                const W wv = ws_[wi];
+                const bool defer = net->defer_wgrad;
+                const size_t need = std::max<size_t>(cg_conv2d_wgrad_workspace_bytes_grouped(G, GEO(wv.g)), 4096);
+                void* wsp = nullptr; size_t wsb = 0;
+                if (defer) {
+                    if (!dry && s0.loc_ws_bytes[wi] < need) { s0.loc_ws[wi] = alloc(need); s0.loc_ws_bytes[wi] = need; }
+                    wsp = s0.loc_ws[wi]; wsb = s0.loc_ws_bytes[wi];
+                    if (!dry) pend[cs]++;
+                } else ws_need(need);
+                const size_t xs = (size_t)wv.x.phys() / G * 4, ds = (size_t)wv.dy.phys() / G * 4;
+                emit([=](Run& c) {
+                    const float *x[4], *d_[4]; float *gw[4], *gb[4];
+                    for (int b = 0; b < G; ++b) {
+                        const Mod& L = *n_->mods[qv[b]->kids[0]];
+                        const Mod* lay = n_->mods[L.kids[wv.li]].get();
+                        x[b] = (const float*)((const char*)c.P(wv.x) + b * xs); d_[b] = (const float*)((const char*)c.P(wv.dy) + b * ds);
+                        gw[b] = lay->gw; gb[b] = lay->gb;
+                    }
+                    if (defer) return k->conv2d_wgrad_grouped_deferred(c.CS(), G, x, d_, gw, gb, GEO(wv.g), c.scale, wsp, wsb);
+                    return k->conv2d_wgrad_grouped(c.CS(), G, x, d_, gw, gb, GEO(wv.g), c.scale, c.W(), c.WB());
+                });
+            }
+        }
+        vector<Val> outs = G == 1 ? vector<Val>{gx} : split(gx, G);
+        for (int b = 0; b < G; ++b) S(*qs[b]).gin = outs[b];
+        return outs;
+    }
+
     // ---------------------------------------------------------------------------------------- nn.Concat(2)
     std::string signature(const Mod& m) {   // two modules with equal signatures run the same launches with the same geometry
         std::string s = "(" + std::to_string(m.kind);
@@ -1459,7 +1595,9 @@ struct Compiler {
         MS& s = S(m);
         Mod* mp = &m;
         switch (m.kind) {
-        case K_SEQ: return walk_back(m, in, go, acc, false);
+        case K_SEQ:
+            if (s.loc_fused && s.locG == 1) return bwd_loc({&m}, {go}, acc)[0];
+            return walk_back(m, in, go, acc, false);
         case K_CONCAT: return bwd_concat(m, in, go, acc);
         case K_CONCATTABLE: {
             vector<Val> gs;
@@ -1732,7 +1870,9 @@ struct Compiler {
         const KTable* k = K();
         const int G = (int)mods.size();
         switch (m0.kind) {
-        case K_SEQ: return gbwd_seq(mods, ins, gouts, acc, ctx);
+        case K_SEQ:
+            if (S(m0).loc_fused && S(m0).locG == G) return bwd_loc(mods, gouts, acc);
+            return gbwd_seq(mods, ins, gouts, acc, ctx);
         case K_CONCATTABLE: {
             const size_t nch = m0.kids.size();
             vector<vector<Val>> per_child;
@@ -2081,7 +2221,7 @@ std::string prog_key(Net* n, int nd, const long* dims, int fmt) {
     k += "|w" + std::to_string(n->world) + (n->sync_bn ? "s" : "-") + (n->bucket_overlap ? "b" : "-");
     k += "|o" + std::to_string(n->overlap_groups) + std::to_string(n->defer_wgrad) + std::to_string(n->winograd) + std::to_string(n->fusion) +
          std::to_string(n->stacking) + std::to_string(n->grouped) + std::to_string(n->share_pool) + std::to_string(n->sampler_shared) +
-         std::to_string(n->view_fuse) + std::to_string(n->cat_fuse) + "m" + std::to_string(n->wino_min_tiles);
+         std::to_string(n->view_fuse) + std::to_string(n->cat_fuse) + std::to_string(n->fuse_locnet) + "m" + std::to_string(n->wino_min_tiles);
     return k;
 }
 
@@ -2101,6 +2241,7 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_VIEW_FUSE"))) n->view_fuse = atoi(e) != 0;
     if ((e = getenv("CG_CAT_FUSE"))) n->cat_fuse = atoi(e) != 0;
     if ((e = getenv("CG_FUSION"))) n->fusion = atoi(e) != 0;
+    if ((e = getenv("CG_FUSE_LOCNET"))) n->fuse_locnet = atoi(e) != 0;
     *net = n;
     return 0;
 }
@@ -2122,7 +2263,7 @@ int cg_net_set_option(void* net, const char* name, long value) {
     struct { const char* nm; int* p; } tab[] = {
         {"overlap_groups", &n->overlap_groups}, {"defer_wgrad", &n->defer_wgrad}, {"winograd", &n->winograd}, {"share_pool", &n->share_pool},
         {"sampler_shared", &n->sampler_shared}, {"view_fuse", &n->view_fuse}, {"cat_fuse", &n->cat_fuse}, {"stacking", &n->stacking},
-        {"grouped", &n->grouped}, {"fusion", &n->fusion}};
+        {"grouped", &n->grouped}, {"fusion", &n->fusion}, {"fuse_locnet", &n->fuse_locnet}};
     if (!strcmp(name, "trace")) {
         CG_REQUIRE(n->progs.empty(), "cg_net_set_option: trace must be chosen before the first pass");
         n->trace = value != 0; n->K = n->trace ? &kTraceTable : &kRealTable;

@@ -406,6 +406,31 @@ int cg_bilinear_sampler_forward_shared(void* stream, int ngroups, const float* i
 int cg_bilinear_sampler_backward_shared(void* stream, int ngroups, const float* img, const float* grid, const float* gout,
                                         float* gimg, float* ggrid, int N, int Hi, int Wi, int C, int Ho, int Wo);
 
+/* ---- the localisation network of a spatial transformer in one launch each way (csrc/locnet.hip) ----------------------
+ * models.lua:842-860: AvgPool(2) -> conv3x3 Cin->16 -> LeakyReLU -> conv3x3 16->16 -> LeakyReLU -> AvgPool(2) -> View ->
+ * Linear(16 (S/2)^2 -> 64) -> LeakyReLU -> Linear(64 -> P), then models.lua:877-878: AffineTransformMatrixGenerator ->
+ * AffineGridGeneratorBHWD.  One workgroup per sample keeps the chain's activations in LDS; per element the arithmetic is that of
+ * the separate entry points up to fp32 re-association of the convolution / linear sums.  S = spatial size after the first
+ * pooling (the transformer's input is [.., 2S, 2S, Cin] NHWC), a power of two >= 8; cg_locnet_supported() == 0: use the modules.
+ * `ngroups` (<= 4) networks of identical shape run in one launch, group g on samples [g*n, (g+1)*n) (x_shared != 0: every group
+ * reads the SAME n input samples - D32_st3's three branches all look at the trunk's output, models.lua:653-678).
+ * weights: host array of 8 device pointers per group, canonical Torch7 layouts: conv1 weight [16][Cin][3][3], conv1 bias,
+ * conv2 weight [16][16][3][3], conv2 bias, linear1 weight [64][16 (S/2)^2] (input index in (c, y, x) order, as nn.View leaves it),
+ * linear1 bias, linear2 weight [P][64], linear2 bias.
+ * forward outputs: grid [G n][Hg][Wg][2] (what cg_affine_grid_forward writes) and the activations the backward and the weight
+ * gradients need: pooled [G n][S][S][Cin], h1 = LeakyReLU(conv1) [G n][S][S][16], m2 = LeakyReLU(conv2) [G n][S][S][16],
+ * h2 = its 2x2 average in (c, y, x) order [G n][16 (S/2)^2], h3 = LeakyReLU(linear1) [G n][64], params [G n][P].
+ * backward: ggrid -> gx [G n][2S][2S][Cin] (gradient w.r.t. the transformer's input through the localisation branch) and the
+ * gradients w.r.t. the pre-activations: g4 [G n][P], g3 [G n][64], ga2 / ga1 [G n][S][S][16] - the weight gradients are
+ * cg_conv2d_wgrad(pooled, ga1), (h1, ga2), (h2, g3) and (h3, g4) with the layers' geometries. */
+int cg_locnet_supported(int S, int Cin, int P);
+int cg_locnet_forward(void* stream, int ngroups, int n_per_group, const float* x, int x_shared, const float* const* weights, int S, int Cin,
+                      int P, int use_rot, int use_scale, int use_trans, float slope, int Hg, int Wg, float* pooled, float* h1, float* m2,
+                      float* h2, float* h3, float* params, float* grid);
+int cg_locnet_backward(void* stream, int ngroups, int n_per_group, const float* const* weights, int S, int Cin, int P, int use_rot,
+                       int use_scale, int use_trans, float slope, int Hg, int Wg, const float* h1, const float* m2, const float* h3,
+                       const float* params, const float* ggrid, float* ga1, float* ga2, float* g3, float* g4, float* gx);
+
 /* ---- collectives of the data-parallel step (csrc/comm.hip; RCCL over xGMI) ---------------------------------
  * The reference is single-GPU (train.lua:108-112).  The step shards on the batch: one process per GPU,
  * parameters replicated, and two exchanges per update:
@@ -460,7 +485,7 @@ int cg_comm_sync(void* comm);
  * cg_net_params_changed: the parameters moved (optimiser step, checkpoint load): re-pack before the next pass.
  * cg_net_set_training: module:training() / :evaluate() (utils/nn_utils.lua:334-349); id -1 = every module.
  * cg_net_set_option: "overlap_groups", "defer_wgrad", "winograd", "winograd_min_tiles", "share_pool", "sampler_shared",
- *   "view_fuse", "cat_fuse", "stacking", "grouped", "fusion" (0/1: ablation switches, results unchanged up to fp32
+ *   "view_fuse", "cat_fuse", "stacking", "grouped", "fusion", "fuse_locnet" (0/1: ablation switches, results unchanged up to fp32
  *   re-association); "trace" 1 (before the first pass): launches go to recording stubs instead of the GPU, cg_net_trace_take
  *   returns the text (one `call|<entry point>|<args>` line per launch; pointers as r<region>+<offset>, regions = the plan's
  *   allocations in order plus what cg_net_trace_region registered) - how the planner is tested without a GPU.

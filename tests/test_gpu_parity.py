@@ -226,26 +226,37 @@ def test_dropout_masks_share_the_counter_stream(cg):
     close(P.forward(cg.Tensor.from_numpy(x)).numpy(), Oc.forward(x), tol=1e-7)
 
 
-def test_spatial_transformer_module(cg):
-    """createSpatialTransformer (models.lua:814-906) end to end, with a non-identity classifier."""
+@pytest.mark.parametrize("size,ch,rot,scale,trans", [(16, 8, True, True, True), (32, 3, True, False, False), (16, 64, True, True, True),
+                                                      (64, 3, True, False, False), (32, 64, True, True, True)])
+def test_spatial_transformer_module(cg, size, ch, rot, scale, trans):
+    """createSpatialTransformer (models.lua:814-906) end to end, with a non-identity classifier, at the shapes D32_st3 uses at
+    32x32 and 64x64 (first transformer: C planes at full size, rotation only; branch transformers: 64 planes at half size).  The
+    planned pass runs the localisation branch as cg_locnet_forward / _backward (csrc/locnet.hip) and its weight gradients on the
+    GEMM path; CG_FUSE_LOCNET=0 / the per-module walk run the ten modules."""
     cg.manual_seed(5); rng = O.RNG(5)
-    P = cg.models.createSpatialTransformer(True, True, True, 16, 8, False)
-    Oc = O.SpatialTransformer(True, True, True, 16, 8, rng)
+    P = cg.models.createSpatialTransformer(rot, scale, trans, size, ch, False)
+    Oc = O.SpatialTransformer(rot, scale, trans, size, ch, rng)
     rs = np.random.RandomState(4)
-    wcls = (rs.randn(4, 64) * 0.05).astype(f32)
+    nP = int(rot) + int(scale) + 2 * int(trans)
+    wcls = (rs.randn(nP, 64) * 0.05).astype(f32)
     P.modules[0].modules[1].modules[0].modules[-1].weight.copy(wcls)
     Oc.loc.mods[-1].weight[...] = wcls
     for (pp, _), po in zip(Oc.parameters(), P.parameters()[0]):
         np.testing.assert_array_equal(pp, po.numpy())
-    x = rs.rand(5, 8, 16, 16).astype(f32); dy = rs.randn(5, 8, 16, 16).astype(f32)
+    x = rs.rand(5, ch, size, size).astype(f32); dy = rs.randn(5, ch, size, size).astype(f32)
     xin = cg.Tensor.from_numpy(x)
     close(P.forward(xin).numpy(), Oc.forward(x), tol=3e-5, what="st fwd")
+    assert P._planned_last
+    names = {type(m).__name__ for m in P.listModules()}
+    assert "AffineGridGeneratorBHWD" in names
     P.zeroGradParameters()
     gi = P.backward(xin, cg.Tensor.from_numpy(dy)).numpy()
     go = Oc.backward(dy)
     close(gi, go, K=4096, tol=5e-5, what="st gradInput")
     for (_, go_), gp in zip(Oc.parameters(), P.parameters()[1]):
         bulk_close(gp.numpy(), go_, max_rel=2e-3, mean_rel=2e-4, what="st param grad")
+    if (size, ch) != (16, 8):
+        return
     # identity initialisation reproduces the input exactly (models.lua:859-860)
     P2 = cg.models.createSpatialTransformer(True, False, False, 32, 3, False)
     x2 = rs.rand(2, 3, 32, 32).astype(f32)
@@ -824,7 +835,7 @@ def test_plan_options_are_result_neutral(cg, which):
     import ctypes
     res = {}
     for name, opts in (("default", {}), ("immediate", {"defer_wgrad": 0}), ("one stream", {"overlap_groups": 0}),
-                       ("unshared", {"share_pool": 0, "sampler_shared": 0})):
+                       ("unshared", {"share_pool": 0, "sampler_shared": 0}), ("separate localisation modules", {"fuse_locnet": 0})):
         P, _, _ = _pair(cg, 31, which)
         pP, gP = P.getParameters()
         rs = np.random.RandomState(9)
@@ -849,6 +860,8 @@ def test_plan_options_are_result_neutral(cg, which):
         assert np.abs(res[name]).max() > 0
     for name in ("immediate", "one stream", "unshared"):
         np.testing.assert_array_equal(res[name], res["default"], err_msg=name)
+    # the fused localisation launches (csrc/locnet.hip) sum their convolutions in another order than the GEMM kernels: fp32 re-association
+    bulk_close(res["separate localisation modules"], res["default"], max_rel=2e-4, mean_rel=2e-6, what=f"{which} fused vs separate localisation nets")
 
 
 def test_collectives_through_the_c_abi_single_rank(cg):

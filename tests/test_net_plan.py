@@ -38,18 +38,22 @@ def test_segments_and_lockstep_branches_of_the_discriminator():
     r = T.trace("D32_st3", 128)
     f = r["forward"]
     names = [c[0] for c in T.calls(f)]
-    # three identical transformer branches: their localisation nets pool the trunk's output ONCE, convolutions run grouped
-    # (ngroups 3) with the activation in the epilogue, one shared-image sampler launch, one stacked launch per parameter-free layer
+    # the localisation branches (models.lua:842-860 + :877-878) run as ONE launch each: the first transformer's, and the three branch
+    # transformers' together (ngroups 3 on the shared trunk output)
+    loc = T.calls(f, "cg_locnet_forward")
+    assert [(a["ngroups"], a["x_shared"], a["S"], a["Cin"], a["P"]) for _, a in loc] == [("i:1", "i:1", "i:16", "i:3", "i:1"),
+                                                                                       ("i:3", "i:1", "i:8", "i:64", "i:4")]
+    assert not [n for n in names if n.startswith(("cg_affine_", "cg_avgpool2", "cg_leakyrelu"))]
+    # three identical transformer branches: one shared-image sampler launch, convolutions grouped (ngroups 3), pooling stacked
     ex = T.calls(f, "cg_conv2d_forward_ex")
-    assert sum(1 for _, a in ex if a["ngroups"] == "i:3") == 3      # loc conv1+LeakyReLU, loc View+Linear+LeakyReLU, branch conv2+PReLU
+    assert sum(1 for _, a in ex if a["ngroups"] == "i:3") == 1          # branch conv2 + PReLU
     grouped = T.calls(f, "cg_conv2d_forward_grouped")
-    assert len(grouped) == 3 and all(a["ngroups"] == "i:3" for _, a in grouped)       # loc conv2, loc classifier, branch conv1
+    assert len(grouped) == 1 and all(a["ngroups"] == "i:3" for _, a in grouped)       # branch conv1 (PReLU goes with the pooling)
     assert len(T.calls(f, "cg_bilinear_sampler_forward_shared")) == 1 and len(T.calls(f, "cg_bilinear_sampler_forward")) == 1
-    assert names.count("cg_avgpool2_forward") == 2       # ST0's localisation net + ONE shared by the three branch nets
     pools = T.calls(f, "cg_act_pool2_mask_forward")
-    assert sorted(a["ngroups"] for _, a in pools) == ["i:1", "i:1", "i:1", "i:3", "i:3"]
+    assert sorted(a["ngroups"] for _, a in pools) == ["i:1", "i:1", "i:3"]
     assert names.count("cg_concat_channels") == 1 and "cg_copy_channels" not in names
-    # nn.View -> nn.Linear on the NHWC map: no layout pass in front of the 20480 -> 256 layer or the localisation nets' linears
+    # nn.View -> nn.Linear on the NHWC map: no layout pass in front of the 20480 -> 256 layer
     assert "cg_nhwc_to_nchw" not in names
     # side stream: the two-convolution branch runs on s1 between fork and join
     s1 = [c for c in T.calls(f) if c[1]["stream"] == "s1"]
@@ -64,10 +68,19 @@ def test_segments_and_lockstep_branches_of_the_discriminator():
     assert b[-1].startswith("call|cg_conv2d_wgrad_flush|s0")
     assert len(T.calls(b, "cg_bilinear_sampler_backward_shared")) == 1
     assert len(T.calls(b, "cg_prelu_backward_grouped")) == 1      # the PReLUs behind the branches' second convolutions (the first ones are inside act_pool)
+    lb = T.calls(b, "cg_locnet_backward")
+    assert [a["ngroups"] for _, a in lb] == ["i:3", "i:1"]
+    # each localisation backward is followed by the four weight gradients of its layers (conv1, conv2, linear1, linear2)
+    for i, l in enumerate(b):
+        if "cg_locnet_backward" in l:
+            assert all("cg_conv2d_wgrad_grouped_deferred" in x for x in b[i + 1:i + 5])
     # updateGradInput only (fevalG_on_D's pass through D, adversarial.lua:192-193): no weight gradient of any kind
     u = r["updateGradInput"]
     assert not [c for c in T.calls(u) if "wgrad" in c[0]]
-    assert r["stats"]["launches_forward"] < 45 and r["stats"]["launches_backward"] < 70
+    assert r["stats"]["launches_forward"] <= 28 and r["stats"]["launches_backward"] <= 48
+    # the same network with the localisation nets as separate modules (cg_net_set_option fuse_locnet 0): ~1.5x the launches
+    r0 = T.trace("D32_st3", 128, options=[("fuse_locnet", 0)])
+    assert r0["stats"]["launches_forward"] >= 40 and not T.calls(r0["forward"], "cg_locnet_forward")
 
 
 def test_generator_plan_uses_epilogue_statistics_and_winograd_at_the_benchmarked_batch():
