@@ -815,7 +815,7 @@ struct Compiler {
         case K_SEQ: {
             // sibling localisation branches on the SAME input (D32_st3's three transformers): one fused launch for the group
             LocDesc ld;
-            bool same = G <= 4 && match_loc(m0, ins[0], ld);
+            bool same = G <= 4 && net->fuse_locnet != 2 && match_loc(m0, ins[0], ld);
             for (int b = 1; same && b < G; ++b) {
                 LocDesc lb;
                 same = ins[b].key() == ins[0].key() && ins[b].same_shape(ins[0]) && match_loc(*mods[b], ins[b], lb) && lb.S == ld.S && lb.Cin == ld.Cin &&
@@ -1236,12 +1236,12 @@ struct Compiler {
         if (d.P != d.ur + d.us + 2 * d.ut) return false;
         return cg_locnet_supported(d.S, d.Cin, d.P) != 0;
     }
-    static void loc_weights(const vector<Mod*>& qs, Net* n, const float* w[32]) {
+    static void loc_weights(const vector<Mod*>& qs, Net* n, const float* w[48]) {
         for (size_t b = 0; b < qs.size(); ++b) {
             const Mod& L = *n->mods[qs[b]->kids[0]];
             const Mod *c1 = n->mods[L.kids[1]].get(), *c2 = n->mods[L.kids[3]].get(), *l1 = n->mods[L.kids[7]].get(), *l2 = n->mods[L.kids[9]].get();
-            const float* v[8] = {c1->w, c1->b, c2->w, c2->b, l1->w, l1->b, l2->w, l2->b};
-            for (int k = 0; k < 8; ++k) w[8 * b + k] = v[k];
+            const float* v[12] = {c1->w, c1->b, c2->w, c2->b, l1->w, l1->b, l2->w, l2->b, c1->wf, c1->wb, c2->wf, c2->wb};
+            for (int k = 0; k < 12; ++k) w[12 * b + k] = v[k];
         }
     }
     vector<Val> fwd_loc(const vector<Mod*>& qs, const Val& in, const LocDesc& d) {
@@ -1252,9 +1252,13 @@ struct Compiler {
         Val pooled = buf(q0, "loc.pooled", {G * N, Cin, S_, S_}, NHWC), h1 = buf(q0, "loc.h1", {G * N, 16, S_, S_}, NHWC),
             m2 = buf(q0, "loc.m2", {G * N, 16, S_, S_}, NHWC), h2 = buf(q0, "loc.h2", {G * N, K3}), h3 = buf(q0, "loc.h3", {G * N, 64}),
             prm = buf(q0, "loc.params", {G * N, d.P}), grid = buf(q0, "loc.grid", {G * N, d.Hg, d.Wg, 2});
+        for (Mod* q : qs) {   // the two convolutions' packed copies (refreshed with every other layer's after a parameter update)
+            const Mod& L = M(q->kids[0]);
+            need_plain(M(L.kids[1]), false); need_plain(M(L.kids[3]), false);
+        }
         Net* n_ = net; vector<Mod*> qv = qs; const LocDesc dd = d; Val x = in;
         emit([=](Run& c) {
-            const float* w[32];
+            const float* w[48];
             loc_weights(qv, n_, w);
             return k->locnet_forward(c.CS(), G, (int)N, c.P(x), 1, w, dd.S, dd.Cin, dd.P, dd.ur, dd.us, dd.ut, dd.slope, dd.Hg, dd.Wg, c.P(pooled), c.P(h1),
                                      c.P(m2), c.P(h2), c.P(h3), c.P(prm), c.P(grid));
@@ -1287,7 +1291,7 @@ struct Compiler {
             g4 = buf(q0, "loc.g4", {G * N, d.P}), gx = buf(q0, "loc.gx", {G * N, Cin, 2 * S_, 2 * S_}, NHWC);
         Net* n_ = net; vector<Mod*> qv = qs; const LocDesc dd = d;
         emit([=](Run& c) {
-            const float* w[32];
+            const float* w[48];
             loc_weights(qv, n_, w);
             return k->locnet_backward(c.CS(), G, (int)N, w, dd.S, dd.Cin, dd.P, dd.ur, dd.us, dd.ut, dd.slope, dd.Hg, dd.Wg, c.P(h1), c.P(m2), c.P(h3), c.P(prm),
                                       c.P(GG), c.P(ga1), c.P(ga2), c.P(g3), c.P(g4), c.P(gx));
@@ -2241,7 +2245,7 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_VIEW_FUSE"))) n->view_fuse = atoi(e) != 0;
     if ((e = getenv("CG_CAT_FUSE"))) n->cat_fuse = atoi(e) != 0;
     if ((e = getenv("CG_FUSION"))) n->fusion = atoi(e) != 0;
-    if ((e = getenv("CG_FUSE_LOCNET"))) n->fuse_locnet = atoi(e) != 0;
+    if ((e = getenv("CG_FUSE_LOCNET"))) n->fuse_locnet = atoi(e);
     *net = n;
     return 0;
 }
@@ -2270,6 +2274,7 @@ int cg_net_set_option(void* net, const char* name, long value) {
         return 0;
     }
     if (!strcmp(name, "winograd_min_tiles")) { n->wino_min_tiles = value; return 0; }
+    if (!strcmp(name, "fuse_locnet")) { n->fuse_locnet = (int)value; return 0; }   // 0 off, 1 every localisation branch, 2 ungrouped ones only
     for (auto& t : tab) if (!strcmp(name, t.nm)) { *t.p = value != 0; return 0; }
     return cg::fail("cg_net_set_option: unknown option %s", name);
 }

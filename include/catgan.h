@@ -414,9 +414,9 @@ int cg_bilinear_sampler_backward_shared(void* stream, int ngroups, const float* 
  * pooling (the transformer's input is [.., 2S, 2S, Cin] NHWC), a power of two >= 8; cg_locnet_supported() == 0: use the modules.
  * `ngroups` (<= 4) networks of identical shape run in one launch, group g on samples [g*n, (g+1)*n) (x_shared != 0: every group
  * reads the SAME n input samples - D32_st3's three branches all look at the trunk's output, models.lua:653-678).
- * weights: host array of 8 device pointers per group, canonical Torch7 layouts: conv1 weight [16][Cin][3][3], conv1 bias,
+ * weights: host array of 12 device pointers per group: canonical Torch7 tensors conv1 weight [16][Cin][3][3], conv1 bias,
  * conv2 weight [16][16][3][3], conv2 bias, linear1 weight [64][16 (S/2)^2] (input index in (c, y, x) order, as nn.View leaves it),
- * linear1 bias, linear2 weight [P][64], linear2 bias.
+ * linear1 bias, linear2 weight [P][64], linear2 bias, then cg_pack_conv_weight's copies wf, wb of conv1 and wf, wb of conv2.
  * forward outputs: grid [G n][Hg][Wg][2] (what cg_affine_grid_forward writes) and the activations the backward and the weight
  * gradients need: pooled [G n][S][S][Cin], h1 = LeakyReLU(conv1) [G n][S][S][16], m2 = LeakyReLU(conv2) [G n][S][S][16],
  * h2 = its 2x2 average in (c, y, x) order [G n][16 (S/2)^2], h3 = LeakyReLU(linear1) [G n][64], params [G n][P].
