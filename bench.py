@@ -284,7 +284,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"] + ", one adversarial.lua D+G update (Adam, D_L2=1e-4, clamps 1/5)",
                        "global_batch": N * world, "parallelism": f"dp{world}", "launch": launch, "executor": "cg_net_* (planned below the C ABI)" if cg.nn.planned else "per-module walk",
-                       "collectives": cg.parallel.comm_backend() if world > 1 else None,
+                       "collectives": cg.parallel.comm_info() if world > 1 else None,
                        "ms_per_sample_reference_unit": 1e3 * dt / args.steps / (N * world / 2)},
             "parity": "oracle unpinned by the reference (it holds no vectors); pinned against PyTorch-CPU autograd at operator and "
                       "whole-step level (tests/test_oracle_vs_torch.py)",

@@ -35,6 +35,7 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     bool tried = false;
 };
 Rccl g_rccl;
@@ -64,6 +65,7 @@ bool load_rccl() {
     CG_SYM(Broadcast, "ncclBroadcast")
     CG_SYM(GetErrorString, "ncclGetErrorString")
 #undef CG_SYM
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.h, "ncclGetVersion"));   // optional
     return true;
 }
 
@@ -150,6 +152,13 @@ int cg_comm_destroy(void* comm) {
     if (c->join) (void)hipEventDestroy(c->join);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
+    return 0;
+}
+
+int cg_comm_version(int* version) {
+    CG_REQUIRE(version, "cg_comm_version: null pointer");
+    *version = 0;
+    if (load_rccl() && g_rccl.GetVersion) (void)g_rccl.GetVersion(version);
     return 0;
 }
 

@@ -210,6 +210,7 @@ struct Net {
     alloc_fn_t alloc_fn = nullptr; void* alloc_user = nullptr;
     hook_fn_t hook = nullptr; void* hook_user = nullptr;
     void *comm_bn = nullptr, *comm_grad = nullptr; int world = 1; int sync_bn = 1; int bucket_overlap = 0;
+    int hook_too = 0;                          // communicator collective AND host hook (cg_net_set_dp bucket_overlap & 2)
     vector<void*> owned;
     vector<Region> regions;
     bool params_dirty = true;
@@ -2101,7 +2102,8 @@ void Compiler::emit_allreduce_sum(const Val& v, long count, int dtype) {
         if (n->trace) { trace_note(n, "hook|allreduce_sum|" + TraceLine::pname(p) + "|" + std::to_string(count)); return 0; }
         if (n->comm_bn) {   // RCCL on the sync-BN communicator's stream, joined back into the compute stream (no host sync)
             if (cg_comm_allreduce(n->comm_bn, c.CS(), p, (size_t)count, dtype, 0)) return 1;
-            return cg_comm_wait(n->comm_bn, c.CS());
+            if (cg_comm_wait(n->comm_bn, c.CS())) return 1;
+            if (!(n->hook_too && n->hook)) return 0;
         }
         if (n->hook) return n->hook(n->hook_user, HOOK_ALLREDUCE_SUM, p, (size_t)count, dtype, c.CS());
         return cg::fail("cg_net: world > 1 with sync-BN but neither a communicator (cg_net_set_dp) nor a host hook is set");
@@ -2120,7 +2122,11 @@ void Compiler::bucket_done(int first_module) {
             emit([=](Run& c) -> int {
                 Net* n = c.net;
                 if (n->trace) { trace_note(n, "hook|bucket_start|" + TraceLine::pname(ptr) + "|" + std::to_string(cnt)); return 0; }
-                if (n->comm_grad) return cg_comm_allreduce(n->comm_grad, c.CS(), ptr, (size_t)cnt, 0, 1);
+                if (n->comm_grad) {
+                    if (cg_comm_allreduce(n->comm_grad, c.CS(), ptr, (size_t)cnt, 0, 1)) return 1;
+                    if (!(n->hook_too && n->hook)) return 0;
+                    if (cg_comm_wait(n->comm_grad, c.CS())) return 1;   // the hook's transport reads what the collective wrote
+                }
                 if (n->hook) return n->hook(n->hook_user, HOOK_BUCKET_START, ptr, (size_t)cnt, 0, c.CS());
                 return cg::fail("cg_net: bucketed all-reduce without a communicator or host hook");
             });
@@ -2296,7 +2302,8 @@ int cg_net_set_hook(void* net, cg_hook_fn hook, void* user) {
 int cg_net_set_dp(void* net, int world, int sync_bn, void* comm_bn, void* comm_grad, int bucket_overlap) {
     Net* n = NET(net);
     CG_REQUIRE(n && world >= 1, "cg_net_set_dp: bad arguments");
-    n->world = world; n->sync_bn = sync_bn != 0; n->comm_bn = comm_bn; n->comm_grad = comm_grad; n->bucket_overlap = bucket_overlap != 0;
+    n->world = world; n->sync_bn = sync_bn != 0; n->comm_bn = comm_bn; n->comm_grad = comm_grad; n->bucket_overlap = (bucket_overlap & 1) != 0;
+    n->hook_too = (bucket_overlap & 2) != 0;
     return 0;
 }
 

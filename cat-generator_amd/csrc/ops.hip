@@ -89,6 +89,90 @@ __global__ void images_u8_to_f32_k(const unsigned char* __restrict__ src, float*
     }
 }
 
+// image.load -> image.scale -> NN_UTILS.rgbToColorSpace (dataset.lua:123-131,166) on the device: 8-bit RGB as decoded, [N][Hs][Ws][3]
+// -> fp32 NHWC [N][Hd][Wd][C].  image.scale's default mode is the torch `image` rock's separable 'bilinear' [upstream, recalled:
+// generic/image.c scaleLinear_rowcol]: first every row to the target width, then every column to the target height, each pass in
+// fp32.  One axis, source length Ls, target length Ld, scale = (float)Ls / Ld (down) or (float)(Ls-1)/(Ld-1) (up):
+//   Ld <  Ls: box average with fractional ends - out[d] = (w0 s[i0] + s[i0+1] + ... + s[i1-1] + f1 s[i1]) / (w0 + ... + f1), where
+//             [i0 + (1-w0), i1 + f1) = [d scale, (d+1) scale) and the last term is dropped when i1 == Ls;
+//   Ld >  Ls: out[d] = (1-f) s[i] + f s[i+1] with i + f = d scale, the last sample copied;          Ld == Ls: a copy.
+// Every operation is a single correctly rounded fp32 one in the order of that loop (no fma), so the host loader's numpy restatement
+// and this kernel agree bit for bit.  One lane per output element.
+// s[k - base] holds source sample k for the few k this target sample touches
+__device__ __forceinline__ float scale_axis(const float* w, int base, int Ls, int Ld, int d) {
+#pragma clang fp contract(off)
+#define s(k) w[(k) - base]
+    if (Ld == Ls) return s(d);
+    if (Ld > Ls) {
+        if (d == Ld - 1 || Ls == 1) return s(Ls == 1 ? 0 : Ls - 1);
+        const float scale = __fdiv_rn((float)(Ls - 1), (float)(Ld - 1));
+        float sf = (float)d * scale;
+        const int si = (int)sf;
+        sf -= (float)si;
+        const float a = (1.f - sf) * s(si), b = sf * s(si + 1);
+        return a + b;
+    }
+    const float scale = __fdiv_rn((float)Ls, (float)Ld);
+    float f0 = (float)d * scale;
+    int i0 = (int)f0;
+    f0 -= (float)i0;
+    if (d == 0) { i0 = 0; f0 = 0.f; }
+    float f1 = (float)(d + 1) * scale;
+    const int i1 = (int)f1;
+    f1 -= (float)i1;
+    float acc = (1.f - f0) * s(i0), n = 1.f - f0;
+    for (int si = i0 + 1; si < i1; ++si) { acc += s(si); n += 1.f; }
+    if (i1 < Ls) { const float t = f1 * s(i1); acc += t; n += f1; }
+    return __fdiv_rn(acc, n);
+#undef s
+}
+__global__ void images_u8_scale_k(const unsigned char* __restrict__ src, float* __restrict__ dst, int N, int Hs, int Ws, int Hd, int Wd, int cs) {
+#pragma clang fp contract(off)
+    const long total = (long)N * Hd * Wd;
+    GRID_STRIDE(i, total) {
+        const int ox = (int)(i % Wd), oy = (int)((i / Wd) % Hd);
+        const long n = i / ((long)Wd * Hd);
+        const unsigned char* im = src + n * (long)Hs * Ws * 3;
+        // vertical footprint of this output row (the second pass reads the first pass's fp32 rows)
+        int y0 = oy, y1 = oy;
+        if (Hd < Hs) {
+            const float scale = __fdiv_rn((float)Hs, (float)Hd);
+            y0 = oy == 0 ? 0 : (int)((float)oy * scale);
+            y1 = min(Hs - 1, (int)((float)(oy + 1) * scale));
+        } else if (Hd > Hs) {
+            const float scale = __fdiv_rn((float)(Hs - 1), (float)(Hd - 1));
+            y0 = (oy == Hd - 1 || Hs == 1) ? Hs - 1 : (int)((float)oy * scale);
+            y1 = min(Hs - 1, y0 + 1);
+        }
+        float rgb[3];
+        for (int c = 0; c < 3; ++c) {
+            float col[8];   // first pass at column ox for the source rows y0..y1 (<= 8 rows: down-scaling factors up to 6)
+            for (int y = y0; y <= y1 && y - y0 < 8; ++y) {
+                // horizontal footprint of ox in row y
+                int x0 = ox, x1 = ox;
+                if (Wd < Ws) {
+                    const float sc = __fdiv_rn((float)Ws, (float)Wd);
+                    x0 = ox == 0 ? 0 : (int)((float)ox * sc);
+                    x1 = min(Ws - 1, (int)((float)(ox + 1) * sc));
+                } else if (Wd > Ws) {
+                    const float sc = __fdiv_rn((float)(Ws - 1), (float)(Wd - 1));
+                    x0 = (ox == Wd - 1 || Ws == 1) ? Ws - 1 : (int)((float)ox * sc);
+                    x1 = min(Ws - 1, x0 + 1);
+                }
+                float row[8];
+                for (int x = x0; x <= x1 && x - x0 < 8; ++x) row[x - x0] = __fdiv_rn((float)im[((long)y * Ws + x) * 3 + c], 255.f);
+                col[y - y0] = scale_axis(row, x0, Ws, Wd, ox);
+            }
+            rgb[c] = scale_axis(col, y0, Hs, Hd, oy);
+        }
+        if (cs == 0) { dst[3 * i] = rgb[0]; dst[3 * i + 1] = rgb[1]; dst[3 * i + 2] = rgb[2]; }
+        else {
+            const float t0 = 0.21f * rgb[0], t1 = 0.72f * rgb[1], t2 = 0.07f * rgb[2];   // z = ((0 + .21 r) + .72 g) + .07 b (nn_utils.lua:268-270)
+            dst[i] = (t0 + t1) + t2;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- activations
 // Memory-bound elementwise kernels move 16 B per lane (float4) when the buffers are 16-B aligned; `n4` counts
 // whole float4s, the (<4)-element tail is handled by the last lanes with scalar accesses.
@@ -1164,6 +1248,13 @@ int cg_stream_wait_event(void* stream, void* event) {
 int cg_images_u8_to_f32(void* stream, const unsigned char* src, float* dst, long npixels, int colorspace) {
     CG_REQUIRE(src && dst && npixels > 0 && (colorspace == 0 || colorspace == 1), "cg_images_u8_to_f32: bad arguments");
     EW_LAUNCH(images_u8_to_f32_k, npixels, src, dst, npixels, colorspace); return 0;
+}
+
+int cg_images_u8_scale_to_f32(void* stream, const unsigned char* src, float* dst, int N, int Hs, int Ws, int Hd, int Wd, int colorspace) {
+    CG_REQUIRE(src && dst && N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && (colorspace == 0 || colorspace == 1), "cg_images_u8_scale_to_f32: bad arguments");
+    CG_REQUIRE(Hs <= 6 * Hd && Ws <= 6 * Wd, "cg_images_u8_scale_to_f32: down-scaling by more than 6 is not supported");
+    const long total = (long)N * Hd * Wd;
+    EW_LAUNCH(images_u8_scale_k, total, src, dst, N, Hs, Ws, Hd, Wd, colorspace); return 0;
 }
 
 int cg_prelu_forward(void* stream, const float* x, const float* alpha, float* y, long n) {

@@ -1,13 +1,17 @@
 """dataset.lua restated: list + sort the image files of the configured directories
-(dataset.lua:57-83), load `count` random ones (torch.randperm, :158-168), scale to width x height (image.scale,
-bilinear, :129-131) and convert the colour space (NN_UTILS.rgbToColorSpace, nn_utils.lua:223-278: 'rgb' or 'y' with
-weights 0.21/0.72/0.07).  Host-side input pipeline: decoding uses PIL; the result is a float array in [0,1] that
-adversarial.TrainData uploads to HBM once per epoch (the reference reloads N_epoch images per epoch, train.lua:225).
+(dataset.lua:57-83), load `count` random ones (torch.randperm, :158-168), image.load them as floats in [0,1] (:166), scale the
+FLOAT image to width x height (image.scale, :129-131) and convert the colour space (NN_UTILS.rgbToColorSpace,
+nn_utils.lua:223-278: 'rgb' or 'y' with weights 0.21/0.72/0.07).  PIL only decodes; the scaling is `image_scale` below - the `image`
+rock's default separable 'bilinear' [upstream, recalled: box averaging when shrinking, linear interpolation when enlarging] in fp32,
+the arithmetic cg_images_u8_scale_to_f32 performs on the device (oracle/oracle.py holds the independent restatement the tests
+compare both with).  The result is a float array in [0,1] that adversarial.TrainData uploads to HBM once per epoch (the reference
+reloads N_epoch images per epoch, train.lua:225).
 
 AsyncLoader is the production form of the same thing: the NEXT epoch's images are decoded by a worker
-thread straight into a page-locked buffer as 8-bit RGB (a quarter of the fp32 bytes over PCIe), copied on a copy stream
-while the current epoch trains, converted on the device (cg_images_u8_to_f32: /255, colour space) into the second of two
-HBM pools, and handed to the compute stream through an event - no host synchronisation on the training path."""
+thread straight into a page-locked buffer as 8-bit RGB at their own size (a quarter of the fp32 bytes over PCIe), copied on a copy
+stream while the current epoch trains, scaled and converted on the device (cg_images_u8_scale_to_f32: /255, image.scale, colour
+space) into the second of two HBM pools, and handed to the compute stream through an event - no host synchronisation on the
+training path."""
 import os
 import threading
 
@@ -122,9 +126,51 @@ def _prefetch_pick(count):
 
 
 def _decode(path):
-    """One file as 8-bit RGB [height, width, 3] (image.load + image.scale, dataset.lua:129-131)."""
+    """One file as 8-bit RGB [H, W, 3] at its own size (what image.load reads before it divides by 255)."""
     from PIL import Image
-    return np.asarray(Image.open(path).convert("RGB").resize((width, height), Image.BILINEAR), dtype=np.uint8)
+    return np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
+
+
+def _scale_axis(a, Ld):
+    """image.scale along the LAST axis of a float32 array [upstream, recalled: generic/image.c scaleLinear_rowcol]: every operation a
+    single fp32 one in the loop's order (the device kernel images_u8_scale_k does the same sequence)."""
+    f32 = np.float32
+    Ls = a.shape[-1]
+    if Ld == Ls:
+        return a.copy()
+    out = np.empty(a.shape[:-1] + (Ld,), f32)
+    if Ld > Ls:      # linear interpolation, corner aligned; the last sample is copied
+        scale = f32(Ls - 1) / f32(Ld - 1) if Ld > 1 else f32(0)
+        for d in range(Ld - 1):
+            sf = f32(d) * scale
+            si = int(sf)
+            sf = f32(sf - f32(si))
+            out[..., d] = a[..., 0] if Ls == 1 else (f32(1) - sf) * a[..., si] + sf * a[..., si + 1]
+        out[..., Ld - 1] = a[..., Ls - 1]
+        return out
+    scale = f32(Ls) / f32(Ld)      # box average, fractional ends weighted
+    i0, f0 = 0, f32(0)
+    for d in range(Ld):
+        f1 = f32(d + 1) * scale
+        i1 = int(f1)
+        f1 = f32(f1 - f32(i1))
+        acc = (f32(1) - f0) * a[..., i0]
+        n = f32(1) - f0
+        for si in range(i0 + 1, i1):
+            acc = acc + a[..., si]
+            n = f32(n + f32(1))
+        if i1 < Ls:
+            acc = acc + f1 * a[..., i1]
+            n = f32(n + f1)
+        out[..., d] = acc / n
+        i0, f0 = i1, f1
+    return out
+
+
+def image_scale(img, w, h):
+    """image.scale(img, w, h) for a float32 [C, H, W] image: rows to the target width first, then columns to the target height."""
+    t = _scale_axis(np.ascontiguousarray(img, dtype=np.float32), w)
+    return np.ascontiguousarray(_scale_axis(np.ascontiguousarray(t.transpose(0, 2, 1)), h).transpose(0, 2, 1))
 
 
 def loadRandomImages(count):
@@ -132,7 +178,8 @@ def loadRandomImages(count):
     files = _pick(count)
     data = np.empty((len(files), 3, height, width), np.float32)
     for i, f in enumerate(files):
-        data[i] = _decode(f).astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)
+        img = _decode(f).astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)      # image.load(path, 3, 'float')
+        data[i] = image_scale(img, width, height)
     return _Data(rgbToColorSpace(data, colorSpace))
 
 
@@ -148,7 +195,12 @@ class AsyncLoader:
         self._ct, self._T, self.L = ctypes, Tensor, lib()
         self.count, self.depth = int(count), int(depth)
         self.C = 1 if colorSpace == "y" else 3
-        self.nbytes = self.count * height * width * 3
+        if paths is None:
+            loadPaths()
+        if not paths:
+            raise FileNotFoundError(f"no *.{fileExtension} images under {dirs}")
+        self.Hs, self.Ws = _decode(paths[0]).shape[:2]      # the dataset is written at one size (generate_dataset.py: 64 x 64)
+        self.nbytes = self.count * self.Hs * self.Ws * 3
         self.copy_stream = ctypes.c_void_p()
         self.L.stream_create(ctypes.byref(self.copy_stream))
         self.slots = []
@@ -158,7 +210,7 @@ class AsyncLoader:
             self.L.malloc(ctypes.byref(dev_u8), self.nbytes)
             self.L.event_create(ctypes.byref(ev_ready)); self.L.event_create(ctypes.byref(ev_free))
             pool = Tensor.empty((self.count, self.C, height, width), "nhwc")
-            staging = np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_uint8)), shape=(self.count, height, width, 3))
+            staging = np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_uint8)), shape=(self.count, self.Hs, self.Ws, 3))
             self.slots.append(dict(host=host, staging=staging, dev_u8=dev_u8, ready=ev_ready, free=ev_free, pool=pool, n=0, used=False))
         self.k = 0
         self._thread = None
@@ -174,7 +226,10 @@ class AsyncLoader:
         def work():
             try:
                 for i, f in enumerate(files):
-                    slot["staging"][i] = _decode(f)
+                    im = _decode(f)
+                    if im.shape[:2] != (self.Hs, self.Ws):
+                        raise ValueError(f"{f}: {im.shape[1]}x{im.shape[0]} pixels, the dataset's other images have {self.Ws}x{self.Hs}")
+                    slot["staging"][i] = im
             except Exception as e:   # surfaced by next()
                 self._err = e
         self._thread = threading.Thread(target=work, daemon=True)
@@ -184,8 +239,8 @@ class AsyncLoader:
         L, cs, n = self.L, self.copy_stream, slot["n"]
         if slot["used"]:
             L.stream_wait_event(cs, slot["free"])      # the training stream has finished reading this pool
-        L.memcpy_h2d(cs, slot["dev_u8"], slot["host"], n * height * width * 3)
-        L.images_u8_to_f32(cs, slot["dev_u8"], slot["pool"].ptr, n * height * width, 1 if colorSpace == "y" else 0)
+        L.memcpy_h2d(cs, slot["dev_u8"], slot["host"], n * self.Hs * self.Ws * 3)
+        L.images_u8_scale_to_f32(cs, slot["dev_u8"], slot["pool"].ptr, n, self.Hs, self.Ws, height, width, 1 if colorSpace == "y" else 0)
         L.event_record(slot["ready"], cs)
 
     def next(self):

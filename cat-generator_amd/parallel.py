@@ -14,7 +14,7 @@ import warnings
 import torch
 import torch.distributed as dist
 
-_S = {"world": 1, "rank": 0, "init": False, "sync_bn": True, "comm_grad": None, "comm_bn": None}
+_S = {"world": 1, "rank": 0, "init": False, "sync_bn": True, "comm_grad": None, "comm_bn": None, "hybrid": False}
 
 
 def init_from_env(backend=None):
@@ -31,7 +31,9 @@ def init_from_env(backend=None):
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         _S["init"] = True
     _S["world"], _S["rank"] = world, rank
-    if world > 1 and torch.cuda.is_available() and os.environ.get("CG_COMM", "abi") != "torch":
+    if world > 1 and torch.cuda.is_available() and os.environ.get("CG_COMM") == "abi1":
+        _init_single_rank_comms()
+    elif world > 1 and torch.cuda.is_available() and os.environ.get("CG_COMM", "abi") != "torch":
         _init_abi_comms(world, rank)
     return rank, world
 
@@ -96,8 +98,27 @@ def _init_abi_comms(world, rank):
 
 
 def comm_backend():
-    """'abi' when device tensors travel through cg_comm_* (csrc/comm.hip), else 'torch'."""
+    """'abi' when device tensors travel through cg_comm_* (csrc/comm.hip), 'abi1+torch' in the hybrid test mode, else 'torch'."""
+    if _S["hybrid"]:
+        return "abi1+torch"
     return "abi" if _S["comm_grad"] is not None else "torch"
+
+
+def comm_info():
+    """What the bench line prints about the collectives: backend, communicator size as RCCL reports it, RCCL version."""
+    from .tensor import lib
+    out = {"backend": comm_backend(), "world": _S["world"]}
+    try:
+        v = ctypes.c_int(0)
+        lib().comm_version(ctypes.byref(v))
+        out["rccl_version"] = v.value
+        if _S["comm_grad"] is not None:
+            n, r = ctypes.c_int(-1), ctypes.c_int(-1)
+            lib().comm_size(_S["comm_grad"], ctypes.byref(n), ctypes.byref(r))
+            out["comm_nranks"], out["comm_rank"] = n.value, r.value
+    except Exception as e:
+        out["error"] = str(e)[:100]
+    return out
 
 
 def comm_handle(name):
@@ -105,9 +126,31 @@ def comm_handle(name):
     return _S.get(name)
 
 
+def hybrid():
+    """CG_COMM=abi1: single-rank cg_comm_* communicators per process (collectives degenerate to device copies) PLUS torch.distributed
+    for the cross-rank sum - the functional mode for boxes whose ranks share one GPU (RCCL refuses duplicate devices): the
+    communicators' fork / join events, the gradient buckets started inside cg_net_backward and the separate sync-BN communicator all
+    execute; results equal the torch-only transport."""
+    return _S["hybrid"]
+
+
+def _init_single_rank_comms():
+    from .tensor import lib
+    L = lib()
+    for name in ("comm_grad", "comm_bn"):
+        buf = ctypes.create_string_buffer(128)
+        L.comm_unique_id(buf, 128)
+        h = ctypes.c_void_p()
+        L.comm_init(ctypes.byref(h), 1, 0, buf.raw, 128)
+        _S[name] = h
+    _S["hybrid"] = True
+
+
 def attach(world, rank):
     """Use an already initialised process group (tests)."""
     _S["world"], _S["rank"] = world, rank
+    if world > 1 and torch.cuda.is_available() and os.environ.get("CG_COMM") == "abi1" and _S["comm_grad"] is None:
+        _init_single_rank_comms()
 
 
 def shutdown():
@@ -146,6 +189,8 @@ def allreduce_sum_(t):
             assert t.dtype in (torch.float64, torch.float32) and t.is_contiguous()
             lib().comm_allreduce(_S["comm_bn"], stream(), t.data_ptr(), t.numel(), 1 if t.dtype == torch.float64 else 0, 0)
             lib().comm_wait(_S["comm_bn"], stream())
+            if _S["hybrid"]:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
@@ -158,7 +203,8 @@ def allreduce_mean_(t):
             from .tensor import lib, stream
             lib().comm_allreduce(_S["comm_grad"], stream(), t.data_ptr(), t.numel(), 0, 1)
             lib().comm_wait(_S["comm_grad"], stream())
-            return t
+            if not _S["hybrid"]:
+                return t
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         if t.is_cuda:
             from .tensor import lib, stream
@@ -196,6 +242,9 @@ class _PendingAbi:
     def finish(self):
         from .tensor import lib, stream
         lib().comm_wait(_S["comm_grad"], stream())
+        if _S["hybrid"]:      # the cross-rank part of the hybrid test transport
+            dist.all_reduce(self.t, op=dist.ReduceOp.SUM)
+            lib().scale(stream(), self.t.data_ptr(), 1.0 / _S["world"], self.t.numel())
         return self.t
 
 
@@ -208,6 +257,19 @@ def allreduce_mean_async(t):
             assert t.dtype == torch.float32 and t.is_contiguous()
             lib().comm_allreduce(_S["comm_grad"], stream(), t.data_ptr(), t.numel(), 0, 1)
             return _PendingAbi(t)
+        return _Pending(t, dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+    return _Pending(t, None)
+
+
+def allreduce_sum_torch(t):
+    """The plan's host hook: SUM over ranks through torch.distributed only (the communicator part, if any, already ran in the plan)."""
+    if _S["world"] > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def allreduce_mean_async_torch(t):
+    if _S["world"] > 1:
         return _Pending(t, dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
     return _Pending(t, None)
 

@@ -151,10 +151,10 @@ class PlannedNet:
             t = self._view(buf, count, torch.float64 if dtype == 1 else torch.float32)
             if what == 0:
                 assert t is not None, "sync-BN sums live in the plan's own buffers"
-                parallel.allreduce_sum_(t)
+                parallel.allreduce_sum_torch(t)
             else:
                 g = self._grad_view(buf, count)
-                self.pending.append(parallel.allreduce_mean_async(g))
+                self.pending.append(parallel.allreduce_mean_async_torch(g))
             return 0
         except Exception as e:   # no exception may cross the C ABI
             import traceback
@@ -215,7 +215,7 @@ class PlannedNet:
                     L.net_set_training(h, self.ids[id(m)], int(bool(m.train)))
             self._train = train
         dp = (parallel.world_size(), parallel.sync_bn_active(), parallel.comm_handle("comm_bn"), parallel.comm_handle("comm_grad"),
-              bool(getattr(self.root, "_bucket_overlap", False)))
+              int(bool(getattr(self.root, "_bucket_overlap", False))) | (2 if parallel.hybrid() else 0))
         if dp != self._dp:
             L.net_set_dp(h, dp[0], int(dp[1]), dp[2], dp[3], int(dp[4]))
             self._dp = dp

@@ -78,6 +78,12 @@ int cg_stream_wait_event(void* stream, void* event);
  * colorspace 0 'rgb' (3 planes, v / 255), 1 'y' (1 plane, 0.21 R + 0.72 G + 0.07 B of the scaled values,
  * nn_utils.lua:253-277).  Every operation is a single correctly rounded fp32 one, in the host loader's order. */
 int cg_images_u8_to_f32(void* stream, const unsigned char* src, float* dst, long npixels, int colorspace);
+/* The loader's whole per-image arithmetic (dataset.lua:123-131,166) on the device: image.load's floats (byte / 255) -> image.scale to
+ * Hd x Wd -> colour space, from the decoded 8-bit image at its own size [N][Hs][Ws][3] to the fp32 NHWC pool [N][Hd][Wd][C].
+ * image.scale = the `image` rock's default separable 'bilinear' [upstream, recalled]: rows first, then columns, each pass in fp32;
+ * shrinking an axis averages the source samples a target sample covers (fractional ends weighted), enlarging interpolates
+ * linearly between the two neighbours (corner aligned), equal sizes copy.  Shrink factors up to 6 per axis. */
+int cg_images_u8_scale_to_f32(void* stream, const unsigned char* src, float* dst, int N, int Hs, int Ws, int Hd, int Wd, int colorspace);
 
 /* ---- convolution / linear (implicit GEMM on fp32 MFMA) -------------------
  * Replaces cudnn.SpatialConvolution (models.lua:206,212,218,222),
@@ -452,6 +458,7 @@ int cg_comm_unique_id(void* id_out, size_t id_bytes);
 int cg_comm_init(void** comm, int nranks, int rank, const void* unique_id, size_t id_bytes);
 int cg_comm_destroy(void* comm);
 int cg_comm_size(void* comm, int* nranks, int* rank);
+int cg_comm_version(int* version);   /* RCCL's ncclGetVersion code (e.g. 22606), 0 when RCCL is not loadable */
 int cg_comm_allreduce(void* comm, void* compute_stream, void* buf, size_t count, int dtype, int op);
 int cg_comm_broadcast(void* comm, void* compute_stream, void* buf, size_t count, int dtype, int root);
 int cg_comm_wait(void* comm, void* compute_stream);
@@ -494,6 +501,8 @@ int cg_comm_sync(void* comm);
  * cg_net_set_dp: data parallelism: world size, sync-BN on/off, the two cg_comm_* communicators (sync-BN sums /
  *   gradient buckets; NULL: the host hook carries the exchange), bucket_overlap != 0: cg_net_backward starts the all-reduce
  *   (average) of each gradient bucket of the root nn.Sequential as soon as its backward is complete (join: cg_comm_wait).
+ *   bucket_overlap & 2: BOTH transports - the communicator's collective, then the host hook on the same buffer (functional tests
+ *   with single-rank communicators on one GPU: the cg_comm_* fork / join path runs, the cross-rank sum travels over the hook).
  * cg_net_set_hook: host transport for those exchanges when no communicator is set: hook(user, what, buf, count, dtype, stream),
  *   what 0 = in-place SUM of `count` elements (dtype as cg_comm_allreduce) ordered on `stream`, 1 = start the averaging
  *   all-reduce of a gradient bucket (the host finishes them after cg_net_backward).

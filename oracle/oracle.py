@@ -697,6 +697,74 @@ def get_parameters(net):
     return flat, gflat
 
 
+# ---------------------------------------------------------------- input pipeline (dataset.lua:123-131,166)
+def image_scale(img, w, h):
+    """image.scale(img, w, h), default mode 'bilinear', of the torch `image` rock [upstream, RECALLED - the rock is not in the
+    reference tree; assumption stated here and in DESIGN.md]: generic/image.c scales every row to the target width into a float
+    temporary, then every column to the target height (scaleLinear_rowcol).  Along one axis (source length Ls, target Ld):
+      Ld == Ls  copy
+      Ld >  Ls  scale = (float)(Ls-1)/(Ld-1); for d < Ld-1: s = d*scale, i = (long)s, f = s - i, out = (1-f) src[i] + f src[i+1];
+                out[Ld-1] = src[Ls-1]
+      Ld <  Ls  scale = (float)Ls/Ld; running (i0, f0) = (0, 0); for each d: s1 = (d+1)*scale, i1 = (long)s1, f1 = s1 - i1;
+                acc = (1-f0) src[i0], n = 1-f0; for si in (i0, i1): acc += src[si], n += 1; if i1 < Ls: acc += f1 src[i1], n += f1;
+                out = acc / n; (i0, f0) = (i1, f1)
+    all in fp32.  img: float32 [C, H, W].  Scalar loops, one rounding per operation: the checker of dataset.image_scale (numpy, vectorised
+    over the other axes) and of cg_images_u8_scale_to_f32 (device)."""
+    def axis(src, Ld):
+        Ls = len(src)
+        out = [f32(0)] * Ld
+        if Ld == Ls:
+            return list(src)
+        if Ld > Ls:
+            scale = f32(f32(Ls - 1) / f32(Ld - 1))
+            for d in range(Ld - 1):
+                sf = f32(f32(d) * scale)
+                i = int(sf)
+                f = f32(sf - f32(i))
+                out[d] = src[0] if Ls == 1 else f32(f32(f32(f32(1) - f) * src[i]) + f32(f * src[i + 1]))
+            out[Ld - 1] = src[Ls - 1]
+            return out
+        scale = f32(f32(Ls) / f32(Ld))
+        i0, f0 = 0, f32(0)
+        for d in range(Ld):
+            s1 = f32(f32(d + 1) * scale)
+            i1 = int(s1)
+            f1 = f32(s1 - f32(i1))
+            acc = f32(f32(f32(1) - f0) * src[i0])
+            n = f32(f32(1) - f0)
+            for si in range(i0 + 1, i1):
+                acc = f32(acc + src[si]); n = f32(n + f32(1))
+            if i1 < Ls:
+                acc = f32(acc + f32(f1 * src[i1])); n = f32(n + f1)
+            out[d] = f32(acc / n)
+            i0, f0 = i1, f1
+        return out
+    img = np.asarray(img, dtype=f32)
+    C, H, W = img.shape
+    tmp = np.empty((C, H, w), f32)
+    for c in range(C):
+        for y in range(H):
+            tmp[c, y] = axis([f32(v) for v in img[c, y]], w)
+    out = np.empty((C, h, w), f32)
+    for c in range(C):
+        for x in range(w):
+            out[c, :, x] = axis([f32(v) for v in tmp[c, :, x]], h)
+    return out
+
+
+def load_image(u8_hwc, w, h, color_space="rgb"):
+    """One image of the pool: image.load(path, 3, 'float') (bytes / 255) -> image.scale -> rgbToColorSpace (nn_utils.lua:223-278; 'y':
+    z = 0 + 0.21 r, + 0.72 g, + 0.07 b)."""
+    img = (np.asarray(u8_hwc, dtype=np.uint8).astype(f32) / f32(255)).transpose(2, 0, 1)
+    img = image_scale(img, w, h)
+    if color_space == "y":
+        z = f32(0.21) * img[0]
+        z = z + f32(0.72) * img[1]
+        z = z + f32(0.07) * img[2]
+        return z[None].astype(f32)
+    return img
+
+
 # ---------------------------------------------------------------- criterion / optim
 def bce_forward(p, t):
     """nn.BCECriterion, sizeAverage, eps=1e-12 [upstream] (train.lua:181)."""

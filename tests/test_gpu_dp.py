@@ -87,7 +87,7 @@ def test_closed_accuracy_gate_under_overlapped_collectives():
 
 
 # ------------------------------------------------------------------ 2 ranks x N/2 == 1 rank x N on the HIP path
-def _shard_worker(rank, world, port, overlap, q):
+def _shard_worker(rank, world, port, overlap, q, comm="torch"):
     """world == 1: the full batch in one process; world == 2: rank r takes rows [r*N/2R, (r+1)*N/2R) of the real / noise
     draws (SURVEY.md 8e partitioning).  Dropout probabilities are set to 0 so that no mask depends on the position of a
     sample in the counter stream - everything else (sync-BN, gradient buckets, overlap, fused penalty / clamp / Adam) is
@@ -95,12 +95,18 @@ def _shard_worker(rank, world, port, overlap, q):
     try:
         sys.path.insert(0, ROOT)
         torch.cuda.set_device(0)
+        os.environ["CG_COMM"] = comm
         if world > 1:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
             dist.init_process_group("gloo", rank=rank, world_size=world)
         cg = importlib.import_module("cat-generator_amd")
         if world > 1:
             cg.parallel.attach(world, rank)
+            want = "abi1+torch" if comm == "abi1" else "torch"
+            assert cg.parallel.comm_backend() == want, (cg.parallel.comm_backend(), want)
+            if comm == "abi1":   # both communicators exist, sized 1, and RCCL reports its version
+                info = cg.parallel.comm_info()
+                assert info["comm_nranks"] == 1 and info["rccl_version"] > 20000, info
         cg.manual_seed(11)
         G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
         for net in (G, D):
@@ -132,11 +138,11 @@ def _shard_worker(rank, world, port, overlap, q):
         q.put((rank, None, None, None, f"{type(e).__name__}: {e}\n{traceback.format_exc()[-1500:]}"))
 
 
-def _run_sharded(world, overlap):
+def _run_sharded(world, overlap, comm="torch"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29950 + os.getpid() % 40 + (5 if overlap else 0)
-    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, overlap, q)) for r in range(world)]
+    port = 29950 + os.getpid() % 40 + (5 if overlap else 0) + (11 if comm != "torch" else 0)
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, overlap, q, comm)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=400) for _ in procs], key=lambda r: r[0])
@@ -148,15 +154,18 @@ def _run_sharded(world, overlap):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("overlap", [False, True])
-def test_two_ranks_on_half_batches_equal_one_rank_on_the_full_batch(overlap):
+@pytest.mark.parametrize("overlap,comm", [(False, "torch"), (True, "torch"), (True, "abi1")])
+def test_two_ranks_on_half_batches_equal_one_rank_on_the_full_batch(overlap, comm):
     """with the global batch split over two ranks (sync-BN statistics and the mean of the flat gradients
     exchanged; `overlap`: D's all-reduce under the G-step's generator forward, G's in buckets under its backward) the
     gradients handed to Adam and the parameters after two iterations equal the single-rank run on the full batch, up
     to fp32 re-association of the batch reductions.  Both ranks run the HIP kernels on the one GPU of this box; the
-    transport is gloo (RCCL refuses two ranks on one device) - the collectives' placement and order are the product's."""
+    transport is gloo (RCCL refuses two ranks on one device) - the collectives' placement and order are the product's.
+    comm = "abi1" (CG_COMM=abi1): every exchange ALSO goes through the cg_comm_* entry points on single-rank communicators
+    (one for the gradients, one for the sync-BN sums: fork / join events, the buckets cg_net_backward starts, _PendingAbi), so that
+    code runs here although its cross-rank arithmetic needs a multi-GPU node."""
     full = _run_sharded(1, overlap)[0]
-    r0, r1 = _run_sharded(2, overlap)
+    r0, r1 = _run_sharded(2, overlap, comm)
     np.testing.assert_array_equal(r0[2], r1[2]); np.testing.assert_array_equal(r0[3], r1[3])   # replicas
     for it in range(2):
         for k, name in ((0, "D"), (1, "G")):
