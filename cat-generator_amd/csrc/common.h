@@ -55,6 +55,9 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // stream, allocated on the stream's first use (which therefore must not happen inside a graph capture: warm up first).
 constexpr size_t kColScratchBytes = 8u << 20;
 void* col_scratch(hipStream_t stream);   // nullptr + cg::fail() on error
+// Drop every weight-gradient reduction still queued by cg_conv2d_wgrad_*_deferred (any stream): a pass that failed half way must not
+// leave partial sums behind for the next flush to add to a gradient.
+void wgrad_discard_all();
 
 // grid for memory-bound grid-stride kernels: enough blocks to fill 256 CUs x 8
 static inline int ew_grid(long n, int per_block = 256) {

@@ -2595,6 +2595,11 @@ int cg_conv2d_wgrad_pending(void* stream, int* njobs) {
     return 0;
 }
 
+void cg::wgrad_discard_all() {
+    std::lock_guard<std::mutex> lk(g_red_mu);
+    for (auto& kv : g_red_queue) kv.second.clear();
+}
+
 int cg_conv2d_wgrad_flush(void* stream) {
     hipStream_t st = cg::S(stream);
     std::vector<RedJob> jobs;

@@ -2186,7 +2186,7 @@ int run_ops(Net* n, vector<Op>& ops, Run& c) {
     for (Op& op : ops) {
         c.cur = op.sidx;
         const int rc = op.fn(c);
-        if (rc) { g_cur_net = nullptr; return rc; }
+        if (rc) { g_cur_net = nullptr; cg::wgrad_discard_all(); return rc; }   // a failed pass leaves no queued reductions behind
     }
     g_cur_net = nullptr;
     return 0;

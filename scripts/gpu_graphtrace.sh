@@ -1,10 +1,11 @@
 #!/bin/bash
-# kernel trace of the hipGraph-replayed bench (real inter-kernel gaps, unlike the eager trace)
+# kernel trace of the hipGraph-replayed bench (real inter-kernel gaps, unlike the eager trace).  The bench launches eagerly by
+# default since round 3 (same kernels, same order); --graph keeps the tracer's per-launch cost out of the gaps.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"; ROOTD=$PWD
 TAG=${TAG:-r02g}
 export TMPDIR=/tmp
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$ROOTD/gpurun_out/prof_$TAG" -o $TAG -- python "$ROOTD/bench.py" --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-roofline > "$ROOTD/gpurun_out/prof_graph.log" 2>&1); echo "rc=$?"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$ROOTD/gpurun_out/prof_$TAG" -o $TAG -- python "$ROOTD/bench.py" --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-roofline ${BENCH_ARGS:---graph} > "$ROOTD/gpurun_out/prof_graph.log" 2>&1); echo "rc=$?"
 f=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, re, sys, collections
