@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels behind include/catgan.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -79,20 +80,117 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// true in exactly one workgroup of the grid: the last one to arrive at this point (everything the others wrote before their
-// arrival is visible to it).  counter must be zero before the launch; the last workgroup leaves it at zero again.
+// Cross-workgroup hand-over of the partial sums.  The eight XCDs have private L2s, so an agent-scope fence costs a write-back
+// walk plus an invalidate of the XCD's whole L2; issued by every wave of every workgroup (__threadfence in all threads) that is
+// 128 walks per XCD, serialised: +30 us on an 18 us reduction (measured).  CG_COL_HANDOVER picks the protocol:
+//   0  __threadfence() in every thread on both sides (the textbook form)
+//   3  one release fence per WORKGROUP (thread 0, after the barrier that orders the other waves' stores before it - fences are
+//      cumulative), one acquire fence per wave of the finishing workgroups only
+//   4  no fences: partials are published and read with returning agent-scope atomics (swap / or-with-zero), which execute at the
+//      device's coherence point like the double atomicAdds this replaces
+// Same box, ms per step: 0 = 7.23, 3 = 7.13 - 7.16, 4 = 7.12 - 7.15 (profiles/r03_colreduce_handover.txt).  Tried and RACY (wrong sums
+// about once in three runs of the parity file): write-through stores + sc1 loads with only s_waitcnt in front of the ticket - a
+// store's vmcnt acknowledgement does not mean the write-through has reached the other XCDs' view.
+#ifndef CG_COL_HANDOVER
+#define CG_COL_HANDOVER 3
+#endif
+__device__ __forceinline__ void st_agent(double* p, double v) {
+#if CG_COL_HANDOVER == 4
+    const unsigned long long old = __hip_atomic_exchange((unsigned long long*)p, (unsigned long long)__double_as_longlong(v),
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(old));   // keep the returning form: its s_waitcnt means the swap has been performed
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+#if CG_COL_HANDOVER == 4
+    unsigned long long zero = 0ull;
+    asm volatile("" : "+v"(zero));   // opaque, or the compiler turns the idempotent read-modify-write into a plain load
+    return __longlong_as_double((long long)__hip_atomic_fetch_or((unsigned long long*)const_cast<double*>(p), zero, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT));
+#else
+    return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+// true in exactly one workgroup of the grid: the last one to arrive at this point.  What the others published with st_agent before
+// their arrival is visible to its ld_agent loads.  counter must be zero before the launch; the last workgroup leaves it at zero again.
 __device__ __forceinline__ bool last_block_arrives(unsigned* counter, unsigned total) {
     __shared__ int last_flag;
+#if CG_COL_HANDOVER == 0
     __threadfence();
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = atomicAdd(counter, 1u);
+#if CG_COL_HANDOVER == 3
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = (t == total - 1) ? 1 : 0;
-        if (last_flag) *counter = 0u;
+        if (last_flag) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+#if CG_COL_HANDOVER == 0
     if (last_flag) __threadfence();
+#elif CG_COL_HANDOVER == 3
+    if (last_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     return last_flag != 0;
+}
+
+// ---- second stage of the deterministic column reductions ------------------------------------------------------------
+// A launch of `chunks` row chunks leaves chunks x nk fp64 partials.  Adding them in ONE workgroup costs chunks dependent-latency
+// loads per column (measured: 256 chunks = 90 us on the tail of an 18 us kernel), so the sum is a fixed two-level tree: chunks are
+// grouped G at a time, the last workgroup to arrive of a GROUP adds its G rows (16 loads in flight per column) into the group's row,
+// the last group to finish adds the group rows.  Which workgroup does a sum depends on timing, the ORDER of every addition does not.
+struct ColTree {
+    int G, ngroups;
+    unsigned* counters;   // [0] groups finished, [1 + g] arrivals of group g; all zero between launches
+    double* part;         // [chunks][nk]
+    double* grp;          // [ngroups][nk]
+    double* extra;        // caller-defined tail (e.g. the PReLU slope partials)
+};
+constexpr int kColTreeMaxGroups = 32;
+static inline bool col_tree_layout(char* scr, long chunks, size_t nk, size_t nextra, ColTree& t) {
+    t.G = (int)std::max<long>(16, (chunks + kColTreeMaxGroups - 1) / kColTreeMaxGroups);
+    t.ngroups = (int)((chunks + t.G - 1) / t.G);
+    t.counters = (unsigned*)scr;
+    t.part = (double*)(scr + 256);
+    t.grp = t.part + (size_t)chunks * nk;
+    t.extra = t.grp + (size_t)t.ngroups * nk;
+    return 256 + sizeof(double) * ((size_t)chunks * nk + (size_t)t.ngroups * nk + nextra) <= kColScratchBytes;
+}
+
+// out[k] = rows[0][k] + rows[1][k] + ... in row order, loads 16 rows ahead of the additions (rows published with st_agent)
+__device__ __forceinline__ void col_sum_rows(const double* rows, int nrows, int nk, double* out) {
+    for (int k = threadIdx.x; k < nk; k += blockDim.x) {
+        double t = 0.0;
+        int y = 0;
+        for (; y + 16 <= nrows; y += 16) {
+            double v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = ld_agent(&rows[(size_t)(y + j) * nk + k]);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t += v[j];
+        }
+        for (; y < nrows; ++y) t += ld_agent(&rows[(size_t)y * nk + k]);
+        st_agent(&out[k], t);
+    }
+}
+
+// called by every workgroup after it stored its partial row (chunk = its row chunk, blocks_per_chunk = workgroups sharing a chunk);
+// true in the one workgroup that wrote the final sums
+__device__ __forceinline__ bool col_tree_finish(const ColTree& t, int chunk, int chunks, unsigned blocks_per_chunk, int nk, double* sums) {
+    const int g = chunk / t.G;
+    const int in_group = min(t.G, chunks - g * t.G);
+    if (!last_block_arrives(t.counters + 1 + g, (unsigned)in_group * blocks_per_chunk)) return false;
+    col_sum_rows(t.part + (size_t)g * t.G * nk, in_group, nk, t.grp + (size_t)g * nk);
+    if (!last_block_arrives(t.counters, (unsigned)t.ngroups)) return false;
+    col_sum_rows(t.grp, t.ngroups, nk, sums);
+    return true;
 }
 
 // block-wide sum for 256-thread blocks; result valid in thread 0

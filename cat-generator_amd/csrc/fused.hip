@@ -280,16 +280,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_v4k(const float* __restrict__ 
 // backward statistics of PReLU(BN(x)) from x and the gradient dy w.r.t. the PReLU output:
 //   u = (x - mean) * invstd * gamma + beta (recomputed, bit-equal to the forward);  d = u > 0 ? dy : alpha * dy
 //   sums[c] = sum d, sums[C + c] = sum d * xhat, sums[2C] = sum_{u <= 0} u * dy   (fp64; block = QB channel quads x RL row
-//   lanes as colreduce4_k; per-workgroup partials go to the stream's scratch and the last workgroup to arrive adds them up in a
-//   fixed order: no floating-point atomics, the same bits on every run)
+//   lanes as colreduce4_k; per-workgroup partials go to the stream's scratch and are added in the fixed two-level order of
+//   cg::ColTree: no floating-point atomics, the same bits on every run)
 template <int QB>
 __global__ __launch_bounds__(256) void bn_act_bwd_stats_k(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* alpha, long M, int C, long rows_per_block,
-                                                          double* __restrict__ sums, unsigned* counter, double* part,
-                                                          double* part_alpha) {
+                                                          double* __restrict__ sums, cg::ColTree tree) {
     constexpr int RL = 256 / QB;
+    double* part = tree.part;
+    double* part_alpha = tree.extra;
     __shared__ double sh[2][RL][QB * 4 + 2];
     __shared__ double shg[4];
     const int ql = threadIdx.x % QB, rl = threadIdx.x / QB;
@@ -336,21 +337,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stats_k(const float* __restric
         double t = 0.0;
 #pragma unroll
         for (int r = 0; r < RL; ++r) t += sh[which][r][cl];
-        part[(size_t)blockIdx.y * (2 * C) + which * C + c] = t;
+        cg::st_agent(&part[(size_t)blockIdx.y * (2 * C) + which * C + c], t);
     }
     {
         const double t = alpha ? block_sum_256(ga, shg) : 0.0;
-        if (threadIdx.x == 0) part_alpha[blockIdx.y * gridDim.x + blockIdx.x] = t;
+        if (threadIdx.x == 0) cg::st_agent(&part_alpha[blockIdx.y * gridDim.x + blockIdx.x], t);
     }
-    if (cg::last_block_arrives(counter, gridDim.x * gridDim.y)) {
-        const int chunks = (int)gridDim.y;
-        for (int k = threadIdx.x; k < 2 * C; k += 256) {
-            double t = 0.0;
-            for (int y = 0; y < chunks; ++y) t += part[(size_t)y * (2 * C) + k];
-            sums[k] = t;
-        }
+    if (cg::col_tree_finish(tree, (int)blockIdx.y, (int)gridDim.y, gridDim.x, 2 * C, sums)) {
         double a = 0.0;
-        for (int i = threadIdx.x; i < (int)(gridDim.x * gridDim.y); i += 256) a += part_alpha[i];
+        for (int i = threadIdx.x; i < (int)(gridDim.x * gridDim.y); i += 256) a += cg::ld_agent(&part_alpha[i]);
         a = block_sum_256(a, shg);
         if (threadIdx.x == 0) sums[2 * C] = a;
     }
@@ -614,17 +609,14 @@ int cg_bn_act_backward_stats(void* stream, const float* x, const float* dy, cons
     const dim3 grid(cblocks, (unsigned)chunks);
     char* scr = (char*)cg::col_scratch(cg::S(stream));
     if (!scr) return 1;
-    const size_t np = (size_t)chunks * 2 * C, na = (size_t)chunks * cblocks;
-    CG_REQUIRE(256 + sizeof(double) * (np + na) <= cg::kColScratchBytes, "cg_bn_act_backward_stats: partials exceed the scratch");
-    unsigned* counter = (unsigned*)scr;
-    double* part = (double*)(scr + 256);
-    double* part_alpha = part + np;
+    cg::ColTree tree;
+    CG_REQUIRE(cg::col_tree_layout(scr, chunks, (size_t)2 * C, (size_t)chunks * cblocks, tree), "cg_bn_act_backward_stats: partials exceed the scratch");
     if (qb == 32)
         hipLaunchKernelGGL(bn_act_bwd_stats_k<32>, grid, dim3(256), 0, cg::S(stream), x, dy, save_mean, save_invstd, gamma, beta, alpha,
-                           M, C, rows_per_block, sums, counter, part, part_alpha);
+                           M, C, rows_per_block, sums, tree);
     else
         hipLaunchKernelGGL(bn_act_bwd_stats_k<16>, grid, dim3(256), 0, cg::S(stream), x, dy, save_mean, save_invstd, gamma, beta, alpha,
-                           M, C, rows_per_block, sums, counter, part, part_alpha);
+                           M, C, rows_per_block, sums, tree);
     CG_LAUNCH_CHECK();
     return 0;
 }

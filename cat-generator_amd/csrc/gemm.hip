@@ -2595,11 +2595,6 @@ int cg_conv2d_wgrad_pending(void* stream, int* njobs) {
     return 0;
 }
 
-void cg::wgrad_discard_all() {
-    std::lock_guard<std::mutex> lk(g_red_mu);
-    for (auto& kv : g_red_queue) kv.second.clear();
-}
-
 int cg_conv2d_wgrad_flush(void* stream) {
     hipStream_t st = cg::S(stream);
     std::vector<RedJob> jobs;
@@ -2831,3 +2826,8 @@ int cg_pack_conv_weight_ups2(void* stream, const float* w, float* wf_ph, float* 
 }
 
 }  // extern "C"
+
+void cg::wgrad_discard_all() {
+    std::lock_guard<std::mutex> lk(g_red_mu);
+    for (auto& kv : g_red_queue) kv.second.clear();
+}

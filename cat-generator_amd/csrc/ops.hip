@@ -361,20 +361,11 @@ __global__ void bce_bwd_k(const float* p, const float* t, float* dp, long n) {
 // ------------------------------------------------------------- column reduces
 // x: [M][C].  grid = (ceil(C/64), row chunks); block = 64 channels x 4 row lanes.
 // MODE 0: (x, x^2)   MODE 1: (dy, dy*xhat)   MODE 2: (dy, 0)
-// Second stage of the column reductions, run by the last workgroup to arrive: sums[k] = part[0][k] + part[1][k] + ... in chunk
-// order (nk = number of sums; part rows are nk doubles).
-__device__ __forceinline__ void colreduce_finish(const double* part, int chunks, int nk, double* sums) {
-    for (int k = threadIdx.x; k < nk; k += blockDim.x) {
-        double t = 0.0;
-        for (int y = 0; y < chunks; ++y) t += part[(size_t)y * nk + k];
-        sums[k] = t;
-    }
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_k(const float* x, const float* dy, const float* mean,
                                                    const float* invstd, long M, int C, long rows_per_block,
-                                                   double* sums, unsigned* counter, double* part) {
+                                                   double* sums, cg::ColTree tree) {
+    double* part = tree.part;
     __shared__ double sh1[4][64], sh2[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -409,10 +400,10 @@ __global__ __launch_bounds__(256) void colreduce_k(const float* x, const float* 
         const double t1 = sh1[0][cl] + sh1[1][cl] + sh1[2][cl] + sh1[3][cl];
         const double t2 = sh2[0][cl] + sh2[1][cl] + sh2[2][cl] + sh2[3][cl];
         const int nk = (MODE == 2 ? 1 : 2) * C;
-        part[(size_t)blockIdx.y * nk + c] = t1;
-        if (MODE != 2) part[(size_t)blockIdx.y * nk + C + c] = t2;
+        cg::st_agent(&part[(size_t)blockIdx.y * nk + c], t1);
+        if (MODE != 2) cg::st_agent(&part[(size_t)blockIdx.y * nk + C + c], t2);
     }
-    if (last_block_arrives(counter, gridDim.x * gridDim.y)) colreduce_finish(part, (int)gridDim.y, (MODE == 2 ? 1 : 2) * C, sums);
+    cg::col_tree_finish(tree, (int)blockIdx.y, (int)gridDim.y, gridDim.x, (MODE == 2 ? 1 : 2) * C, sums);
 }
 
 // float4 form (C % 4 == 0, 16-byte aligned rows): block = QB channel quads x RL row lanes (QB*RL = 256), four
@@ -420,8 +411,9 @@ __global__ __launch_bounds__(256) void colreduce_k(const float* x, const float* 
 template <int MODE, int QB>
 __global__ __launch_bounds__(256) void colreduce4_k(const float* x, const float* dy, const float* mean,
                                                     const float* invstd, long M, int C, long rows_per_block,
-                                                    double* sums, unsigned* counter, double* part) {
+                                                    double* sums, cg::ColTree tree) {
     constexpr int RL = 256 / QB;
+    double* part = tree.part;
     __shared__ double sh[2][RL][QB * 4 + 2];
     const int ql = threadIdx.x % QB, rl = threadIdx.x / QB;
     const int q = blockIdx.x * QB + ql;          // channel quad
@@ -467,9 +459,9 @@ __global__ __launch_bounds__(256) void colreduce4_k(const float* x, const float*
         double t = 0.0;
 #pragma unroll
         for (int r = 0; r < RL; ++r) t += sh[which][r][cl];
-        part[(size_t)blockIdx.y * ((MODE == 2 ? 1 : 2) * C) + which * C + c] = t;
+        cg::st_agent(&part[(size_t)blockIdx.y * ((MODE == 2 ? 1 : 2) * C) + which * C + c], t);
     }
-    if (last_block_arrives(counter, gridDim.x * gridDim.y)) colreduce_finish(part, (int)gridDim.y, (MODE == 2 ? 1 : 2) * C, sums);
+    cg::col_tree_finish(tree, (int)blockIdx.y, (int)gridDim.y, gridDim.x, (MODE == 2 ? 1 : 2) * C, sums);
 }
 
 __global__ void bias_grad_finish_k(const double* sums, float* gb, int C, float scale) {
@@ -1324,13 +1316,12 @@ static int colreduce_launch(void* stream, int mode, const float* x, const float*
     const long rows_per_block = ((M + chunks - 1) / chunks + 3) / 4 * 4;
     chunks = (M + rows_per_block - 1) / rows_per_block;
     dim3 grid(cblocks, (unsigned)chunks);
-    // deterministic two-stage sum inside one launch: partials in the stream's scratch, the last workgroup adds them in order
+    // deterministic sum inside one launch: partials in the stream's scratch, added in a fixed two-level order (cg::ColTree)
     char* scr = (char*)cg::col_scratch(cg::S(stream));
     if (!scr) return 1;
-    CG_REQUIRE(256 + sizeof(double) * (size_t)chunks * nsums * C <= cg::kColScratchBytes, "column reduce: %ld chunks x %d sums exceed the scratch", chunks, nsums * C);
-    unsigned* counter = (unsigned*)scr;
-    double* part = (double*)(scr + 256);
-#define CG_COLRED(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, cg::S(stream), x, dy, mean, invstd, M, C, rows_per_block, sums, counter, part)
+    cg::ColTree tree;
+    CG_REQUIRE(cg::col_tree_layout(scr, chunks, (size_t)nsums * C, 0, tree), "column reduce: %ld chunks x %d sums exceed the scratch", chunks, nsums * C);
+#define CG_COLRED(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, cg::S(stream), x, dy, mean, invstd, M, C, rows_per_block, sums, tree)
     if (v4 && qb == 32) {
         if (mode == 0) CG_COLRED((colreduce4_k<0, 32>)); else if (mode == 1) CG_COLRED((colreduce4_k<1, 32>)); else CG_COLRED((colreduce4_k<2, 32>));
     } else if (v4) {
