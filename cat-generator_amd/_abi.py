@@ -71,7 +71,7 @@ class Lib:
                 raise CatganError(f"libcatgan_hip.so does not export {name} declared in catgan.h") from e
             fn.restype = _CTYPES[ret]
             fn.argtypes = [_CTYPES[t] for t, _ in args]
-            if ret == "int" and name != "cg_abi_version":
+            if ret == "int" and name != "cg_abi_version" and not name.endswith("_supported"):   # predicates return 0 / 1, not a status
                 setattr(self, name[3:], self._checked(fn, name))
             else:
                 setattr(self, name[3:], fn)

@@ -69,6 +69,15 @@ static inline int ew_grid(long n, int per_block = 256) {
 }
 
 // ---- device-side helpers -------------------------------------------------
+// the engine's counter-based generator: splitmix64 of (seed, counter), 24-bit mantissa uniform in [0,1)
+// (host twin tensor.SplitMix, oracle twin orc_rng_u01)
+__device__ __forceinline__ float u01(uint64_t seed, uint64_t ctr) {
+    uint64_t z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -166,6 +166,123 @@ __global__ __launch_bounds__(256) void sum4_v4k(const float* a, const float* b, 
     }
 }
 
+// nn.Concat(2) -> nn.SpatialDropout (training) in one pass.  DROPFWD: whole = concat * mask with the mask drawn in the kernel -
+// element (n, c) of the [N][Ct] mask is draw offset + n*Ct + c of the counter stream, what rng_bernoulli_k would have produced -
+// and stored by the thread that owns pixel 0 of the sample; !DROPFWD: the branches' gradient slices = whole * mask (mask read).
+template <bool DROPFWD>
+__global__ __launch_bounds__(256) void concat4_drop_v4k(Cat4 b, float* __restrict__ whole, float* __restrict__ noise, long total4, int Ct4,
+                                                        long HW, float keep, float value, uint64_t seed, uint64_t offset,
+                                                        const uint64_t* __restrict__ base) {
+    if (DROPFWD && base) offset += *base;
+    V4_LOOP(i, total4) {
+        const int c = (int)(i % Ct4);
+        const long m = i / Ct4;
+        const long n = m / HW;
+        float* p; int cl, cw;
+        if (c < b.c0) { p = b.p0; cl = c; cw = b.c0; }
+        else if (c < b.c0 + b.c1) { p = b.p1; cl = c - b.c0; cw = b.c1; }
+        else if (c < b.c0 + b.c1 + b.c2) { p = b.p2; cl = c - b.c0 - b.c1; cw = b.c2; }
+        else { p = b.p3; cl = c - b.c0 - b.c1 - b.c2; cw = b.c3; }
+        const long mi = n * Ct4 + c;
+        if (DROPFWD) {
+            const uint64_t ctr = offset + (uint64_t)mi * 4u;
+            float4 mk;
+            mk.x = cg::u01(seed, ctr) < keep ? value : 0.f;
+            mk.y = cg::u01(seed, ctr + 1) < keep ? value : 0.f;
+            mk.z = cg::u01(seed, ctr + 2) < keep ? value : 0.f;
+            mk.w = cg::u01(seed, ctr + 3) < keep ? value : 0.f;
+            if (m == n * HW) stv(noise, mi, mk);
+            float4 v = ldv(p, m * cw + cl);
+            v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+            stv(whole, i, v);
+        } else {
+            const float4 mk = ldv(noise, mi);
+            float4 v = ldv(whole, i);
+            v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+            stv(p, m * cw + cl, v);
+        }
+    }
+}
+
+// The discriminator's head nn.Dropout -> nn.Linear(F, O <= 4) -> nn.Sigmoid (models.lua:699-701), one wave per sample:
+// mask drawn in place (element n*F + f of the [N][F] mask = draw offset + n*F + f), xd = x * mask, z = xd . w[o] + b[o], p = sigmoid(z)
+template <int O>
+__global__ __launch_bounds__(256) void head_fwd_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                  float* __restrict__ noise, float* __restrict__ xd, float* __restrict__ z,
+                                                  float* __restrict__ p, int N, int F, float keep, float value, uint64_t seed,
+                                                  uint64_t offset, const uint64_t* __restrict__ base) {
+    if (base) offset += *base;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) acc[o] = 0.f;
+    for (int f = lane; f < F; f += 64) {
+        const long i = (long)n * F + f;
+        const float mk = cg::u01(seed, offset + (uint64_t)i) < keep ? value : 0.f;
+        const float v = x[i] * mk;
+        noise[i] = mk; xd[i] = v;
+#pragma unroll
+        for (int o = 0; o < O; ++o) acc[o] += v * w[(long)o * F + f];
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        const float t = cg::wave_sum(acc[o]);
+        if (lane == 0) {
+            const float zz = t + (b ? b[o] : 0.f);
+            z[(long)n * O + o] = zz;
+            p[(long)n * O + o] = 1.f / (1.f + expf(-zz));
+        }
+    }
+}
+
+// backward of the head from dp = dLoss/dp:  gz = dp p (1 - p);  gw[o][f] += scale sum_n gz[n][o] xd[n][f];  gb[o] += scale sum_n gz[n][o];
+// gx[n][f] = mask[n][f] sum_o gz[n][o] w[o][f].  Workgroup = 64 features x 4 sample lanes; a feature's four partial sums are added
+// in lane order, every sum runs in sample order: the same bits on every run.
+template <int O>
+__global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ dp, const float* __restrict__ p, const float* __restrict__ xd,
+                                                  const float* __restrict__ noise, const float* __restrict__ w, float* __restrict__ gx,
+                                                  float* gw, float* gb, int N, int F, float scale) {
+    extern __shared__ float sh[];            // gz[N][O], then part[4][64][O]
+    float* gz = sh;
+    float* part = sh + (size_t)N * O;
+    for (int i = threadIdx.x; i < N * O; i += 256) { const float v = p[i]; gz[i] = dp[i] * (1.f - v) * v; }
+    __syncthreads();
+    const int fl = threadIdx.x & 63, nl = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + fl;
+    float acc[O], wv[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) { acc[o] = 0.f; wv[o] = f < F ? w[(long)o * F + f] : 0.f; }
+    if (f < F) {
+#pragma unroll 4
+        for (int n = nl; n < N; n += 4) {
+            const long i = (long)n * F + f;
+            const float h = gw ? xd[i] : 0.f, mk = noise[i];
+            float g = 0.f;
+#pragma unroll
+            for (int o = 0; o < O; ++o) { const float t = gz[n * O + o]; acc[o] += t * h; g += t * wv[o]; }
+            gx[i] = g * mk;
+        }
+    }
+    if (!gw) return;
+#pragma unroll
+    for (int o = 0; o < O; ++o) part[(nl * 64 + fl) * O + o] = acc[o];
+    __syncthreads();
+    if (nl == 0 && f < F) {
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            const float t = ((part[fl * O + o] + part[(64 + fl) * O + o]) + part[(128 + fl) * O + o]) + part[(192 + fl) * O + o];
+            gw[(long)o * F + f] += scale * t;
+        }
+    }
+    if (gb && blockIdx.x == 0 && threadIdx.x < O) {
+        float t = 0.f;
+        for (int n = 0; n < N; ++n) t += gz[n * O + threadIdx.x];
+        gb[threadIdx.x] += scale * t;
+    }
+}
+
 struct GalphaTab { float* g0; float* g1; float* g2; float* g3; };
 // galpha[group] += scale * sum_b gpart[group][b]: one workgroup per group, fixed summation order
 __global__ __launch_bounds__(256) void galpha_groups_reduce_k(const double* gpart, int nparts, GalphaTab gt, float scale) {
@@ -566,6 +683,69 @@ int cg_sum_n(void* stream, int n, const float* const* src, float* out, long coun
     for (int i = 0; i < n; ++i) CG_REQUIRE(src[i] && al16(src[i]), "cg_sum_n: tensor %d", i);
     hipLaunchKernelGGL(sum4_v4k, dim3(cg::ew_grid(count / 4)), dim3(256), 0, cg::S(stream), src[0], src[1], n > 2 ? src[2] : nullptr,
                        n > 3 ? src[3] : nullptr, out, n, count / 4);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+static int cat4_drop_args(int n, float* const* p, const int* C, const float* whole, const float* noise, Cat4& b, long& Ct, const char* who) {
+    CG_REQUIRE(n >= 1 && n <= 4 && p && C && whole && noise, "%s: 1..4 branches", who);
+    float* pp[4] = {nullptr, nullptr, nullptr, nullptr}; int c4[4] = {0, 0, 0, 0};
+    Ct = 0;
+    for (int i = 0; i < n; ++i) {
+        CG_REQUIRE(p[i] && C[i] > 0 && C[i] % 4 == 0 && al16(p[i]), "%s: branch %d needs a multiple of 4 channels and an aligned tensor", who, i);
+        pp[i] = p[i]; c4[i] = C[i] / 4; Ct += C[i];
+    }
+    CG_REQUIRE(al16(whole) && al16(noise), "%s: unaligned tensor", who);
+    b = Cat4{pp[0], pp[1], pp[2], pp[3], c4[0], c4[1], c4[2], c4[3]};
+    return 0;
+}
+
+int cg_concat_channels_dropout(void* stream, int n, const float* const* src, const int* C, float* dst, float* noise, int N, long HW,
+                               float keep_prob, float value, uint64_t seed, uint64_t offset, const uint64_t* base) {
+    Cat4 b; long Ct;
+    if (cat4_drop_args(n, (float* const*)src, C, dst, noise, b, Ct, "cg_concat_channels_dropout")) return 1;
+    CG_REQUIRE(N > 0 && HW > 0, "cg_concat_channels_dropout: empty tensor");
+    const long total4 = (long)N * HW * (Ct / 4);
+    hipLaunchKernelGGL(concat4_drop_v4k<true>, dim3(cg::ew_grid(total4)), dim3(256), 0, cg::S(stream), b, dst, noise, total4, (int)(Ct / 4), HW,
+                       keep_prob, value, seed, offset, base);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cg_split_channels_masked(void* stream, int n, const float* src, const float* noise, float* const* dst, const int* C, int N, long HW) {
+    Cat4 b; long Ct;
+    if (cat4_drop_args(n, dst, C, src, noise, b, Ct, "cg_split_channels_masked")) return 1;
+    CG_REQUIRE(N > 0 && HW > 0, "cg_split_channels_masked: empty tensor");
+    const long total4 = (long)N * HW * (Ct / 4);
+    hipLaunchKernelGGL(concat4_drop_v4k<false>, dim3(cg::ew_grid(total4)), dim3(256), 0, cg::S(stream), b, (float*)src, (float*)noise, total4,
+                       (int)(Ct / 4), HW, 0.f, 0.f, (uint64_t)0, (uint64_t)0, (const uint64_t*)nullptr);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cg_drop_linear_sigmoid_supported(int N, int F, int O) { return N > 0 && F > 0 && O >= 1 && O <= 4 && (size_t)N * O * 4 + 4 * 64 * 4 * 4 <= 60000; }
+
+int cg_drop_linear_sigmoid_forward(void* stream, const float* x, const float* w, const float* b, float* noise, float* xd, float* z, float* p,
+                                   int N, int F, int O, float keep_prob, float value, uint64_t seed, uint64_t offset, const uint64_t* base) {
+    CG_REQUIRE(x && w && noise && xd && z && p, "cg_drop_linear_sigmoid_forward: null pointer");
+    CG_REQUIRE(cg_drop_linear_sigmoid_supported(N, F, O), "cg_drop_linear_sigmoid_forward: unsupported shape N=%d F=%d O=%d", N, F, O);
+    const dim3 grid(cg::cdiv(N, 4));
+#define CG_HEAD_F(OO) hipLaunchKernelGGL(head_fwd_k<OO>, grid, dim3(256), 0, cg::S(stream), x, w, b, noise, xd, z, p, N, F, keep_prob, value, seed, offset, base)
+    switch (O) { case 1: CG_HEAD_F(1); break; case 2: CG_HEAD_F(2); break; case 3: CG_HEAD_F(3); break; default: CG_HEAD_F(4); break; }
+#undef CG_HEAD_F
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cg_drop_linear_sigmoid_backward(void* stream, const float* dp, const float* p, const float* xd, const float* noise, const float* w,
+                                    float* gx, float* gw, float* gb, int N, int F, int O, float scale) {
+    CG_REQUIRE(dp && p && noise && w && gx && (xd || !gw), "cg_drop_linear_sigmoid_backward: null pointer");
+    CG_REQUIRE(cg_drop_linear_sigmoid_supported(N, F, O), "cg_drop_linear_sigmoid_backward: unsupported shape N=%d F=%d O=%d", N, F, O);
+    const dim3 grid(cg::cdiv(F, 64));
+    const size_t lds = ((size_t)N * O + 4 * 64 * O) * sizeof(float);
+#define CG_HEAD_B(OO) hipLaunchKernelGGL(head_bwd_k<OO>, grid, dim3(256), lds, cg::S(stream), dp, p, xd, noise, w, gx, gw, gb, N, F, scale)
+    switch (O) { case 1: CG_HEAD_B(1); break; case 2: CG_HEAD_B(2); break; case 3: CG_HEAD_B(3); break; default: CG_HEAD_B(4); break; }
+#undef CG_HEAD_B
     CG_LAUNCH_CHECK();
     return 0;
 }

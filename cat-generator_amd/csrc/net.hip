@@ -151,7 +151,7 @@ struct Geo {   // the 10 geometry arguments of the convolution entry points
 #define GEO(g) (g).N, (g).Hp, (g).Wp, (g).Cin, (g).Cout, (g).kH, (g).kW, (g).padH, (g).padW, (g).ups
 
 struct Seg { int kind; int i, j; };   // kinds below; modules [i, j) of a Sequential
-enum { S_ONE = 0, S_GEMM_ACT, S_ACT_POOL, S_VIEW_GEMM, S_VIEW_GEMM_ACT, S_GEMM_BN_ACT };
+enum { S_ONE = 0, S_GEMM_ACT, S_ACT_POOL, S_VIEW_GEMM, S_VIEW_GEMM_ACT, S_GEMM_BN_ACT, S_CAT_DROP, S_HEAD };
 
 // What a module left behind in one compiled plan (the attributes the Python twin kept on the module objects).
 struct MS {
@@ -174,6 +174,8 @@ struct MS {
     bool ran_set = false;
     void* wg_ws = nullptr; size_t wg_ws_bytes = 0; bool wg_pending = false;   // deferred weight-gradient workspace
     bool loc_fused = false; int locG = 0; long locN = 0;                      // [locnet, AffMat, AffGrid] ran as cg_locnet_forward
+    bool cat_drop = false;                                                   // nn.Concat: the SpatialDropout behind it ran inside its launch
+    bool head_fused = false; Val hz;                                         // nn.Dropout: [Dropout, Linear, Sigmoid] ran as one launch (hz = the linear output)
     void* loc_ws[4] = {nullptr, nullptr, nullptr, nullptr}; size_t loc_ws_bytes[4] = {0, 0, 0, 0};
     std::map<std::string, Val> bufs;
 };
@@ -195,6 +197,7 @@ struct Prog {
     unsigned long opt_epoch = 0;
     vector<std::pair<float*, long>> buckets;   // gradient buckets of the root Sequential (first module index order)
     vector<int> bucket_first;
+    std::map<int, int> ups_first_op;           // module id of a layer behind a folded upsampling -> index of its first forward op
 };
 
 typedef void* (*alloc_fn_t)(void* user, size_t bytes);
@@ -207,6 +210,7 @@ struct Net {
     std::map<std::string, std::unique_ptr<Prog>> progs;
     Prog* last = nullptr;                      // plan of the most recent forward (what backward continues)
     vector<hipStream_t> side; vector<hipEvent_t> side_ev; hipEvent_t fork_ev = nullptr;
+    hipEvent_t pack_fork_ev = nullptr, pack_ev = nullptr;   // weight re-packing beside the head of the forward pass (sync_packs)
     alloc_fn_t alloc_fn = nullptr; void* alloc_user = nullptr;
     hook_fn_t hook = nullptr; void* hook_user = nullptr;
     void *comm_bn = nullptr, *comm_grad = nullptr; int world = 1; int sync_bn = 1; int bucket_overlap = 0;
@@ -216,7 +220,7 @@ struct Net {
     bool params_dirty = true;
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
-        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1;
+        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1;
     long wino_min_tiles = 2048;
     std::string trace_log;
     const KTable* K = &kRealTable;
@@ -488,6 +492,7 @@ struct Compiler {
     }
     void need_ups(Mod& m, bool wino) {
         if (dry) return;
+        if (ops == &pr->fwd && !pr->ups_first_op.count(m.id)) pr->ups_first_op[m.id] = (int)ops->size();
         if (!m.wf_ph) {
             const size_t n = cg_pack_conv_weight_ups2_floats((int)m.ia[1], (int)m.ia[0], (int)m.kH(), (int)((m.kH() - 1) / 2));
             m.wf_ph = (float*)alloc(n * 4); m.wb_ph = (float*)alloc(n * 4);
@@ -960,6 +965,10 @@ struct Compiler {
                 } else if (m.is_act() && nx && nx->is_pool()) {
                     const bool drop = nx2 && nx2->kind == K_SDROP && nx2->train;
                     kind = S_ACT_POOL; j = i + (drop ? 3 : 2);
+                } else if (net->head_fuse && net->cat_fuse && m.kind == K_CONCAT && nx && nx->kind == K_SDROP && nx->train) {
+                    kind = S_CAT_DROP; j = i + 2;
+                } else if (net->head_fuse && m.kind == K_DROP && m.train && nx && nx->kind == K_LINEAR && nx->ia[1] <= 4 && nx2 && nx2->kind == K_SIGMOID) {
+                    kind = S_HEAD; j = i + 3;
                 }
             }
             out.push_back(Seg{kind, i, j});
@@ -979,6 +988,8 @@ struct Compiler {
             case S_ACT_POOL: cur = fwd_act_pool({kid(sg.i)}, {kid(sg.i + 1)}, sg.j - sg.i == 3 ? vector<Mod*>{kid(sg.i + 2)} : vector<Mod*>{}, {cur}, nullptr)[0]; break;
             case S_VIEW_GEMM: cur = fwd_view_gemm({kid(sg.i)}, {kid(sg.i + 1)}, {}, {cur}, nullptr)[0]; break;
             case S_VIEW_GEMM_ACT: cur = fwd_view_gemm({kid(sg.i)}, {kid(sg.i + 1)}, {kid(sg.i + 2)}, {cur}, nullptr)[0]; break;
+            case S_CAT_DROP: cur = fwd_concat(*kid(sg.i), cur, kid(sg.i + 1)); break;
+            case S_HEAD: cur = fwd_head(*kid(sg.i), *kid(sg.i + 1), *kid(sg.i + 2), cur); break;
             default: cur = fwd_gemm_bn_act(*kid(sg.i), *kid(sg.i + 1), *kid(sg.i + 2), cur); break;
             }
             if (failed) break;
@@ -998,6 +1009,7 @@ struct Compiler {
             case S_ACT_POOL: cur = fwd_act_pool(col(sg.i), col(sg.i + 1), sg.j - sg.i == 3 ? col(sg.i + 2) : vector<Mod*>{}, cur, &ctx); break;
             case S_VIEW_GEMM: cur = fwd_view_gemm(col(sg.i), col(sg.i + 1), {}, cur, &ctx); break;
             case S_VIEW_GEMM_ACT: cur = fwd_view_gemm(col(sg.i), col(sg.i + 1), col(sg.i + 2), cur, &ctx); break;
+            case S_CAT_DROP: case S_HEAD: for (int t = sg.i; t < sg.j; ++t) cur = gfwd(col(t), cur, ctx); break;   // no lockstep form: module by module
             default: {   // not a lockstep case on the path: branch after branch, each at its own stream position
                 vector<Val> outs;
                 for (size_t b = 0; b < qs.size(); ++b) {
@@ -1398,7 +1410,8 @@ struct Compiler {
         --dry; pr = save; rng = r0; ops = so;
         return n;
     }
-    Val fwd_concat(Mod& q, const Val& in) {
+    // drop: the nn.SpatialDropout (training) right behind this nn.Concat in its Sequential, to run inside the concat launch
+    Val fwd_concat(Mod& q, const Val& in, Mod* drop = nullptr) {
         const KTable* k = K();
         const int nb = (int)q.kids.size();
         vector<Val> outs(nb);
@@ -1437,6 +1450,23 @@ struct Compiler {
         long Ct = 0; bool all4 = true;
         for (auto& o : outs) { s.sizes.push_back(o.d[1]); Ct += o.d[1]; all4 = all4 && o.d[1] % 4 == 0; }
         Val out = buf(q, "out", {N, Ct, H, W}, NHWC);
+        s.cat_drop = false;
+        if (drop && net->fusion && net->cat_fuse && nb <= 4 && all4) {   // concat and the dropout behind it in one launch
+            vector<long> sz = s.sizes;
+            MS& sd = S(*drop);
+            Val noise = buf(*drop, "noise", {N, Ct});
+            const long off = rng; rng += N * Ct;
+            const float pdrop = drop->fa[0];
+            emit([=](Run& c) {
+                const float* src[4]; int cc[4];
+                for (int i = 0; i < nb; ++i) { src[i] = c.P(outs[i]); cc[i] = (int)sz[i]; }
+                return k->concat_channels_dropout(c.CS(), nb, src, cc, c.P(out), c.P(noise), (int)N, H * W, 1.0f - pdrop, 1.0f, c.seed, c.roff + (uint64_t)off, c.rbase);
+            });
+            s.cat_drop = true;
+            s.out = Val();            // the undropped concatenation is never stored
+            sd.noise = noise; sd.out = out;
+            return out;
+        }
         if (net->fusion && net->cat_fuse && nb <= 4 && all4) {   // one launch for all branches
             vector<long> sz = s.sizes;
             emit([=](Run& c) {
@@ -1453,12 +1483,16 @@ struct Compiler {
             }
         }
         s.out = out;
+        if (drop) return fwd(*drop, out);
         return out;
     }
-    Val bwd_concat(Mod& q, const Val& in, const Val& go, bool acc) {
+    Val bwd_concat(Mod& q, const Val& in, const Val& go_, bool acc, Mod* drop = nullptr) {
         const KTable* k = K();
         const int nb = (int)q.kids.size();
         MS& s = S(q);
+        const bool masked = drop && s.cat_drop;                 // the split launch multiplies by the dropout mask
+        Val go = go_;
+        if (drop && !masked) go = bwd(*drop, s.out, go_, acc);   // the forward ran the two modules separately
         // channel slices of the gradient, one per branch; the slices of a lockstep group are the parts of one block
         Val g = as_nhwc(go);
         const long N = g.d[0], Ct = g.d[1], H = g.d[2], W = g.d[3];
@@ -1479,7 +1513,16 @@ struct Compiler {
             if (!have[i]) dst[i] = buf(q, "gslice" + std::to_string(i), {N, s.sizes[i], H, W}, NHWC);
             all4 = all4 && s.sizes[i] % 4 == 0;
         }
-        if (net->fusion && net->cat_fuse && nb <= 4 && all4) {
+        if (masked) {
+            vector<long> sz = s.sizes;
+            Val noise = S(*drop).noise;
+            emit([=](Run& c) {
+                float* d_[4]; int cc[4];
+                for (int i = 0; i < nb; ++i) { d_[i] = c.P(dst[i]); cc[i] = (int)sz[i]; }
+                return k->split_channels_masked(c.CS(), nb, c.P(g), c.P(noise), d_, cc, (int)N, H * W);
+            });
+            S(*drop).gin = Val();
+        } else if (net->fusion && net->cat_fuse && nb <= 4 && all4) {
             vector<long> sz = s.sizes;
             emit([=](Run& c) {
                 float* d_[4]; int cc[4];
@@ -1533,6 +1576,49 @@ struct Compiler {
         }
         s.gin = accv;
         return accv;
+    }
+
+    // [nn.Dropout (training), nn.Linear(F, O <= 4), nn.Sigmoid]: the discriminator's head (models.lua:699-701) as one launch each way
+    Val fwd_head(Mod& drop, Mod& lin, Mod& sig, const Val& in) {
+        const KTable* k = K();
+        Val x = as_plain(in);
+        const long N = x.d[0], F = lin.ia[0], O = lin.ia[1];
+        MS &sd = S(drop), &sl = S(lin), &ss = S(sig);
+        sd.head_fused = false;
+        if (x.nd != 2 || x.d[1] != F || !cg_drop_linear_sigmoid_supported((int)N, (int)F, (int)O)) {
+            Val a = fwd(drop, in);
+            Val b = fwd(lin, a);
+            return fwd(sig, b);
+        }
+        Val noise = buf_like(drop, "noise", x, PLAIN), xd = buf_like(drop, "out", x, PLAIN);
+        Val z = buf(lin, "out", {N, O}), p = buf(sig, "out", {N, O});
+        const long off = rng; rng += N * F;
+        const float pdrop = drop.fa[0];
+        Mod* lp = &lin;
+        emit([=](Run& c) {
+            if (!lp->w) return cg::fail("cg_net: layer %d has no weight bound (cg_net_bind)", lp->id);
+            return k->drop_linear_sigmoid_forward(c.CS(), c.P(x), lp->w, lp->b, c.P(noise), c.P(xd), c.P(z), c.P(p), (int)N, (int)F, (int)O, 1.0f - pdrop,
+                                                  1.0f / (1.0f - pdrop), c.seed, c.roff + (uint64_t)off, c.rbase);
+        });
+        sd.head_fused = true; sd.noise = noise; sd.out = xd; sd.x = x;
+        sl.x = xd; sl.out = z; sl.map_in = false;
+        ss.out = p;
+        return p;
+    }
+    Val bwd_head(Mod& drop, Mod& lin, Mod& sig, const Val& go, bool acc) {
+        const KTable* k = K();
+        MS &sd = S(drop), &sl = S(lin), &ss = S(sig);
+        Val g = as_plain(go);
+        const long N = sd.x.d[0], F = lin.ia[0], O = lin.ia[1];
+        Val gi = buf_like(drop, "gin", sd.x, PLAIN);
+        Val p = ss.out, xd = sd.out, noise = sd.noise;
+        Mod* lp = &lin;
+        emit([=](Run& c) {
+            return k->drop_linear_sigmoid_backward(c.CS(), c.P(g), c.P(p), c.P(xd), c.P(noise), lp->w, c.P(gi), acc ? lp->gw : nullptr, acc ? lp->gb : nullptr,
+                                                   (int)N, (int)F, (int)O, acc ? c.scale : 0.f);
+        });
+        ss.gin = Val(); sl.gin = Val(); sd.gin = gi;
+        return gi;
     }
 
     // ---------------------------------------------------------------------------------------- backward of one module
@@ -1793,6 +1879,10 @@ struct Compiler {
                 cur = bwd_act_pool({&kid(sg.i)}, {&kid(sg.i + 1)}, sg.j - sg.i == 3 ? vector<Mod*>{&kid(sg.i + 2)} : vector<Mod*>{}, {cur}, acc)[0];
             } else if (sg.kind == S_GEMM_BN_ACT && S(kid(sg.i + 1)).bn_fused) {
                 cur = bwd_gemm_bn_act(kid(sg.i), kid(sg.i + 1), kid(sg.i + 2), inp, cur, acc);
+            } else if (sg.kind == S_CAT_DROP) {
+                cur = bwd_concat(kid(sg.i), inp, cur, acc, &kid(sg.i + 1));
+            } else if (sg.kind == S_HEAD && S(kid(sg.i)).head_fused) {
+                cur = bwd_head(kid(sg.i), kid(sg.i + 1), kid(sg.i + 2), cur, acc);
             } else {   // S_ONE, S_GEMM_ACT (both outputs exist), or a chain whose forward ran unfused
                 for (int t = sg.j - 1; t >= sg.i; --t) {
                     Val mi = t == sg.i ? inp : S(kid(t - 1)).out;
@@ -2168,6 +2258,10 @@ int ensure_streams(Net* n, int nstreams) {
         n->side.push_back(s); n->side_ev.push_back(e);
     }
     if (!n->fork_ev) CG_HIP(hipEventCreateWithFlags(&n->fork_ev, hipEventDisableTiming));
+    if (!n->pack_ev) {
+        CG_HIP(hipEventCreateWithFlags(&n->pack_fork_ev, hipEventDisableTiming));
+        CG_HIP(hipEventCreateWithFlags(&n->pack_ev, hipEventDisableTiming));
+    }
     return 0;
 }
 
@@ -2181,9 +2275,17 @@ void fill_run(Net* n, Prog* pr, Run& c, void* stream) {
     if (n->trace) { n->trace_streams.assign(4, nullptr); for (int t = 0; t < 4; ++t) n->trace_streams[t] = (void*)c.st[t]; if (!stream) n->trace_streams[0] = nullptr; }
 }
 
-int run_ops(Net* n, vector<Op>& ops, Run& c) {
+// join_before: index of the first op that needs the weights sync_packs re-packed on the side stream (-1: nothing pending)
+int run_ops(Net* n, vector<Op>& ops, Run& c, int join_before = -1) {
     g_cur_net = n;
+    int at = 0;
     for (Op& op : ops) {
+        if (at++ == join_before) {
+            if (n->trace) trace_note(n, "event|wait|packs|all");
+            else
+                for (int t = 0; t < c.pr->nstreams; ++t)
+                    if (t != 1 && hipStreamWaitEvent(c.st[t], n->pack_ev, 0) != hipSuccess) { g_cur_net = nullptr; return cg::fail("cg_net: hipStreamWaitEvent failed"); }
+        }
         c.cur = op.sidx;
         const int rc = op.fn(c);
         if (rc) { g_cur_net = nullptr; cg::wgrad_discard_all(); return rc; }   // a failed pass leaves no queued reductions behind
@@ -2193,13 +2295,18 @@ int run_ops(Net* n, vector<Op>& ops, Run& c) {
 }
 
 // Refresh the kernel-side weight copies after a parameter update: every plain layer of the net in ONE launch
-// (cg_pack_conv_weight_batch), layers behind a folded upsampling with their own (phase-summed / Winograd) packing.
-int sync_packs(Net* n, void* stream) {
+// (cg_pack_conv_weight_batch), layers behind a folded upsampling with their own (phase-summed / Winograd) packing.  Only the first
+// of those is needed at once: the others are packed on side stream 1 beside the head of the pass (option pack_overlap), and
+// *join_before is the forward op in front of which the pass has to wait for them.
+int sync_packs(Net* n, Prog* pr, Run& c, int* join_before) {
+    *join_before = -1;
     if (n->params_dirty) {
         for (auto& mp : n->mods) { mp->dirty_plain = true; mp->dirty_ups = true; }
         n->params_dirty = false;
     }
+    void* stream = c.S(0);
     vector<const float*> w; vector<float*> wf, wb; vector<int> co, ci, kh, kw, mp_;
+    vector<Mod*> ups;
     g_cur_net = n;
     for (auto& up : n->mods) {
         Mod& m = *up;
@@ -2212,13 +2319,33 @@ int sync_packs(Net* n, void* stream) {
             else { co.push_back((int)m.ia[1]); ci.push_back((int)m.ia[0]); kh.push_back((int)m.kH()); kw.push_back((int)m.kW()); mp_.push_back(0); }
             m.dirty_plain = false;
         }
-        if (m.wf_ph && m.dirty_ups) {
-            if (n->K->pack_conv_weight_ups2(stream, m.w, m.wf_ph, m.wb_ph, (int)m.ia[1], (int)m.ia[0], (int)m.kH(), (int)((m.kH() - 1) / 2))) return 1;
-            if (m.wino && n->K->conv2d_ups2_wino_pack(stream, m.wf_ph, m.wb_ph, m.u_fwd, m.u_bwd, (int)m.ia[1], (int)m.ia[0])) return 1;
-            m.dirty_ups = false;
-        }
+        if (m.wf_ph && m.dirty_ups) ups.push_back(&m);
     }
     if (!w.empty() && n->K->pack_conv_weight_batch(stream, (int)w.size(), w.data(), wf.data(), wb.data(), co.data(), ci.data(), kh.data(), kw.data(), mp_.data())) return 1;
+    auto first_op = [&](const Mod* m) { auto it = pr->ups_first_op.find(m->id); return it == pr->ups_first_op.end() ? -1 : it->second; };
+    std::stable_sort(ups.begin(), ups.end(), [&](const Mod* a, const Mod* b) { return first_op(a) < first_op(b); });   // unknown to this plan first
+    const bool can_side = n->pack_overlap && c.st[1] != c.st[0];
+    bool forked = false;
+    for (size_t i = 0; i < ups.size(); ++i) {
+        Mod& m = *ups[i];
+        const int fo = first_op(&m);
+        const bool on_side = can_side && i >= 1 && fo > 0 && fo < (int)pr->fwd.size();
+        if (on_side && !forked) {
+            forked = true;
+            if (n->trace) trace_note(n, "event|record|packs_fork|s0\nevent|wait|packs_fork|s1");
+            else if (hipEventRecord(n->pack_fork_ev, c.st[0]) != hipSuccess || hipStreamWaitEvent(c.st[1], n->pack_fork_ev, 0) != hipSuccess)
+                return cg::fail("cg_net: cannot fork the packing stream");
+        }
+        void* st = on_side ? c.S(1) : stream;
+        if (n->K->pack_conv_weight_ups2(st, m.w, m.wf_ph, m.wb_ph, (int)m.ia[1], (int)m.ia[0], (int)m.kH(), (int)((m.kH() - 1) / 2))) return 1;
+        if (m.wino && n->K->conv2d_ups2_wino_pack(st, m.wf_ph, m.wb_ph, m.u_fwd, m.u_bwd, (int)m.ia[1], (int)m.ia[0])) return 1;
+        if (on_side && (*join_before < 0 || fo < *join_before)) *join_before = fo;
+        m.dirty_ups = false;
+    }
+    if (forked) {
+        if (n->trace) trace_note(n, "event|record|packs|s1");
+        else if (hipEventRecord(n->pack_ev, c.st[1]) != hipSuccess) return cg::fail("cg_net: hipEventRecord failed");
+    }
     g_cur_net = nullptr;
     return 0;
 }
@@ -2231,7 +2358,8 @@ std::string prog_key(Net* n, int nd, const long* dims, int fmt) {
     k += "|w" + std::to_string(n->world) + (n->sync_bn ? "s" : "-") + (n->bucket_overlap ? "b" : "-");
     k += "|o" + std::to_string(n->overlap_groups) + std::to_string(n->defer_wgrad) + std::to_string(n->winograd) + std::to_string(n->fusion) +
          std::to_string(n->stacking) + std::to_string(n->grouped) + std::to_string(n->share_pool) + std::to_string(n->sampler_shared) +
-         std::to_string(n->view_fuse) + std::to_string(n->cat_fuse) + std::to_string(n->fuse_locnet) + "m" + std::to_string(n->wino_min_tiles);
+         std::to_string(n->view_fuse) + std::to_string(n->cat_fuse) + std::to_string(n->fuse_locnet) + std::to_string(n->head_fuse) + "m" +
+         std::to_string(n->wino_min_tiles);
     return k;
 }
 
@@ -2252,6 +2380,8 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_CAT_FUSE"))) n->cat_fuse = atoi(e) != 0;
     if ((e = getenv("CG_FUSION"))) n->fusion = atoi(e) != 0;
     if ((e = getenv("CG_FUSE_LOCNET"))) n->fuse_locnet = atoi(e);
+    if ((e = getenv("CG_PACK_OVERLAP"))) n->pack_overlap = atoi(e) != 0;
+    if ((e = getenv("CG_HEAD_FUSE"))) n->head_fuse = atoi(e) != 0;
     *net = n;
     return 0;
 }
@@ -2263,6 +2393,7 @@ int cg_net_destroy(void* net) {
     for (auto s : n->side) hipStreamDestroy(s);
     for (auto e : n->side_ev) hipEventDestroy(e);
     if (n->fork_ev) hipEventDestroy(n->fork_ev);
+    if (n->pack_ev) { hipEventDestroy(n->pack_fork_ev); hipEventDestroy(n->pack_ev); }
     delete n;
     return 0;
 }
@@ -2273,7 +2404,8 @@ int cg_net_set_option(void* net, const char* name, long value) {
     struct { const char* nm; int* p; } tab[] = {
         {"overlap_groups", &n->overlap_groups}, {"defer_wgrad", &n->defer_wgrad}, {"winograd", &n->winograd}, {"share_pool", &n->share_pool},
         {"sampler_shared", &n->sampler_shared}, {"view_fuse", &n->view_fuse}, {"cat_fuse", &n->cat_fuse}, {"stacking", &n->stacking},
-        {"grouped", &n->grouped}, {"fusion", &n->fusion}, {"fuse_locnet", &n->fuse_locnet}};
+        {"grouped", &n->grouped}, {"fusion", &n->fusion}, {"fuse_locnet", &n->fuse_locnet}, {"pack_overlap", &n->pack_overlap},
+        {"head_fuse", &n->head_fuse}};
     if (!strcmp(name, "trace")) {
         CG_REQUIRE(n->progs.empty(), "cg_net_set_option: trace must be chosen before the first pass");
         n->trace = value != 0; n->K = n->trace ? &kTraceTable : &kRealTable;
@@ -2392,15 +2524,16 @@ int cg_net_forward(void* net, void* stream, const float* x, int nd, const long* 
         CG_REQUIRE(!pr->out.is_tab, "cg_net_forward: the root module returns a table");
         pr->out = C.materialise(pr->out);
         pr->draws = C.rng;
-        if (ensure_streams(n, pr->nstreams)) return 1;
+        if (ensure_streams(n, std::max(pr->nstreams, n->pack_overlap && pr->ups_first_op.size() >= 2 ? 2 : 1))) return 1;
         it = n->progs.emplace(key, std::move(pr)).first;
     }
     Prog* pr = it->second.get();
     Run c;
     fill_run(n, pr, c, stream);
-    if (sync_packs(n, stream)) return 1;
+    int join_before = -1;
+    if (sync_packs(n, pr, c, &join_before)) return 1;
     c.x = x; c.seed = rng_seed; c.roff = rng_offset; c.rbase = rng_base;
-    if (run_ops(n, pr->fwd, c)) return 1;
+    if (run_ops(n, pr->fwd, c, join_before)) return 1;
     n->last = pr;
     if (draws) *draws = (uint64_t)pr->draws;
     if (y) *y = c.P(pr->out);

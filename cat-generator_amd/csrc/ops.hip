@@ -617,14 +617,7 @@ __global__ void mask_mul_k(const float* x, const float* mask, float* y, long tot
         y[i] = x[i] * m;
     }
 }
-__device__ __forceinline__ float u01(uint64_t seed, uint64_t ctr) {
-    // splitmix64 of (seed, counter); 24-bit mantissa uniform in [0,1)
-    uint64_t z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
+using cg::u01;
 __global__ void rng_bernoulli_k(float* out, long n, float keep, float value, uint64_t seed, uint64_t offset,
                                 const uint64_t* base) {
     if (base) offset += *base;

@@ -369,6 +369,22 @@ int cg_copy_channels(void* stream, const float* src, float* dst, long M,
 int cg_concat_channels(void* stream, int n, const float* const* src, const int* C, float* dst, long M);
 int cg_split_channels(void* stream, int n, const float* src, float* const* dst, const int* C, long M);
 int cg_sum_n(void* stream, int n, const float* const* src, float* out, long count);
+/* nn.Concat(2) followed by nn.SpatialDropout in training mode (models.lua:688-693) in one launch: the mask element of sample
+ * s, channel c is drawn inside the kernel from draw offset + s*Ct + c of the counter stream (the value cg_rng_bernoulli_dev
+ * puts there) and stored in noise[N][Ct]; dst = concat * mask.  cg_split_channels_masked is the backward: the branches' gradient
+ * slices from the gradient w.r.t. the dropped tensor, dst[b][m][c] = src[m][off_b + c] * noise[s][off_b + c]. */
+int cg_concat_channels_dropout(void* stream, int n, const float* const* src, const int* C, float* dst, float* noise, int N, long HW,
+                               float keep_prob, float value, uint64_t seed, uint64_t offset, const uint64_t* base);
+int cg_split_channels_masked(void* stream, int n, const float* src, const float* noise, float* const* dst, const int* C, int N, long HW);
+/* The discriminator's head nn.Dropout -> nn.Linear(F, O) -> nn.Sigmoid (models.lua:699-701) for O <= 4, one launch each way.
+ * forward: noise[N][F] drawn in place (element i = draw offset + i), xd = x * noise, z = xd w^T + b (w canonical [O][F]), p = sigmoid(z).
+ * backward from dp = dLoss/dp: gx = noise * ((dp p (1-p)) w); with gw != NULL also gw += scale * gz^T xd, gb += scale * colsum(gz)
+ * (accGradParameters; NULL = updateGradInput only, the G-step of adversarial.lua:155-167). */
+int cg_drop_linear_sigmoid_supported(int N, int F, int O);
+int cg_drop_linear_sigmoid_forward(void* stream, const float* x, const float* w, const float* b, float* noise, float* xd, float* z, float* p,
+                                   int N, int F, int O, float keep_prob, float value, uint64_t seed, uint64_t offset, const uint64_t* base);
+int cg_drop_linear_sigmoid_backward(void* stream, const float* dp, const float* p, const float* xd, const float* noise, const float* w,
+                                    float* gx, float* gw, float* gb, int N, int F, int O, float scale);
 /* dst[i] = src[idx[i]] for rows of rowlen floats: D-batch assembly from the
  * real-image pool (adversarial.lua:225-230). */
 int cg_gather_rows(void* stream, const float* src, const int32_t* idx, float* dst,
@@ -492,8 +508,9 @@ int cg_comm_sync(void* comm);
  * cg_net_params_changed: the parameters moved (optimiser step, checkpoint load): re-pack before the next pass.
  * cg_net_set_training: module:training() / :evaluate() (utils/nn_utils.lua:334-349); id -1 = every module.
  * cg_net_set_option: "overlap_groups", "defer_wgrad", "winograd", "winograd_min_tiles", "share_pool", "sampler_shared",
- *   "view_fuse", "cat_fuse", "stacking", "grouped", "fusion", "fuse_locnet" (0/1: ablation switches, results unchanged up to fp32
- *   re-association); "trace" 1 (before the first pass): launches go to recording stubs instead of the GPU, cg_net_trace_take
+ *   "view_fuse", "cat_fuse", "stacking", "grouped", "fusion", "fuse_locnet", "pack_overlap" (0/1: ablation switches, results unchanged
+ *   up to fp32 re-association; pack_overlap: after a parameter update the weights of all but the first layer behind a folded
+ *   upsampling are re-packed on a side stream beside the head of the forward pass); "trace" 1 (before the first pass): launches go to recording stubs instead of the GPU, cg_net_trace_take
  *   returns the text (one `call|<entry point>|<args>` line per launch; pointers as r<region>+<offset>, regions = the plan's
  *   allocations in order plus what cg_net_trace_region registered) - how the planner is tested without a GPU.
  * cg_net_set_allocator: device memory for the plan's buffers from the host's allocator (must return zeroed memory, owned by

@@ -19,7 +19,7 @@ CASES = [("G32up-c", 8), ("G32up", 16), ("D32_st3", 8), ("G32up-c@64", 4), ("D32
 def text(which, N):
     # one stream, and the localisation nets as separate modules (the configuration the deleted executor was compared in; the fused
     # localisation launches of csrc/locnet.hip came later and are covered by structure tests + the GPU parity suite)
-    r = T.trace(which, N, options=[("overlap_groups", 0), ("fuse_locnet", 0)])
+    r = T.trace(which, N, options=[("overlap_groups", 0), ("fuse_locnet", 0), ("pack_overlap", 0), ("head_fuse", 0)])
     out = [f"# {which} batch {N}: draws {r['draws']}"]
     for phase in ("forward", "backward", "updateGradInput"):
         out.append(f"## {phase}")

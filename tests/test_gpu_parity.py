@@ -758,11 +758,72 @@ def test_fused_chain_entry_points_against_oracle_modules(cg):
     close(galpha.numpy(), np.asarray(Ao.grad_weight, f32).reshape(1), K=M * C, what="dalpha")
 
 
+def test_concat_dropout_and_head_launches(cg):
+    """csrc/fused.hip: nn.Concat -> nn.SpatialDropout and nn.Dropout -> nn.Linear(F, 1) -> nn.Sigmoid as single launches.  The masks
+    drawn inside the launches are bit-equal to cg_rng_bernoulli_dev at the same offsets; the concat / split results are bit-equal to
+    the separate kernels; the head against float64 numpy."""
+    import ctypes
+    L, st = cg.lib(), cg.tensor.stream()
+    rs = np.random.RandomState(12)
+    N, H, Cs = 6, 4, (8, 8, 8, 16)
+    Ct = sum(Cs)
+    seed, off = 1234567, 777
+    srcs = [cg.nn.as_nhwc(cg.Tensor.from_numpy(rs.randn(N, c, H, H).astype(f32))) for c in Cs]
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.ptr for t in ts])
+    cc = (ctypes.c_int * 4)(*Cs)
+    out, noise = cg.Tensor.empty((N, Ct, H, H), "nhwc"), cg.Tensor.zeros((N, Ct))
+    L.concat_channels_dropout(st, 4, arr(srcs), cc, out.ptr, noise.ptr, N, H * H, 0.5, 1.0, seed, off, None)
+    ref_noise, cat, ref = cg.Tensor.zeros((N, Ct)), cg.Tensor.empty((N, Ct, H, H), "nhwc"), cg.Tensor.empty((N, Ct, H, H), "nhwc")
+    L.rng_bernoulli_dev(st, ref_noise.ptr, N * Ct, 0.5, 1.0, seed, off, None)
+    L.concat_channels(st, 4, arr(srcs), cc, cat.ptr, N * H * H)
+    L.mask_mul(st, cat.ptr, ref_noise.ptr, ref.ptr, N, H * H, Ct, 1)
+    np.testing.assert_array_equal(noise.numpy(), ref_noise.numpy())
+    assert 0.3 < noise.numpy().mean() < 0.7
+    np.testing.assert_array_equal(out.numpy(), ref.numpy())
+    g = cg.nn.as_nhwc(cg.Tensor.from_numpy(rs.randn(N, Ct, H, H).astype(f32)))
+    d1 = [cg.Tensor.empty((N, c, H, H), "nhwc") for c in Cs]; d0 = [cg.Tensor.empty((N, c, H, H), "nhwc") for c in Cs]
+    L.split_channels_masked(st, 4, g.ptr, noise.ptr, arr(d1), cc, N, H * H)
+    gm = cg.Tensor.empty((N, Ct, H, H), "nhwc")
+    L.mask_mul(st, g.ptr, noise.ptr, gm.ptr, N, H * H, Ct, 1)
+    L.split_channels(st, 4, gm.ptr, arr(d0), cc, N * H * H)
+    for a, b in zip(d1, d0):
+        np.testing.assert_array_equal(a.numpy(), b.numpy())
+    # the head, O = 1 (models.lua:700) and O = 3
+    for Nn, F, Oo in ((128, 256, 1), (10, 100, 3)):
+        assert L.drop_linear_sigmoid_supported(Nn, F, Oo) == 1
+        x = rs.randn(Nn, F).astype(f32); w = (rs.randn(Oo, F) * 0.1).astype(f32); b = rs.randn(Oo).astype(f32)
+        dp = rs.randn(Nn, Oo).astype(f32)
+        xt, wt, bt = cg.Tensor.from_numpy(x), cg.Tensor.from_numpy(w), cg.Tensor.from_numpy(b)
+        nz, xd, z, p = cg.Tensor.zeros((Nn, F)), cg.Tensor.zeros((Nn, F)), cg.Tensor.zeros((Nn, Oo)), cg.Tensor.zeros((Nn, Oo))
+        L.drop_linear_sigmoid_forward(st, xt.ptr, wt.ptr, bt.ptr, nz.ptr, xd.ptr, z.ptr, p.ptr, Nn, F, Oo, 0.5, 2.0, seed, off + 5, None)
+        rn = cg.Tensor.zeros((Nn, F))
+        L.rng_bernoulli_dev(st, rn.ptr, Nn * F, 0.5, 2.0, seed, off + 5, None)
+        np.testing.assert_array_equal(nz.numpy(), rn.numpy())
+        m = rn.numpy().astype(np.float64)
+        xd_ref = x * rn.numpy()
+        np.testing.assert_array_equal(xd.numpy(), xd_ref)
+        z_ref = xd_ref.astype(np.float64) @ w.astype(np.float64).T + b
+        close(z.numpy(), z_ref, K=F, what=f"head z O={Oo}")
+        p_ref = 1.0 / (1.0 + np.exp(-z_ref))
+        close(p.numpy(), p_ref, tol=2e-6, what=f"head p O={Oo}")
+        gx, gw, gb = cg.Tensor.zeros((Nn, F)), cg.Tensor.from_numpy(np.ones((Oo, F), f32)), cg.Tensor.from_numpy(np.ones(Oo, f32))
+        dpt = cg.Tensor.from_numpy(dp)
+        L.drop_linear_sigmoid_backward(st, dpt.ptr, p.ptr, xd.ptr, nz.ptr, wt.ptr, gx.ptr, gw.ptr, gb.ptr, Nn, F, Oo, 0.5)
+        pn = p.numpy().astype(np.float64)
+        gz = dp * pn * (1 - pn)
+        close(gx.numpy(), (gz @ w.astype(np.float64)) * m, K=Oo, what=f"head gx O={Oo}")
+        close(gw.numpy(), 1.0 + 0.5 * gz.T @ xd_ref.astype(np.float64), K=Nn, what=f"head gw O={Oo}")     # accumulate semantics
+        close(gb.numpy(), 1.0 + 0.5 * gz.sum(0), K=Nn, what=f"head gb O={Oo}")
+        gx2 = cg.Tensor.zeros((Nn, F))
+        L.drop_linear_sigmoid_backward(st, dpt.ptr, p.ptr, None, nz.ptr, wt.ptr, gx2.ptr, None, None, Nn, F, Oo, 0.0)   # updateGradInput only
+        np.testing.assert_array_equal(gx2.numpy(), gx.numpy())
+
+
 @pytest.mark.parametrize("which", ["G", "D"])
 def test_planned_pass_matches_the_per_module_walk(cg, which):
     """The planned executor (cg_net_*: fused segments, lockstep branches, side stream, deferred reductions) against the plain
-    nn.Module walk - one C call per module method - on the real networks (training mode, batch 6): same outputs (bit-equal where
-    no batch statistics are involved), same gradients up to the summation order of the slope / statistics reductions."""
+    nn.Module walk - one C call per module method - on the real networks (training mode, batch 6): same outputs and gradients
+    up to the summation order of the slope / statistics reductions and of the fused head's dot product."""
     res = {}
     for planned in (True, False):
         cg.nn.planned = planned
@@ -791,7 +852,7 @@ def test_planned_pass_matches_the_per_module_walk(cg, which):
             cg.nn.planned = True
     (o1, g1, p1), (o0, g0, p0) = res[True], res[False]
     if which == "D":
-        np.testing.assert_array_equal(o1, o0)
+        close(o1, o0, tol=1e-6, what="D output planned vs per-module")     # the head's 256-term dot product runs in another order
         close(g1, g0, tol=1e-6, what="D gradInput planned vs per-module")
     else:
         close(o1, o0, tol=2e-6, what="G output planned vs per-module")
@@ -835,7 +896,8 @@ def test_plan_options_are_result_neutral(cg, which):
     import ctypes
     res = {}
     for name, opts in (("default", {}), ("immediate", {"defer_wgrad": 0}), ("one stream", {"overlap_groups": 0}),
-                       ("unshared", {"share_pool": 0, "sampler_shared": 0}), ("separate localisation modules", {"fuse_locnet": 0})):
+                       ("unshared", {"share_pool": 0, "sampler_shared": 0}), ("separate localisation modules", {"fuse_locnet": 0}),
+                       ("packing on the pass's stream", {"pack_overlap": 0}), ("head modules one by one", {"head_fuse": 0})):
         P, _, _ = _pair(cg, 31, which)
         pP, gP = P.getParameters()
         rs = np.random.RandomState(9)
@@ -858,10 +920,12 @@ def test_plan_options_are_result_neutral(cg, which):
         assert n.value == 0, f"{name}: weight-gradient reductions still queued after cg_net_backward"
         res[name] = gP.numpy().copy()
         assert np.abs(res[name]).max() > 0
-    for name in ("immediate", "one stream", "unshared"):
+    for name in ("immediate", "one stream", "unshared", "packing on the pass's stream"):
         np.testing.assert_array_equal(res[name], res["default"], err_msg=name)
     # the fused localisation launches (csrc/locnet.hip) sum their convolutions in another order than the GEMM kernels: fp32 re-association
     bulk_close(res["separate localisation modules"], res["default"], max_rel=2e-4, mean_rel=2e-6, what=f"{which} fused vs separate localisation nets")
+    # the fused head (csrc/fused.hip head_fwd_k) adds its 256 products in another order than the GEMM
+    bulk_close(res["head modules one by one"], res["default"], max_rel=2e-4, mean_rel=2e-6, what=f"{which} fused vs separate head")
 
 
 def test_collectives_through_the_c_abi_single_rank(cg):

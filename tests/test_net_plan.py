@@ -52,7 +52,11 @@ def test_segments_and_lockstep_branches_of_the_discriminator():
     assert len(T.calls(f, "cg_bilinear_sampler_forward_shared")) == 1 and len(T.calls(f, "cg_bilinear_sampler_forward")) == 1
     pools = T.calls(f, "cg_act_pool2_mask_forward")
     assert sorted(a["ngroups"] for _, a in pools) == ["i:1", "i:1", "i:3"]
-    assert names.count("cg_concat_channels") == 1 and "cg_copy_channels" not in names
+    # nn.Concat -> nn.SpatialDropout in one launch, mask drawn inside; [nn.Dropout, nn.Linear(256, 1), nn.Sigmoid] in one launch
+    assert names.count("cg_concat_channels_dropout") == 1 and "cg_concat_channels" not in names and "cg_copy_channels" not in names
+    assert names[-1] == "cg_drop_linear_sigmoid_forward" and "cg_sigmoid_forward" not in names and "cg_mask_mul" not in names
+    head = T.calls(f, "cg_drop_linear_sigmoid_forward")[0][1]
+    assert (head["N"], head["F"], head["O"]) == ("i:128", "i:256", "i:1")
     # nn.View -> nn.Linear on the NHWC map: no layout pass in front of the 20480 -> 256 layer
     assert "cg_nhwc_to_nchw" not in names
     # side stream: the two-convolution branch runs on s1 between fork and join
@@ -60,9 +64,12 @@ def test_segments_and_lockstep_branches_of_the_discriminator():
     assert {c[0] for c in s1} == {"cg_conv2d_forward", "cg_act_pool2_mask_forward", "cg_rng_bernoulli_dev", "cg_conv2d_forward_ex"}
     ev = [l for l in f if l.startswith("event|")]
     assert ev == ["event|record|fork|s0", "event|wait|fork|s1", "event|record|join1|s1", "event|wait|join1|s0"]
-    assert f.index("event|wait|join1|s0") < next(i for i, l in enumerate(f) if "cg_concat_channels" in l)
+    assert f.index("event|wait|join1|s0") < next(i for i, l in enumerate(f) if "cg_concat_channels_dropout" in l)
     # backward: weight-gradient reductions deferred, one flush per stream, grads of the three branches in grouped launches
     b = r["backward"]
+    bn = [c[0] for c in T.calls(b)]
+    assert bn[0] == "cg_drop_linear_sigmoid_backward" and bn.count("cg_split_channels_masked") == 1 and "cg_split_channels" not in bn
+    assert "cg_sigmoid_backward" not in bn and "cg_mask_mul" not in bn
     assert len(T.calls(b, "cg_conv2d_wgrad_flush")) == 2 and not T.calls(b, "cg_conv2d_wgrad")
     assert {a["stream"] for _, a in T.calls(b, "cg_conv2d_wgrad_flush")} == {"s0", "s1"}
     assert b[-1].startswith("call|cg_conv2d_wgrad_flush|s0")
@@ -77,10 +84,19 @@ def test_segments_and_lockstep_branches_of_the_discriminator():
     # updateGradInput only (fevalG_on_D's pass through D, adversarial.lua:192-193): no weight gradient of any kind
     u = r["updateGradInput"]
     assert not [c for c in T.calls(u) if "wgrad" in c[0]]
-    assert r["stats"]["launches_forward"] <= 28 and r["stats"]["launches_backward"] <= 48
+    hb = T.calls(u, "cg_drop_linear_sigmoid_backward")[0][1]
+    assert hb["gw"] == "n" and hb["gb"] == "n"
+    assert r["stats"]["launches_forward"] <= 23 and r["stats"]["launches_backward"] <= 44
+    # head_fuse 0: the modules of the head one by one, every draw at the same position of the counter stream
+    rh = T.trace("D32_st3", 128, options=[("head_fuse", 0)])
+    assert rh["draws"] == r["draws"]
+    hn = [c[0] for c in T.calls(rh["forward"])]
+    assert hn.count("cg_concat_channels") == 1 and hn[-1] == "cg_sigmoid_forward" and hn.count("cg_mask_mul") == 2
+    off = lambda calls, name: [a["offset"] for _, a in T.calls(calls, name)]
+    assert off(f, "cg_concat_channels_dropout") + off(f, "cg_drop_linear_sigmoid_forward") == off(rh["forward"], "cg_rng_bernoulli_dev")[-2:]
     # the same network with the localisation nets as separate modules (cg_net_set_option fuse_locnet 0): ~1.5x the launches
     r0 = T.trace("D32_st3", 128, options=[("fuse_locnet", 0)])
-    assert r0["stats"]["launches_forward"] >= 40 and not T.calls(r0["forward"], "cg_locnet_forward")
+    assert r0["stats"]["launches_forward"] >= 35 and not T.calls(r0["forward"], "cg_locnet_forward")
 
 
 def test_generator_plan_uses_epilogue_statistics_and_winograd_at_the_benchmarked_batch():
@@ -174,6 +190,10 @@ def test_dropout_draws_follow_the_oracle_order():
         elif name == "cg_rng_bernoulli_dev_grouped":
             n, G = int(a["n_per_group"][2:]), int(a["ngroups"][2:])
             spans += [(int(a[f"off{g}"][2:]), n) for g in range(G)]
+        elif name == "cg_concat_channels_dropout":      # mask drawn inside the launch: [N][sum of the branches' channels]
+            spans.append((int(a["offset"][2:]), int(a["N"][2:]) * sum(int(c) for c in a["C"].split(":", 1)[1].split(","))))
+        elif name == "cg_drop_linear_sigmoid_forward":  # [N][F]
+            spans.append((int(a["offset"][2:]), int(a["N"][2:]) * int(a["F"][2:])))
     spans.sort()
     pos = 5000
     for off, n in spans:
@@ -225,3 +245,27 @@ def test_per_module_walk_is_still_the_protocol():
     assert type(net) is cg.nn.Sequential and not net._planned_last
     assert [type(m).__name__ for m in net.modules[:3]] == ["Linear", "PReLU", "View"]
     assert cg.nn.planned is True
+
+
+def test_weight_packing_runs_beside_the_head_of_the_pass():
+    """After a parameter update only the FIRST layer behind a folded upsampling needs its phase-summed weights at once; the others
+    (and the Winograd-domain kernels) are re-packed on side stream 1, and the pass waits for them right in front of the first launch
+    that reads them.  pack_overlap 0 keeps everything on the pass's own stream."""
+    r = T.trace("G32up-c", 64)
+    first = r["first_forward"]
+    packs = [l.split("|") for l in first if l.startswith("call|cg_pack_conv_weight_ups2") or l.startswith("call|cg_conv2d_ups2_wino_pack")]
+    assert [p[2] for p in packs] == ["s0", "s1", "s1", "s1"]
+    side_outputs = set()
+    for p in packs[1:]:
+        side_outputs.update(t for t in (p[4:6] if "wino" not in p[1] else p[5:7]))
+    wait = first.index("event|wait|packs|all")
+    assert first.index("event|record|packs|s1") < wait
+    readers = [i for i, l in enumerate(first) if l.startswith("call|cg_conv2d") and "pack" not in l and any(t in l.split("|") or any(t in a for a in l.split("|")) for t in side_outputs)]
+    assert readers and min(readers) == wait + 1, (wait, readers[:3])
+    # the second pass (nothing dirty) has no packing and no events
+    assert not any("pack" in l for l in r["forward"])
+    r0 = T.trace("G32up-c", 64, options=[("pack_overlap", 0)])
+    assert all(l.split("|")[2] == "s0" for l in r0["first_forward"] if l.startswith("call|"))
+    assert not any(l.startswith("event|") and "packs" in l for l in r0["first_forward"])
+    strip = lambda ls: [l for l in ls if not (l.startswith("event|") and "packs" in l)]
+    assert [l.replace("|s1|", "|s0|") for l in strip(first)] == r0["first_forward"]
