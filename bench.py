@@ -27,9 +27,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA = 157.3e12               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM = 8.0e12                       # HBM3E spec (6.29 TB/s measured with a float4 copy)
-PMC_FILE = "r03a_pmc_kernels.json"       # counter passes of the roofline launches (scripts/pmc_kernels.sh), newest round first
-if not os.path.exists(os.path.join(ROOT, "profiles", PMC_FILE)):
-    PMC_FILE = "r02b_pmc_kernels.json"
+# counter passes of the roofline launches (scripts/pmc_kernels.sh), newest first
+PMC_FILE = next((f for f in ("r03_pmc_kernels.json", "r03a_pmc_kernels.json", "r02b_pmc_kernels.json")
+                 if os.path.exists(os.path.join(ROOT, "profiles", f))), "r02b_pmc_kernels.json")
 
 CONFIGS = {   # BASELINE.json configs (index + 1)
     2: dict(name="BASELINE configs[1]: G32up-c + D32_st3, 32x32 RGB, batch 128 per GPU", gen="G32up-c", ch=3, size=32, batch=128,

@@ -486,7 +486,8 @@ int cg_comm_sync(void* comm);
  * module, with the constructor calls of models.lua (:138-160, 196-228, 640-711, 814-906).  The library plans the pass:
  * fused segments of nn.Sequential (conv|linear -> PReLU|LeakyReLU in the GEMM epilogue; activation -> 2x2 pooling ->
  * SpatialDropout in one pass; conv -> SpatialBatchNormalization (training) -> PReLU with the statistics in the GEMM epilogue;
- * nn.View -> nn.Linear on the NHWC map), lockstep execution of identical nn.Concat branches (grouped GEMM launches, stacked
+ * nn.View -> nn.Linear on the NHWC map; nn.Concat -> nn.SpatialDropout; nn.Dropout -> nn.Linear -> nn.Sigmoid; a spatial transformer's
+ * whole localisation branch), lockstep execution of identical nn.Concat branches (grouped GEMM launches, stacked
  * parameter-free layers, shared pooling / sampling), the other branch group on a side stream, deferred + batched weight-
  * gradient reductions, one batched weight re-pack per parameter update, sync-BN and gradient-bucket collectives in place.
  * Per-element arithmetic is that of the per-module entry points above; every buffer is allocated when a (net, input shape)
@@ -508,9 +509,11 @@ int cg_comm_sync(void* comm);
  * cg_net_params_changed: the parameters moved (optimiser step, checkpoint load): re-pack before the next pass.
  * cg_net_set_training: module:training() / :evaluate() (utils/nn_utils.lua:334-349); id -1 = every module.
  * cg_net_set_option: "overlap_groups", "defer_wgrad", "winograd", "winograd_min_tiles", "share_pool", "sampler_shared",
- *   "view_fuse", "cat_fuse", "stacking", "grouped", "fusion", "fuse_locnet", "pack_overlap" (0/1: ablation switches, results unchanged
- *   up to fp32 re-association; pack_overlap: after a parameter update the weights of all but the first layer behind a folded
- *   upsampling are re-packed on a side stream beside the head of the forward pass); "trace" 1 (before the first pass): launches go to recording stubs instead of the GPU, cg_net_trace_take
+ *   "view_fuse", "cat_fuse", "stacking", "grouped", "fusion", "fuse_locnet", "head_fuse", "pack_overlap" (0/1: ablation switches,
+ *   results unchanged up to fp32 re-association; fuse_locnet: a spatial transformer's localisation branch as one launch each way,
+ *   cg_locnet_*; head_fuse: nn.Concat -> nn.SpatialDropout and nn.Dropout -> nn.Linear(., <= 4) -> nn.Sigmoid as one launch each,
+ *   masks drawn inside; pack_overlap: after a parameter update the weights of all but the first layer behind a folded upsampling
+ *   are re-packed on a side stream beside the head of the forward pass); "trace" 1 (before the first pass): launches go to recording stubs instead of the GPU, cg_net_trace_take
  *   returns the text (one `call|<entry point>|<args>` line per launch; pointers as r<region>+<offset>, regions = the plan's
  *   allocations in order plus what cg_net_trace_region registered) - how the planner is tested without a GPU.
  * cg_net_set_allocator: device memory for the plan's buffers from the host's allocator (must return zeroed memory, owned by

@@ -3,7 +3,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"; ROOTD=$PWD
 SRC=${1:-r03}
-for k in conv2 dconv2 conv3 loc; do
+for k in conv2 dconv2 conv3; do
   bash scripts/pmc.sh k_$k python $ROOTD/scripts/kbench.py 128 --only $k > gpurun_out/pmc_k_$k.txt 2>&1
   tail -3 gpurun_out/pmc_k_$k.txt
 done
@@ -14,12 +14,11 @@ want = {"nn64x128": ("k_conv2", "igemm_nng_kernel<64, 128, 2, 2, 32>"),
         "tn128x128": ("k_conv2", "igemm_tng_kernel<128, 128, 2, 2>"),
         "nn128x64": ("k_dconv2", "igemm_nn_kernel<128, 64, 2, 2, true, true, 16"),
         "wino_g16": ("k_conv3", "wino_gemm_g_kernel<16>"),
-        "wino_g32": ("k_conv3", "wino_gemm_g_kernel<32>"),
-        "nn128x32": ("k_loc", "igemm_nn_kernel<128, 32, 4, 1")}
+        "wino_g32": ("k_conv3", "wino_gemm_g_kernel<32>")}
 out = {}
 for key, (tag, pat) in want.items():
     j = json.loads(subprocess.check_output([sys.executable, f"{root}/scripts/pmc_json.py", f"{root}/gpurun_out/pmc", tag, pat]))
-    j["source"] = f"profiles/{src}_pmc_kernels.json: scripts/pmc_kernels.sh = 4 separate rocprofv3 --kernel-trace --pmc passes of `python scripts/kbench.py 128 --only {tag[2:]}`"
+    j["source"] = f"profiles/{src}_pmc_kernels.json: scripts/pmc_kernels.sh = separate rocprofv3 --kernel-trace --pmc passes of `python scripts/kbench.py 128 --only {tag[2:]}`"
     out[key] = j
 json.dump(out, open(f"{root}/gpurun_out/pmc/{src}_pmc_kernels.json", "w"), indent=1)
 for k, v in out.items():
