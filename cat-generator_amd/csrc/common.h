@@ -53,7 +53,8 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // workgroup writes its per-channel partials here, the LAST one to arrive (a ticket counter, kept at the front of the block and
 // left at zero again) adds them up in a fixed order - no floating-point atomics, so a batch-norm layer gives the same bits on
 // every run (the property the reference protects by pinning stn's sampler to the CPU, models.lua:889-899).  One block per
-// stream, allocated on the stream's first use (which therefore must not happen inside a graph capture: warm up first).
+// stream out of a pool of eight allocated on the FIRST use of any stream (that one must be outside a graph capture; a stream that
+// first appears inside a capture takes a pooled block without allocating).
 constexpr size_t kColScratchBytes = 8u << 20;
 void* col_scratch(hipStream_t stream);   // nullptr + cg::fail() on error
 // Drop every weight-gradient reduction still queued by cg_conv2d_wgrad_*_deferred (any stream): a pass that failed half way must not

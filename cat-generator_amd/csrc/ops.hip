@@ -36,25 +36,35 @@ int g_opt_state[OPT_COUNT];   // 0 = not read yet, 1 = default / environment, 2 
 }  // namespace cg
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 namespace cg {
 void* col_scratch(hipStream_t stream) {
+    // a pool of blocks allocated (and their ticket counters zeroed) on the FIRST use, handed to streams as they appear: a stream
+    // that shows up inside a graph capture (torch.cuda.graph captures on a stream of its own) needs no allocation then
+    constexpr int kPool = 8;
     static std::unordered_map<hipStream_t, void*> blocks;
+    static std::vector<void*> pool;
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
     auto it = blocks.find(stream);
     if (it != blocks.end()) return it->second;
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (stream && hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
-        cg::fail("column reduce: first use of this stream inside a graph capture (run one pass on it before cg_graph_begin)");
-        return nullptr;
+    if (pool.empty()) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+            cg::fail("column reduce: more than %d streams, the next one first used inside a graph capture (run one pass on it before cg_graph_begin)", kPool);
+            return nullptr;
+        }
+        char* p = nullptr;
+        if (hipMalloc((void**)&p, kColScratchBytes * kPool) != hipSuccess || hipMemset(p, 0, kColScratchBytes * kPool) != hipSuccess) {
+            cg::fail("column reduce: cannot allocate %zu bytes of scratch", kColScratchBytes * kPool);
+            return nullptr;
+        }
+        for (int i = kPool - 1; i >= 0; --i) pool.push_back(p + (size_t)i * kColScratchBytes);
     }
-    void* p = nullptr;
-    if (hipMalloc(&p, kColScratchBytes) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) {
-        cg::fail("column reduce: cannot allocate %zu bytes of scratch", kColScratchBytes);
-        return nullptr;
-    }
-    blocks[stream] = p;
-    return p;
+    void* blk = pool.back();
+    pool.pop_back();
+    blocks[stream] = blk;
+    return blk;
 }
 unsigned long g_opt_epoch = 1;   // bumped by cg_set_option: compiled plans (net.hip) re-derive workspace sizes / dispatch-dependent rows
 long opt(Opt o) {

@@ -758,6 +758,28 @@ def test_fused_chain_entry_points_against_oracle_modules(cg):
     close(galpha.numpy(), np.asarray(Ao.grad_weight, f32).reshape(1), K=M * C, what="dalpha")
 
 
+def test_column_reduction_captured_on_a_stream_of_its_own(cg):
+    """The deterministic column reductions keep their partials in a per-stream scratch.  torch.cuda.graph captures on a stream the
+    library has never seen: it must get a block without allocating (bench.py times its roofline kernels this way), and the replayed
+    sums must equal the eager ones bit for bit."""
+    L = cg.lib()
+    rs = np.random.RandomState(4)
+    M, C = 4096, 128
+    x = cg.Tensor.from_numpy(rs.randn(M, C).astype(f32))
+    eager = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+    L.bn_stats(cg.tensor.stream(), x.ptr, M, C, eager.data_ptr())         # first use of the scratch pool: outside any capture
+    torch.cuda.synchronize()
+    sums = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        L.bn_stats(cg.tensor.stream(), x.ptr, M, C, sums.data_ptr())
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(sums, eager)
+    ref = np.concatenate([x.numpy().astype(np.float64).sum(0), (x.numpy().astype(np.float64) ** 2).sum(0)])
+    close(sums.cpu().numpy(), ref, K=M, what="captured bn_stats")
+
+
 def test_concat_dropout_and_head_launches(cg):
     """csrc/fused.hip: nn.Concat -> nn.SpatialDropout and nn.Dropout -> nn.Linear(F, 1) -> nn.Sigmoid as single launches.  The masks
     drawn inside the launches are bit-equal to cg_rng_bernoulli_dev at the same offsets; the concat / split results are bit-equal to
