@@ -98,9 +98,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 //      cumulative), one acquire fence per wave of the finishing workgroups only
 //   4  no fences: partials are published and read with returning agent-scope atomics (swap / or-with-zero), which execute at the
 //      device's coherence point like the double atomicAdds this replaces
-// Same box, ms per step: 0 = 7.23, 3 = 7.13 - 7.16, 4 = 7.12 - 7.15 (profiles/r03_colreduce_handover.txt).  Tried and RACY (wrong sums
-// about once in three runs of the parity file): write-through stores + sc1 loads with only s_waitcnt in front of the ticket - a
-// store's vmcnt acknowledgement does not mean the write-through has reached the other XCDs' view.
+// Same box, ms per step: 0 = 7.23, 3 = 7.13 - 7.16, 4 = 7.12 - 7.15 (profiles/r03_colreduce_handover.txt).  A fence-free form with
+// write-through (sc1) stores / sc1 loads and only s_waitcnt in front of the ticket measured 7.10 - 7.13 but is NOT covered by the
+// documented memory model (is a store's vmcnt acknowledgement its visibility to the other XCDs?) and failed parity runs that a
+// later-found host-side race (the scratch's memset against non-blocking streams, see col_scratch) may or may not explain: not shipped.
 #ifndef CG_COL_HANDOVER
 #define CG_COL_HANDOVER 3
 #endif

@@ -55,7 +55,9 @@ void* col_scratch(hipStream_t stream) {
             return nullptr;
         }
         char* p = nullptr;
-        if (hipMalloc((void**)&p, kColScratchBytes * kPool) != hipSuccess || hipMemset(p, 0, kColScratchBytes * kPool) != hipSuccess) {
+        // the memset runs on the null stream, which non-blocking streams do not wait for: finish it before any kernel draws a ticket
+        if (hipMalloc((void**)&p, kColScratchBytes * kPool) != hipSuccess || hipMemset(p, 0, kColScratchBytes * kPool) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
             cg::fail("column reduce: cannot allocate %zu bytes of scratch", kColScratchBytes * kPool);
             return nullptr;
         }
