@@ -95,7 +95,7 @@ def time_kernel(fn, iters=20, warm=3):
 
 
 def kernel_rooflines(cg, N):
-    """The kernels that carry the step (time shares from profiles/r03_per_step_breakdown.txt), each timed in isolation with
+    """The kernels that carry the step (time shares from profiles/r03_graph_replay_breakdown.txt), each timed in isolation with
     HIP events on the launch stream at the benchmarked batch, EXECUTED MFMA FLOPs per launch / duration against the fp32 MFMA
     peak.  `traffic` / MFMA-pipe utilisation come from the committed PMC pass of the same launches (profiles/r03_pmc_kernels.json,
     scripts/pmc_kernels.sh; bench.py cannot run rocprofv3 on itself) and carry their source."""
@@ -141,18 +141,18 @@ def kernel_rooflines(cg, N):
     direct = 2.0 * N * 16 * 16 * 256 * 512 * 9
     entry("nn64x128", "igemm_nng_kernel<64,128,2,2,32> (gemm.hip; LDS-direct loads)",
           f"updateGradInput of upsample2 -> conv3x3 512->256 @8->16, batch {N}: one implicit GEMM, M={N * 64} K=4096 N=512",
-          2.0 * N * 64 * 4096 * 512, t, direct, "19 % of the step's kernel time (16 launches)")
+          2.0 * N * 64 * 4096 * 512, t, direct, "18 % of the step's kernel time (16 launches; profiles/r03_graph_replay_breakdown.txt)")
     # (2) igemm_tng_kernel<128,128> (LDS-direct loads): weight gradient of the same layer (4 phases, split over pixels) + its reduce kernels
     t = time_kernel(lambda: m.accGradParameters(xin, dy))
     entry("tn128x128", "igemm_tng_kernel<128,128,2,2> + wgrad_reduce_kernel<true> + bias_part_reduce_kernel (gemm.hip)",
           f"accGradParameters of the same layer, batch {N}: launch GROUP (TN GEMM + deterministic split reduce)",
-          2.0 * N * 64 * 4 * 2048 * 256, t, direct, "12 % (10 launches)", {"timed": "launch group, not the GEMM kernel alone"})
+          2.0 * N * 64 * 4 * 2048 * 256, t, direct, "11 % (9 launches)", {"timed": "launch group, not the GEMM kernel alone"})
     # (3) igemm_nn_kernel<128,64,...,16>: D's 64->64 3x3 convolution at 32x32 (models.lua:648)
     m2, x2, dy2 = conv(64, 64, 3, 32, N, 0)
     t = time_kernel(lambda: m2.updateOutput(x2))
     f2 = 2.0 * N * 32 * 32 * 64 * 64 * 9
     entry("nn128x64", "igemm_nn_kernel<128,64,2,2,true,true,16> (gemm.hip)",
-          f"updateOutput of conv3x3 64->64 @32x32, batch {N}: M={N * 1024} K=576 N=64", f2, t, f2, "9 % (8 launches)")
+          f"updateOutput of conv3x3 64->64 @32x32, batch {N}: M={N * 1024} K=576 N=64", f2, t, f2, "8 % (8 launches)")
     # (4) wino_gemm_g_kernel<16>: the 16 Winograd-domain GEMMs + in-register output transform of G's upsample2 -> conv5x5
     m3, x3, dy3 = conv(256, 128, 5, 16, N, 1)
     if getattr(m3, "_wino", False):
