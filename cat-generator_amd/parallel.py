@@ -14,7 +14,7 @@ import warnings
 import torch
 import torch.distributed as dist
 
-_S = {"world": 1, "rank": 0, "init": False, "sync_bn": True, "comm_grad": None, "comm_bn": None, "hybrid": False}
+_S = {"world": 1, "rank": 0, "init": False, "sync_bn": True, "comm_grad": None, "comm_bn": None, "hybrid": False, "selftest": None}
 
 
 def init_from_env(backend=None):
@@ -94,7 +94,53 @@ def _init_abi_comms(world, rank):
             warnings.warn(f"cg_comm_init failed on some rank ({err or 'another rank'}); device collectives fall back to "
                           "torch.distributed on every rank")
             return
+    # first multi-rank execution of the transport: one checked all-reduce per communicator before anything depends on it
+    ok, msg = True, ""
+    if os.environ.get("CG_COMM_SELFTEST", "1") != "0":
+        for h in made:
+            ok, msg = _selftest(L, h, world, rank)
+            if not agree(ok):
+                warnings.warn(f"cg_comm_* self-test failed on some rank ({msg or 'another rank'}); device collectives fall back to "
+                              "torch.distributed on every rank")
+                _S["selftest"] = "failed: " + (msg or "another rank")
+                return          # the communicators are left alone: destroying one with a collective stuck in it may block
+        _S["selftest"] = "ok"
     _S["comm_grad"], _S["comm_bn"] = made
+
+
+def _selftest(L, h, nranks, rank, timeout_s=None):
+    """One small all-reduce (sum) on communicator `h`, checked against the closed form, with a host-side deadline: the first
+    multi-rank execution of cg_comm_* should fail HERE - where every rank can still agree to use torch.distributed instead -
+    rather than inside the first training step.  -> (ok, message)."""
+    import threading
+    timeout_s = timeout_s or float(os.environ.get("CG_COMM_SELFTEST_TIMEOUT", "120"))
+    from .tensor import stream
+    res = {}
+
+    def run():
+        try:
+            buf = torch.full((1024,), float(rank + 1), dtype=torch.float32, device="cuda")
+            L.comm_allreduce(h, stream(), buf.data_ptr(), buf.numel(), 0, 0)
+            L.comm_wait(h, stream())
+            got = buf.cpu()                                      # blocks until the collective has completed
+            want = float(nranks * (nranks + 1) // 2)
+            res["ok"] = bool(torch.all(got == want).item())
+            res["msg"] = "" if res["ok"] else f"all-reduce gave {got[0].item()} instead of {want}"
+        except Exception as e:                                   # noqa: BLE001 - any failure means: do not use this transport
+            res["ok"], res["msg"] = False, str(e)[:200]
+
+    dev = torch.cuda.current_device()
+
+    def entry():
+        torch.cuda.set_device(dev)
+        run()
+
+    t = threading.Thread(target=entry, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        return False, f"no completion within {timeout_s:.0f} s"
+    return res.get("ok", False), res.get("msg", "")
 
 
 def comm_backend():
@@ -108,6 +154,8 @@ def comm_info():
     """What the bench line prints about the collectives: backend, communicator size as RCCL reports it, RCCL version."""
     from .tensor import lib
     out = {"backend": comm_backend(), "world": _S["world"]}
+    if _S["selftest"]:
+        out["selftest"] = _S["selftest"]
     try:
         v = ctypes.c_int(0)
         lib().comm_version(ctypes.byref(v))
@@ -142,8 +190,12 @@ def _init_single_rank_comms():
         L.comm_unique_id(buf, 128)
         h = ctypes.c_void_p()
         L.comm_init(ctypes.byref(h), 1, 0, buf.raw, 128)
+        ok, msg = _selftest(L, h, 1, 0)
+        if not ok:
+            raise RuntimeError(f"cg_comm_* self-test failed on a single-rank communicator: {msg}")
         _S[name] = h
     _S["hybrid"] = True
+    _S["selftest"] = "ok (single-rank communicators)"
 
 
 def attach(world, rank):
