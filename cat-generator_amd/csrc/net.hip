@@ -2195,7 +2195,7 @@ void Compiler::emit_allreduce_sum(const Val& v, long count, int dtype) {
             if (cg_comm_wait(n->comm_bn, c.CS())) return 1;
             if (!(n->hook_too && n->hook)) return 0;
         }
-        if (n->hook) return n->hook(n->hook_user, HOOK_ALLREDUCE_SUM, p, (size_t)count, dtype, c.CS());
+        if (n->hook) return n->hook(n->hook_user, HOOK_ALLREDUCE_SUM, p, (size_t)count, dtype, c.CS()) ? cg::fail("cg_net: the host hook failed (sync-BN all-reduce of %ld elements)", count) : 0;
         return cg::fail("cg_net: world > 1 with sync-BN but neither a communicator (cg_net_set_dp) nor a host hook is set");
     });
 }
@@ -2217,7 +2217,7 @@ void Compiler::bucket_done(int first_module) {
                     if (!(n->hook_too && n->hook)) return 0;
                     if (cg_comm_wait(n->comm_grad, c.CS())) return 1;   // the hook's transport reads what the collective wrote
                 }
-                if (n->hook) return n->hook(n->hook_user, HOOK_BUCKET_START, ptr, (size_t)cnt, 0, c.CS());
+                if (n->hook) return n->hook(n->hook_user, HOOK_BUCKET_START, ptr, (size_t)cnt, 0, c.CS()) ? cg::fail("cg_net: the host hook failed (gradient bucket of %ld elements)", cnt) : 0;
                 return cg::fail("cg_net: bucketed all-reduce without a communicator or host hook");
             });
         }
