@@ -8,6 +8,6 @@ python -c "import importlib; importlib.import_module('cat-generator_amd.build').
 for e in "$@"; do
   D="-DCG_EXP=$e"; [ "$e" = trace ] && D="-DCG_TRACE"
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I/opt/rocm/include $D -c "$ROOTD/cat-generator_amd/csrc/gemm.hip" -o "$L/obj/gemm_exp$e.o" &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$L/obj/gemm_exp$e.o" "$L/obj/winograd.o" "$L/obj/ops.o" "$L/obj/fused.o" "$L/obj/comm.o" -o "$L/libcatgan_hip_exp$e.so" -ldl && echo built exp$e ) &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$L/obj/gemm_exp$e.o" "$L/obj/winograd.o" "$L/obj/ops.o" "$L/obj/fused.o" "$L/obj/comm.o" "$L/obj/locnet.o" "$L/obj/net.o" -o "$L/libcatgan_hip_exp$e.so" -ldl && echo built exp$e ) &
 done
 wait
