@@ -218,6 +218,7 @@ struct Net {
     vector<void*> owned;
     vector<Region> regions;
     bool params_dirty = true;
+    bool fresh_allocs = false;                 // library-owned buffers were allocated + zeroed since the last device synchronise
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
         cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1;
@@ -325,8 +326,9 @@ struct Compiler {
         } else if (net->alloc_fn) {
             p = net->alloc_fn(net->alloc_user, bytes);      // host allocator: zero-initialised device memory
         } else {
-            if (hipMalloc(&p, bytes) != hipSuccess) p = nullptr;
-            else hipMemset(p, 0, bytes);
+            // the memset is ordered on the null stream only: cg_net_forward / _backward synchronise once after compiling (fresh_allocs)
+            if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) p = nullptr;
+            else net->fresh_allocs = true;
         }
         if (!p) { err("cg_net: allocation of %zu bytes failed", bytes); return nullptr; }
         if (!net->alloc_fn || net->trace) net->owned.push_back(p);
@@ -2249,6 +2251,14 @@ void collect_params(Net* n, const Mod& m, vector<std::pair<float*, long>>& out) 
     for (int c : m.kids) collect_params(n, *n->mods[c], out);
 }
 
+// Buffers the library allocated while compiling were zeroed by hipMemset on the NULL stream, which the (non-blocking) streams the
+// pass runs on do not wait for: finish the memsets before the first launch can touch them.
+int settle_allocs(Net* n) {
+    if (n->fresh_allocs && !n->trace) CG_HIP(hipDeviceSynchronize());
+    n->fresh_allocs = false;
+    return 0;
+}
+
 int ensure_streams(Net* n, int nstreams) {
     if (n->trace) return 0;
     while ((int)n->side.size() < nstreams - 1) {
@@ -2389,11 +2399,11 @@ int cg_net_create(void** net) {
 int cg_net_destroy(void* net) {
     Net* n = NET(net);
     if (!n) return 0;
-    for (void* p : n->owned) { if (n->trace) free(p); else hipFree(p); }
-    for (auto s : n->side) hipStreamDestroy(s);
-    for (auto e : n->side_ev) hipEventDestroy(e);
-    if (n->fork_ev) hipEventDestroy(n->fork_ev);
-    if (n->pack_ev) { hipEventDestroy(n->pack_fork_ev); hipEventDestroy(n->pack_ev); }
+    for (void* p : n->owned) { if (n->trace) free(p); else (void)hipFree(p); }
+    for (auto s : n->side) (void)hipStreamDestroy(s);
+    for (auto e : n->side_ev) (void)hipEventDestroy(e);
+    if (n->fork_ev) (void)hipEventDestroy(n->fork_ev);
+    if (n->pack_ev) { (void)hipEventDestroy(n->pack_fork_ev); (void)hipEventDestroy(n->pack_ev); }
     delete n;
     return 0;
 }
@@ -2525,6 +2535,7 @@ int cg_net_forward(void* net, void* stream, const float* x, int nd, const long* 
         pr->out = C.materialise(pr->out);
         pr->draws = C.rng;
         if (ensure_streams(n, std::max(pr->nstreams, n->pack_overlap && pr->ups_first_op.size() >= 2 ? 2 : 1))) return 1;
+        if (settle_allocs(n)) return 1;
         it = n->progs.emplace(key, std::move(pr)).first;
     }
     Prog* pr = it->second.get();
@@ -2581,6 +2592,7 @@ int cg_net_backward(void* net, void* stream, const float* x, const float* gy, in
         pr->gin[acc] = gi;
         pr->have_bwd[acc] = true;
         if (ensure_streams(n, pr->nstreams)) return 1;
+        if (settle_allocs(n)) return 1;
     }
     Run c;
     fill_run(n, pr, c, stream);
@@ -2639,7 +2651,7 @@ int cg_graph_end(void* stream, void** graph_exec) {
     CG_HIP(hipStreamEndCapture(cg::S(stream), &g));
     hipGraphExec_t ex = nullptr;
     hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) return cg::fail("cg_graph_end: hipGraphInstantiate -> %s", hipGetErrorString(e));
     *graph_exec = (void*)ex;
     return 0;
