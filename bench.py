@@ -179,15 +179,16 @@ def cpu_baselines():
     nproc = os.cpu_count() or 1
     rs = np.random.RandomState(0)
 
-    def batch():
-        return (rs.rand(N // 2, 3, 32, 32).astype(np.float32), (rs.rand(N // 2, 100) * 2 - 1).astype(np.float32),
-                (rs.rand(N, 100) * 2 - 1).astype(np.float32))
+    def batch(n=None):
+        n = n or N
+        return (rs.rand(n // 2, 3, 32, 32).astype(np.float32), (rs.rand(n // 2, 100) * 2 - 1).astype(np.float32),
+                (rs.rand(n, 100) * 2 - 1).astype(np.float32))
 
-    def run(T, steps):
-        T.step(*batch())
+    def run(T, steps, n=None):
+        T.step(*batch(n))
         t0 = time.time()
         for _ in range(steps):
-            T.step(*batch())
+            T.step(*batch(n))
         return time.time() - t0
 
     res = []
@@ -199,6 +200,15 @@ def cpu_baselines():
                     "sample": f"{steps} G+D steps of G32up-c/D32_st3 at batch {N} (configs[0]) after 1 warm-up, oracle/ (C im2col+SGEMM, "
                               f"OpenMP {O.num_threads()} threads" + (", the reference's default --threads" if threads == 4 else
                                                                      ", one per sample of the batch") + f"), {dt:.1f} s"})
+    # the port's loops are parallel over the samples of a batch: its widest line is configs[1]'s half batch on as many threads
+    if nproc >= 32:
+        nb = 64 if nproc >= 64 else 32
+        O.set_num_threads(nb)
+        rng = O.RNG(1)
+        dt = run(O.Trainer(O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng)), 3, nb)
+        res.append({"value": nb * 3 / dt, "unit": "images/sec", "cores": O.num_threads(), "nproc": nproc, "kind": "port",
+                    "sample": f"3 G+D steps at batch {nb} after 1 warm-up, oracle/ (C im2col+SGEMM, OpenMP {O.num_threads()} threads, one per "
+                              f"sample), {dt:.1f} s"})
     torch.set_num_threads(min(nproc, 64))
     rng = O.RNG(1)
     steps = 6
@@ -206,8 +216,9 @@ def cpu_baselines():
     res.append({"value": N * steps / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "nproc": nproc, "kind": "port",
                 "sample": f"{steps} G+D steps at batch {N}, PyTorch-CPU eager ({torch.__version__}, autograd, {torch.get_num_threads()} threads) on "
                           f"the same graphs (oracle/torch_ref.py), {dt:.1f} s"})
-    best = dict(res[0])
-    best["others"] = res[1:]
+    oracle_lines = [r for r in res if "oracle/" in r["sample"]]
+    best = dict(max(oracle_lines, key=lambda r: r["value"]))      # headline: the port's fastest configuration on this host
+    best["others"] = [r for r in res if r["sample"] != best["sample"]]
     return best
 
 
@@ -219,7 +230,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config number (1-based)")
     ap.add_argument("--batch-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="(default) launch eagerly: with the planned executor a step costs the host ~0.3 ms")
+    ap.add_argument("--no-graph", action="store_true", help="(default) launch eagerly: with the planned executor a step costs the host ~1.1 ms")
     ap.add_argument("--graph", action="store_true", help="capture the iteration once (cg_graph_*) and replay the hipGraph")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     args = ap.parse_args()
@@ -241,7 +252,7 @@ def main():
     pool = np.random.RandomState(100 + rank).rand(1024, *dims).astype(np.float32)
     data = cg.adversarial.TrainData(pool)
 
-    # Round 3: eager launches are the default.  With the plan below the C ABI the host needs ~0.3 ms to enqueue a 7 ms step, and
+    # Round 3: eager launches are the default.  With the plan below the C ABI the host needs 1.1 ms to enqueue a 7 ms step, and
     # measured on one box eager beats the hipGraph replay (7.18 vs 7.35 ms/step: the replay serialises part of the cross-stream
     # overlap); --graph keeps the capture path (cg_graph_begin / _end / _launch) measurable.
     use_graph = args.graph and not args.no_graph
