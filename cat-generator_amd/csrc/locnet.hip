@@ -93,15 +93,18 @@ __device__ void conv3x3_lds(const float* in, int CP, int C, const float* wl, int
                 o[0] = acc[q][0]; o[1] = acc[q][1]; o[2] = acc[q][2]; o[3] = acc[q][3];
             }
         } else {
-            float* o = part + ((size_t)r * items + id) * 16;
+            // part[r][k][item]: consecutive lanes (items) store to consecutive banks (an item-major [item][16] layout put 32 lanes on two banks)
+            float* o = part + (size_t)r * items * 16 + id;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { o[q * 4] = acc[q][0]; o[q * 4 + 1] = acc[q][1]; o[q * 4 + 2] = acc[q][2]; o[q * 4 + 3] = acc[q][3]; }
+            for (int q = 0; q < 4; ++q) {
+                o[(q * 4) * items] = acc[q][0]; o[(q * 4 + 1) * items] = acc[q][1]; o[(q * 4 + 2) * items] = acc[q][2]; o[(q * 4 + 3) * items] = acc[q][3];
+            }
         }
     }
     __syncthreads();
     if (R > 1) {
         for (int e = tid; e < items * 16; e += NT) {
-            const int id = e >> 4, k = e & 15, q = k >> 2, c = k & 3;
+            const int k = e / items, id = e - k * items, q = k >> 2, c = k & 3;
             const int grp = id % nq, o0 = (id / nq) * 4;
             float v = part[e];
             for (int r = 1; r < R; ++r) v += part[(size_t)r * items * 16 + e];      // fixed order
