@@ -1638,7 +1638,7 @@ __device__ __host__ __forceinline__ int phase_map(int a, int d, int pad) { retur
 template <bool UPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* gw, int Cin, int Cout, int k, int KK,
                                                            int pad, int kp, int S, float scale, int CI_T, long sstride) {
-    extern __shared__ float sh[];  // [KK][CI_T][33]
+    extern __shared__ float sh[];  // [CI_T][KK][33]
     const int ci0 = blockIdx.x * CI_T, co0 = blockIdx.y * 32;
     const long plane = (long)(UPS ? kp * kp : KK) * Cin * Cout;
     const int n1 = KK * CI_T * 32;
@@ -1662,7 +1662,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
                 for (int sp = 0; sp < S; ++sp) s += part[(long)sp * sstride + o];
             }
         }
-        sh[(tap * CI_T + ci_l) * 33 + co_l] = s;
+        sh[(ci_l * KK + tap) * 33 + co_l] = s;   // row = position in the output run: the transposed read below walks rows with stride 33 (odd: conflict-free)
     }
     __syncthreads();
     const int run = CI_T * KK;
@@ -1672,7 +1672,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
         const int ci = ci0 + ci_l, co = co0 + co_l;
         if (ci < Cin && co < Cout) {
             float* dst = gw + ((long)co * Cin + ci) * KK + tap;
-            *dst += scale * sh[(tap * CI_T + ci_l) * 33 + co_l];
+            *dst += scale * sh[j * 33 + co_l];
         }
     }
 }
