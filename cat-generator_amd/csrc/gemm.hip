@@ -484,6 +484,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void i
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     using Set0 = std::integral_constant<int, 0>;
+    CG_STAMP(6);   // trace builds: end of the integer set-up (tile origin, tap-validity masks, descriptors)
     if (T > 0) {
         load_tile(ks, Set0{});
         store_tile(std::integral_constant<int, 0>{}, Set0{});

@@ -42,6 +42,9 @@ def report(tag, fn):
     print(f"   span (first start .. last end) {end.max():.1f} us")
     print(f"   start offset [us]   {q(st)}")
     print(f"   prologue     [us]   {q(pro)}")
+    if (t[:, 6] != 0).all():     # igemm_nn_kernel also stamps the end of its integer set-up
+        print(f"     set-up     [us]   {q((t[:, 6] - t[:, 0]) / 100.0)}")
+        print(f"     1st tile   [us]   {q((t[:, 1] - t[:, 6]) / 100.0)}")
     print(f"   K loop       [us]   {q(loop)}")
     print(f"   epilogue     [us]   {q(epi)}")
     print(f"   end time     [us]   {q(end)}")
@@ -62,6 +65,11 @@ def conv(N, Cin, H, Cout, k, ups):
 
 
 N = 128
+if "--dconv2" in sys.argv:
+    m2, x2, dy2 = conv(N, 64, 32, 64, 3, 0)
+    report("D.conv2 64->64 @32 forward (igemm_nn<128,64,..,16>)", lambda: m2.updateOutput(x2))
+    report("D.conv2 64->64 @32 data gradient", lambda: m2.updateGradInput(x2, dy2))
+    sys.exit(0)
 m, xin, dy = conv(N, 512, 8, 256, 3, 1)
 report("G.conv2 512->256 @8->16 dgrad (igemm_nn<64,128,..,32>, M 8192 K 4096 N 512)", lambda: m.updateGradInput(xin, dy))
 report("G.conv2 forward (4 phases)", lambda: m.updateOutput(xin))
