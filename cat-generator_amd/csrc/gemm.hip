@@ -88,6 +88,7 @@ struct Geom {
     int nphase;            // 1 or 4 (blockIdx.z)
     int ntaps, Ktot;       // per phase; Ktot = ntaps*Cin
     TapDesc td;
+    int minoff0, minoff1, minoff2, minoff3;   // per phase: min(0, smallest tap element offset) - host-computed (finish_geom), the kernels' descriptor base
 };
 
 constexpr int MAXG = 4;  // groups per launch: same geometry, separate tensors (D32_st3's identical branches)
@@ -152,9 +153,9 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, float* lds, uns
 #endif
 }
 
-__device__ __forceinline__ void tap_decode(const Geom& g, int t, int pa, int pb, int& ty, int& tx, int& off) {
+__host__ __device__ __forceinline__ void tap_decode(const Geom& g, int t, int pa, int pb, int& ty, int& tx, int& off) {
     const TapDesc& d = g.td;
-    const int grp = t / d.kk;
+    const int grp = d.ngroups > 1 ? t / d.kk : 0;
     const int tt = t - grp * d.kk;
     const int ry = tt / d.kw, rx = tt - (tt / d.kw) * d.kw;
     int a = pa, b = pb;
@@ -252,11 +253,11 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void i
     // range of tiles - neighbours then share their A rows / B columns through one L2 instead of eight
     int bid = blockIdx.x;
     if ((a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-    const int tn = bid % ntn, tm = bid / ntn;
+    const int tn = ntn == 1 ? 0 : bid % ntn, tm = ntn == 1 ? bid : bid / ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
     const int zz = blockIdx.z;
-    const int group = zz / g.nphase;
+    const int group = g.nphase == 1 ? zz : (g.nphase == 4 ? zz >> 2 : zz / g.nphase);
     const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
     const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
     const float* gbias = sel4(group, a.b0, a.b1, a.b2, a.b3);
@@ -316,12 +317,8 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void i
                     if (r_ok[p] && (unsigned)(r_oy[p] + ty) < (unsigned)g.Hv) cur[p] |= (unsigned long long)xb[p] << sh;
             }
         }
-        for (int t = 0; t < g.ntaps; ++t) {
-            int ty, tx, off;
-            tap_decode(g, t, pa, pb, ty, tx, off);
-            minoff = min(minoff, off);
-        }
-        tapi = ks / g.Cin;
+        minoff = sel4(phase, g.minoff0, g.minoff1, g.minoff2, g.minoff3);   // host-computed (finish_geom)
+        tapi = ks == 0 ? 0 : ks / g.Cin;
         ci0 = ks - tapi * g.Cin;
         { int ty, tx; tap_decode(g, tapi, pa, pb, ty, tx, toff); }
 #pragma unroll
@@ -670,11 +667,11 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
     const int ntn = (g.Cout + BN - 1) / BN;
     int bid = blockIdx.x;
     if ((a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-    const int tn = bid % ntn, tm = bid / ntn;
+    const int tn = ntn == 1 ? 0 : bid % ntn, tm = ntn == 1 ? bid : bid / ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
     const int zz = blockIdx.z;
-    const int group = zz / g.nphase;
+    const int group = g.nphase == 1 ? zz : (g.nphase == 4 ? zz >> 2 : zz / g.nphase);
     const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
     const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
     const float* gbias = sel4(group, a.b0, a.b1, a.b2, a.b3);
@@ -729,12 +726,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
                     if (r_ok[p] && (unsigned)(r_oy[p] + ty) < (unsigned)g.Hv) cur[p] |= (unsigned long long)xb[p] << sh;
             }
         }
-        for (int t = 0; t < g.ntaps; ++t) {
-            int ty, tx, off;
-            tap_decode(g, t, pa, pb, ty, tx, off);
-            minoff = min(minoff, off);
-        }
-        tapi = ks / g.Cin;
+        minoff = sel4(phase, g.minoff0, g.minoff1, g.minoff2, g.minoff3);   // host-computed (finish_geom)
+        tapi = ks == 0 ? 0 : ks / g.Cin;
         ci0 = ks - tapi * g.Cin;
         { int ty, tx; tap_decode(g, tapi, pa, pb, ty, tx, toff); }
 #pragma unroll
@@ -961,10 +954,10 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
     } else if ((a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) {
         bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // see igemm_nn_kernel
     }
-    const int tn = bid % ntn, tm = bid / ntn;
+    const int tn = ntn == 1 ? 0 : bid % ntn, tm = ntn == 1 ? bid : bid / ntn;
     const int m0 = tm * BM, n0 = tn * BN;  // m0: row of dW (tap,ci)
     const int zz = blockIdx.z;
-    const int group = zz / g.nphase;
+    const int group = g.nphase == 1 ? zz : (g.nphase == 4 ? zz >> 2 : zz / g.nphase);
     const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
     const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
     const float* gdy = sel4(group, a.d0, a.d1, a.d2, a.d3);
@@ -1016,11 +1009,7 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
     int l_minoff = 0;
     __amdgpu_buffer_rsrc_t rsx_l = rsx;
     if (lean) {
-        for (int t = 0; t < g.ntaps; ++t) {
-            int ty, tx, off;
-            tap_decode(g, t, pa, pb, ty, tx, off);
-            l_minoff = min(l_minoff, off);
-        }
+        l_minoff = sel4(phase, g.minoff0, g.minoff1, g.minoff2, g.minoff3);   // host-computed (finish_geom)
         rsx_l = __builtin_amdgcn_make_buffer_rsrc((void*)(gx + l_minoff), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int q = 0; q < APASS; ++q) {
@@ -1248,10 +1237,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tnq_kernel(TNArgs a, int flat) {
     } else if ((a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) {
         bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     }
-    const int tn = bid % ntn, tm = bid / ntn;
+    const int tn = ntn == 1 ? 0 : bid % ntn, tm = ntn == 1 ? bid : bid / ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int zz = blockIdx.z;
-    const int group = zz / g.nphase;
+    const int group = g.nphase == 1 ? zz : (g.nphase == 4 ? zz >> 2 : zz / g.nphase);
     const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
     const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
     const float* gdy = sel4(group, a.d0, a.d1, a.d2, a.d3);
@@ -1278,11 +1267,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tnq_kernel(TNArgs a, int flat) {
         int off;
         tap_decode(g, tap, pa, pb, c_ty, c_tx, off);
         c_off = off + (mc - tap * g.Cin);
-        for (int t = 0; t < g.ntaps; ++t) {
-            int ty, tx, o2;
-            tap_decode(g, t, pa, pb, ty, tx, o2);
-            l_minoff = min(l_minoff, o2);
-        }
+        l_minoff = sel4(phase, g.minoff0, g.minoff1, g.minoff2, g.minoff3);   // host-computed (finish_geom)
     }
     __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(gx + l_minoff), 0, 0x7fffffff, 0x00020000);
     __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)gdy, 0, 0x7fffffff, 0x00020000);
@@ -1484,10 +1469,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int flat) {
     } else if ((a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) {
         bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     }
-    const int tn = bid % ntn, tm = bid / ntn;
+    const int tn = ntn == 1 ? 0 : bid % ntn, tm = ntn == 1 ? bid : bid / ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int zz = blockIdx.z;
-    const int group = zz / g.nphase;
+    const int group = g.nphase == 1 ? zz : (g.nphase == 4 ? zz >> 2 : zz / g.nphase);
     const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
     const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
     const float* gdy = sel4(group, a.d0, a.d1, a.d2, a.d3);
@@ -1509,11 +1494,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int flat) {
         int off;
         tap_decode(g, tap, pa, pb, c_ty, c_tx, off);
         c_off = off + (mc - tap * g.Cin);
-        for (int t = 0; t < g.ntaps; ++t) {
-            int ty, tx, o2;
-            tap_decode(g, t, pa, pb, ty, tx, o2);
-            l_minoff = min(l_minoff, o2);
-        }
+        l_minoff = sel4(phase, g.minoff0, g.minoff1, g.minoff2, g.minoff3);   // host-computed (finish_geom)
     }
     __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(gx + l_minoff), 0, 0x7fffffff, 0x00020000);
     __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)gdy, 0, 0x7fffffff, 0x00020000);
@@ -2244,6 +2225,14 @@ static int finish_geom(Geom& g, long N) {
     g.lgHW = (lw >= 0 && lh >= 0) ? lw + lh : -1;
     g.Ktot = g.ntaps * g.Cin;
     if (g.ntaps > 64) return cg::fail("conv2d: more than 64 taps");
+    int mo[4] = {0, 0, 0, 0};
+    for (int ph = 0; ph < g.nphase; ++ph)
+        for (int t = 0; t < g.ntaps; ++t) {
+            int ty, tx, off;
+            tap_decode(g, t, ph >> 1, ph & 1, ty, tx, off);
+            mo[ph] = std::min(mo[ph], off);
+        }
+    g.minoff0 = mo[0]; g.minoff1 = mo[1]; g.minoff2 = mo[2]; g.minoff3 = mo[3];
     return 0;
 }
 
