@@ -216,7 +216,7 @@ def cpu_baselines():
     res.append({"value": N * steps / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "nproc": nproc, "kind": "port",
                 "sample": f"{steps} G+D steps at batch {N}, PyTorch-CPU eager ({torch.__version__}, autograd, {torch.get_num_threads()} threads) on "
                           f"the same graphs (oracle/torch_ref.py), {dt:.1f} s"})
-    oracle_lines = [r for r in res if "oracle/" in r["sample"]]
+    oracle_lines = [r for r in res if "oracle/ (C" in r["sample"]]      # the C port, not the PyTorch-CPU line
     best = dict(max(oracle_lines, key=lambda r: r["value"]))      # headline: the port's fastest configuration on this host
     best["others"] = [r for r in res if r["sample"] != best["sample"]]
     return best

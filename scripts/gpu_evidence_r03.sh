@@ -10,8 +10,10 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
   echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q -rP -p no:cacheprovider > gpurun_out/${TAG}_pytest.log 2>&1; echo "rc=$?"; tail -5 gpurun_out/${TAG}_pytest.log
   grep -h "^\[grad\]\|^\[adam\]" gpurun_out/${TAG}_pytest.log > gpurun_out/${TAG}_step_gradients_vs_oracle.txt 2>/dev/null
 fi
-echo "== PMC"; bash scripts/pmc_kernels.sh $TAG 2>&1 | tail -10
-cp gpurun_out/pmc/${TAG}_pmc_kernels.json profiles/${TAG}_pmc_kernels.json 2>/dev/null
+if [ "${SKIP_PMC:-0}" != "1" ]; then
+  echo "== PMC"; bash scripts/pmc_kernels.sh $TAG 2>&1 | tail -10
+  cp gpurun_out/pmc/${TAG}_pmc_kernels.json profiles/${TAG}_pmc_kernels.json 2>/dev/null
+fi
 echo "== default bench under rocprofv3 --kernel-trace --stats"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOTD/gpurun_out/prof_${TAG}d" -o ${TAG}d -- python "$ROOTD/bench.py" --no-cpu-baseline > "$ROOTD/gpurun_out/${TAG}_bench_line_traced.json" 2> "$ROOTD/gpurun_out/prof_bench_default.log"); echo "rc=$?"
 g=$(find gpurun_out/prof_${TAG}d -name "*kernel_stats.csv" | head -1); [ -n "$g" ] && cp "$g" gpurun_out/${TAG}_bench_default_kernel_stats.csv
