@@ -195,6 +195,30 @@ __device__ __forceinline__ long out_row(const Geom& g, int m, int pa, int pb) {
 template <int BKT>
 __device__ __forceinline__ int a_swizzle(int kv) { return BKT == 32 ? ((kv & 7) << 2) : ((kv & 3) << 3); }
 
+// Lean epilogue of the NN kernels for a FULL tile whose output rows are consecutive ([row][Cout], i.e. stride-1 layers and split
+// partials): one buffer store per value at (per-lane byte offset) + (row offset in an SGPR).  The generic loop below it - bounds checks,
+// 64-bit addresses and an output-row decode per row - is ~2000 instructions per wave; with all workgroups of a launch reaching their
+// epilogue together that was 10 us in which no MFMA ran (profiles/r03_wg_timeline_nn_kernels.txt).
+template <int MI, int NI, bool ACT>
+__device__ __forceinline__ void nn_store_lean(const f32x16 (&acc)[MI][NI], const float (&bj)[NI], float* ybase, float* zbase, unsigned vo,
+                                              int c4, int act, float aslope) {
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(ACT ? zbase : ybase), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int soff = (i * 32 + (r & 3) + 8 * (r >> 2)) * c4;   // wave-uniform
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const float v = acc[i][j][r] + bj[j];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)(vo + j * 128), soff, 0);
+                if (ACT) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(apply_act(act, v, aslope)), rz, (int)(vo + j * 128), soff, 0);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // NN: Y[m][n] = sum_k A(m,k) * W[k][n]
 // ---------------------------------------------------------------------------
@@ -584,6 +608,19 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void i
         bj[j] = (add_bias && n < g.Cout) ? gbias[n] : 0.f;
         s1[j] = 0.f; s2[j] = 0.f;
     }
+    {
+        // lean path: full tile, consecutive output rows, byte offsets inside the 2 GB a buffer descriptor spans
+        const bool lin = partial || (g.so == 1 && g.nphase == 1);
+        const long rows_total = partial ? (long)a.nsplit * a.ngroups * g.nphase * g.M : (long)g.M;
+        if (lin && !stats && m0 + BM <= g.M && n0 + BN <= g.Cout && rows_total * g.Cout < 0x1fffffffL) {
+            const long rowbase = partial ? (long)(split * (a.ngroups * g.nphase) + zz) * g.M : 0L;
+            const unsigned vo = ((unsigned)(rowbase + m0 + wm0 + 4 * h) * (unsigned)g.Cout + (unsigned)(n0 + wn0 + l31)) * 4u;
+            if (act) nn_store_lean<MI, NI, true>(acc, bj, yout, zout, vo, g.Cout * 4, act, aslope);
+            else nn_store_lean<MI, NI, false>(acc, bj, yout, nullptr, vo, g.Cout * 4, 0, 0.f);
+            CG_STAMP(3);
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -840,6 +877,19 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
         const int n = n0 + wn0 + j * 32 + l31;
         bj[j] = (add_bias && n < g.Cout) ? gbias[n] : 0.f;
         s1[j] = 0.f; s2[j] = 0.f;
+    }
+    {
+        // lean path: full tile, consecutive output rows, byte offsets inside the 2 GB a buffer descriptor spans
+        const bool lin = partial || (g.so == 1 && g.nphase == 1);
+        const long rows_total = partial ? (long)a.nsplit * a.ngroups * g.nphase * g.M : (long)g.M;
+        if (lin && !stats && m0 + BM <= g.M && n0 + BN <= g.Cout && rows_total * g.Cout < 0x1fffffffL) {
+            const long rowbase = partial ? (long)(split * (a.ngroups * g.nphase) + zz) * g.M : 0L;
+            const unsigned vo = ((unsigned)(rowbase + m0 + wm0 + 4 * h) * (unsigned)g.Cout + (unsigned)(n0 + wn0 + l31)) * 4u;
+            if (act) nn_store_lean<MI, NI, true>(acc, bj, yout, zout, vo, g.Cout * 4, act, aslope);
+            else nn_store_lean<MI, NI, false>(acc, bj, yout, nullptr, vo, g.Cout * 4, 0, 0.f);
+            CG_STAMP(3);
+            return;
+        }
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {

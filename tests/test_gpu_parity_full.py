@@ -246,6 +246,39 @@ def test_forced_nn_tile_variants(cg, tile, bk32, splits, stage):
         run_conv(cg, 2, 64, 4, 4, 32, 5, 1, seed=tile % 83, wino=False)
 
 
+@pytest.mark.parametrize("tile", NN_TILES)
+@pytest.mark.parametrize("splits", [0, 3])
+@pytest.mark.parametrize("glds", [0, 3])
+def test_lean_epilogue_on_full_tiles(cg, tile, splits, glds):
+    """nn_store_lean (gemm.hip): FULL tiles with consecutive output rows take the buffer-store epilogue (direct output and split-K
+    partials), everything else the generic one.  Shapes whose M and Cout are multiples of every block tile, both staging families,
+    with and without split-K, against the oracle; then conv -> PReLU through the planned executor (activation in the epilogue, two
+    outputs) against the per-module walk (convolution, then cg_prelu_forward), which must agree bit for bit."""
+    with options(cg, CG_NN_TILE=tile, CG_NN_SPLITS=splits, CG_NN_GLDS=glds, CG_SKINNY=0):
+        run_conv(cg, 4, 64, 16, 16, 128, 3, 0, seed=11)          # M = 1024, Cout = 128
+        run_conv(cg, 2, 32, 16, 16, 64, 5, 0, seed=12)           # M = 512, Cout = 64
+        outs = []
+        for planned in (True, False):
+            cg.nn.planned = planned
+            try:
+                cg.manual_seed(3)
+                net = cg.nn.Sequential()
+                net.add(cg.nn.SpatialConvolution(64, 64, 3, 3, 1, 1, 1)); net.add(cg.nn.PReLU(None, None, True))
+                net.add(cg.nn.SpatialConvolution(64, 128, 3, 3, 1, 1, 1)); net.add(cg.nn.LeakyReLU(0.2))
+                p, g = net.getParameters()
+                x = cg.nn.as_nhwc(cg.Tensor.from_numpy(np.random.RandomState(5).randn(4, 64, 16, 16).astype(f32)))
+                y = cg.nn.as_plain(net.forward(x)).numpy()
+                dy = cg.Tensor.from_numpy(np.random.RandomState(6).randn(*y.shape).astype(f32))
+                g.zero()
+                gi = cg.nn.as_plain(net.backward(x, dy)).numpy()
+                outs.append((y, gi, g.numpy().copy()))
+            finally:
+                cg.nn.planned = True
+        np.testing.assert_array_equal(outs[0][0], outs[1][0])
+        np.testing.assert_array_equal(outs[0][1], outs[1][1])
+        close(outs[0][2], outs[1][2], K=1024, tol=4e-5, what="flat gradient planned vs per-module")
+
+
 def run_linear(cg, N, i, o, seed=0):
     rs = np.random.RandomState(seed)
     m = cg.nn.Linear(i, o)
