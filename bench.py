@@ -152,7 +152,7 @@ def kernel_rooflines(cg, N):
     t = time_kernel(lambda: m2.updateOutput(x2))
     f2 = 2.0 * N * 32 * 32 * 64 * 64 * 9
     entry("nn128x64", "igemm_nn_kernel<128,64,2,2,true,true,16> (gemm.hip)",
-          f"updateOutput of conv3x3 64->64 @32x32, batch {N}: M={N * 1024} K=576 N=64", f2, t, f2, "8 % (8 launches)")
+          f"updateOutput of conv3x3 64->64 @32x32, batch {N}: M={N * 1024} K=576 N=64", f2, t, f2, "8.5 % (8 launches)")
     # (4) wino_gemm_g_kernel<16>: the 16 Winograd-domain GEMMs + in-register output transform of G's upsample2 -> conv5x5
     m3, x3, dy3 = conv(256, 128, 5, 16, N, 1)
     if getattr(m3, "_wino", False):
