@@ -1,3 +1,4 @@
+"""Debug: one SpatialConvolution (forward / backward) against the oracle at a chosen shape, printing the worst element."""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)

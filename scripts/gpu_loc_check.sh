@@ -1,4 +1,5 @@
 #!/bin/bash
+# the fused localisation launches (csrc/locnet.hip): transformer / planned-pass parity tests, then the step with CG_FUSE_LOCNET 0 / 1 / 2
 cd "${GRAFT_REPO_ROOT:-.}"; ROOTD=$PWD; export TMPDIR=/tmp; mkdir -p gpurun_out
 timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider -x -k "spatial_transformer or planned_pass or plan_options or reproducible or discriminator" 2>&1 | tail -4
 for v in 1 0; do CG_FUSE_LOCNET=$v python scripts/dbench.py 128 30; done

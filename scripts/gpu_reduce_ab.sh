@@ -1,4 +1,5 @@
 #!/bin/bash
+# wgrad_reduce_kernel after its LDS layout change: full-size + forced-variant weight-gradient tests, D forward + backward and the step, old vs new library
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+# one hipGraph-replayed step as a timeline (scripts/graph_timeline.py) - superseded by scripts/gpu_trace_only.sh, kept for the r02b files it produced
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"; ROOTD=$PWD
 export TMPDIR=/tmp
