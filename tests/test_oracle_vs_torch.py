@@ -312,3 +312,22 @@ def _bulk(a, b, what):
     q = np.quantile(d, [0.5, 0.99])
     print(f"[{what}] rel-l2 {rel:.2e} median {q[0]:.2e} p99 {q[1]:.2e} max {d.max():.2e}")
     assert rel <= 2e-3 and q[0] <= 1e-5 and q[1] <= 1e-3 and d.max() <= 5e-2, (what, rel, q, d.max())
+
+
+def test_image_scale_rule_against_torch_interpolate():
+    """oracle.image_scale (the recalled torch `image` rock rule the loader, its device kernel and the tests share; dataset.lua:129-131)
+    against two independent formulations in PyTorch: integer-factor reduction = box mean (`mode='area'`), enlargement with the
+    (Ls-1)/(Ld-1) mapping = bilinear with align_corners=True.  It pins the restatement's arithmetic, not Torch7's convention."""
+    rs = np.random.RandomState(21)
+    img = rs.rand(3, 64, 48).astype(f32)
+    t = torch.from_numpy(img)[None]
+    down = O.image_scale(img, 24, 32)                       # (w, h): 48 -> 24, 64 -> 32, the reference's 64 -> 32 case in both axes
+    ref = torch.nn.functional.interpolate(t, size=(32, 24), mode="area")[0].numpy()
+    np.testing.assert_allclose(down, ref, rtol=0, atol=3e-7)
+    third = O.image_scale(img, 16, 64)                      # 48 -> 16 (factor 3) along x only
+    ref3 = torch.nn.functional.interpolate(t, size=(64, 16), mode="area")[0].numpy()
+    np.testing.assert_allclose(third, ref3, rtol=0, atol=3e-7)
+    small = rs.rand(2, 9, 7).astype(f32)
+    up = O.image_scale(small, 19, 33)                       # 7 -> 19, 9 -> 33
+    refu = torch.nn.functional.interpolate(torch.from_numpy(small)[None], size=(33, 19), mode="bilinear", align_corners=True)[0].numpy()
+    np.testing.assert_allclose(up, refu, rtol=0, atol=2e-6)
