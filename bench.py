@@ -309,12 +309,22 @@ def main():
                           "direct_count_tflops": per_gpu * w["W"] / 1e12, "peak_tflops": PEAK_FP32_MFMA / 1e12},
             "event_ms_per_step": e0.elapsed_time(e1) / args.steps, "finite": finite,
         }
+        # The headline numbers above are complete; the two legs below are measured live and must never cost the driver its line.
         if not args.no_kernel_roofline and args.config == 2:
-            top = kernel_rooflines(cg, N)
-            res["roofline"] = top[0]          # the kernel with the largest share of the step
-            res["roofline_top"] = top
+            try:
+                top = kernel_rooflines(cg, N)
+                res["roofline"] = top[0]          # the kernel with the largest share of the step
+                res["roofline_top"] = top
+            except Exception as e:                # noqa: BLE001
+                sw = res["step_work"]
+                res["roofline"] = {"bound": "mfma", "kernel": "whole step (the live per-kernel timing failed: " + str(e)[:160] + ")",
+                                   "achieved": sw["executed_tflops"], "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
+                                   "frac": sw["executed_frac"], "traffic": None, "timed_live": False}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baselines()
+            try:
+                res["cpu_baseline"] = cpu_baselines()
+            except Exception as e:                # noqa: BLE001
+                res["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": "failed: " + str(e)[:160]}
         print(json.dumps(res), flush=True)
     cg.parallel.shutdown()
 
