@@ -326,6 +326,8 @@ def main():
             except Exception as e:                # noqa: BLE001
                 res["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": "failed: " + str(e)[:160]}
         print(json.dumps(res), flush=True)
+    if world > 1:
+        cg.parallel.barrier()      # rank 0 was still timing kernels: tear the communicators down together
     cg.parallel.shutdown()
 
 
