@@ -235,6 +235,12 @@ def main():
     ap.add_argument("--no-kernel-roofline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: libraries write banners there from C (RCCL's version block at communicator init,
+    # gloo's "connected to N peer ranks"), so everything but the result goes to stderr from here on
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     cg = importlib.import_module("cat-generator_amd")
     rank, world = cg.parallel.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -325,7 +331,8 @@ def main():
                 res["cpu_baseline"] = cpu_baselines()
             except Exception as e:                # noqa: BLE001
                 res["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": "failed: " + str(e)[:160]}
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
     if world > 1:
         cg.parallel.barrier()      # rank 0 was still timing kernels: tear the communicators down together
     cg.parallel.shutdown()
