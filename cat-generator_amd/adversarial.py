@@ -201,7 +201,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
             buf["idx"].copy_(torch.from_numpy(np.asarray(idx, dtype=np.int32)), non_blocking=True)
         lib().gather_rows(stream(), trainData.pool.ptr, buf["idx"].data_ptr(), inputs.ptr, half, rowlen)
         # (1.2) sampled data
-        noise = nn.to_device(noise_D) if noise_D is not None else nn_utils.createNoiseInputs(S, half)
+        noise = nn.to_device(noise_D) if noise_D is not None else nn_utils.stepNoiseInputs(S, half)
         samples = nn.as_nhwc(nn_utils.createImagesFromNoise(S, noise, False))
         lib().memcpy_d2d(stream(), inputs.ptr + half * rowlen * 4, samples.ptr, half * rowlen * 4)
         S._last_fake = samples.clone() if S.keep_outputs else samples
@@ -218,7 +218,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
                 ev_fork.record()
                 side.wait_event(ev_fork)
                 with torch.cuda.stream(side):
-                    st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.createNoiseInputs(S, N)
+                    st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.stepNoiseInputs(S, N)
                     st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
                     ev_join.record()
                 st["join"] = ev_join
@@ -234,7 +234,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         if st["overlap"]:
             fD, gD = fevalD(S.PARAMETERS_D)
             if "samples_pre" not in st:
-                st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.createNoiseInputs(S, N)
+                st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.stepNoiseInputs(S, N)
                 st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
             st.pop("pendingD").finish()
             getattr(optim, m)(lambda _x: (fD, gD), S.PARAMETERS_D, S.OPTSTATE[m]["D"], fused=fused)
@@ -246,7 +246,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
     # ----------------------------------------------------------------- (2) update G (:253-266)
     for _ in range(OPT["G_iterations"]):
         if "samples_pre" not in st:
-            st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.createNoiseInputs(S, N)
+            st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.stepNoiseInputs(S, N)
         # upstream multiplies the L1 sign term by G_L2 (:206): keep that in the fused form too
         fused = dict(l1=OPT["G_L2"] if OPT["G_L1"] != 0 or OPT["G_L2"] != 0 else 0.0, l2=OPT["G_L2"],
                      clamp=OPT["G_clamp"]) if OPT["fused_update"] else None
@@ -290,15 +290,37 @@ class GraphedIteration:
         torch.cuda.synchronize()
         ts = {k: S.OPTSTATE["adam"][k]["t"] for k in ("D", "G")}
         self.exec = ctypes.c_void_p()
+        # The capture goes through hipStreamBeginCapture directly (not torch.cuda.graph, which would give it a private memory pool):
+        # an allocation made while capturing would have its address baked into the graph while torch's caching allocator stays free
+        # to hand the block to someone else.  The warm-up passes above exist so that nothing allocates here - and this is checked,
+        # not assumed: torch's allocation counter and every plan's buffer count must not move across the capture.
+        assert not getattr(S, "keep_outputs", False), "GraphedIteration: keep_outputs clones tensors inside the step; switch it off"
+        before = self._alloc_marks()
         with torch.cuda.stream(self.stream):
             lib().graph_begin(stream())
             try:
                 self._body()
             finally:
                 lib().graph_end(stream(), ctypes.byref(self.exec))
+        after = self._alloc_marks()
+        if after != before:
+            lib().graph_destroy(self.exec)
+            self.exec = ctypes.c_void_p()
+            raise RuntimeError(f"GraphedIteration: device memory was allocated while the iteration was being captured (torch "
+                               f"allocations / plan buffers {before} -> {after}); the graph would replay on addresses the allocator "
+                               f"may reuse.  Run more warm-up iterations or find the late allocation.")
         for k in ("D", "G"):   # capture launched nothing: the host step count must not move (it is what a checkpoint stores)
             S.OPTSTATE["adam"][k]["t"] = ts[k]
         self.replays = 0
+
+    @staticmethod
+    def _alloc_marks():
+        """(allocations torch's caching allocator has served so far, buffers every live plan owns)"""
+        from . import planned
+        st = torch.cuda.memory_stats()
+        nblocks = sum(len(pn.blocks) for pn in planned.LIVE)
+        nbytes = sum(pn.stats()["bytes"] for pn in planned.LIVE)
+        return (int(st.get("allocation.all.allocated", 0)), nblocks, int(nbytes))
 
     def _body(self):
         r = rng()

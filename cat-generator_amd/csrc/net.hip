@@ -211,6 +211,7 @@ struct Net {
     Prog* last = nullptr;                      // plan of the most recent forward (what backward continues)
     vector<hipStream_t> side; vector<hipEvent_t> side_ev; hipEvent_t fork_ev = nullptr;
     hipEvent_t pack_fork_ev = nullptr, pack_ev = nullptr;   // weight re-packing beside the head of the forward pass (sync_packs)
+    hipEvent_t wg_fork_ev[4] = {nullptr, nullptr, nullptr, nullptr}, wg_join_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // weight-gradient streams (option wgrad_stream)
     alloc_fn_t alloc_fn = nullptr; void* alloc_user = nullptr;
     hook_fn_t hook = nullptr; void* hook_user = nullptr;
     void *comm_bn = nullptr, *comm_grad = nullptr; int world = 1; int sync_bn = 1; int bucket_overlap = 0;
@@ -221,7 +222,7 @@ struct Net {
     bool fresh_allocs = false;                 // library-owned buffers were allocated + zeroed since the last device synchronise
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
-        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1;
+        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 1;
     long wino_min_tiles = 2048;
     std::string trace_log;
     const KTable* K = &kRealTable;
@@ -231,7 +232,7 @@ struct Net {
 
 struct Run {
     Net* net; Prog* pr;
-    hipStream_t st[4];
+    hipStream_t st[8];                          // [0] the caller's, [1..3] side streams of branch groups, [4 + s] the weight-gradient stream beside stream s
     const float* x = nullptr; const float* gy = nullptr;
     uint64_t seed = 0, roff = 0; const uint64_t* rbase = nullptr;
     float scale = 1.f;
@@ -302,7 +303,8 @@ struct Compiler {
     long rng = 0;            // counter-stream draws so far, relative to the pass's start
     int dry = 0;             // > 0: shape / draw bookkeeping only (no allocation, no ops, no module state kept)
     bool failed = false;
-    int pend[4] = {0, 0, 0, 0};   // deferred weight-gradient reductions queued per stream index
+    int pend[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // deferred weight-gradient reductions queued per stream index
+    bool wg_used[4] = {false, false, false, false};   // the weight-gradient stream beside stream s has work to join
     bool acc_pass = false;        // compiling Module:backward (weight gradients deferred) rather than updateGradInput
 
     Compiler(Net* n, Prog* p) : net(n), pr(p) {}
@@ -1313,6 +1315,8 @@ struct Compiler {
         });
         if (acc) {
             // weight gradients of the four layers on the GEMM path (grouped over the sibling branches), reductions deferred
+            wg_fork();
+            const int s_ = wg_enter();
             struct W { int li; Val x, dy; Geo g; };
             const W ws_[4] = {
                 {1, pooled, ga1, Geo{(int)N, (int)S_, (int)S_, (int)Cin, 16, 3, 3, 1, 1, 0}},
@@ -1342,6 +1346,7 @@ struct Compiler {
                     return k->conv2d_wgrad_grouped(c.CS(), G, x, d_, gw, gb, GEO(wv.g), c.scale, c.W(), c.WB());
                 });
             }
+            wg_leave(s_);
         }
         vector<Val> outs = G == 1 ? vector<Val>{gx} : split(gx, G);
         for (int b = 0; b < G; ++b) S(*qs[b]).gin = outs[b];
@@ -1402,6 +1407,47 @@ struct Compiler {
         const KTable* k = K();
         emit([=](Run& c) { return k->conv2d_wgrad_flush(c.CS()); });
         pend[cs] = 0;
+    }
+    // ---- weight gradients beside the data-gradient chain (option wgrad_stream).  accGradParameters of a layer reads the layer's saved
+    // input and its gradOutput, and nothing before the optimiser step (or the layer's gradient bucket) reads what it writes; the data
+    // gradient is what every layer in front of it waits for.  So in Module:backward the weight-gradient launches (GEMM, partial
+    // reductions, the Winograd-domain path, the localisation nets' four) go to stream 4 + s, forked from stream s at the point where
+    // gradOutput is complete, and are joined into stream 0 once, at the end of the pass.  The launch-bound kernels between two data
+    // gradients (BN backward sums, activation / pooling backward, sampler and localisation backward) then run under a GEMM instead of
+    // alone on the chip (profiles/r04_wgrad_stream_ab.txt).
+    bool wg_on() const { return net->wgrad_stream && net->fusion && acc_pass && !dry && cs < 4; }
+    void wg_fork() {   // call on stream s where the gradOutput the weight gradient reads is complete
+        if (!wg_on()) return;
+        const int s = cs;
+        emit([=](Run& c) { return c.net->trace ? (trace_note(c.net, "event|record|wgfork" + std::to_string(s) + "|s" + std::to_string(s)), 0)
+                                                : (hipEventRecord(c.net->wg_fork_ev[s], (hipStream_t)c.S(s)) == hipSuccess ? 0 : 1); });
+    }
+    int wg_enter() {   // later launches go to the weight-gradient stream; returns the stream index to hand back to wg_leave
+        const int s = cs;
+        if (!wg_on()) return s;
+        use_stream(4 + s);
+        cs = 4 + s;
+        emit([=](Run& c) { return c.net->trace ? (trace_note(c.net, "event|wait|wgfork" + std::to_string(s) + "|s" + std::to_string(4 + s)), 0)
+                                                : (hipStreamWaitEvent((hipStream_t)c.S(4 + s), c.net->wg_fork_ev[s], 0) == hipSuccess ? 0 : 1); });
+        wg_used[s] = true;
+        return s;
+    }
+    void wg_leave(int s) { cs = s; }
+    void wg_join_all() {   // end of the pass: reductions still queued on the weight-gradient streams, then stream 0 waits for them
+        if (dry) return;
+        const int back = cs;
+        for (int s = 0; s < 4; ++s) {
+            if (!wg_used[s]) continue;
+            cs = 4 + s;
+            flush_wgrad();
+            emit([=](Run& c) { return c.net->trace ? (trace_note(c.net, "event|record|wgjoin" + std::to_string(s) + "|s" + std::to_string(4 + s)), 0)
+                                                    : (hipEventRecord(c.net->wg_join_ev[s], (hipStream_t)c.S(4 + s)) == hipSuccess ? 0 : 1); });
+            cs = 0;
+            emit([=](Run& c) { return c.net->trace ? (trace_note(c.net, "event|wait|wgjoin" + std::to_string(s) + "|s0"), 0)
+                                                    : (hipStreamWaitEvent((hipStream_t)c.S(0), c.net->wg_join_ev[s], 0) == hipSuccess ? 0 : 1); });
+            wg_used[s] = false;
+        }
+        cs = back;
     }
     long count_draws(Mod& m, const Val& in) {   // counter-stream draws of one forward of `m` (no launches, no state kept)
         Prog tmp; tmp.net = net;
@@ -1698,8 +1744,9 @@ struct Compiler {
             return table_sum(m, gs);
         }
         case K_LINEAR: case K_CONV: {
+            if (acc) wg_fork();
             Val gi = dgrad(m, go);
-            if (acc) wgrad(m, go);
+            if (acc) { const int s_ = wg_enter(); wgrad(m, go); wg_leave(s_); }
             return gi;
         }
         case K_PRELU: {
@@ -2038,6 +2085,7 @@ struct Compiler {
             const Geo g = gin[0].g;
             ws_need(cg_conv2d_workspace_bytes_grouped(G, GEO(g)));
             vector<Mod*> ms_ = mods;
+            if (acc) wg_fork();
             emit([=](Run& c) {
                 const float *x[4], *w[4]; float* y[4];
                 for (int b = 0; b < G; ++b) { x[b] = c.P(gin[b].x); w[b] = wsel(ms_[b], gin[b].wsel); y[b] = c.P(gin[b].out); }
@@ -2046,6 +2094,7 @@ struct Compiler {
             vector<Val> outs;
             for (int b = 0; b < G; ++b) { S(*mods[b]).gin = gin[b].out; outs.push_back(gin[b].out); }
             if (acc) {
+                const int s_ = wg_enter();
                 vector<PrepAcc> ap;
                 for (int b = 0; b < G; ++b) ap.push_back(prep_acc(*mods[b], gouts[b]));
                 const Geo ga = ap[0].g;
@@ -2064,6 +2113,7 @@ struct Compiler {
                     if (defer) return k->conv2d_wgrad_grouped_deferred(c.CS(), G, x, d_, gw, gb, GEO(ga), c.scale, wsp, wsb);
                     return k->conv2d_wgrad_grouped(c.CS(), G, x, d_, gw, gb, GEO(ga), c.scale, c.W(), c.WB());
                 });
+                wg_leave(s_);
             }
             return outs;
         }
@@ -2209,7 +2259,11 @@ void Compiler::bucket_done(int first_module) {
     for (int t = bucket_done_upto - 1; t >= first_module; --t) {
         for (size_t bi = 0; bi < pr->bucket_first.size(); ++bi) {
             if (pr->bucket_first[bi] != t) continue;
-            flush_wgrad();   // the bucket's weight gradients may still be queued as deferred reductions
+            // the bucket's weight gradients are on the weight-gradient stream (behind everything this stream has issued: fork here), maybe
+            // still queued as deferred reductions; its collective starts from there
+            wg_fork();
+            const int s_ = wg_enter();
+            flush_wgrad();
             float* ptr = pr->buckets[bi].first; const long cnt = pr->buckets[bi].second;
             emit([=](Run& c) -> int {
                 Net* n = c.net;
@@ -2222,6 +2276,7 @@ void Compiler::bucket_done(int first_module) {
                 if (n->hook) return n->hook(n->hook_user, HOOK_BUCKET_START, ptr, (size_t)cnt, 0, c.CS()) ? cg::fail("cg_net: the host hook failed (gradient bucket of %ld elements)", cnt) : 0;
                 return cg::fail("cg_net: bucketed all-reduce without a communicator or host hook");
             });
+            wg_leave(s_);
         }
     }
     bucket_done_upto = first_module;
@@ -2263,10 +2318,21 @@ int ensure_streams(Net* n, int nstreams) {
     if (n->trace) return 0;
     while ((int)n->side.size() < nstreams - 1) {
         hipStream_t s; hipEvent_t e;
-        CG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        const int idx = (int)n->side.size() + 1;
+        if (idx >= 4 && n->wgrad_prio) {   // weight-gradient streams: lowest priority, the data-gradient chain is what the pass waits for
+            int least = 0, greatest = 0;
+            CG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            CG_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
+        } else
+            CG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         CG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         n->side.push_back(s); n->side_ev.push_back(e);
     }
+    for (int t = 0; t < 4 && nstreams > 4; ++t)
+        if (!n->wg_fork_ev[t]) {
+            CG_HIP(hipEventCreateWithFlags(&n->wg_fork_ev[t], hipEventDisableTiming));
+            CG_HIP(hipEventCreateWithFlags(&n->wg_join_ev[t], hipEventDisableTiming));
+        }
     if (!n->fork_ev) CG_HIP(hipEventCreateWithFlags(&n->fork_ev, hipEventDisableTiming));
     if (!n->pack_ev) {
         CG_HIP(hipEventCreateWithFlags(&n->pack_fork_ev, hipEventDisableTiming));
@@ -2278,11 +2344,11 @@ int ensure_streams(Net* n, int nstreams) {
 void fill_run(Net* n, Prog* pr, Run& c, void* stream) {
     c.net = n; c.pr = pr;
     c.st[0] = (hipStream_t)stream;
-    for (int t = 1; t < 4; ++t) {
+    for (int t = 1; t < 8; ++t) {
         if (n->trace) c.st[t] = (hipStream_t)(uintptr_t)(0x1000 + t);
         else c.st[t] = t - 1 < (int)n->side.size() ? n->side[t - 1] : (hipStream_t)stream;
     }
-    if (n->trace) { n->trace_streams.assign(4, nullptr); for (int t = 0; t < 4; ++t) n->trace_streams[t] = (void*)c.st[t]; if (!stream) n->trace_streams[0] = nullptr; }
+    if (n->trace) { n->trace_streams.assign(8, nullptr); for (int t = 0; t < 8; ++t) n->trace_streams[t] = (void*)c.st[t]; if (!stream) n->trace_streams[0] = nullptr; }
 }
 
 // join_before: index of the first op that needs the weights sync_packs re-packed on the side stream (-1: nothing pending)
@@ -2368,7 +2434,8 @@ std::string prog_key(Net* n, int nd, const long* dims, int fmt) {
     k += "|w" + std::to_string(n->world) + (n->sync_bn ? "s" : "-") + (n->bucket_overlap ? "b" : "-");
     k += "|o" + std::to_string(n->overlap_groups) + std::to_string(n->defer_wgrad) + std::to_string(n->winograd) + std::to_string(n->fusion) +
          std::to_string(n->stacking) + std::to_string(n->grouped) + std::to_string(n->share_pool) + std::to_string(n->sampler_shared) +
-         std::to_string(n->view_fuse) + std::to_string(n->cat_fuse) + std::to_string(n->fuse_locnet) + std::to_string(n->head_fuse) + "m" +
+         std::to_string(n->view_fuse) + std::to_string(n->cat_fuse) + std::to_string(n->fuse_locnet) + std::to_string(n->head_fuse) +
+         std::to_string(n->wgrad_stream) + "m" +
          std::to_string(n->wino_min_tiles);
     return k;
 }
@@ -2392,6 +2459,8 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_FUSE_LOCNET"))) n->fuse_locnet = atoi(e);
     if ((e = getenv("CG_PACK_OVERLAP"))) n->pack_overlap = atoi(e) != 0;
     if ((e = getenv("CG_HEAD_FUSE"))) n->head_fuse = atoi(e) != 0;
+    if ((e = getenv("CG_WGRAD_STREAM"))) n->wgrad_stream = atoi(e) != 0;
+    if ((e = getenv("CG_WGRAD_PRIO"))) n->wgrad_prio = atoi(e) != 0;
     *net = n;
     return 0;
 }
@@ -2404,6 +2473,7 @@ int cg_net_destroy(void* net) {
     for (auto e : n->side_ev) (void)hipEventDestroy(e);
     if (n->fork_ev) (void)hipEventDestroy(n->fork_ev);
     if (n->pack_ev) { (void)hipEventDestroy(n->pack_fork_ev); (void)hipEventDestroy(n->pack_ev); }
+    for (int t = 0; t < 4; ++t) if (n->wg_fork_ev[t]) { (void)hipEventDestroy(n->wg_fork_ev[t]); (void)hipEventDestroy(n->wg_join_ev[t]); }
     delete n;
     return 0;
 }
@@ -2415,7 +2485,7 @@ int cg_net_set_option(void* net, const char* name, long value) {
         {"overlap_groups", &n->overlap_groups}, {"defer_wgrad", &n->defer_wgrad}, {"winograd", &n->winograd}, {"share_pool", &n->share_pool},
         {"sampler_shared", &n->sampler_shared}, {"view_fuse", &n->view_fuse}, {"cat_fuse", &n->cat_fuse}, {"stacking", &n->stacking},
         {"grouped", &n->grouped}, {"fusion", &n->fusion}, {"fuse_locnet", &n->fuse_locnet}, {"pack_overlap", &n->pack_overlap},
-        {"head_fuse", &n->head_fuse}};
+        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}};
     if (!strcmp(name, "trace")) {
         CG_REQUIRE(n->progs.empty(), "cg_net_set_option: trace must be chosen before the first pass");
         n->trace = value != 0; n->K = n->trace ? &kTraceTable : &kRealTable;
@@ -2521,7 +2591,10 @@ int cg_net_forward(void* net, void* stream, const float* x, int nd, const long* 
     CG_REQUIRE(!n->mods.empty(), "cg_net_forward: empty net");
     const std::string key = prog_key(n, nd, dims, fmt);
     auto it = n->progs.find(key);
-    if (it != n->progs.end() && it->second->opt_epoch != cg::g_opt_epoch) { n->progs.erase(it); it = n->progs.end(); }   // cg_set_option moved the dispatch
+    if (it != n->progs.end() && it->second->opt_epoch != cg::g_opt_epoch) {   // cg_set_option moved the dispatch
+        if (n->last == it->second.get()) n->last = nullptr;   // a failed recompile must not leave backward a dangling plan
+        n->progs.erase(it); it = n->progs.end();
+    }
     if (it == n->progs.end()) {
         std::unique_ptr<Prog> pr(new Prog());
         pr->net = n; pr->opt_epoch = cg::g_opt_epoch;
@@ -2587,7 +2660,7 @@ int cg_net_backward(void* net, void* stream, const float* x, const float* gy, in
         Val go = pr->out; go.ext = EXT_GY; go.off = 0; go.p = nullptr; go.fmt = gy_fmt; go.blk = 0; go.gi = go.gc = 0;
         Val gi = root.kind == K_SEQ ? C.walk_back(root, pr->in, go, acc != 0, true) : C.bwd(root, pr->in, go, acc != 0);
         if (C.failed) return cg::fail("%s", n->err);
-        if (acc) C.flush_wgrad();
+        if (acc) { C.flush_wgrad(); C.wg_join_all(); }
         CG_REQUIRE(!gi.is_tab, "cg_net_backward: the root module's gradInput is a table");
         pr->gin[acc] = gi;
         pr->have_bwd[acc] = true;

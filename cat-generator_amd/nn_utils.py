@@ -13,13 +13,23 @@ from .tensor import Tensor, lib, rng, stream
 
 
 def createNoiseInputs(S, N):
-    """U(-1,1) noise [N, noiseDim], generated on the device from the engine's counter stream.  One persistent buffer per N (the
-    D-step's half batch and the G-step's full batch never share one): a captured iteration (cg_graph_*) must find its noise at
-    the same address on every replay, and nothing on the path keeps a noise tensor across two calls."""
+    """U(-1,1) noise [N, noiseDim] (utils/nn_utils.lua:35-39), generated on the device from the engine's counter stream.  A FRESH
+    tensor per call, as upstream: callers keep what they get (train.lua:220 holds VIS_NOISE_INPUTS for the whole run)."""
+    return _fill_noise(Tensor.empty((N, S.OPT["noiseDim"])))
+
+
+def stepNoiseInputs(S, N):
+    """The training iteration's private form of createNoiseInputs: one persistent buffer per N (the D-step's half batch and the
+    G-step's full batch never share one).  A captured iteration (cg_graph_*) must find its noise at the same address on every
+    replay, and the step itself never keeps a noise tensor across two calls; nothing outside adversarial.iteration may use this."""
     cache = S.__dict__.setdefault("_noise_bufs", {})
     t = cache.get(N)
     if t is None:
         t = cache[N] = Tensor.empty((N, S.OPT["noiseDim"]))
+    return _fill_noise(t)
+
+
+def _fill_noise(t):
     r = rng()
     lib().rng_uniform_dev(stream(), t.ptr, t.nElement(), -1.0, 1.0, r.seed, r.take(t.nElement()), r.base_ptr())
     return t

@@ -11,6 +11,7 @@ The per-module protocol (updateOutput / updateGradInput / accGradParameters on a
 what the reference's nn.Module API promises for any module used on its own - and doubles as the unfused reference the planned
 passes are tested against.
 """
+import contextlib
 import ctypes
 import os
 import weakref
@@ -78,8 +79,8 @@ def describe(m):
 class _Raw:
     """A device address as an array-interface object, so torch can view memory the library allocated."""
 
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    def __init__(self, ptr, n, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
 class PlannedNet:
@@ -146,15 +147,23 @@ class PlannedNet:
         return None
 
     def _hook(self, _user, what, buf, count, dtype, _stream):
-        """Transport of the plan's collectives when no cg_comm_* communicator is bound (gloo tests, CG_COMM=torch)."""
+        """Transport of the plan's collectives when no cg_comm_* communicator is bound (gloo tests, CG_COMM=torch).  The plan hands
+        over the HIP stream the exchange belongs on (a branch group's side stream, the weight-gradient stream a bucket's gradients
+        were produced on): torch's collective is issued with that stream current, so it is ordered against the kernels that produce
+        and consume the buffer."""
         try:
-            t = self._view(buf, count, torch.float64 if dtype == 1 else torch.float32)
-            if what == 0:
-                assert t is not None, "sync-BN sums live in the plan's own buffers"
-                parallel.allreduce_sum_torch(t)
-            else:
-                g = self._grad_view(buf, count)
-                self.pending.append(parallel.allreduce_mean_async_torch(g))
+            ctx = contextlib.nullcontext()
+            if _stream and torch.cuda.is_available() and int(_stream) != int(stream() or 0):
+                ctx = torch.cuda.stream(torch.cuda.ExternalStream(int(_stream)))
+            with ctx:
+                if what == 0:
+                    t = self._view(buf, count, torch.float64 if dtype == 1 else torch.float32)
+                    if t is None:      # the library's own allocator (CG_NET_ALLOC=lib): wrap the raw device address
+                        t = torch.as_tensor(_Raw(buf, count, "<f8" if dtype == 1 else "<f4"), device=device())
+                    parallel.allreduce_sum_torch(t)
+                else:
+                    g = self._grad_view(buf, count)
+                    self.pending.append(parallel.allreduce_mean_async_torch(g))
             return 0
         except Exception as e:   # no exception may cross the C ABI
             import traceback

@@ -19,7 +19,9 @@ CASES = [("G32up-c", 8), ("G32up", 16), ("D32_st3", 8), ("G32up-c@64", 4), ("D32
 def text(which, N):
     # one stream, and the localisation nets as separate modules (the configuration the deleted executor was compared in; the fused
     # localisation launches of csrc/locnet.hip came later and are covered by structure tests + the GPU parity suite)
-    r = T.trace(which, N, options=[("overlap_groups", 0), ("fuse_locnet", 0), ("pack_overlap", 0), ("head_fuse", 0)])
+    # ... and the weight gradients in line on the one stream (option wgrad_stream, round 4, moves them beside the data-gradient chain:
+    # same launches, other stream - tests/test_net_plan.py::test_weight_gradients_run_beside_the_data_gradient_chain)
+    r = T.trace(which, N, options=[("overlap_groups", 0), ("fuse_locnet", 0), ("pack_overlap", 0), ("head_fuse", 0), ("wgrad_stream", 0)])
     out = [f"# {which} batch {N}: draws {r['draws']}"]
     for phase in ("forward", "backward", "updateGradInput"):
         out.append(f"## {phase}")

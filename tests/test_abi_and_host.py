@@ -108,3 +108,20 @@ def test_host_rng_is_the_oracle_stream(cg):
     np.testing.assert_array_equal(r.u01(17), O.u01(17, 77, 1000))
 
 
+
+
+def test_generated_tables_are_fresh(tmp_path):
+    """cat-generator_amd/csrc/net_ktable.inc and tools/abi_dispatch.inc are GENERATED from include/catgan.h by build.py (they are
+    not tracked): what the built library / tools/abi_replay were compiled from must be what the generators produce from the header
+    as it stands, or a stale table would shadow an entry point that changed."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script, rel in (("gen_net_ktable.py", "cat-generator_amd/csrc/net_ktable.inc"), ("gen_abi_dispatch.py", "tools/abi_dispatch.inc")):
+        have = os.path.join(root, rel)
+        assert os.path.exists(have), f"{rel} missing: run python __graft_entry__.py (build.py generates it)"
+        spec = importlib.util.spec_from_file_location(script[:-3], os.path.join(root, "scripts", script))
+        gen = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gen)
+        out = tmp_path / os.path.basename(rel)
+        gen.main(str(out))
+        assert open(have).read() == out.read_text(), f"{rel} is stale against include/catgan.h: rebuild"

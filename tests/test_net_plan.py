@@ -70,9 +70,11 @@ def test_segments_and_lockstep_branches_of_the_discriminator():
     bn = [c[0] for c in T.calls(b)]
     assert bn[0] == "cg_drop_linear_sigmoid_backward" and bn.count("cg_split_channels_masked") == 1 and "cg_split_channels" not in bn
     assert "cg_sigmoid_backward" not in bn and "cg_mask_mul" not in bn
+    # (the weight-gradient launches and their flushes sit on s4 / s5 beside the two branch groups' streams s0 / s1: next test)
     assert len(T.calls(b, "cg_conv2d_wgrad_flush")) == 2 and not T.calls(b, "cg_conv2d_wgrad")
-    assert {a["stream"] for _, a in T.calls(b, "cg_conv2d_wgrad_flush")} == {"s0", "s1"}
-    assert b[-1].startswith("call|cg_conv2d_wgrad_flush|s0")
+    assert {a["stream"] for _, a in T.calls(b, "cg_conv2d_wgrad_flush")} == {"s4", "s5"}
+    assert b[-6:] == [b[-6], "event|record|wgjoin0|s4", "event|wait|wgjoin0|s0", b[-3], "event|record|wgjoin1|s5", "event|wait|wgjoin1|s0"]
+    assert b[-6].startswith("call|cg_conv2d_wgrad_flush|s4") and b[-3].startswith("call|cg_conv2d_wgrad_flush|s5")
     assert len(T.calls(b, "cg_bilinear_sampler_backward_shared")) == 1
     assert len(T.calls(b, "cg_prelu_backward_grouped")) == 1      # the PReLUs behind the branches' second convolutions (the first ones are inside act_pool)
     lb = T.calls(b, "cg_locnet_backward")
@@ -80,13 +82,14 @@ def test_segments_and_lockstep_branches_of_the_discriminator():
     # each localisation backward is followed by the four weight gradients of its layers (conv1, conv2, linear1, linear2)
     for i, l in enumerate(b):
         if "cg_locnet_backward" in l:
-            assert all("cg_conv2d_wgrad_grouped_deferred" in x for x in b[i + 1:i + 5])
+            assert b[i + 1].startswith("event|record|wgfork") and b[i + 2].startswith("event|wait|wgfork")
+            assert all("cg_conv2d_wgrad_grouped_deferred" in x for x in b[i + 3:i + 7])
     # updateGradInput only (fevalG_on_D's pass through D, adversarial.lua:192-193): no weight gradient of any kind
     u = r["updateGradInput"]
     assert not [c for c in T.calls(u) if "wgrad" in c[0]]
     hb = T.calls(u, "cg_drop_linear_sigmoid_backward")[0][1]
     assert hb["gw"] == "n" and hb["gb"] == "n"
-    assert r["stats"]["launches_forward"] <= 23 and r["stats"]["launches_backward"] <= 44
+    assert r["stats"]["launches_forward"] <= 23 and len(T.calls(b)) <= 44 and r["stats"]["launches_backward"] <= 66   # ops: launches + stream events
     # head_fuse 0: the modules of the head one by one, every draw at the same position of the counter stream
     rh = T.trace("D32_st3", 128, options=[("head_fuse", 0)])
     assert rh["draws"] == r["draws"]
@@ -109,6 +112,7 @@ def test_generator_plan_uses_epilogue_statistics_and_winograd_at_the_benchmarked
     b = [c[0] for c in T.calls(r["backward"])]
     assert b.count("cg_conv2d_ups2_wino_dgrad") == 1 and b.count("cg_conv2d_ups2_wino_wgrad") == 1
     assert b.count("cg_conv2d_dgrad_ups2") == 2 and b.count("cg_bn_act_backward") == 3 and b[-1] == "cg_conv2d_wgrad_flush"
+    assert r["backward"][-2:] == ["event|record|wgjoin0|s4", "event|wait|wgjoin0|s0"]
     small = [c[0] for c in T.calls(T.trace("G32up-c", 8)["forward"])]
     assert "cg_conv2d_ups2_wino_forward_stats" not in small        # below 2048 tiles the direct phase kernels run
 
@@ -233,9 +237,58 @@ def test_data_parallel_exchanges_sit_inside_the_plan():
     assert offs == [lin + c1 + c2 + c3, lin + c1 + c2, lin + c1, lin, 0]
     for i, _ in buckets[:-1]:
         # complete gradients: the deferred reductions flushed, or the layer's own immediate (Winograd-domain) weight gradient
-        assert "cg_conv2d_wgrad_flush" in b[i - 1] or "cg_conv2d_ups2_wino_wgrad" in b[i - 1] or b[i - 1].startswith("hook|")
+        # (on the weight-gradient stream s4, which first takes up everything s0 has issued: BN / PReLU gradients of the bucket)
+        prev = [l for l in b[:i] if not l.startswith("event|")][-1]
+        assert "cg_conv2d_wgrad_flush|s4" in prev or "cg_conv2d_ups2_wino_wgrad|s4" in prev or prev.startswith("hook|")
+        assert b[i - 1] == "event|wait|wgfork0|s4" or "cg_conv2d_wgrad_flush|s4" in b[i - 1]
     for (i0, _), (i1, _) in zip(buckets, buckets[1:]):                                   # the next layer's backward runs under the bucket
         assert sum(1 for l in b[i0:i1] if l.startswith("call|")) >= 3
+
+
+@pytest.mark.parametrize("which,N", [("D32_st3", 128), ("G32up-c", 128), ("G32up", 256), ("D32_st3@64", 64)])
+def test_weight_gradients_run_beside_the_data_gradient_chain(which, N):
+    """Option wgrad_stream (default on): Module:backward issues every accGradParameters launch - GEMM, Winograd-domain, the
+    localisation nets' four, the deferred reductions - on stream 4 + s, forked from stream s where the layer's gradOutput is complete
+    and joined into s0 once, at the end of the pass.  Nothing else changes: with the stream column and the fork / join events removed
+    the plan IS the in-line plan (wgrad_stream 0, the configuration the golden sequences hold) up to the position of the launches
+    that moved, and no data-gradient launch waits for a weight gradient."""
+    r1 = T.trace(which, N)
+    r0 = T.trace(which, N, options=[("wgrad_stream", 0)])
+    b1, b0 = r1["backward"], r0["backward"]
+    is_w = lambda l: l.startswith("call|cg_conv2d_wgrad") or l.startswith("call|cg_conv2d_ups2_wino_wgrad")
+    # same launches, same arguments (workspace of the stream aside), same relative order within the weight gradients and within the rest
+    def strip(l):
+        f = l.split("|")
+        f[2] = "s"
+        return "|".join(f)
+    calls1 = [l for l in T.canon(b1) if l.startswith("call|")]
+    calls0 = [l for l in T.canon(b0) if l.startswith("call|")]
+    nonflush = lambda ls: [strip(l) for l in ls if "wgrad_flush" not in l]
+    assert sorted(nonflush(calls1)) == sorted(nonflush(calls0))
+    assert [strip(l) for l in calls1 if not is_w(l)] == [strip(l) for l in calls0 if not is_w(l)]
+    assert nonflush([l for l in calls1 if is_w(l)]) == nonflush([l for l in calls0 if is_w(l)])
+    # where they run
+    w1 = [l.split("|")[2] for l in b1 if is_w(l)]
+    assert w1 and set(w1) <= {"s4", "s5"} and not [l for l in b1 if l.startswith("call|") and not is_w(l) and l.split("|")[2] in ("s4", "s5")]
+    assert all(l.split("|")[2] in ("s0", "s1") for l in b0 if is_w(l))
+    # every weight-gradient launch on s(4+k) is behind a wait on the fork event recorded on s(k) AFTER the launch that produced its
+    # gradOutput; the pass ends by joining the weight-gradient streams into s0
+    last_fork = {}
+    for l in b1:
+        f = l.split("|")
+        if f[0] == "event" and f[2].startswith("wgfork"):
+            if f[1] == "record":
+                last_fork[f[2]] = "recorded"
+            else:
+                assert last_fork.get(f[2]) == "recorded" and f[3] == "s%d" % (4 + int(f[2][-1]))
+                last_fork[f[2]] = "waited"
+    joins = [l for l in b1 if l.startswith("event|") and "wgjoin" in l]
+    assert joins and b1[-1] == joins[-1] and all(j.endswith("|s0") for j in joins if "|wait|" in j)
+    for k in {s[1] for s in set(w1)}:
+        assert "event|record|wgjoin%d|s%s" % (int(k) - 4, k) in b1
+    # updateGradInput (no weight gradients) is untouched
+    assert T.canon(r1["updateGradInput"]) == T.canon(r0["updateGradInput"]) and not [l for l in r1["updateGradInput"] if "wgfork" in l or "wgjoin" in l]
+    assert T.canon(r1["forward"]) == T.canon(r0["forward"])
 
 
 def test_per_module_walk_is_still_the_protocol():
