@@ -271,17 +271,21 @@ def main():
         except Exception as e:  # capture is an optimisation, not a requirement
             launch = f"eager (graph capture failed: {type(e).__name__}: {str(e)[:160]})"
             step = lambda: cg.adversarial.iteration(S, data)
-    for _ in range(args.warmup):
-        step()
-    cg.parallel.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
+    # experiment switch (profiles/r04_wgrad_stream_ab.txt): run the step on a stream of the given HIP priority (-1 = high)
+    prio = os.environ.get("CG_BENCH_STREAM_PRIO")
+    run_stream = torch.cuda.Stream(priority=int(prio)) if prio else torch.cuda.current_stream()
+    with torch.cuda.stream(run_stream):
+        for _ in range(args.warmup):
+            step()
+        cg.parallel.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(args.steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
     cg.parallel.barrier()
     dt = time.perf_counter() - t0
     if world > 1:   # MAX over ranks on the host channel

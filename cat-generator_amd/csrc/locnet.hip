@@ -403,6 +403,454 @@ __global__ __launch_bounds__(NT) void locnet_bwd_k(LocBwd a) {
     }
 }
 
+
+// ================================================================================================ round 4: the same chain on the MFMA
+// The kernels above keep one sample's maps AND kernels in ~100 KB of LDS (one workgroup of 768 threads per CU, the 384 samples of
+// the three branch transformers in 1.5 rounds) and run the two convolutions at VALU + LDS-read rates with the nine taps split over
+// threads whose partial sums meet in LDS: 114 us forward / 116-166 us backward for the three-branch launch at batch 128, ~0.01 of any
+// roofline (profiles/r03_locnet_phases.txt).  Here, for the shapes D32_st3 uses at 32x32 (S 16 / 3 planes; S 8 / 64 planes):
+//   * both convolutions are implicit GEMMs on v_mfma_f32_16x16x4_f32 (M = 16 pixels, N = the 16 output planes, K = 4 input planes of
+//     one tap per instruction): the A operand is ONE ds_read_b32 per lane out of a zero-haloed [(S+2)^2][C + 2] image - no bounds
+//     test, the tap a compile-time address offset, pixel stride = 2 (mod 32) so that 16 pixels x 2 K-lanes fill 32 distinct banks -
+//     and the B operand (the packed kernel) sits in REGISTERS: each wave loads its 36 fragments straight from L2 at the top of the
+//     kernel, before the input is even pooled.  No kernel copy in LDS, no tap split, no partial-sum round trip (the 64-plane first
+//     convolution splits its INPUT PLANES over the four waves instead: 36 K-steps each, one fixed-order 4-term sum at the end);
+//   * a workgroup is 4 waves and 30-50 KB of LDS: 3-5 samples share a CU, so the launch is one round and the dependent phases of one
+//     sample (global load -> pool -> conv -> conv -> pool -> 2 linear layers -> grid) hide under the others';
+//   * the 16 K3 x 64 linear layer streams its rows as 16-byte loads, 4-8 rows in flight per wave, against register-held input.
+// Buffers, layouts and entry points are unchanged (the weight gradients stay on the GEMM path); sums re-associate within fp32
+// (K-steps of 4 input planes accumulate in tap order).  cg_set_option("CG_LOCNET_V1") / environment CG_LOCNET_V1=1 selects the VALU kernels.
+namespace v2 {
+
+constexpr int NW = 4, NT2 = 64 * NW;
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int S_, int CIN_> struct Cfg {
+    static constexpr int S = S_, CIN = CIN_, S2 = S * S, SP = S + 2, NP = SP * SP, MT = S2 / 16;
+    static constexpr int CK1 = (CIN + 3) & ~3;          // input planes per tap as GEMM K (zero-padded to the K-step)
+    static constexpr int CP1 = CK1 + 2, CP2 = LC + 2;   // LDS pixel strides: = 2 (mod 4), 6 / 18 / 66 fill the 32 banks of a ds_read_b32 group
+    static constexpr bool KSPLIT = CIN >= 4 * NW * 4;   // conv 1: input planes over the waves (else: M tiles over the waves)
+    static constexpr int NCH1 = KSPLIT ? CK1 / (4 * NW) : CK1 / 4;   // K-steps per tap a wave runs in conv 1
+    static constexpr int NMT1 = KSPLIT ? MT : MT / NW;  // M tiles per wave in conv 1
+    static constexpr int NMT2 = MT / NW;                // ... in conv 2 (M split)
+    static constexpr int Sh = S / 2, K3 = LC * Sh * Sh;
+    static constexpr int RS = 20;                        // row stride of the K-split partials
+    static_assert(MT % NW == 0 && (S & (S - 1)) == 0, "shape");
+    // forward LDS (floats)
+    static constexpr int F_P = 0, F_H1 = F_P + NP * CP1, F_M2 = F_H1 + NP * CP2, F_H2 = F_M2 + S2 * (LC + 1), F_H3 = F_H2 + K3, F_PRM = F_H3 + LH,
+                         F_TOT = F_PRM + 8;
+    static constexpr int F_RED = F_P;                    // the K-split partials reuse the pooled input's image once every wave is through with it
+    static_assert(!KSPLIT || NW * S2 * RS <= NP * CP1, "partials fit the input image");
+    // backward
+    static constexpr bool NSPLIT = CIN >= 16 * NW;      // conv 1 data gradient: output (= the layer's input) planes over the waves
+    static constexpr int CQ = (CIN + 3) & ~3;
+    static constexpr int B_GA2 = 0, B_GA1 = B_GA2 + NP * CP2, B_GP = B_GA1 + NP * CP2, B_GH2 = B_GP + S2 * (CQ + 1), B_G3 = B_GH2 + K3,
+                         B_G4 = B_G3 + LH, B_TOT = B_G4 + 8;
+    static_assert((NP * CP1) % 4 == 0 && (NP * CP2) % 4 == 0 && (S2 * (LC + 1)) % 4 == 0, "16-byte sections");
+};
+
+__device__ __forceinline__ int pp(int pix, int S, int SP) { return ((pix / S) + 1) * SP + (pix % S) + 1; }   // S: compile-time power of two
+
+// acc[m] += A_m (16 pixels x 4 planes) * B (4 planes x 16) over 9 taps x NCH K-steps.  in: zero-haloed LDS image, pixel stride CP;
+// ab[m]: this lane's element of tile m at tap (0,0), plane kq (+ the wave's plane offset); b: this lane's B elements, [tap][K-step].
+template <int NMT, int NCH, int CP, int SP>
+__device__ __forceinline__ void conv_mfma(const float* in, const int (&ab)[NMT], const float (&b)[9 * NCH], f4 (&acc)[NMT]) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int toff = ((t / 3 - 1) * SP + (t % 3 - 1)) * CP;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+#pragma unroll
+            for (int m = 0; m < NMT; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(in[ab[m] + toff + 4 * j], b[t * NCH + j], acc[m], 0, 0, 0);
+        }
+    }
+}
+
+// B fragments of a 16 -> 16 convolution from a packed copy w[(tap*16 + k)][16]: lane (n = l & 15, kq = l >> 4) takes w[(t*16 + 4j + kq)][n]
+__device__ __forceinline__ void load_b16(const float* __restrict__ w, int lane, float (&b)[36]) {
+    const int n = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[t * 4 + j] = w[((t * LC + 4 * j + kq) * LC) + n];
+}
+
+template <int S, int CIN>
+__global__ __launch_bounds__(NT2) void locnet_fwd2_k(LocFwd a) {
+    using C = Cfg<S, CIN>;
+    extern __shared__ float sm[];
+    float *pP = sm + C::F_P, *h1P = sm + C::F_H1, *m2 = sm + C::F_M2, *red = sm + C::F_RED, *h2 = sm + C::F_H2, *h3 = sm + C::F_H3, *prm = sm + C::F_PRM;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    const int smp = blockIdx.x, g = smp / a.N, ns = smp - g * a.N;
+    const LocW w = a.g[g];
+    const float sl = a.slope;
+    constexpr int S2 = C::S2, SP = C::SP;
+
+    // (0) B fragments of both convolutions: the first loads of the kernel, in flight while the input is pooled
+    float b1[9 * C::NCH1], b2[36];
+    if (C::KSPLIT) {
+        const int cb = (C::CK1 / NW) * wv;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < C::NCH1; ++j) b1[t * C::NCH1 + j] = w.wf1[((t * CIN + cb + 4 * j + kq) * LC) + n];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < C::NCH1; ++j) { const int ci = 4 * j + kq; b1[t * C::NCH1 + j] = ci < CIN ? w.wf1[((t * CIN + ci) * LC) + n] : 0.f; }
+    }
+    load_b16(w.wf2, lane, b2);
+    // (1) zero the haloed images (the interiors are overwritten below)
+    {
+        float4* z = reinterpret_cast<float4*>(sm);
+        for (int i = tid; i < C::F_M2 / 4; i += NT2) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    // (2) AvgPool(2,2,2,2) of the sample (cg_avgpool2_forward's order of additions)
+    {
+        const float* xs = a.x + (size_t)(a.x_shared ? ns : smp) * (4 * S2) * CIN;
+        float* pb = a.pbuf + (size_t)smp * S2 * CIN;
+        if (CIN % 4 == 0) {
+            constexpr int C4 = CIN / 4 > 0 ? CIN / 4 : 1;
+            for (int i = tid; i < S2 * C4; i += NT2) {
+                const int c4 = i % C4, pix = i / C4, px = pix % S, py = pix / S;
+                const float4* q = reinterpret_cast<const float4*>(xs + ((size_t)(2 * py) * (2 * S) + 2 * px) * CIN) + c4;
+                const float4 v0 = q[0], v1 = q[C4], v2 = q[2 * S * C4], v3 = q[2 * S * C4 + C4];
+                float4 v;
+                v.x = (v0.x + v1.x + v2.x + v3.x) * 0.25f; v.y = (v0.y + v1.y + v2.y + v3.y) * 0.25f;
+                v.z = (v0.z + v1.z + v2.z + v3.z) * 0.25f; v.w = (v0.w + v1.w + v2.w + v3.w) * 0.25f;
+                float2* d = reinterpret_cast<float2*>(pP + pp(pix, S, SP) * C::CP1 + 4 * c4);   // 8-byte aligned: CP1 is even
+                d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
+                reinterpret_cast<float4*>(pb)[i] = v;
+            }
+        } else {
+            for (int i = tid; i < S2 * CIN; i += NT2) {
+                const int c = i % CIN, pix = i / CIN, px = pix % S, py = pix / S;
+                const size_t b = ((size_t)(2 * py) * (2 * S) + 2 * px) * CIN + c;
+                const float v = (xs[b] + xs[b + CIN] + xs[b + (size_t)2 * S * CIN] + xs[b + (size_t)2 * S * CIN + CIN]) * 0.25f;
+                pP[pp(pix, S, SP) * C::CP1 + c] = v;
+                pb[i] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // (3) conv3x3 CIN -> 16, bias, LeakyReLU
+    {
+        f4 acc[C::NMT1];
+        int ab[C::NMT1];
+#pragma unroll
+        for (int m = 0; m < C::NMT1; ++m) {
+            acc[m] = (f4){0.f, 0.f, 0.f, 0.f};
+            const int mt = C::KSPLIT ? m : wv * C::NMT1 + m;
+            ab[m] = pp(mt * 16 + n, S, SP) * C::CP1 + kq + (C::KSPLIT ? (C::CK1 / NW) * wv : 0);
+        }
+        conv_mfma<C::NMT1, C::NCH1, C::CP1, SP>(pP, ab, b1, acc);
+        if (C::KSPLIT) {
+            __syncthreads();   // every wave has read its planes of the input image: the partials go on top of it
+#pragma unroll
+            for (int m = 0; m < C::NMT1; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(wv * S2 + m * 16 + kq * 4 + r) * C::RS + n] = acc[m][r];
+            __syncthreads();
+            for (int e = tid; e < S2 * LC; e += NT2) {
+                const int c = e & (LC - 1), pix = e >> 4;
+                float v = red[pix * C::RS + c];
+#pragma unroll
+                for (int q = 1; q < NW; ++q) v += red[(q * S2 + pix) * C::RS + c];     // fixed order
+                v = lrelu(v + w.b1[c], sl);
+                h1P[pp(pix, S, SP) * C::CP2 + c] = v;
+                a.h1buf[((size_t)smp * S2 + pix) * LC + c] = v;
+            }
+        } else {
+            const float bias = w.b1[n];
+#pragma unroll
+            for (int m = 0; m < C::NMT1; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pix = (wv * C::NMT1 + m) * 16 + kq * 4 + r;
+                    const float v = lrelu(acc[m][r] + bias, sl);
+                    h1P[pp(pix, S, SP) * C::CP2 + n] = v;
+                    a.h1buf[((size_t)smp * S2 + pix) * LC + n] = v;
+                }
+        }
+    }
+    __syncthreads();
+    // (4) conv3x3 16 -> 16, bias, LeakyReLU
+    {
+        f4 acc[C::NMT2];
+        int ab[C::NMT2];
+#pragma unroll
+        for (int m = 0; m < C::NMT2; ++m) {
+            acc[m] = (f4){0.f, 0.f, 0.f, 0.f};
+            ab[m] = pp((wv * C::NMT2 + m) * 16 + n, S, SP) * C::CP2 + kq;
+        }
+        conv_mfma<C::NMT2, 4, C::CP2, SP>(h1P, ab, b2, acc);
+        const float bias = w.b2[n];
+#pragma unroll
+        for (int m = 0; m < C::NMT2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pix = (wv * C::NMT2 + m) * 16 + kq * 4 + r;
+                const float v = lrelu(acc[m][r] + bias, sl);
+                m2[pix * (LC + 1) + n] = v;
+                a.m2buf[((size_t)smp * S2 + pix) * LC + n] = v;
+            }
+    }
+    __syncthreads();
+    // (5) AvgPool(2); i = (c, py, px): nn.View(16*h*h) flattens the NCHW map
+    for (int i = tid; i < C::K3; i += NT2) {
+        const int px = i % C::Sh, py = (i / C::Sh) % C::Sh, c = i / (C::Sh * C::Sh);
+        const float* q = m2 + ((2 * py) * S + 2 * px) * (LC + 1) + c;
+        const float pv = (q[0] + q[LC + 1] + q[S * (LC + 1)] + q[(S + 1) * (LC + 1)]) * 0.25f;
+        h2[i] = pv;
+        a.h2buf[(size_t)smp * C::K3 + i] = pv;
+    }
+    __syncthreads();
+    // (6) Linear(K3 -> 64) + LeakyReLU: a wave takes 16 outputs, RB rows at a time; lane l holds input elements 4l + 256j .. +3 and
+    // reads the same columns of every row as 16-byte loads (a row = K3 / 256 coalesced 1 KB requests per wave)
+    {
+        constexpr int KJ = C::K3 / 256, RB = KJ >= 4 ? 4 : 8;
+        static_assert(C::K3 % 256 == 0, "K3");
+        float4 hv[KJ];
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) hv[j] = *reinterpret_cast<const float4*>(h2 + 4 * lane + 256 * j);
+        const float* wr = w.w3 + (size_t)(16 * wv) * C::K3 + 4 * lane;
+#pragma unroll 1
+        for (int ob = 0; ob < 16; ob += RB) {
+            float4 wq[RB][KJ];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) wq[r][j] = *reinterpret_cast<const float4*>(wr + (size_t)(ob + r) * C::K3 + 256 * j);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                float sv = 0.f;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) sv += hv[j].x * wq[r][j].x + hv[j].y * wq[r][j].y + hv[j].z * wq[r][j].z + hv[j].w * wq[r][j].w;
+                sv = cg::wave_sum(sv);
+                if (lane == 0) {
+                    const int o = 16 * wv + ob + r;
+                    const float v = lrelu(sv + w.b3[o], sl);
+                    h3[o] = v;
+                    a.h3buf[(size_t)smp * LH + o] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // (7) Linear(64 -> P): one wave, lane k holds h3[k]
+    if (wv == 0) {
+        const float hk = h3[lane];
+        for (int p_ = 0; p_ < a.P; ++p_) {
+            const float sv = cg::wave_sum(hk * w.w4[p_ * LH + lane]);
+            if (lane == 0) { const float v = sv + w.b4[p_]; prm[p_] = v; a.params[(size_t)smp * a.P + p_] = v; }
+        }
+    }
+    __syncthreads();
+    // (8) AffineTransformMatrixGenerator + AffineGridGeneratorBHWD
+    float T[6];
+    affine_T(prm, a.ur, a.us, a.ut, T);
+    const int H = a.Hg, W = a.Wg;
+    float2* gr = reinterpret_cast<float2*>(a.grid + (size_t)smp * H * W * 2);
+    for (int i = tid; i < H * W; i += NT2) {
+        const int ii = i / W, j = i - ii * W;
+        const float y = H > 1 ? -1.f + 2.f * (float)ii / (float)(H - 1) : -1.f;
+        const float x = W > 1 ? -1.f + 2.f * (float)j / (float)(W - 1) : -1.f;
+        gr[i] = make_float2(T[0] * y + T[1] * x + T[2], T[3] * y + T[4] * x + T[5]);
+    }
+}
+
+template <int S, int CIN>
+__global__ __launch_bounds__(NT2) void locnet_bwd2_k(LocBwd a) {
+    using C = Cfg<S, CIN>;
+    extern __shared__ float sm[];
+    __shared__ double shd[6][NW];
+    __shared__ float gTs[6];
+    float *ga2P = sm + C::B_GA2, *ga1P = sm + C::B_GA1, *gp = sm + C::B_GP, *gh2 = sm + C::B_GH2, *g3s = sm + C::B_G3, *g4s = sm + C::B_G4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    const int smp = blockIdx.x, g = smp / a.N;
+    const LocW w = a.g[g];
+    const float sl = a.slope;
+    constexpr int S2 = C::S2, SP = C::SP, K3 = C::K3, Sh = C::Sh, CQ = C::CQ;
+
+    // (0) B fragments of both data-gradient convolutions (cg_pack_conv_weight's flipped copies [((8 - t)*16 + co)][ci])
+    float b2[36], b1[36];
+    load_b16(w.wb2, lane, b2);
+    {
+        const int nb = C::NSPLIT ? 16 * wv + n : n;       // output plane (= input plane of the layer) this lane's B column is
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b1[t * 4 + j] = nb < CIN ? w.wb1[((t * LC + 4 * j + kq) * CIN) + nb] : 0.f;
+    }
+    {
+        float4* z = reinterpret_cast<float4*>(sm);
+        for (int i = tid; i < C::B_GP / 4; i += NT2) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // (1) affine_grid_backward: gT[r][:] = sum_{i,j} ggrid[i,j,r] * (y_i, x_j, 1)   (fp64 block sums, fixed order)
+    const int H = a.Hg, W = a.Wg;
+    {
+        const float2* gg = reinterpret_cast<const float2*>(a.ggrid + (size_t)smp * H * W * 2);
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = tid; i < H * W; i += NT2) {
+            const int ii = i / W, j = i - ii * W;
+            const float y = H > 1 ? -1.f + 2.f * (float)ii / (float)(H - 1) : -1.f;
+            const float x = W > 1 ? -1.f + 2.f * (float)j / (float)(W - 1) : -1.f;
+            const float2 gv = gg[i];
+            acc[0] += gv.x * y; acc[1] += gv.x * x; acc[2] += gv.x;
+            acc[3] += gv.y * y; acc[4] += gv.y * x; acc[5] += gv.y;
+        }
+        for (int k = 0; k < 6; ++k) {
+            const double t = cg::wave_sum(acc[k]);
+            if (lane == 0) shd[k][wv] = t;
+        }
+    }
+    __syncthreads();
+    // (2) affine_matrix_backward (cg_affine_matrix_backward's formulas), one lane
+    if (tid == 0) {
+        float gT[6];
+        for (int k = 0; k < 6; ++k) { double t = 0.0; for (int q = 0; q < NW; ++q) t += shd[k][q]; gT[k] = (float)t; gTs[k] = gT[k]; }
+        const float* prm = a.params + (size_t)smp * a.P;
+        float T[6], cs[5];
+        affine_T(prm, a.ur, a.us, a.ut, T, cs);
+        const float c = cs[0], s = cs[1], sc = cs[2], tx = cs[3], ty = cs[4];
+        int k = 0;
+        if (a.ur) {
+            const float d0 = -s * sc, d1 = -c * sc, d2 = -s * sc * tx - c * sc * ty;
+            const float d3 = c * sc, d4 = -s * sc, d5 = c * sc * tx - s * sc * ty;
+            g4s[k++] = gT[0] * d0 + gT[1] * d1 + gT[2] * d2 + gT[3] * d3 + gT[4] * d4 + gT[5] * d5;
+        }
+        if (a.us) g4s[k++] = gT[0] * c + gT[1] * (-s) + gT[2] * (c * tx - s * ty) + gT[3] * s + gT[4] * c + gT[5] * (s * tx + c * ty);
+        if (a.ut) {
+            g4s[k] = gT[2] * (c * sc) + gT[5] * (s * sc);
+            g4s[k + 1] = gT[2] * (-s * sc) + gT[5] * (c * sc);
+        }
+        for (int q = 0; q < a.P; ++q) a.g4[(size_t)smp * a.P + q] = g4s[q];
+    }
+    __syncthreads();
+    // (3) Linear(64 -> P) backward + LeakyReLU backward
+    if (tid < LH) {
+        float s = 0.f;
+        for (int q = 0; q < a.P; ++q) s += w.w4[q * LH + tid] * g4s[q];
+        const float h = a.h3buf[(size_t)smp * LH + tid];
+        const float v = h >= 0.f ? s : sl * s;
+        g3s[tid] = v;
+        a.g3[(size_t)smp * LH + tid] = v;
+    }
+    __syncthreads();
+    // (4) Linear(K3 -> 64) backward: gh2[i] = sum_o w3[o][i] g3[o]; a thread owns K3 / 256 consecutive columns (one 16-byte or 4-byte
+    // load per row), 16 rows in flight, rows added in order
+    {
+        constexpr int CW = K3 / NT2;      // 1 or 4
+        static_assert(CW == 1 || CW == 4, "K3");
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* wc = w.w3 + CW * tid;
+#pragma unroll 1
+        for (int o0 = 0; o0 < LH; o0 += 16) {
+            float wq[16][CW];
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                if (CW == 4) { const float4 t = *reinterpret_cast<const float4*>(wc + (size_t)(o0 + o) * K3); wq[o][0] = t.x; wq[o][1 % CW] = t.y; wq[o][2 % CW] = t.z; wq[o][3 % CW] = t.w; }
+                else wq[o][0] = wc[(size_t)(o0 + o) * K3];
+            }
+#pragma unroll
+            for (int o = 0; o < 16; ++o)
+#pragma unroll
+                for (int j = 0; j < CW; ++j) s4[j] += wq[o][j] * g3s[o0 + o];
+        }
+#pragma unroll
+        for (int j = 0; j < CW; ++j) gh2[CW * tid + j] = s4[j];
+    }
+    __syncthreads();
+    // (5) AvgPool backward (x 0.25) + LeakyReLU backward at conv 2's output -> ga2 (haloed image + global, for the weight gradient)
+    for (int i = tid; i < S2 * LC; i += NT2) {
+        const int c = i & (LC - 1), pix = i >> 4, y = pix / S, x = pix % S;
+        const float gv = gh2[c * Sh * Sh + (y >> 1) * Sh + (x >> 1)] * 0.25f;
+        const float m = a.m2buf[((size_t)smp * S2 + pix) * LC + c];
+        const float v = m >= 0.f ? gv : sl * gv;
+        ga2P[pp(pix, S, SP) * C::CP2 + c] = v;
+        a.ga2[((size_t)smp * S2 + pix) * LC + c] = v;
+    }
+    __syncthreads();
+    // (6) conv 2 data gradient, LeakyReLU backward at conv 1's output -> ga1
+    {
+        f4 acc[C::NMT2];
+        int ab[C::NMT2];
+#pragma unroll
+        for (int m = 0; m < C::NMT2; ++m) {
+            acc[m] = (f4){0.f, 0.f, 0.f, 0.f};
+            ab[m] = pp((wv * C::NMT2 + m) * 16 + n, S, SP) * C::CP2 + kq;
+        }
+        conv_mfma<C::NMT2, 4, C::CP2, SP>(ga2P, ab, b2, acc);
+#pragma unroll
+        for (int m = 0; m < C::NMT2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pix = (wv * C::NMT2 + m) * 16 + kq * 4 + r;
+                const float h = a.h1buf[((size_t)smp * S2 + pix) * LC + n];
+                const float v = h >= 0.f ? acc[m][r] : sl * acc[m][r];
+                ga1P[pp(pix, S, SP) * C::CP2 + n] = v;
+                a.ga1[((size_t)smp * S2 + pix) * LC + n] = v;
+            }
+    }
+    __syncthreads();
+    // (7) conv 1 data gradient: N = the layer's input planes (64: one 16-plane tile per wave over all pixels; 3: zero-padded tile, pixels over the waves)
+    {
+        constexpr int NMT = C::NSPLIT ? C::MT : C::MT / NW;
+        f4 acc[NMT];
+        int ab[NMT];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+            acc[m] = (f4){0.f, 0.f, 0.f, 0.f};
+            const int mt = C::NSPLIT ? m : wv * NMT + m;
+            ab[m] = pp(mt * 16 + n, S, SP) * C::CP2 + kq;
+        }
+        conv_mfma<NMT, 4, C::CP2, SP>(ga1P, ab, b1, acc);
+        const int nb = C::NSPLIT ? 16 * wv + n : n;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pix = (C::NSPLIT ? m : wv * NMT + m) * 16 + kq * 4 + r;
+                if (nb < CQ) gp[pix * (CQ + 1) + nb] = acc[m][r];
+            }
+    }
+    __syncthreads();
+    // (8) AvgPool backward to the transformer's input resolution
+    float* gx = a.gx + (size_t)smp * (4 * S2) * CIN;
+    for (int i = tid; i < 4 * S2 * CIN; i += NT2) {
+        const int c = i % CIN, xx = (i / CIN) % (2 * S), yy = i / (CIN * 2 * S);
+        gx[i] = gp[((yy >> 1) * S + (xx >> 1)) * (CQ + 1) + c] * 0.25f;
+    }
+}
+
+template <int S, int CIN> int launch_fwd(hipStream_t st, const LocFwd& a, int nblk) {
+    using C = Cfg<S, CIN>;
+    constexpr size_t lds = (size_t)C::F_TOT * 4;
+    static bool granted = false;
+    if (lds > 64 * 1024 && !granted) { CG_HIP(hipFuncSetAttribute((const void*)locnet_fwd2_k<S, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); granted = true; }
+    hipLaunchKernelGGL((locnet_fwd2_k<S, CIN>), dim3(nblk), dim3(NT2), lds, st, a);
+    return 0;
+}
+template <int S, int CIN> int launch_bwd(hipStream_t st, const LocBwd& a, int nblk) {
+    using C = Cfg<S, CIN>;
+    constexpr size_t lds = (size_t)C::B_TOT * 4;
+    static bool granted = false;
+    if (lds > 64 * 1024 && !granted) { CG_HIP(hipFuncSetAttribute((const void*)locnet_bwd2_k<S, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); granted = true; }
+    hipLaunchKernelGGL((locnet_bwd2_k<S, CIN>), dim3(nblk), dim3(NT2), lds, st, a);
+    return 0;
+}
+inline bool has(int S, int Cin) { return (S == 16 && Cin == 3) || (S == 8 && Cin == 64); }
+inline bool enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CG_LOCNET_V1"); v = (e && atoi(e) != 0) ? 0 : 1; }
+    return v != 0;
+}
+
+}  // namespace v2
+
 size_t fwd_lds_floats(int S, int Cin) { return (size_t)fwd_lds(S, Cin).total; }
 size_t bwd_lds_floats(int S, int Cin) { return (size_t)bwd_lds(S, Cin).total; }
 
@@ -434,6 +882,12 @@ int cg_locnet_forward(void* stream, int ngroups, int n_per_group, const float* x
     a.x = x; a.x_shared = x_shared; a.G = ngroups; a.N = n_per_group; a.S = S; a.Cin = Cin; a.P = P; a.Hg = Hg; a.Wg = Wg;
     a.ur = use_rot ? 1 : 0; a.us = use_scale ? 1 : 0; a.ut = use_trans ? 1 : 0; a.slope = slope;
     a.pbuf = pooled; a.h1buf = h1; a.m2buf = m2; a.h2buf = h2; a.h3buf = h3; a.params = params; a.grid = grid;
+    if (v2::enabled() && v2::has(S, Cin)) {   // the MFMA kernels (round 4)
+        const int rc = S == 16 ? v2::launch_fwd<16, 3>(cg::S(stream), a, ngroups * n_per_group) : v2::launch_fwd<8, 64>(cg::S(stream), a, ngroups * n_per_group);
+        if (rc) return rc;
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = fwd_lds_floats(S, Cin) * 4;
     static size_t granted = 64 * 1024;
     if (lds > granted) { CG_HIP(hipFuncSetAttribute((const void*)locnet_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); granted = lds; }
@@ -458,6 +912,12 @@ int cg_locnet_backward(void* stream, int ngroups, int n_per_group, const float* 
     a.ur = use_rot ? 1 : 0; a.us = use_scale ? 1 : 0; a.ut = use_trans ? 1 : 0; a.slope = slope;
     a.h1buf = h1; a.m2buf = m2; a.h3buf = h3; a.params = params; a.ggrid = ggrid;
     a.ga1 = ga1; a.ga2 = ga2; a.g3 = g3; a.g4 = g4; a.gx = gx;
+    if (v2::enabled() && v2::has(S, Cin)) {
+        const int rc = S == 16 ? v2::launch_bwd<16, 3>(cg::S(stream), a, ngroups * n_per_group) : v2::launch_bwd<8, 64>(cg::S(stream), a, ngroups * n_per_group);
+        if (rc) return rc;
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = bwd_lds_floats(S, Cin) * 4;
     static size_t granted = 64 * 1024;
     if (lds > granted) { CG_HIP(hipFuncSetAttribute((const void*)locnet_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); granted = lds; }

@@ -222,7 +222,7 @@ struct Net {
     bool fresh_allocs = false;                 // library-owned buffers were allocated + zeroed since the last device synchronise
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
-        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 1;
+        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0;
     long wino_min_tiles = 2048;
     std::string trace_log;
     const KTable* K = &kRealTable;
@@ -2319,10 +2319,13 @@ int ensure_streams(Net* n, int nstreams) {
     while ((int)n->side.size() < nstreams - 1) {
         hipStream_t s; hipEvent_t e;
         const int idx = (int)n->side.size() + 1;
-        if (idx >= 4 && n->wgrad_prio) {   // weight-gradient streams: lowest priority, the data-gradient chain is what the pass waits for
+        // experiment switches (CG_WGRAD_PRIO; profiles/r04_wgrad_stream_ab.txt): 1 = the weight-gradient streams at the LOWEST priority
+        // (measured: 11.1 ms per step against 6.8 - the low-priority queue's waves appear to be context-switched out whenever the
+        // other queues have work); 2 = the branch groups' side streams at the HIGHEST priority instead (the caller does the same for its own)
+        if ((idx >= 4 && n->wgrad_prio == 1) || (idx < 4 && n->wgrad_prio == 2)) {
             int least = 0, greatest = 0;
             CG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            CG_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
+            CG_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, idx >= 4 ? least : greatest));
         } else
             CG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         CG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2460,7 +2463,7 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_PACK_OVERLAP"))) n->pack_overlap = atoi(e) != 0;
     if ((e = getenv("CG_HEAD_FUSE"))) n->head_fuse = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_STREAM"))) n->wgrad_stream = atoi(e) != 0;
-    if ((e = getenv("CG_WGRAD_PRIO"))) n->wgrad_prio = atoi(e) != 0;
+    if ((e = getenv("CG_WGRAD_PRIO"))) n->wgrad_prio = atoi(e);
     *net = n;
     return 0;
 }

@@ -39,21 +39,24 @@ int g_opt_state[OPT_COUNT];   // 0 = not read yet, 1 = default / environment, 2 
 #include <vector>
 namespace cg {
 void* col_scratch(hipStream_t stream) {
-    // a pool of blocks allocated (and their ticket counters zeroed) on the FIRST use, handed to streams as they appear: a stream
-    // that shows up inside a graph capture (torch.cuda.graph captures on a stream of its own) needs no allocation then
-    constexpr int kPool = 8;
+    // a pool of blocks allocated (and their ticket counters zeroed) in chunks of kPool, handed to streams as they appear.  A stream
+    // that shows up inside a graph capture (torch.cuda.graph captures on a stream of its own) must find a free block - nothing can
+    // be allocated then - so every hand-over outside a capture leaves at least kReserve blocks behind (a plan's side and
+    // weight-gradient streams, several nets per process: streams are not scarce any more).
+    constexpr int kPool = 8, kReserve = 4;
     static std::unordered_map<hipStream_t, void*> blocks;
     static std::vector<void*> pool;
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
     auto it = blocks.find(stream);
     if (it != blocks.end()) return it->second;
-    if (pool.empty()) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (stream && hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
-            cg::fail("column reduce: more than %d streams, the next one first used inside a graph capture (run one pass on it before cg_graph_begin)", kPool);
-            return nullptr;
-        }
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    const bool capturing = stream && hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+    if (capturing && pool.empty()) {
+        cg::fail("column reduce: no scratch block left for a stream first used inside a graph capture (run one pass on it before cg_graph_begin)");
+        return nullptr;
+    }
+    if (!capturing && (int)pool.size() <= kReserve) {
         char* p = nullptr;
         // the memset runs on the null stream, which non-blocking streams do not wait for: finish it before any kernel draws a ticket
         if (hipMalloc((void**)&p, kColScratchBytes * kPool) != hipSuccess || hipMemset(p, 0, kColScratchBytes * kPool) != hipSuccess ||
@@ -61,7 +64,7 @@ void* col_scratch(hipStream_t stream) {
             cg::fail("column reduce: cannot allocate %zu bytes of scratch", kColScratchBytes * kPool);
             return nullptr;
         }
-        for (int i = kPool - 1; i >= 0; --i) pool.push_back(p + (size_t)i * kColScratchBytes);
+        for (int i = kPool - 1; i >= 0; --i) pool.insert(pool.begin(), p + (size_t)i * kColScratchBytes);   // older blocks go first
     }
     void* blk = pool.back();
     pool.pop_back();

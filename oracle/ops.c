@@ -88,37 +88,44 @@ static void transpose(const float* A, int rows, int cols, float* At) { /* At[col
         for (int c = 0; c < cols; ++c) At[(size_t)c * rows + r] = A[(size_t)r * cols + c];
 }
 
-/* THNN unfolded-copy: col[(ci*kH+ky)*kW+kx][oy*Wo+ox] = x[ci][oy+ky-padH][ox+kx-padW] */
-static void im2col(const float* x, int C, int H, int W, int kH, int kW, int padH, int padW, int Ho, int Wo, float* col) {
+/* THNN unfolded-copy, columns [p0, p0 + pc) of it: col[(ci*kH+ky)*kW+kx][p - p0] = x[ci][oy+ky-padH][ox+kx-padW], p = oy*Wo+ox.
+ * The convolutions below walk the output pixels in blocks of pc columns so that the unfolded block (K x pc floats) stays in a
+ * core's L2 (THNN unfolds the whole image: 26 MB per thread for the 5x5 256->128 layer at 32x32, which is what kept this port from
+ * scaling past ~16 threads).  Every output element still accumulates its K products in the same order. */
+static void im2col_cols(const float* x, int C, int H, int W, int kH, int kW, int padH, int padW, int Wo, int p0, int pc,
+                        float* col) {
     for (int ci = 0; ci < C; ++ci)
         for (int ky = 0; ky < kH; ++ky)
             for (int kx = 0; kx < kW; ++kx) {
-                float* dst = col + (size_t)((ci * kH + ky) * kW + kx) * Ho * Wo;
-                for (int oy = 0; oy < Ho; ++oy) {
-                    const int iy = oy + ky - padH;
-                    for (int ox = 0; ox < Wo; ++ox) {
-                        const int ix = ox + kx - padW;
-                        dst[oy * Wo + ox] =
-                            (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((size_t)ci * H + iy) * W + ix] : 0.f;
-                    }
+                float* dst = col + (size_t)((ci * kH + ky) * kW + kx) * pc;
+                int oy = p0 / Wo, ox = p0 % Wo;
+                for (int q = 0; q < pc; ++q) {
+                    const int iy = oy + ky - padH, ix = ox + kx - padW;
+                    dst[q] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((size_t)ci * H + iy) * W + ix] : 0.f;
+                    if (++ox == Wo) { ox = 0; ++oy; }
                 }
             }
 }
-static void col2im_add(const float* col, int C, int H, int W, int kH, int kW, int padH, int padW, int Ho, int Wo,
-                       float* x) {
+static void col2im_add_cols(const float* col, int C, int H, int W, int kH, int kW, int padH, int padW, int Wo, int p0, int pc,
+                            float* x) {
     for (int ci = 0; ci < C; ++ci)
         for (int ky = 0; ky < kH; ++ky)
             for (int kx = 0; kx < kW; ++kx) {
-                const float* src = col + (size_t)((ci * kH + ky) * kW + kx) * Ho * Wo;
-                for (int oy = 0; oy < Ho; ++oy) {
-                    const int iy = oy + ky - padH;
-                    if (iy < 0 || iy >= H) continue;
-                    for (int ox = 0; ox < Wo; ++ox) {
-                        const int ix = ox + kx - padW;
-                        if (ix >= 0 && ix < W) x[((size_t)ci * H + iy) * W + ix] += src[oy * Wo + ox];
-                    }
+                const float* src = col + (size_t)((ci * kH + ky) * kW + kx) * pc;
+                int oy = p0 / Wo, ox = p0 % Wo;
+                for (int q = 0; q < pc; ++q) {
+                    const int iy = oy + ky - padH, ix = ox + kx - padW;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) x[((size_t)ci * H + iy) * W + ix] += src[q];
+                    if (++ox == Wo) { ox = 0; ++oy; }
                 }
             }
+}
+/* output pixels per block: K x pc floats <= 1 MB, a multiple of 16 (the sgemm kernel's vector width) */
+static int col_block(int K, int P) {
+    int pc = (256 * 1024) / (K > 0 ? K : 1);
+    pc &= ~15;
+    if (pc < 16) pc = 16;
+    return pc < P ? pc : P;
 }
 
 /* nn.SpatialConvolution / cudnn.SpatialConvolution updateOutput, stride 1
@@ -126,19 +133,22 @@ static void col2im_add(const float* col, int C, int H, int W, int kH, int kW, in
  * out[n] = bias (broadcast) + W[Cout][Cin*kH*kW] * im2col(x[n]). */
 void orc_conv2d_forward(const float* x, const float* w, const float* b, float* y, int N, int Cin, int H, int W,
                         int Cout, int kH, int kW, int padH, int padW) {
-    const int Ho = H + 2 * padH - kH + 1, Wo = W + 2 * padW - kW + 1, K = Cin * kH * kW;
+    const int Ho = H + 2 * padH - kH + 1, Wo = W + 2 * padW - kW + 1, K = Cin * kH * kW, P = Ho * Wo, PC = col_block(K, P);
 #pragma omp parallel
     {
-        float* col = (float*)malloc(sizeof(float) * (size_t)K * Ho * Wo);
+        float* col = (float*)malloc(sizeof(float) * (size_t)K * PC);
 #pragma omp for schedule(dynamic, 1)
         for (int n = 0; n < N; ++n) {
-            float* yn = y + (size_t)n * Cout * Ho * Wo;
+            float* yn = y + (size_t)n * Cout * P;
             for (int co = 0; co < Cout; ++co) {
                 const float bv = b ? b[co] : 0.f;
-                for (int p = 0; p < Ho * Wo; ++p) yn[(size_t)co * Ho * Wo + p] = bv;
+                for (int p = 0; p < P; ++p) yn[(size_t)co * P + p] = bv;
             }
-            im2col(x + (size_t)n * Cin * H * W, Cin, H, W, kH, kW, padH, padW, Ho, Wo, col);
-            sgemm_nn(Cout, Ho * Wo, K, w, K, col, Ho * Wo, yn, Ho * Wo, 1);
+            for (int p0 = 0; p0 < P; p0 += PC) {
+                const int pc = p0 + PC <= P ? PC : P - p0;
+                im2col_cols(x + (size_t)n * Cin * H * W, Cin, H, W, kH, kW, padH, padW, Wo, p0, pc, col);
+                sgemm_nn(Cout, pc, K, w, K, col, pc, yn + p0, P, 1);
+            }
         }
         free(col);
     }
@@ -147,18 +157,21 @@ void orc_conv2d_forward(const float* x, const float* w, const float* b, float* y
 /* updateGradInput: col = W^T * dy[n]; dx[n] = col2im(col). */
 void orc_conv2d_backward_data(const float* dy, const float* w, float* dx, int N, int Cin, int H, int W, int Cout,
                               int kH, int kW, int padH, int padW) {
-    const int Ho = H + 2 * padH - kH + 1, Wo = W + 2 * padW - kW + 1, K = Cin * kH * kW;
+    const int Ho = H + 2 * padH - kH + 1, Wo = W + 2 * padW - kW + 1, K = Cin * kH * kW, P = Ho * Wo, PC = col_block(K, P);
     float* wt = (float*)malloc(sizeof(float) * (size_t)K * Cout);
     transpose(w, Cout, K, wt);
 #pragma omp parallel
     {
-        float* col = (float*)malloc(sizeof(float) * (size_t)K * Ho * Wo);
+        float* col = (float*)malloc(sizeof(float) * (size_t)K * PC);
 #pragma omp for schedule(dynamic, 1)
         for (int n = 0; n < N; ++n) {
-            sgemm_nn(K, Ho * Wo, Cout, wt, Cout, dy + (size_t)n * Cout * Ho * Wo, Ho * Wo, col, Ho * Wo, 0);
             float* dxn = dx + (size_t)n * Cin * H * W;
             memset(dxn, 0, sizeof(float) * (size_t)Cin * H * W);
-            col2im_add(col, Cin, H, W, kH, kW, padH, padW, Ho, Wo, dxn);
+            for (int p0 = 0; p0 < P; p0 += PC) {
+                const int pc = p0 + PC <= P ? PC : P - p0;
+                sgemm_nn(K, pc, Cout, wt, Cout, dy + (size_t)n * Cout * P + p0, P, col, pc, 0);
+                col2im_add_cols(col, Cin, H, W, kH, kW, padH, padW, Wo, p0, pc, dxn);
+            }
         }
         free(col);
     }
@@ -168,7 +181,7 @@ void orc_conv2d_backward_data(const float* dy, const float* w, float* dx, int N,
 /* accGradParameters: gw += scale * sum_n dy[n] * im2col(x[n])^T ; gb += scale * sum dy. */
 void orc_conv2d_backward_weight(const float* x, const float* dy, float* gw, float* gb, int N, int Cin, int H, int W,
                                 int Cout, int kH, int kW, int padH, int padW, float scale) {
-    const int Ho = H + 2 * padH - kH + 1, Wo = W + 2 * padW - kW + 1, K = Cin * kH * kW, P = Ho * Wo;
+    const int Ho = H + 2 * padH - kH + 1, Wo = W + 2 * padW - kW + 1, K = Cin * kH * kW, P = Ho * Wo, PC = col_block(K, P);
     int nthreads = 1;
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();
@@ -181,14 +194,17 @@ void orc_conv2d_backward_weight(const float* x, const float* dy, float* gw, floa
 #ifdef _OPENMP
         tid = omp_get_thread_num();
 #endif
-        float* col = (float*)malloc(sizeof(float) * (size_t)K * P);
-        float* colt = (float*)malloc(sizeof(float) * (size_t)K * P);
+        float* col = (float*)malloc(sizeof(float) * (size_t)K * PC);
+        float* colt = (float*)malloc(sizeof(float) * (size_t)K * PC);
         float* a = acc + (size_t)tid * Cout * K;
 #pragma omp for schedule(static)
         for (int n = 0; n < N; ++n) {
-            im2col(x + (size_t)n * Cin * H * W, Cin, H, W, kH, kW, padH, padW, Ho, Wo, col);
-            transpose(col, K, P, colt); /* colt[P][K] */
-            sgemm_nn(Cout, K, P, dy + (size_t)n * Cout * P, P, colt, K, a, K, 1);
+            for (int p0 = 0; p0 < P; p0 += PC) {
+                const int pc = p0 + PC <= P ? PC : P - p0;
+                im2col_cols(x + (size_t)n * Cin * H * W, Cin, H, W, kH, kW, padH, padW, Wo, p0, pc, col);
+                transpose(col, K, pc, colt); /* colt[pc][K] */
+                sgemm_nn(Cout, K, pc, dy + (size_t)n * Cout * P + p0, P, colt, K, a, K, 1);
+            }
         }
         free(col);
         free(colt);
