@@ -5,11 +5,17 @@
     -- `require 'LeakyReLU'` ... resolve to the shims in lua/ (each a few lines) and models.lua / adversarial.lua /
     -- weight-init.lua / utils/nn_utils.lua run as written.
 
-NOT EXECUTED in the build container (no Lua of any kind there; SURVEY.md Appendix C).  Three things stand in for that:
-scripts/check_lua_binding.py verifies every C.cg_* call in these files against include/catgan.h (name and arity);
-cat-generator_amd/nn.py with nn.fusion = False is the executable twin, class for class and call for call; and
-tools/abi_step.cpp drives a whole G+D update through the same entry points with no interpreter and no PyTorch in the
-process (tests/test_abi_step.py compares it with the Python host). ]]
+NOT EXECUTED in the build container (no Lua of any kind there; SURVEY.md Appendix C).  What stands in for that:
+  * scripts/check_lua_binding.py: every C.cg_* call in lua/ against include/catgan.h (name and arity), block structure of every file,
+    the builder tables of catgan.net against planned.py / csrc/net.hip, and - round 4 - every `require`, every `namespace.function`
+    call and every method name of the reference's adversarial.lua / models.lua / train.lua / weight-init.lua / utils/nn_utils.lua /
+    dataset.lua resolved against a provider in lua/ (tests/golden/lua_reference_names.json holds the list for machines without
+    /root/reference);
+  * cat-generator_amd/nn.py with nn.planned = False is the executable twin of catgan.nn, class for class and call for call;
+    cat-generator_amd/t7.py that of catgan.t7 (torch.save / torch.load);
+  * tools/abi_replay.cpp replays the call sequence of a whole G+D update - the cg_net_* sequence catgan.net issues at the benchmarked
+    batch - through the same entry points with no interpreter and no PyTorch in the process, bit-equal to the Python host
+    (tests/test_abi_step.py). ]]
 local abi = require 'catgan.ffi'
 local T = require 'catgan.tensor'
 local N = require 'catgan.nn'

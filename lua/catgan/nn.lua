@@ -110,6 +110,18 @@ end
 function Module:float() return self end
 function Module:type() return self end
 function Module:reset() end
+-- node:clearState() (utils/nn_utils.lua:429, NN_UTILS.prepareNetworkForSave before torch.save): drop everything a pass left behind -
+-- outputs, gradInputs, masks, persistent buffers, packed weight copies, the compiled plan - so that a checkpoint holds parameters
+-- and constructor fields only.  The next forward rebuilds them.
+local TRANSIENT = { 'output', 'gradInput', 'noise', 'finput', 'fgradInput', '_planned_last', '_pnet', '_pnet_n', '_wf', '_wb', '_wb_ph', '_u_bwd',
+                    '_ph_version', '_ph_ptr', '_packed_ptr', '_loss', '_in_shape', '_g', '_bsums_g', '_sizes', '_count', 'save_std', 'save_mean' }
+function Module:clearState()
+   for _, m in ipairs(self:listModules()) do
+      for _, k in ipairs(TRANSIENT) do rawset(m, k, nil) end
+      m._bufs = {}
+   end
+   return self
+end
 function Module:own_parameters()   -- { {module, 'weight', 'gradWeight'}, ... } in Torch7 order (weight, then bias)
    local out = {}
    if self.weight then out[#out + 1] = { self, 'weight', 'gradWeight' } end
@@ -881,5 +893,58 @@ function BCE:backward(input, target)
    self.gradInput = host and self._g:float() or self._g
    return self.gradInput
 end
+
+-- ------------------------------------------------------------------------------------ the validator's two extra classes
+-- create_V32 / create_V16 (models.lua:763-799) end in Linear -> nn.BatchNormalization -> ... -> nn.SoftMax.  V is outside the
+-- hot-path scope (it is trained by train_v.lua), but the UNCHANGED train.lua loads one (train.lua:119-123), puts it in evaluate()
+-- mode and utils/nn_utils.lua:686-711 (rateWithV) runs it forward once per epoch.  So: inference only, on the host, on [N, n] tensors.
+local BN1 = class('nn.BatchNormalization')
+function BN1:__init(n, eps, momentum, affine)
+   Module.__init(self)
+   self.eps, self.momentum = eps or 1e-5, momentum or 0.1
+   self.running_mean, self.running_var = Host.new(n):zero(), Host.new(n):fill(1)
+   if affine ~= false then self.weight, self.bias = Host.new(n):uniform(0, 1), Host.new(n):zero(); self.gradWeight, self.gradBias = Host.new(n):zero(), Host.new(n):zero() end
+end
+function BN1:updateOutput(input)
+   assert(not self.train, 'nn.BatchNormalization: training mode is outside the hot-path scope (V is trained by train_v.lua); call :evaluate()')
+   local dev = input.__typename == 'torch.CudaTensor'
+   local x = dev and input:float() or input
+   local N, n = x.shape[1], x.shape[2]
+   local out = Host.new(N, n)
+   local xd, od = x:data(), out:data()
+   local mean, var = self.running_mean:float():data(), self.running_var:float():data()
+   local w, b = self.weight and self.weight:float():data(), self.bias and self.bias:float():data()
+   for i = 0, N - 1 do
+      for j = 0, n - 1 do
+         local v = (xd[i * n + j] - mean[j]) / math.sqrt(var[j] + self.eps)
+         od[i * n + j] = w and v * w[j] + b[j] or v
+      end
+   end
+   self.output = dev and out:cuda() or out
+   return self.output
+end
+function BN1:updateGradInput() error('nn.BatchNormalization: backward is outside the hot-path scope') end
+nn.BatchNormalization = BN1
+
+local SoftMax = class('nn.SoftMax')
+function SoftMax:updateOutput(input)
+   local dev = input.__typename == 'torch.CudaTensor'
+   local x = dev and input:float() or input
+   local n = x.shape[#x.shape]
+   local rows = x.n / n
+   local out = Host.new(x.shape)
+   local xd, od = x:data(), out:data()
+   for i = 0, rows - 1 do
+      local mx = -math.huge
+      for j = 0, n - 1 do mx = math.max(mx, xd[i * n + j]) end
+      local sum = 0
+      for j = 0, n - 1 do local e = math.exp(xd[i * n + j] - mx); od[i * n + j] = e; sum = sum + e end
+      for j = 0, n - 1 do od[i * n + j] = od[i * n + j] / sum end
+   end
+   self.output = dev and out:cuda() or out
+   return self.output
+end
+function SoftMax:updateGradInput() error('nn.SoftMax: backward is outside the hot-path scope') end
+nn.SoftMax = SoftMax
 
 return { nn = nn, cudnn = cudnn }

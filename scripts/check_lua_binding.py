@@ -146,7 +146,167 @@ def check_net_builder():
     return errs
 
 
+# ---- 5. the reference's host files against the providers in lua/ -------------------------------------------------------------------
+REF_FILES = ["adversarial.lua", "models.lua", "train.lua", "weight-init.lua", "utils/nn_utils.lua", "dataset.lua"]
+MANIFEST = os.path.join(ROOT, "tests", "golden", "lua_reference_names.json")
+LUA_STD = {"math": {"abs", "ceil", "cos", "exp", "floor", "huge", "log", "max", "min", "pi", "pow", "random", "randomseed", "sin", "sqrt"},
+           "os": {"clock", "date", "execute", "exit", "getenv", "remove", "rename", "time"},
+           "string": {"byte", "char", "find", "format", "gmatch", "gsub", "len", "lower", "match", "rep", "reverse", "sub", "upper"},
+           "table": {"concat", "insert", "remove", "sort", "unpack"}, "io": {"close", "flush", "lines", "open", "popen", "read", "write"}}
+STRING_METHODS = LUA_STD["string"]
+# globals of the reference that hold one of its own modules / objects: name -> the table its functions are defined on
+REF_OWN = {"ADVERSARIAL": "adversarial", "DATASET": "dataset", "MODELS": "models", "NN_UTILS": "nn_utils", "TRAIN_DATA": "result",
+           "adversarial": "adversarial", "dataset": "dataset", "models": "models", "nn_utils": "nn_utils"}
+# globals that are one of OUR providers under another name
+ALIAS = {"DISP": "display"}
+
+
+def reference_names(refdir):
+    """What the reference files pull in: {'requires': {module: [file:line]}, 'calls': {'ns.fn': [...]}, 'methods': {name: [...]},
+    'defines': [ 'tbl.fn' / 'tbl:fn' defined by the files themselves ]} - identifiers only, no code."""
+    req, calls, meth, defines = {}, {}, {}, set()
+    for f in REF_FILES:
+        raw = open(os.path.join(refdir, f)).read()
+        src = strip_lua(raw)
+        for m in re.finditer(r"\brequire\b", src):
+            q = re.match(r"require\s*\(?\s*['\"]([^'\"]+)['\"]", raw[m.start():])
+            if q:
+                req.setdefault(q.group(1), []).append(f"{f}:{src.count(chr(10), 0, m.start()) + 1}")
+        for m in re.finditer(r"pcall\(\s*require\s*,\s*['\"]", src):
+            q = re.match(r"pcall\(\s*require\s*,\s*['\"]([^'\"]+)['\"]", raw[m.start():])
+            if q:
+                req.setdefault(q.group(1), []).append(f"{f}:{src.count(chr(10), 0, m.start()) + 1}")
+        for m in re.finditer(r"(?<![\w.:])([A-Za-z_]\w*)((?:\.\w+)+)\s*[\({]", src):
+            calls.setdefault(m.group(1) + m.group(2), []).append(f"{f}:{src.count(chr(10), 0, m.start()) + 1}")
+        for m in re.finditer(r":(\w+)\s*[\({]", src):
+            meth.setdefault(m.group(1), []).append(f"{f}:{src.count(chr(10), 0, m.start()) + 1}")
+        for m in re.finditer(r"\bfunction\s+([A-Za-z_]\w*)([.:])(\w+)", src):
+            defines.add(m.group(1) + m.group(2) + m.group(3))
+    trim = lambda d: {k: v[:3] for k, v in sorted(d.items())}
+    return {"files": REF_FILES, "requires": trim(req), "calls": trim(calls), "methods": trim(meth), "defines": sorted(defines)}
+
+
+def provider_index():
+    """Names the files under lua/ define: functions 'ns.fn' (function ns.fn / ns.fn = / multiple assignment / table-constructor keys),
+    methods (function Cls:m / function Cls.m / Cls.m =), classes (class('nn.X')), modules (lua/<path>.lua)."""
+    fns, methods, modules = set(), set(), set()
+    for d, _, fs in os.walk(os.path.join(ROOT, "lua")):
+        for f in fs:
+            if not f.endswith(".lua"):
+                continue
+            path = os.path.join(d, f)
+            rel = os.path.relpath(path, os.path.join(ROOT, "lua"))[:-4].replace(os.sep, ".")
+            modules.add(rel[:-5] if rel.endswith(".init") else rel)
+            raw = open(path).read()
+            src = strip_lua(raw)
+            for m in re.finditer(r"\bfunction\s+([A-Za-z_]\w*)([.:])(\w+)", src):
+                fns.add(m.group(1) + "." + m.group(3)); methods.add(m.group(3))
+            for m in re.finditer(r"(?<![\w.])([A-Za-z_]\w*)\.(\w+)\s*(?:=(?!=)|,)", src):      # ns.fn = ... / ns.a, ns.b = ...
+                fns.add(m.group(1) + "." + m.group(2)); methods.add(m.group(2))
+            for m in re.finditer(r"class\('(nn|cudnn)\.(\w+)'", raw):
+                fns.add(m.group(1) + "." + m.group(2))
+            # table constructors bound to a name: `local torch = { FloatTensor = ..., }`, `cutorch = { setDevice = ... }`
+            for m in re.finditer(r"(?:local\s+)?([A-Za-z_]\w*)\s*=\s*\{", src):
+                depth, j = 0, m.end() - 1
+                body_start = j + 1
+                while j < len(src):
+                    if src[j] == "{":
+                        depth += 1
+                    elif src[j] == "}":
+                        depth -= 1
+                        if depth == 0:
+                            break
+                    j += 1
+                body = src[body_start:j]
+                # top-level keys only
+                dd, k0, keys = 0, 0, []
+                for k, ch in enumerate(body):
+                    if ch in "{(":
+                        dd += 1
+                    elif ch in "})":
+                        dd -= 1
+                    elif dd == 0:
+                        mm = re.match(r"\s*([A-Za-z_]\w*)\s*=(?!=)", body[k:]) if (k == 0 or body[k - 1] in ",;{\n ") and (k == 0 or not body[k - 1].isalnum()) else None
+                        if mm and (k == 0 or body[:k].rstrip().endswith((",", ";")) or body[:k].strip() == ""):
+                            keys.append(mm.group(1))
+                for key in keys:
+                    fns.add(m.group(1) + "." + key)
+    return fns, methods, modules
+
+
+def check_reference(refdir=None):
+    import json
+    errs = []
+    have_ref = refdir and all(os.path.exists(os.path.join(refdir, f)) for f in REF_FILES)
+    if have_ref:
+        names = reference_names(refdir)
+        if os.path.exists(MANIFEST) and json.load(open(MANIFEST)) != names:
+            errs.append("tests/golden/lua_reference_names.json is out of date: python scripts/check_lua_binding.py --write-manifest")
+    elif os.path.exists(MANIFEST):
+        names = json.load(open(MANIFEST))
+    else:
+        return ["no reference tree and no tests/golden/lua_reference_names.json: cannot check the reference's names"], None
+    fns, methods, modules = provider_index()
+    own_modules = {f[:-4].replace("/", ".") for f in names["files"]}
+    own_defs = set(names["defines"])
+    for mod, where in names["requires"].items():
+        if mod not in modules and mod not in own_modules:
+            errs.append(f"{where[0]}: require '{mod}' has no provider (lua/{mod.replace('.', '/')}.lua)")
+    for call, where in names["calls"].items():
+        parts = call.split(".")
+        root, fn = parts[0], parts[-1]
+        if root in LUA_STD:
+            if fn not in LUA_STD[root]:
+                errs.append(f"{where[0]}: {call} is not standard Lua 5.1")
+            continue
+        if root in REF_OWN:
+            tbl = REF_OWN[root]
+            if f"{tbl}.{fn}" not in own_defs and f"{tbl}:{fn}" not in own_defs:
+                errs.append(f"{where[0]}: {call}: the reference does not define {tbl}.{fn} itself")
+            continue
+        if root in ("OPT", "self", "opt", "m", "node", "v", "tmp", "result", "data", "images", "arg", "module", "model", "net", "this"):
+            continue        # field reads of values, not namespaces
+        ns = ALIAS.get(root, root)
+        if f"{ns}.{fn}" not in fns:
+            errs.append(f"{where[0]}: {call} has no provider in lua/")
+    for m_, where in names["methods"].items():
+        if m_ in methods or m_ in STRING_METHODS:
+            continue
+        if any(d.endswith(":" + m_) or d.endswith("." + m_) for d in own_defs):
+            continue
+        errs.append(f"{where[0]}: method :{m_}() is defined by no class in lua/")
+    return errs, names
+
+
+def check_t7():
+    """6. lua/catgan/t7.lua (torch.save / torch.load) against its executable twin cat-generator_amd/t7.py: same object tags, same
+    class names on disk, same version header."""
+    errs = []
+    py = open(os.path.join(ROOT, "cat-generator_amd", "t7.py")).read()
+    lua = open(os.path.join(ROOT, "lua", "catgan", "t7.lua")).read()
+    pat = r"TYPE_NIL, TYPE_NUMBER, TYPE_STRING, TYPE_TABLE, TYPE_TORCH, TYPE_BOOLEAN = ([\d, ]+)"
+    a_, b_ = re.search(pat, py), re.search(pat, lua)
+    if not a_ or not b_ or [x.strip() for x in a_.group(1).split(",")] != [x.strip() for x in b_.group(1).split(",")]:
+        errs.append("lua/catgan/t7.lua: object type tags differ from cat-generator_amd/t7.py")
+    for name in ("torch.FloatTensor", "torch.CudaTensor", "torch.FloatStorage", "torch.CudaStorage", "V 1"):
+        if name not in lua:
+            errs.append(f"lua/catgan/t7.lua does not write '{name}'")
+    for name in ("torch.FloatTensor", "torch.CudaTensor", "torch.CudaStorage", "V 1", 'replace("Tensor", "Storage")'):   # t7.py derives the storage names
+        if name not in py:
+            errs.append(f"cat-generator_amd/t7.py does not write '{name}'")
+    for fn in ("int", "long", "double", "string"):
+        if not re.search(r"function Writer:%s\(" % fn, lua) or not re.search(r"function Reader:%s\(" % fn, lua):
+            errs.append(f"lua/catgan/t7.lua: Writer / Reader lack :{fn}()")
+    return errs
+
+
 def main():
+    if "--write-manifest" in sys.argv:
+        import json
+        refdir = os.environ.get("CATGAN_REFERENCE", "/root/reference")
+        json.dump(reference_names(refdir), open(MANIFEST, "w"), indent=1, sort_keys=True)
+        print("wrote", MANIFEST)
+        return 0
     P = protos()
     errs, ncalls, files = [], 0, []
     for d, _, fs in os.walk(os.path.join(ROOT, "lua")):
@@ -187,8 +347,14 @@ def main():
         if c not in defined and not re.search(r"name\s*=\s*'%s'|pool_class\('%s'" % (re.escape(c), re.escape(c)), src_all):
             errs.append(f"lua/: class or function {c} is not defined")
     errs += check_net_builder()
+    errs += check_t7()
+    ref_errs, names = check_reference(os.environ.get("CATGAN_REFERENCE", "/root/reference"))
+    errs += ref_errs
     for e in errs:
         print(e)
+    if names:
+        print(f"reference host files {', '.join(names['files'])}: {len(names['requires'])} requires, {len(names['calls'])} namespace calls, "
+              f"{len(names['methods'])} method names resolved against lua/ ({len(ref_errs)} unresolved)")
     print(f"{len(files)} Lua files, {ncalls} C-ABI calls checked against {len(P)} prototypes, {len(errs)} problems")
     return 1 if errs else 0
 
