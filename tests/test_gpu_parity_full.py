@@ -355,6 +355,21 @@ def _grad_report(tag, a, b):
     return q / scale, d.max() / scale
 
 
+def _outliers(tag, a, b, slices):
+    """{threshold: number of entries with |a - b| > threshold * max|b|} for 1e-4 and 1e-3, the worst ones listed per parameter tensor."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    d = np.abs(a - b) / max(float(np.abs(b).max()), 1e-30)
+    out = {t: int((d > t).sum()) for t in (1e-4, 1e-3)}
+    if out[1e-4]:
+        per = []
+        for off, n, shape in slices:
+            c4, c3 = int((d[off:off + n] > 1e-4).sum()), int((d[off:off + n] > 1e-3).sum())
+            if c4:
+                per.append(f"{shape}@{off}: {c4} > 1e-4" + (f", {c3} > 1e-3" if c3 else "") + f" of {n} (max {d[off:off + n].max():.1e})")
+        print(f"[outliers] {tag}: {out[1e-4]} entries > 1e-4, {out[1e-3]} > 1e-3 of {d.size}; " + "; ".join(per[:12]))
+    return out
+
+
 def _teacher_force(cg, S, T, G, Go):
     """Put the engine into the oracle's state: parameters, Adam m / v / t and the BN running statistics.  With this in front
     of every step each one is a "step 0": engine and oracle see identical parameters, so the tight single-step bounds apply
@@ -426,11 +441,18 @@ def test_training_steps_gradients_and_adam_state(cg, cfg, N):
         for key, g_eng, g_orc, st_e, st_o in (("D", S._last["gD"].numpy(), r["gD"], S.OPTSTATE["adam"]["D"], T.stD),
                                               ("G", S._last["gG"].numpy(), r["gG"], S.OPTSTATE["adam"]["G"], T.stG)):
             q, mx = _grad_report(f"{cfg} N={N} step {step} g{key}", g_eng, g_orc)
-            # bulk: half of the entries agree to fp32 rounding of a long sum, 99 % to 1e-3 of the largest entry
-            assert q[0] <= 2e-5, f"g{key} step {step}: median rel diff {q[0]:.2e}"
-            assert q[1] <= 1e-3, f"g{key} step {step}: p99 rel diff {q[1]:.2e}"
-            assert mx <= 5e-2, f"g{key} step {step}: max rel diff {mx:.2e}"
+            # bulk: half of the entries agree to fp32 rounding of a long sum, 99 % to 5e-5 of the largest entry (measured, rounds 3-4:
+            # median <= 6e-7, p99 <= 8e-6, p99.9 <= 1.5e-5, max <= 1.3e-3; profiles/r03_step_gradients_vs_oracle.txt)
+            assert q[0] <= 5e-6, f"g{key} step {step}: median rel diff {q[0]:.2e}"
+            assert q[1] <= 5e-5, f"g{key} step {step}: p99 rel diff {q[1]:.2e}"
+            assert q[2] <= 2e-4, f"g{key} step {step}: p99.9 rel diff {q[2]:.2e}"
+            assert mx <= 1e-2, f"g{key} step {step}: max rel diff {mx:.2e}"
             assert _rel(g_eng, g_orc) <= 2e-3, f"g{key} step {step}: rel l2 {_rel(g_eng, g_orc):.2e}"
+            # the outliers are COUNTED, not only bounded: kink flips (an activation within fp32 rounding of a PReLU / max-pool / clamp
+            # corner) move isolated entries; a wrong tap or a mis-indexed plane would move a whole row of them
+            bad = _outliers(f"{cfg} N={N} step {step} g{key}", g_eng, g_orc, slices[key])
+            assert bad[1e-4] <= 1e-3 * g_orc.size, f"g{key} step {step}: {bad[1e-4]} entries beyond 1e-4 of the scale"
+            assert bad[1e-3] <= 16, f"g{key} step {step}: {bad[1e-3]} entries beyond 1e-3 of the scale"
             # per parameter tensor (a wrong layer cannot hide behind the big ones)
             for off, n, shape in slices[key]:
                 a, b = g_eng[off:off + n], g_orc[off:off + n]

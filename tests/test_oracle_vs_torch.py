@@ -331,3 +331,153 @@ def test_image_scale_rule_against_torch_interpolate():
     up = O.image_scale(small, 19, 33)                       # 7 -> 19, 9 -> 33
     refu = torch.nn.functional.interpolate(torch.from_numpy(small)[None], size=(33, 19), mode="bilinear", align_corners=True)[0].numpy()
     np.testing.assert_allclose(up, refu, rtol=0, atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 4: the remaining single points of RECALL - stn's conventions (models.lua:877-878) and Torch7's Adam
+# (adversarial.lua:245) - restated a second time, independently of the formulas the oracle types in.
+
+def _hom(rows):
+    return torch.tensor(rows, dtype=torch.float64)
+
+
+def test_transformer_trio_second_restatement_with_explicit_axis_swap():
+    """AffineTransformMatrixGenerator -> AffineGridGeneratorBHWD -> BilinearSamplerBHWD once more, built from SEPARATE homogeneous
+    matrices (rotation, scale, translation multiplied out by torch, not the closed-form entries oracle.AffineMatrix types in) and
+    PyTorch's affine_grid / grid_sample in fp64.  PyTorch's grid is (x, y) with theta acting on (x, y, 1); stn's is (y, x) with T
+    acting on (y, x, 1): the conjugation by the axis swap P = [[0,1,0],[1,0,0],[0,0,1]] is written out here.  A NON-identity
+    rotation + scale + translation, forward and backward (image and the four parameters)."""
+    rs = np.random.RandomState(11)
+    N, H, W, C = 2, 10, 10, 3
+    params = np.array([[0.45, 0.8, 0.25, -0.15], [-0.9, 1.3, -0.2, 0.3]], f32)     # theta, scale, t_x, t_y (stn's order)
+    img = rs.randn(N, H, W, C).astype(f32)
+    gout = rs.randn(N, H, W, C).astype(f32)
+    atm, agg = O.AffineMatrix(True, True, True), O.AffineGrid(H, W)
+    T = atm.forward(params); grid = agg.forward(T)
+    out = O.bilinear_forward(img, grid)
+    gimg, ggrid = O.bilinear_backward(img, grid, gout)
+    gparams = atm.backward(agg.backward(ggrid))
+
+    p = torch.tensor(params.astype(np.float64), requires_grad=True)
+    it = torch.tensor(img.astype(np.float64).transpose(0, 3, 1, 2).copy(), requires_grad=True)
+    P = _hom([[0, 1, 0], [1, 0, 0], [0, 0, 1]])
+    thetas = []
+    for n in range(N):
+        th, sc, tx, ty = p[n, 0], p[n, 1], p[n, 2], p[n, 3]
+        one, zero = torch.ones((), dtype=torch.float64), torch.zeros((), dtype=torch.float64)
+        R = torch.stack([torch.stack([torch.cos(th), -torch.sin(th), zero]), torch.stack([torch.sin(th), torch.cos(th), zero]),
+                         torch.stack([zero, zero, one])])
+        Sm = torch.stack([torch.stack([sc, zero, zero]), torch.stack([zero, sc, zero]), torch.stack([zero, zero, one])])
+        Tr = torch.stack([torch.stack([one, zero, tx]), torch.stack([zero, one, ty]), torch.stack([zero, zero, one])])
+        A_yx = R @ Sm @ Tr                    # stn: acts on (y, x, 1), emits (y, x)
+        A_xy = P @ A_yx @ P                   # the same map in PyTorch's (x, y, 1) -> (x, y) coordinates
+        thetas.append(A_xy[:2])
+        np.testing.assert_allclose(T[n], A_yx[:2].detach().numpy(), atol=2e-6)
+    g_xy = F.affine_grid(torch.stack(thetas), (N, C, H, W), align_corners=True)
+    np.testing.assert_allclose(grid[..., 0], g_xy[..., 1].detach().numpy(), atol=5e-6)      # stn (y, x)  <->  torch (x, y)
+    np.testing.assert_allclose(grid[..., 1], g_xy[..., 0].detach().numpy(), atol=5e-6)
+    ot = F.grid_sample(it, g_xy, mode="bilinear", padding_mode="zeros", align_corners=True)
+    np.testing.assert_allclose(out.transpose(0, 3, 1, 2), ot.detach().numpy(), atol=3e-5)
+    ot.backward(torch.tensor(gout.astype(np.float64).transpose(0, 3, 1, 2).copy()))
+    np.testing.assert_allclose(gimg.transpose(0, 3, 1, 2), it.grad.numpy(), atol=5e-5)
+    np.testing.assert_allclose(gparams, p.grad.numpy(), rtol=2e-4, atol=3e-4)
+
+
+def test_transformer_conventions_as_geometry():
+    """The same conventions stated as geometry, with no formula in between: on a corner-aligned grid, the oracle's transformer with
+    (a) theta = pi/2 reproduces a quarter turn of the image, (b) scale 1/2 samples the central half (a 2x zoom: the output's corners
+    are the input's quarter points), (c) a translation t_x along the FIRST grid coordinate (y) by one pixel pitch shifts the rows.
+    Which way each goes is what is 'recalled' from stnbhwd; the test pins the direction the oracle (and with it the engine) takes."""
+    H = 9
+    x = np.arange(H * H, dtype=f32).reshape(1, H, H, 1)
+    def run(th, sc, tx, ty):
+        atm, agg = O.AffineMatrix(True, True, True), O.AffineGrid(H, H)
+        return O.bilinear_forward(x, agg.forward(atm.forward(np.array([[th, sc, tx, ty]], f32))))[0, :, :, 0]
+    np.testing.assert_allclose(run(0, 1, 0, 0), x[0, :, :, 0], atol=1e-4)
+    # (a) quarter turn: the grid point of output pixel (y, x) is R (y, x) = (c y - s x, s y + c x); theta = +pi/2 gives (-x, y), so
+    # out[i][j] = in[H-1-j][i] - which is numpy.rot90(in, k=-1): the picture turns CLOCKWISE for a positive angle
+    q = run(np.pi / 2, 1, 0, 0)
+    k = [k for k in (1, -1) if np.allclose(q, np.rot90(x[0, :, :, 0], k), atol=1e-3)]
+    assert k == [-1], f"theta = +pi/2 must be numpy.rot90(k=-1) of the image (grid (y,x) <- R (y,x)); got {k}"
+    np.testing.assert_allclose(q, x[0, ::-1, :, 0].T, atol=1e-3)       # out[i][j] = in[H-1-j][i], spelled out
+    # (b) scale 1/2: output corner (0,0) reads the input at (-1/2,-1/2) in normalised coordinates = pixel (H-1)/4
+    z = run(0, 0.5, 0, 0)
+    c = (H - 1) / 4
+    np.testing.assert_allclose(z[0, 0], x[0, int(c), int(c), 0], atol=1e-3)
+    np.testing.assert_allclose(z[-1, -1], x[0, int(3 * c), int(3 * c), 0], atol=1e-3)
+    # (c) translation: the first parameter after the scale moves along y (rows), the second along x; +2/(H-1) = one pixel
+    t = run(0, 1, 2.0 / (H - 1), 0)
+    np.testing.assert_allclose(t[:-1], x[0, 1:, :, 0], atol=1e-3)      # row i shows input row i + 1
+    assert np.allclose(t[-1], 0, atol=1e-3)                            # the last row reads outside: zeros
+    t2 = run(0, 1, 0, 2.0 / (H - 1))
+    np.testing.assert_allclose(t2[:, :-1], x[0, :, 1:, 0], atol=1e-3)
+
+
+def test_torch7_adam_five_steps_against_a_scalar_double_loop():
+    """optim.adam as Torch7 wrote it (adversarial.lua:245 calls it with an empty config): m, v updated, then
+        x <- x - lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps)
+    i.e. epsilon is added to sqrt(v) WITHOUT bias-correcting v first - not PyTorch's form.  Five steps on changing gradients against
+    a plain Python double-precision loop written from that sentence, and against torch.optim.Adam to show the two forms separate
+    where |g| is comparable to eps."""
+    rs = np.random.RandomState(2)
+    x0 = rs.randn(6); gs = [rs.randn(6) * s for s in (1.0, 0.1, 3.0, 1e-3, 0.5)]
+    x, st = x0.astype(f32).copy(), {}
+    xs = []
+    for g in gs:
+        O.adam(x, g.astype(f32), st)
+        xs.append(x.copy())
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    for i in range(6):
+        m = v = 0.0
+        xv = float(np.float32(x0[i]))
+        for t, g in enumerate(gs, 1):
+            gi = float(np.float32(g[i]))
+            m = b1 * m + (1 - b1) * gi
+            v = b2 * v + (1 - b2) * gi * gi
+            xv = xv - lr * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t) * m / (v ** 0.5 + eps)
+            assert abs(xs[t - 1][i] - xv) <= 2e-6 * max(1.0, abs(xv)), (i, t, xs[t - 1][i], xv)
+    # tiny gradients: Torch7's eps placement gives a visibly different first step from PyTorch's (eps after the bias correction)
+    xt = np.array([1.0], f32); stt = {}
+    O.adam(xt, np.array([1e-8], f32), stt)
+    pt = torch.tensor([1.0], requires_grad=True)
+    opt = torch.optim.Adam([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    pt.grad = torch.tensor([1e-8]); opt.step()
+    torch7_step, pytorch_step = 1.0 - float(xt[0]), 1.0 - float(pt.detach()[0])
+    # closed forms: Torch7 lr*sqrt(1-b2)/(1-b1) * (1-b1) g / (sqrt(1-b2) g + eps);  PyTorch lr * g / (g + eps)
+    g = 1e-8
+    assert abs(torch7_step - 1e-3 * np.sqrt(1e-3) * g / (np.sqrt(1e-3) * g + 1e-8)) < 2e-6 + 1e-7
+    assert abs(pytorch_step - 1e-3 * g / (g + 1e-8)) < 2e-6 + 1e-7
+
+
+def test_full_G_gradient_finite_difference():
+    """Central differences through the whole G32up-c (train-mode batch norm included) against the oracle's backward, for a spread of
+    parameters of every layer and a few noise entries: the check that existed for D only (test_full_D_gradient_finite_difference).
+    The oracle computes in fp32, so the differences use a step large against its rounding and the tolerance is that of D's test."""
+    rng = O.RNG(8)
+    G = O.create_G32up_c(3, 100, rng)
+    pG, gG = O.get_parameters(G)
+    rs = np.random.RandomState(3)
+    z = (rs.rand(4, 100) * 2 - 1).astype(f32)
+    w = rs.randn(4, 3, 32, 32).astype(f32)
+
+    def loss():
+        return float((G.forward(z).astype(np.float64) * w).sum())
+
+    gG[...] = 0
+    G.forward(z)
+    gin = G.backward(w)
+    offs, off = [], 0
+    for p_, _ in G.parameters():
+        offs.append((off, p_.size)); off += p_.size
+    idxs = []
+    for o_, n_ in offs:                       # two entries of every parameter tensor (first third / last third)
+        idxs += [o_ + n_ // 3, o_ + (2 * n_) // 3] if n_ > 2 else [o_]
+    idxs = sorted(set(idxs))
+    fd = _finite_diff(loss, pG, idxs, eps=2e-3)
+    scale = np.abs(gG).max()
+    np.testing.assert_allclose(gG[idxs], fd, rtol=0.08, atol=2e-3 * scale)
+    # the noise gradient: the loss is a sum of 12 288 fp32 outputs (|loss| ~ 50, rounding ~ 5e-5), so the step must be large against
+    # that or the difference quotient is noise (5e-5 / 4e-3 = 0.01 at the parameters' step, the size of the gradient itself)
+    zi = [(0, 3), (1, 57), (3, 99), (2, 10)]
+    fdz = _finite_diff(loss, z, zi, eps=2e-2)
+    np.testing.assert_allclose([gin[i] for i in zi], fdz, rtol=0.08, atol=2e-2 * np.abs(gin).max())
