@@ -234,6 +234,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default) launch eagerly: with the planned executor a step costs the host ~1.1 ms")
     ap.add_argument("--graph", action="store_true", help="capture the iteration once (cg_graph_*) and replay the hipGraph")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--strict-comm", action="store_true",
+                    help="N > 1: the engine's transport (cg_comm_*: RCCL through the C ABI) or failure - never the torch.distributed fallback "
+                         "(CG_COMM_STRICT=1).  config.collectives.transport names the transport of a run either way.")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON: libraries write banners there from C (RCCL's version block at communicator init,
@@ -242,6 +245,8 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if args.strict_comm:
+        os.environ["CG_COMM_STRICT"] = "1"
     cg = importlib.import_module("cat-generator_amd")
     rank, world = cg.parallel.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"

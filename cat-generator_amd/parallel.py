@@ -50,6 +50,17 @@ def _init_abi_comms(world, rank):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item() > 0.5)
 
+    # STRICT mode (CG_COMM_STRICT=1, or bench.py --strict-comm): the engine's own transport or nothing.  Every place below that would
+    # move all ranks to torch.distributed raises instead - on every rank, the decision being collective - so that a measured
+    # multi-GPU number can only be cg_comm_*'s.  Default: fall back (a training run prefers running), and say so in comm_info().
+    strict = os.environ.get("CG_COMM_STRICT", "0") == "1"
+
+    def fall_back(msg):
+        _S["fallback"] = msg
+        if strict:
+            raise RuntimeError(f"CG_COMM_STRICT=1: {msg}; refusing to fall back to torch.distributed")
+        warnings.warn(msg + "; device collectives fall back to torch.distributed on every rank")
+
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     # ranks sharing a GPU (functional tests on a 1-GPU box): RCCL refuses duplicate devices.  CG_COMM=abi1 keeps the ABI path
     # alive there with one single-rank communicator pair per process (collectives degenerate to copies; the transport of the
@@ -66,8 +77,8 @@ def _init_abi_comms(world, rank):
     except Exception as e:
         err = str(e)
     if not agree(err is None):
-        if err not in (None, "ranks share a GPU"):
-            warnings.warn(f"cg_comm_* unavailable ({err}); device collectives fall back to torch.distributed on every rank")
+        if err not in (None, "ranks share a GPU") or strict:
+            fall_back(f"cg_comm_* unavailable ({err or 'on another rank'})")
         return
     ids = [None, None]
     if rank == 0:
@@ -91,8 +102,7 @@ def _init_abi_comms(world, rank):
                     L.comm_destroy(h_)
                 except Exception:
                     pass
-            warnings.warn(f"cg_comm_init failed on some rank ({err or 'another rank'}); device collectives fall back to "
-                          "torch.distributed on every rank")
+            fall_back(f"cg_comm_init failed on some rank ({err or 'another rank'})")
             return
     # first multi-rank execution of the transport: one checked all-reduce per communicator before anything depends on it
     ok, msg = True, ""
@@ -100,9 +110,8 @@ def _init_abi_comms(world, rank):
         for h in made:
             ok, msg = _selftest(L, h, world, rank)
             if not agree(ok):
-                warnings.warn(f"cg_comm_* self-test failed on some rank ({msg or 'another rank'}); device collectives fall back to "
-                              "torch.distributed on every rank")
                 _S["selftest"] = "failed: " + (msg or "another rank")
+                fall_back(f"cg_comm_* self-test failed on some rank ({msg or 'another rank'})")
                 return          # the communicators are left alone: destroying one with a collective stuck in it may block
         _S["selftest"] = "ok"
     _S["comm_grad"], _S["comm_bn"] = made
@@ -153,9 +162,15 @@ def comm_backend():
 def comm_info():
     """What the bench line prints about the collectives: backend, communicator size as RCCL reports it, RCCL version."""
     from .tensor import lib
-    out = {"backend": comm_backend(), "world": _S["world"]}
+    out = {"backend": comm_backend(), "world": _S["world"],
+           "transport": {"abi": "cg_comm_* (csrc/comm.hip: RCCL through the C ABI, side stream, event fork / join)",
+                         "abi1+torch": "single-rank cg_comm_* communicators + torch.distributed for the cross-rank sum (functional test mode)",
+                         "torch": "torch.distributed (FALLBACK or CG_COMM=torch: not the engine's transport)"}[comm_backend()],
+           "strict": os.environ.get("CG_COMM_STRICT", "0") == "1"}
     if _S["selftest"]:
         out["selftest"] = _S["selftest"]
+    if _S.get("fallback"):
+        out["fallback_reason"] = _S["fallback"]
     try:
         v = ctypes.c_int(0)
         lib().comm_version(ctypes.byref(v))

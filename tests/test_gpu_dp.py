@@ -186,3 +186,40 @@ def test_two_ranks_on_half_batches_equal_one_rank_on_the_full_batch(overlap, com
         # the LDS-direct-load kernels; mean 1.8e-5)
         d = np.abs(a - b)
         assert d.max() <= 4.2e-3 and d.mean() <= 3e-5, (name, d.max(), d.mean())
+
+
+def _strict_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                          LOCAL_WORLD_SIZE=str(world), CG_COMM="abi", CG_COMM_STRICT="1", CATGAN_DIST_BACKEND="gloo")
+        cg = importlib.import_module("cat-generator_amd")
+        try:
+            cg.parallel.init_from_env()
+            q.put((rank, "no error", cg.parallel.comm_info()))
+        except RuntimeError as e:
+            q.put((rank, str(e), cg.parallel.comm_info()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, f"unexpected {type(e).__name__}: {e}", None))
+
+
+@pytest.mark.timeout(300)
+def test_strict_transport_refuses_the_fallback_on_every_rank():
+    """CG_COMM_STRICT=1 (bench.py --strict-comm): where the default would move every rank to torch.distributed - here: two ranks
+    sharing the box's one GPU, which RCCL refuses - init raises instead, on EVERY rank (the decision is collective), so a multi-GPU
+    number measured in strict mode can only be cg_comm_*'s.  comm_info() names the transport and the reason either way."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + os.getpid() % 40
+    procs = [ctx.Process(target=_strict_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=200) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    for rank, msg, info in res:
+        assert "CG_COMM_STRICT=1" in msg and "refusing to fall back" in msg, (rank, msg)
+        assert info["backend"] == "torch" and info["strict"] is True and "not the engine's transport" in info["transport"]
+        assert "fallback_reason" in info

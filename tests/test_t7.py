@@ -102,3 +102,91 @@ def test_checkpoint_table_export_and_import(tmp_path):
     conv = t7.table_list(raw["G"]["modules"])[4]
     assert conv.typename == "cudnn.SpatialConvolution" and conv["weight"].shape == (512, 512, 3, 3) and conv["output"].size == 0
     assert os.path.getsize(path) > 4 * 2 * (S.PARAMETERS_G.nElement() + n)   # parameters and (zero) gradients, as torch.save writes
+
+
+def test_byte_fixture_of_a_flattened_nested_sequential():
+    """What torch.save writes for a small net AFTER getParameters() (train.lua:184-185 flattens before anything is saved): every
+    weight / bias is a view of ONE torch.FloatStorage (and every gradWeight / gradBias of one other), so the file holds each
+    storage once - at its first use - and back-references (the bare object index) afterwards.  The bytes are assembled here from
+    the documented layout (File.lua writeObject, binary mode; nn classes have no write() of their own, so an instance is its class
+    header `V 1`, its name, and ONE table with its fields):
+
+        nn.Sequential { train = true, modules = { nn.Linear(3 -> 2){ weight, bias, gradWeight, gradBias },
+                                                  nn.Sequential { modules = { nn.PReLU{ weight, gradWeight }, nn.Sigmoid{} } } } }
+        parameters  : FloatStorage P of 9 floats  = [ W(2x3) | b(2) | alpha(1) ]      -> views at offsets 1, 7, 9
+        gradients   : FloatStorage Gs of 9 floats (zeros)                              -> the same offsets
+
+    Reading it gives the module tree with the right values (views resolved through strides / offsets / the shared storage), and
+    the engine imports it (t7_nn.from_t7) as nn modules whose flat parameter vector IS storage P."""
+    P = np.array([0.5, -1.0, 2.0, 1.5, 0.25, -0.75, 0.1, -0.2, 0.25], "<f4")
+    Gs = np.zeros(9, "<f4")
+    idx = iter(range(1, 100))
+
+    def torch_obj(name, payload):
+        return _i(4) + _i(next(idx)) + _s("V 1") + _s(name) + payload
+
+    def table(entries):                       # entries: list of (key bytes, value bytes)
+        return _i(3) + _i(next(idx)) + _i(len(entries)) + b"".join(k + v for k, v in entries)
+
+    key = lambda s: _i(2) + _s(s)
+    num = lambda v: _i(1) + struct.pack("<d", v)
+    storage_ids = {}
+
+    def tensor(sizes, offset, which, data):
+        body = _i(len(sizes)) + b"".join(_q(s) for s in sizes)
+        strides, st = [], 1
+        for s in reversed(sizes):
+            strides.append(st); st *= s
+        body += b"".join(_q(s) for s in reversed(strides)) + _q(offset)
+        head = _i(4) + _i(next(idx)) + _s("V 1") + _s("torch.FloatTensor")
+        if which in storage_ids:                                   # a back-reference: type tag + index, nothing else
+            return head + body + _i(4) + _i(storage_ids[which])
+        sid = next(idx)
+        storage_ids[which] = sid
+        return head + body + _i(4) + _i(sid) + _s("V 1") + _s("torch.FloatStorage") + _q(data.size) + data.tobytes()
+
+    # objects are numbered in order of first appearance: Sequential(1) fields(2) modules(3) Linear(4) fields(5) weight(6) P(7) ...
+    seq_i = next(idx); seq_f = next(idx)
+    def linear():
+        li, lf = next(idx), next(idx)
+        ent = [(key("weight"), tensor([2, 3], 1, "P", P)), (key("bias"), tensor([2], 7, "P", P)),
+               (key("gradWeight"), tensor([2, 3], 1, "G", Gs)), (key("gradBias"), tensor([2], 7, "G", Gs))]
+        return _i(4) + _i(li) + _s("V 1") + _s("nn.Linear") + _i(3) + _i(lf) + _i(len(ent)) + b"".join(k + v for k, v in ent)
+    def inner():
+        si, sf = next(idx), next(idx)
+        mi = next(idx)
+        pi, pf = next(idx), next(idx)
+        pre = [(key("weight"), tensor([1], 9, "P", P)), (key("gradWeight"), tensor([1], 9, "G", Gs)), (key("nOutputPlane"), num(0))]
+        prelu = _i(4) + _i(pi) + _s("V 1") + _s("nn.PReLU") + _i(3) + _i(pf) + _i(len(pre)) + b"".join(k + v for k, v in pre)
+        gi, gf = next(idx), next(idx)
+        sig = _i(4) + _i(gi) + _s("V 1") + _s("nn.Sigmoid") + _i(3) + _i(gf) + _i(0)
+        mods = _i(3) + _i(mi) + _i(2) + num(1) + prelu + num(2) + sig
+        return _i(4) + _i(si) + _s("V 1") + _s("nn.Sequential") + _i(3) + _i(sf) + _i(1) + key("modules") + mods
+    mods_i = next(idx)
+    modules = _i(3) + _i(mods_i) + _i(2) + num(1) + linear() + num(2) + inner()
+    blob = (_i(4) + _i(seq_i) + _s("V 1") + _s("nn.Sequential") + _i(3) + _i(seq_f) + _i(2)
+            + key("train") + _i(5) + _i(1) + key("modules") + modules)
+    assert blob.count(b"torch.FloatStorage") == 2 and blob.count(b"torch.FloatTensor") == 6      # two storages, six views
+
+    net = t7.Reader(io.BytesIO(blob)).read()
+    assert net.typename == "nn.Sequential" and net["train"] is True
+    lin, sub = t7.table_list(net["modules"])
+    assert lin.typename == "nn.Linear" and sub.typename == "nn.Sequential"
+    np.testing.assert_array_equal(lin["weight"], P[0:6].reshape(2, 3))
+    np.testing.assert_array_equal(lin["bias"], P[6:8])
+    prelu, sig = t7.table_list(sub["modules"])
+    assert prelu.typename == "nn.PReLU" and sig.typename == "nn.Sigmoid" and sig.fields == {}
+    np.testing.assert_array_equal(prelu["weight"], P[8:9])
+    np.testing.assert_array_equal(lin["gradWeight"], np.zeros((2, 3), np.float32))
+    # into the engine: the same tree, and its flat parameter vector is storage P (Torch7's depth-first order, weight then bias)
+    t7_nn = importlib.import_module("cat-generator_amd.t7_nn")
+    m = t7_nn.from_t7(net)
+    assert [x.typename for x in m.listModules()] == ["nn.Sequential", "nn.Linear", "nn.Sequential", "nn.PReLU", "nn.Sigmoid"]
+    flat, _ = m.getParameters()
+    np.testing.assert_array_equal(flat.numpy(), P)
+    # and back out: our writer emits the same classes with the same fields (storages per tensor: Torch7 accepts either)
+    out = io.BytesIO()
+    t7.Writer(out).write(t7_nn.to_t7(m))
+    again = t7.Reader(io.BytesIO(out.getvalue())).read()
+    np.testing.assert_array_equal(t7.table_list(again["modules"])[0]["weight"], P[0:6].reshape(2, 3))
+    np.testing.assert_array_equal(t7.table_list(t7.table_list(again["modules"])[1]["modules"])[0]["weight"].reshape(-1), P[8:9])
