@@ -200,6 +200,13 @@ class AsyncLoader:
         if not paths:
             raise FileNotFoundError(f"no *.{fileExtension} images under {dirs}")
         self.Hs, self.Ws = _decode(paths[0]).shape[:2]      # the dataset is written at one size (generate_dataset.py: 64 x 64)
+        # The device kernel scales a batch of ONE source size, and at most 6x down (images_u8_scale_k's box loop).  The reference
+        # (dataset.lua:129-131) scales every image on its own: an image of another size - or all of them, if the source is more than
+        # 6x the target - takes the blocking loader's host path (image_scale, same arithmetic) and is patched into the pool.
+        self.host_all = self.Hs > 6 * height or self.Ws > 6 * width
+        if self.host_all:
+            import warnings
+            warnings.warn(f"AsyncLoader: {self.Ws}x{self.Hs} sources are more than 6x the {width}x{height} target: scaling on the host")
         self.nbytes = self.count * self.Hs * self.Ws * 3
         self.copy_stream = ctypes.c_void_p()
         self.L.stream_create(ctypes.byref(self.copy_stream))
@@ -223,13 +230,20 @@ class AsyncLoader:
         if slot["used"]:
             self.L.event_sync(slot["ready"])   # its previous upload has left the pinned buffer (long ago; costs nothing)
 
+        slot["patches"] = []
+
         def work():
             try:
                 for i, f in enumerate(files):
                     im = _decode(f)
-                    if im.shape[:2] != (self.Hs, self.Ws):
-                        raise ValueError(f"{f}: {im.shape[1]}x{im.shape[0]} pixels, the dataset's other images have {self.Ws}x{self.Hs}")
-                    slot["staging"][i] = im
+                    if self.host_all or im.shape[:2] != (self.Hs, self.Ws):
+                        # loadRandomImages' arithmetic for this one image: /255 -> image.scale -> colour space, as NHWC rows
+                        img = image_scale(im.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0), width, height)
+                        img = rgbToColorSpace(img[None], colorSpace)[0]
+                        slot["patches"].append((i, np.ascontiguousarray(img.transpose(1, 2, 0))))
+                        slot["staging"][i] = 0
+                    else:
+                        slot["staging"][i] = im
             except Exception as e:   # surfaced by next()
                 self._err = e
         self._thread = threading.Thread(target=work, daemon=True)
@@ -241,6 +255,12 @@ class AsyncLoader:
             L.stream_wait_event(cs, slot["free"])      # the training stream has finished reading this pool
         L.memcpy_h2d(cs, slot["dev_u8"], slot["host"], n * self.Hs * self.Ws * 3)
         L.images_u8_scale_to_f32(cs, slot["dev_u8"], slot["pool"].ptr, n, self.Hs, self.Ws, height, width, 1 if colorSpace == "y" else 0)
+        if slot["patches"]:       # images scaled on the host (another source size): over the rows the kernel produced from zeros
+            row = height * width * self.C * 4
+            for i, arr in slot["patches"]:
+                L.memcpy_h2d(cs, slot["pool"].ptr + i * row, arr.ctypes.data, row)
+            L.stream_sync(cs)     # pageable sources: they must outlive the copies
+            slot["patches"] = []
         L.event_record(slot["ready"], cs)
 
     def next(self):

@@ -161,6 +161,20 @@ def test_async_loader_pools_equal_the_blocking_loader(tmp_path, cs):
         assert few.shape[0] == 9
         np.testing.assert_array_equal(cg.nn.as_nhwc(few).numpy(), few_ref)
         ld.close()
+        # a dataset of MIXED sizes (dataset.lua:129-131 scales every image on its own): three files of another size among the nine
+        # take the host path inside the loader and land in the pool with the blocking loader's bits
+        from PIL import Image
+        rs = np.random.RandomState(11)
+        for k, (hh, ww) in enumerate(((48, 80), (64, 40), (100, 100))):
+            Image.fromarray(rs.randint(0, 256, size=(hh, ww, 3)).astype(np.uint8)).save(os.path.join(str(tmp_path), f"odd{k}.jpg"), quality=95)
+        ds.setDirs([str(tmp_path)])
+        ds.seed(9)
+        mixed_ref = [ds.loadRandomImages(12).scaled for _ in range(2)]
+        ds.seed(9)
+        ld = ds.AsyncLoader(12)
+        for e in range(2):
+            np.testing.assert_array_equal(cg.nn.as_nhwc(ld.next()).numpy(), mixed_ref[e])
+        ld.close()
     finally:
         ds.colorSpace = "rgb"
 
