@@ -43,7 +43,7 @@ constexpr int kNumCU = 256;  // MI355X: 8 XCDs x 32 CUs
 enum Opt {
     OPT_SPLIT_TARGET, OPT_SPLIT_MINK, OPT_TN_SMAX, OPT_TN_TARGET, OPT_SKINNY, OPT_GEMM_SLOW, OPT_GEMM_BK32,
     OPT_COLREDUCE_WGS_PER_CU, OPT_WINO_WAVES, OPT_WINO_BK, OPT_NN_TILE, OPT_TN_TILE, OPT_NN_SPLITS, OPT_TN_SPLITS,
-    OPT_EPILOGUE_STATS, OPT_SAMPLER_ATOMICS, OPT_XCD_SWIZZLE, OPT_NN_QUAD, OPT_TN_QUAD, OPT_WINO_QUAD, OPT_NN_PF, OPT_NN_GLDS, OPT_TN_GLDS, OPT_WINO_GLDS, OPT_COUNT
+    OPT_EPILOGUE_STATS, OPT_SAMPLER_ATOMICS, OPT_XCD_SWIZZLE, OPT_NN_QUAD, OPT_TN_QUAD, OPT_WINO_QUAD, OPT_NN_PF, OPT_NN_GLDS, OPT_TN_GLDS, OPT_WINO_GLDS, OPT_EW_WGS_PER_CU, OPT_COUNT
 };
 long opt(Opt o);
 
@@ -65,7 +65,8 @@ void wgrad_discard_all();
 static inline int ew_grid(long n, int per_block = 256) {
     long b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;
-    if (b > kNumCU * 8) b = kNumCU * 8;
+    const long cap = (long)kNumCU * opt(OPT_EW_WGS_PER_CU);   // CG_EW_WGS_PER_CU (default 8)
+    if (b > cap) b = cap;
     return (int)b;
 }
 

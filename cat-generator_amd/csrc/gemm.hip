@@ -92,6 +92,7 @@ struct Geom {
 };
 
 constexpr int MAXG = 4;  // groups per launch: same geometry, separate tensors (D32_st3's identical branches)
+constexpr int kMaxStridedGroups = 16;   // ... or up to 16 equally spaced ones (cg_conv2d_wgrad_strided)
 
 struct NNArgs {
     const float* x0; const float* x1; const float* x2; const float* x3;   // per group (no arrays: see TapDesc)
@@ -128,6 +129,8 @@ struct TNArgs {
     Geom g;
     int pchunk;         // pixels per split (multiple of BK)
     int xcd_swizzle;
+    long xgs, dgs;      // != 0: group g reads x0 + g * xgs / d0 + g * dgs (up to kMaxStridedGroups equally spaced groups: the 16
+                        // Winograd-domain weight-gradient GEMMs of winograd.hip in one launch), x1.. / d1.. unused
 };
 
 template <typename T>
@@ -1009,8 +1012,8 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
     const int zz = blockIdx.z;
     const int group = g.nphase == 1 ? zz : (g.nphase == 4 ? zz >> 2 : zz / g.nphase);
     const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
-    const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
-    const float* gdy = sel4(group, a.d0, a.d1, a.d2, a.d3);
+    const float* gx = a.xgs ? a.x0 + (long)group * a.xgs : sel4(group, a.x0, a.x1, a.x2, a.x3);
+    const float* gdy = a.dgs ? a.d0 + (long)group * a.dgs : sel4(group, a.d0, a.d1, a.d2, a.d3);
     const int ps = split * a.pchunk;
     const int pend = min(g.M, ps + a.pchunk);
     const int T = (pend - ps + BK - 1) / BK;
@@ -1292,8 +1295,8 @@ __global__ __launch_bounds__(256, 2) void igemm_tnq_kernel(TNArgs a, int flat) {
     const int zz = blockIdx.z;
     const int group = g.nphase == 1 ? zz : (g.nphase == 4 ? zz >> 2 : zz / g.nphase);
     const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
-    const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
-    const float* gdy = sel4(group, a.d0, a.d1, a.d2, a.d3);
+    const float* gx = a.xgs ? a.x0 + (long)group * a.xgs : sel4(group, a.x0, a.x1, a.x2, a.x3);
+    const float* gdy = a.dgs ? a.d0 + (long)group * a.dgs : sel4(group, a.d0, a.d1, a.d2, a.d3);
     const int ps = split * a.pchunk;
     const int pend = min(g.M, ps + a.pchunk);
     const int T = (pend - ps) / BKT;
@@ -1524,8 +1527,8 @@ __global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int flat) {
     const int zz = blockIdx.z;
     const int group = g.nphase == 1 ? zz : (g.nphase == 4 ? zz >> 2 : zz / g.nphase);
     const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
-    const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
-    const float* gdy = sel4(group, a.d0, a.d1, a.d2, a.d3);
+    const float* gx = a.xgs ? a.x0 + (long)group * a.xgs : sel4(group, a.x0, a.x1, a.x2, a.x3);
+    const float* gdy = a.dgs ? a.d0 + (long)group * a.dgs : sel4(group, a.d0, a.d1, a.d2, a.d3);
     const int ps = split * a.pchunk;
     const int pend = min(g.M, ps + a.pchunk);
     const int T = (pend - ps) / BK;
@@ -1712,7 +1715,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
 // Same reduction for small weight tensors (where the tiled form above would not fill the chip), all groups of a
 // grouped launch and their bias gradients in ONE launch: grid (weight blocks + bias blocks, ngroups); a workgroup
 // owns 32 consecutive partial elements (or 32 bias channels) and splits the S partials over 8 lanes.
-struct RedPtrs { float* gw0; float* gw1; float* gw2; float* gw3; float* gb0; float* gb1; float* gb2; float* gb3; };
+struct RedPtrs { float* gw0; float* gw1; float* gw2; float* gw3; float* gb0; float* gb1; float* gb2; float* gb3;
+                 long gws; };   // gws != 0: group g accumulates into gw0 + g * gws (strided groups, no bias gradients)
 
 template <bool UPS>
 __device__ __forceinline__ void wgrad_reduce_small_body(float (*sh)[33], int bx, int group, const float* part, const float* bias_part,
@@ -1750,7 +1754,7 @@ __device__ __forceinline__ void wgrad_reduce_small_body(float (*sh)[33], int bx,
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) t += sh[r][ol];
-            float* gw = sel4(group, rp.gw0, rp.gw1, rp.gw2, rp.gw3);
+            float* gw = rp.gws ? rp.gw0 + (long)group * rp.gws : sel4(group, rp.gw0, rp.gw1, rp.gw2, rp.gw3);
             gw[((long)co * Cin + ci) * KK + tap] += scale * t;
         }
     } else {
@@ -2578,7 +2582,7 @@ int cg_conv2d_dgrad_ups2(void* stream, const float* dy, const float* wb_ph, floa
 size_t cg_conv2d_wgrad_workspace_bytes_grouped(int ngroups, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW,
                                                int padH, int padW, int ups) {
     Geom g;
-    if (ngroups < 1 || ngroups > MAXG || conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
+    if (ngroups < 1 || ngroups > kMaxStridedGroups || conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;   // > MAXG: cg_conv2d_wgrad_strided
     const size_t reg = tn_ws_bytes(g, plan_tn(g, ngroups), ngroups);
     return skinny_ok(ngroups, Cin, Cout, kH, kW, padH, padW, ups) ? std::max(reg, skinny_wgrad_ws_bytes(Cin, Cout)) : reg;
 }
@@ -2612,7 +2616,7 @@ int small_reduce(hipStream_t st, bool defer, const RedJob& job, int ngroups) {
 
 int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* const* dy, float* const* gw, float* const* gb, int N,
                int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes,
-               bool defer);
+               bool defer, long xgs = 0, long dgs = 0, long gws = 0);
 }  // namespace
 
 int cg_conv2d_wgrad_grouped(void* stream, int ngroups, const float* const* x, const float* const* dy, float* const* gw,
@@ -2625,6 +2629,20 @@ int cg_conv2d_wgrad_grouped_deferred(void* stream, int ngroups, const float* con
                                      float* const* gb, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW,
                                      int ups, float scale, void* ws, size_t ws_bytes) {
     return wgrad_impl(stream, ngroups, x, dy, gw, gb, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups, scale, ws, ws_bytes, true);
+}
+
+// ngroups (<= 16) weight gradients of ONE geometry whose tensors are equally spaced in memory - group g reads x + g*x_stride and
+// dy + g*dy_stride (floats) and accumulates into gw + g*gw_stride - in one GEMM launch and one reduction.  What the Winograd-domain
+// weight gradient of winograd.hip is: 16 independent [tiles x Cin]^T [tiles x 4 Cout] products, one per transform position
+// (four launches of four groups through cg_conv2d_wgrad_grouped before round 4).  No bias gradients.  Workspace:
+// cg_conv2d_wgrad_workspace_bytes_grouped(ngroups, ...).
+int cg_conv2d_wgrad_strided(void* stream, int ngroups, const float* x, long x_stride, const float* dy, long dy_stride, float* gw,
+                            long gw_stride, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups,
+                            float scale, void* ws, size_t ws_bytes) {
+    CG_REQUIRE(x && dy && gw && x_stride > 0 && dy_stride > 0 && gw_stride > 0, "cg_conv2d_wgrad_strided: bad arguments");
+    CG_REQUIRE(ngroups >= 1 && ngroups <= kMaxStridedGroups, "cg_conv2d_wgrad_strided: 1..%d groups per launch", kMaxStridedGroups);
+    return wgrad_impl(stream, ngroups, &x, &dy, &gw, nullptr, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups, scale, ws, ws_bytes, false,
+                      x_stride, dy_stride, gw_stride);
 }
 
 int cg_conv2d_wgrad_pending(void* stream, int* njobs) {
@@ -2664,14 +2682,16 @@ int cg_conv2d_wgrad_flush(void* stream) {
 namespace {
 int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* const* dy, float* const* gw, float* const* gb, int N,
                int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes,
-               bool defer) {
+               bool defer, long xgs, long dgs, long gws_) {
     CG_REQUIRE(x && dy && gw, "cg_conv2d_wgrad: null pointer");
-    CG_REQUIRE(ngroups >= 1 && ngroups <= MAXG, "cg_conv2d_wgrad: 1..%d groups per launch", MAXG);
+    const bool strided = xgs != 0;     // equally spaced groups: only x[0] / dy[0] / gw[0] are pointers
+    CG_REQUIRE(ngroups >= 1 && ngroups <= (strided ? kMaxStridedGroups : MAXG), "cg_conv2d_wgrad: 1..%d groups per launch", strided ? kMaxStridedGroups : MAXG);
+    CG_REQUIRE(!strided || (!gb && !defer), "cg_conv2d_wgrad: strided groups carry no bias gradient and are not deferred");
     TNArgs a;
     memset(&a, 0, sizeof(a));
     if (conv_geom(a.g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 1;
     const Geom& g = a.g;
-    if (skinny_ok(ngroups, Cin, Cout, kH, kW, padH, padW, ups) && x[0] && dy[0] && gw[0] && (uintptr_t)x[0] % 16 == 0 && ws &&
+    if (!strided && skinny_ok(ngroups, Cin, Cout, kH, kW, padH, padW, ups) && x[0] && dy[0] && gw[0] && (uintptr_t)x[0] % 16 == 0 && ws &&
         ws_bytes >= skinny_wgrad_ws_bytes(Cin, Cout) && (long)N * Hp * Wp < 0x7fffffffL) {
         hipStream_t st = cg::S(stream);
         const long npix = (long)N * Hp * Wp;
@@ -2698,13 +2718,15 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
     const float* xs[MAXG] = {nullptr, nullptr, nullptr, nullptr};
     const float* ds[MAXG] = {nullptr, nullptr, nullptr, nullptr};
     bool veca = Cin % 4 == 0, vecb = Cout % 4 == 0, any_gb = false;
-    for (int i = 0; i < ngroups; ++i) {
+    for (int i = 0; i < (strided ? 1 : ngroups); ++i) {
         CG_REQUIRE(x[i] && dy[i] && gw[i], "cg_conv2d_wgrad: null pointer (group %d)", i);
         xs[i] = x[i]; ds[i] = dy[i];
         veca = veca && ((uintptr_t)x[i] % 16 == 0);
         vecb = vecb && ((uintptr_t)dy[i] % 16 == 0);
         any_gb = any_gb || (gb && gb[i]);
     }
+    if (strided) { veca = veca && xgs % 4 == 0; vecb = vecb && dgs % 4 == 0; }
+    a.xgs = xgs; a.dgs = dgs;
     a.x0 = xs[0]; a.x1 = xs[1]; a.x2 = xs[2]; a.x3 = xs[3];
     a.d0 = ds[0]; a.d1 = ds[1]; a.d2 = ds[2]; a.d3 = ds[3];
     a.ngroups = ngroups; a.part = (float*)ws; a.pchunk = p.pchunk;
@@ -2741,7 +2763,8 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
         memset(&job, 0, sizeof(job));
         float* gws[MAXG] = {nullptr, nullptr, nullptr, nullptr};
         float* gbs[MAXG] = {nullptr, nullptr, nullptr, nullptr};
-        for (int gi = 0; gi < ngroups; ++gi) { gws[gi] = gw[gi]; gbs[gi] = gb ? gb[gi] : nullptr; }
+        for (int gi = 0; gi < (strided ? 1 : ngroups); ++gi) { gws[gi] = gw[gi]; gbs[gi] = gb ? gb[gi] : nullptr; }
+        job.rp.gws = strided ? gws_ : 0;
         job.rp.gw0 = gws[0]; job.rp.gw1 = gws[1]; job.rp.gw2 = gws[2]; job.rp.gw3 = gws[3];
         job.rp.gb0 = gbs[0]; job.rp.gb1 = gbs[1]; job.rp.gb2 = gbs[2]; job.rp.gb3 = gbs[3];
         job.part = (const float*)ws; job.bias_part = a.bias_part;
@@ -2753,11 +2776,12 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
     }
     for (int gi = 0; gi < ngroups; ++gi) {
         const float* pg = (const float*)ws + (long)gi * g.nphase * wplane;
+        float* gwi = strided ? gw[0] + (long)gi * gws_ : gw[gi];
         if (ups)
-            hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), shb, st, pg, gw[gi], Cin, Cout, kH, KK, padH, kp,
+            hipLaunchKernelGGL(wgrad_reduce_kernel<true>, rgrid, dim3(256), shb, st, pg, gwi, Cin, Cout, kH, KK, padH, kp,
                                p.splits, scale, ci_t, sstride);
         else
-            hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), shb, st, pg, gw[gi], Cin, Cout, kH, KK, padH,
+            hipLaunchKernelGGL(wgrad_reduce_kernel<false>, rgrid, dim3(256), shb, st, pg, gwi, Cin, Cout, kH, KK, padH,
                                0, p.splits, scale, ci_t, sstride);
         CG_LAUNCH_CHECK();
         if (gb && gb[gi]) {

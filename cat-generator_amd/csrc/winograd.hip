@@ -763,7 +763,7 @@ size_t cg_conv2d_ups2_wino_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin,
     const size_t T = (size_t)N * (Hp / 2) * (Wp / 2);
     return wino_align(16 * T * 4 * Cout * sizeof(float)) + wino_align((size_t)16 * 4 * Cout * Cin * sizeof(float)) +
            wino_align(sizeof(double) * Cout) +
-           cg_conv2d_wgrad_workspace_bytes_grouped(4, (int)T, 1, 1, Cin, 4 * Cout, 1, 1, 0, 0, 0);
+           cg_conv2d_wgrad_workspace_bytes_grouped(16, (int)T, 1, 1, Cin, 4 * Cout, 1, 1, 0, 0, 0);
 }
 
 // gw_canonical[Cout][Cin][5][5] += scale * dW, gb += scale * sum dy, from the transformed input v the forward left behind.
@@ -786,15 +786,12 @@ int cg_conv2d_ups2_wino_wgrad(void* stream, const float* v, const float* dy, flo
     hipLaunchKernelGGL(wino_dy_transform_kernel, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, st, dy, mdy, N, Hp, Wp, Cout);
     CG_LAUNCH_CHECK();
     CG_HIP(hipMemsetAsync(dut, 0, (size_t)16 * C4 * Cin * sizeof(float), st));
-    for (int q = 0; q < 4; ++q) {  // 16 TN GEMMs dU_xi^T[pco][ci] = sum_tile Mdy_xi[tile][pco] V_xi[tile][ci], four per launch
-        const float* xs[4]; const float* ds[4]; float* gs[4];
-        for (int g = 0; g < 4; ++g) {
-            const long xi = q * 4 + g;
-            xs[g] = v + xi * (long)T * Cin;
-            ds[g] = mdy + xi * (long)T * C4;
-            gs[g] = dut + xi * (long)C4 * Cin;
-        }
-        if (cg_conv2d_wgrad_grouped(stream, 4, xs, ds, gs, nullptr, T, 1, 1, Cin, C4, 1, 1, 0, 0, 0, 1.f, tws, tws_bytes)) return 1;
+    // 16 TN GEMMs dU_xi^T[pco][ci] = sum_tile Mdy_xi[tile][pco] V_xi[tile][ci]: the planes of V, Mdy and dU are equally spaced, so all
+    // 16 run as ONE launch + one reduction (CG_WINO_WGRAD_GROUPS=4: four launches of four, the form of rounds 1-3)
+    static const int groups_per_launch = [] { const char* e = getenv("CG_WINO_WGRAD_GROUPS"); const int v = e ? atoi(e) : 16; return v == 4 ? 4 : 16; }();
+    for (int q = 0; q < 16; q += groups_per_launch) {
+        if (cg_conv2d_wgrad_strided(stream, groups_per_launch, v + q * (long)T * Cin, (long)T * Cin, mdy + q * (long)T * C4, (long)T * C4,
+                                    dut + q * (long)C4 * Cin, (long)C4 * Cin, T, 1, 1, Cin, C4, 1, 1, 0, 0, 0, 1.f, tws, tws_bytes)) return 1;
     }
     hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(cg::ew_grid((long)Cout * Cin)), dim3(256), 0, st, dut, gw_canonical, Cout,
                        Cin, scale);

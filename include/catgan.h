@@ -165,6 +165,13 @@ int cg_conv2d_wgrad_grouped_deferred(void* stream, int ngroups, const float* con
                             int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes);
 int cg_conv2d_wgrad_flush(void* stream);
 int cg_conv2d_wgrad_pending(void* stream, int* njobs);
+/* Up to 16 weight gradients of ONE geometry whose tensors are equally spaced in memory (group g: x + g*x_stride, dy + g*dy_stride,
+ * gw + g*gw_stride, strides in floats) as one GEMM launch + one reduction: the 16 Winograd-domain products of the upsample2 -> 5x5
+ * layer's accGradParameters (models.lua:217-218; cg_conv2d_ups2_wino_wgrad below), which ran as four 4-group launches before.  No
+ * bias gradient.  Workspace: cg_conv2d_wgrad_workspace_bytes_grouped(ngroups, ...) (ngroups <= 16 there for this entry point). */
+int cg_conv2d_wgrad_strided(void* stream, int ngroups, const float* x, long x_stride, const float* dy, long dy_stride,
+                            float* gw_canonical, long gw_stride, int N, int Hp, int Wp, int Cin, int Cout,
+                            int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes);
 
 /* gb[c] += scale * sum_m dy[m][c]   (gradBias of conv / linear).
  * ws: scratch of at least 8*C bytes (fp64 column sums). */
