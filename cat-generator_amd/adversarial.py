@@ -29,9 +29,10 @@ DEFAULT_OPT = dict(  # train.lua:15-49
     batchSize=32, N_epoch=1000, G_L1=0.0, G_L2=0.0, D_L1=0.0, D_L2=1e-4, D_iterations=1, G_iterations=1,
     D_maxAcc=1.01, D_clamp=1.0, G_clamp=5.0, D_optmethod="adam", G_optmethod="adam", noiseDim=100, scale=32,
     seed=1, colorSpace="rgb", fused_update=True, exact_reference_backward=False, overlap_comm=True,
-    # the G-step's generator forward on a side stream beside the D update (single rank): 7.52 -> 7.45 ms/step (round 1: no gain -
-    # the D update's tail was still long enough to fill the chip on its own)
-    concurrent_g_forward=os.environ.get("CG_CONCURRENT_G", "1") != "0",
+    # the G-step's generator forward on a side stream beside the D update (single rank).  Round 2: 7.52 -> 7.45 ms/step.  Round 4: OFF -
+    # beside the generator's GEMMs the launch-bound kernels of D's chain queue for slots, and what the overlap wins
+    # they lose: same box 6.32 / 6.33 with, 6.29 / 6.29 ms without (config #3: 9.64 / 9.54); CG_CONCURRENT_G=1 switches it back on
+    concurrent_g_forward=os.environ.get("CG_CONCURRENT_G", "0") != "0",
 )
 
 

@@ -65,7 +65,9 @@ void wgrad_discard_all();
 static inline int ew_grid(long n, int per_block = 256) {
     long b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;
-    const long cap = (long)kNumCU * opt(OPT_EW_WGS_PER_CU);   // CG_EW_WGS_PER_CU (default 8)
+    // CG_EW_WGS_PER_CU, default 4 (8 until round 4): beside a GEMM from another queue a memory-bound kernel waits for a slot per workgroup,
+    // so fewer, longer-lived workgroups get through sooner - same-box step 6.36 -> 6.27 ms, alone no difference (profiles/r04_sweeps.txt)
+    const long cap = (long)kNumCU * opt(OPT_EW_WGS_PER_CU);
     if (b > cap) b = cap;
     return (int)b;
 }

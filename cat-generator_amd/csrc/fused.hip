@@ -519,7 +519,7 @@ static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // grid whose stride (grid * 256 float4s) is a multiple of C4, so that a thread's channel quad is loop invariant
 static int fixed_channel_grid(long n4, int C4) {
     long b = (n4 + 255) / 256;
-    const long cap = cg::kNumCU * 8;
+    const long cap = (long)cg::kNumCU * cg::opt(cg::OPT_EW_WGS_PER_CU);   // as cg::ew_grid
     if (b > cap) b = cap;
     if (256 % C4 != 0) {
         // stride multiple of C4 needs grid % (C4 / gcd(C4, 256)) == 0

@@ -1779,10 +1779,14 @@ template <bool UPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* part, const float* bias_part, RedPtrs rp, int Cin,
                                                                  int Cout, int k, int KK, int pad, int kp, int S, int P,
                                                                  float scale, long sstride, long gstride, long bsstride,
-                                                                 int wblocks) {
+                                                                 int wblocks, int nblocks) {
     __shared__ float sh[8][33];
-    wgrad_reduce_small_body<UPS>(sh, (int)blockIdx.x, (int)blockIdx.y, part, bias_part, rp, Cin, Cout, k, KK, pad, kp, S, P, scale,
-                                 sstride, gstride, bsstride, wblocks);
+    // blockIdx.x walks the group's wblocks + bblocks blocks with stride gridDim.x (= all of them for short launches)
+    for (int bx = (int)blockIdx.x; bx < nblocks; bx += (int)gridDim.x) {
+        wgrad_reduce_small_body<UPS>(sh, bx, (int)blockIdx.y, part, bias_part, rp, Cin, Cout, k, KK, pad, kp, S, P, scale,
+                                     sstride, gstride, bsstride, wblocks);
+        __syncthreads();
+    }
 }
 
 // The same reduction for SEVERAL layers in one launch (cg_conv2d_wgrad_flush): the deferred form of cg_conv2d_wgrad* runs only
@@ -1798,21 +1802,25 @@ struct RedJob {
 constexpr int kRedJobs = 20;
 struct RedJobTable { RedJob j[kRedJobs]; int n; };
 
-__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedJobTable t) {
+// A workgroup walks blocks b, b + gridDim.x, ... of the `total` 32-element blocks (round 4: the launch used to have one workgroup per
+// block - 31 000 of them for D's flush, each waiting for a slot of its own beside the GEMMs of the other queues; see ew_grid)
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedJobTable t, int total) {
     __shared__ float sh[8][33];
-    const int b = (int)blockIdx.x;
-    int ji = 0;
-    for (int q = 1; q < t.n; ++q)
-        if (b >= t.j[q].block0) ji = q;
-    const RedJob& J = t.j[ji];
-    const int per = J.wblocks + J.bblocks;
-    const int group = (b - J.block0) / per, bx = (b - J.block0) - group * per;
-    if (J.ups)
-        wgrad_reduce_small_body<true>(sh, bx, group, J.part, J.bias_part, J.rp, J.Cin, J.Cout, J.k, J.KK, J.pad, J.kp, J.S, J.P, J.scale,
-                                      J.sstride, J.gstride, J.bsstride, J.wblocks);
-    else
-        wgrad_reduce_small_body<false>(sh, bx, group, J.part, J.bias_part, J.rp, J.Cin, J.Cout, J.k, J.KK, J.pad, J.kp, J.S, J.P, J.scale,
-                                       J.sstride, J.gstride, J.bsstride, J.wblocks);
+    for (int b = (int)blockIdx.x; b < total; b += (int)gridDim.x) {
+        int ji = 0;
+        for (int q = 1; q < t.n; ++q)
+            if (b >= t.j[q].block0) ji = q;
+        const RedJob& J = t.j[ji];
+        const int per = J.wblocks + J.bblocks;
+        const int group = (b - J.block0) / per, bx = (b - J.block0) - group * per;
+        if (J.ups)
+            wgrad_reduce_small_body<true>(sh, bx, group, J.part, J.bias_part, J.rp, J.Cin, J.Cout, J.k, J.KK, J.pad, J.kp, J.S, J.P, J.scale,
+                                          J.sstride, J.gstride, J.bsstride, J.wblocks);
+        else
+            wgrad_reduce_small_body<false>(sh, bx, group, J.part, J.bias_part, J.rp, J.Cin, J.Cout, J.k, J.KK, J.pad, J.kp, J.S, J.P, J.scale,
+                                           J.sstride, J.gstride, J.bsstride, J.wblocks);
+        __syncthreads();   // the block's sums have been read out of `sh` before the next block overwrites them
+    }
 }
 
 // gb[c] += scale * sum_{s,p} bias_part[s*P+p][c]; 32 channels x 8 partial-sum lanes per workgroup
@@ -2596,6 +2604,14 @@ namespace {
 std::mutex g_red_mu;
 std::unordered_map<hipStream_t, std::vector<RedJob>> g_red_queue;
 
+// workgroups of a partial-sum reduction launch: CG_RED_WGS_PER_CU per CU, default 0 = one workgroup per 32-element block.  Unlike the
+// grid-stride element-wise kernels (cg::ew_grid) these do NOT gain from fewer, longer-lived workgroups: same box 6.32 (0) / 6.38 (8) /
+// 6.40 (32) ms per step - a block is a short dependent chain (strided partial loads -> LDS -> one add), so walking blocks serialises latency
+long red_cap() {
+    static const long per_cu = [] { const char* e = getenv("CG_RED_WGS_PER_CU"); return e ? atol(e) : 0L; }();
+    return per_cu > 0 ? per_cu * cg::kNumCU : 0x7fffffffL;
+}
+
 int small_reduce(hipStream_t st, bool defer, const RedJob& job, int ngroups) {
     if (defer) {
         std::lock_guard<std::mutex> lk(g_red_mu);
@@ -2603,13 +2619,15 @@ int small_reduce(hipStream_t st, bool defer, const RedJob& job, int ngroups) {
         g_red_queue[st].back().block0 = ngroups;   // the group count rides here until the flush lays the blocks out
         return 0;
     }
-    dim3 sgrid(job.wblocks + job.bblocks, ngroups);
+    const int nblocks = job.wblocks + job.bblocks;
+    const long cap = std::max<long>(1, red_cap() / std::max(1, ngroups));   // workgroups per group
+    dim3 sgrid((unsigned)std::min<long>(nblocks, cap), ngroups);
     if (job.ups)
         hipLaunchKernelGGL(wgrad_reduce_small_kernel<true>, sgrid, dim3(256), 0, st, job.part, job.bias_part, job.rp, job.Cin, job.Cout,
-                           job.k, job.KK, job.pad, job.kp, job.S, job.P, job.scale, job.sstride, job.gstride, job.bsstride, job.wblocks);
+                           job.k, job.KK, job.pad, job.kp, job.S, job.P, job.scale, job.sstride, job.gstride, job.bsstride, job.wblocks, nblocks);
     else
         hipLaunchKernelGGL(wgrad_reduce_small_kernel<false>, sgrid, dim3(256), 0, st, job.part, job.bias_part, job.rp, job.Cin, job.Cout,
-                           job.k, job.KK, job.pad, job.kp, job.S, job.P, job.scale, job.sstride, job.gstride, job.bsstride, job.wblocks);
+                           job.k, job.KK, job.pad, job.kp, job.S, job.P, job.scale, job.sstride, job.gstride, job.bsstride, job.wblocks, nblocks);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -2673,7 +2691,8 @@ int cg_conv2d_wgrad_flush(void* stream) {
             t.j[q].block0 = blocks;
             blocks += ngroups * (t.j[q].wblocks + t.j[q].bblocks);
         }
-        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, t);
+        const int wgs = (int)std::min<long>(blocks, red_cap());
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(wgs), dim3(256), 0, st, t, blocks);
         CG_LAUNCH_CHECK();
     }
     return 0;

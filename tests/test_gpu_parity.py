@@ -495,6 +495,37 @@ def test_full_batch_step_runs_and_stays_finite(cg):
     assert S.CONFUSION.counts.sum().item() == 256
 
 
+def test_generator_forward_beside_the_discriminator_update_is_result_neutral(cg):
+    """OPT.concurrent_g_forward (the G step's generator forward on a side stream beside fevalD / D's Adam; off by default since round 4,
+    CG_CONCURRENT_G=1): a schedule, not arithmetic - three steps give the same bits either way, through a hipGraph capture too (the
+    side stream is forked from and joined into the capture stream)."""
+    def run(concurrent, graph=False):
+        cg.manual_seed(43)
+        G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
+        S = cg.adversarial.State(dict(batchSize=16, concurrent_g_forward=concurrent), G, D)
+        data = cg.adversarial.TrainData(np.random.RandomState(6).rand(64, 3, 32, 32).astype(f32))
+        if graph:
+            it = cg.adversarial.GraphedIteration(S, data, 16, warmup=2)
+            it()
+        else:
+            S.device_rng = True
+            for k in ("D", "G"):
+                S.OPTSTATE["adam"][k]["device_step"] = True
+            r = cg.tensor.rng(); r.enable_device_base()
+            for _ in range(3):
+                off0 = r.offset
+                cg.adversarial.iteration(S, data, 16)
+                cg.lib().counter_add(cg.tensor.stream(), r.dev_base.data_ptr(), r.offset - off0)
+                r.offset = off0
+        torch.cuda.synchronize()
+        return S.PARAMETERS_G.numpy(), S.PARAMETERS_D.numpy()
+    g0, d0 = run(False)
+    g1, d1 = run(True)
+    g2, d2 = run(True, graph=True)
+    np.testing.assert_array_equal(g0, g1); np.testing.assert_array_equal(d0, d1)
+    np.testing.assert_array_equal(g0, g2); np.testing.assert_array_equal(d0, d2)
+
+
 def test_graph_replay_matches_eager(cg):
     """hipGraph replay of the iteration vs eager launches: same parameters (to drift tolerance) after 3 steps (device-side RNG/Adam
     counters make the replay advance its mask / noise / index streams and step counts exactly like eager mode)."""
