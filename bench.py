@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA = 157.3e12               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM = 8.0e12                       # HBM3E spec (6.29 TB/s measured with a float4 copy)
 # counter passes of the roofline launches (scripts/pmc_kernels.sh), newest first
-PMC_FILE = next((f for f in ("r03_pmc_kernels.json", "r03a_pmc_kernels.json", "r02b_pmc_kernels.json")
+PMC_FILE = next((f for f in ("r04_pmc_kernels.json", "r03_pmc_kernels.json", "r03a_pmc_kernels.json", "r02b_pmc_kernels.json")
                  if os.path.exists(os.path.join(ROOT, "profiles", f))), "r02b_pmc_kernels.json")
 
 CONFIGS = {   # BASELINE.json configs (index + 1)
@@ -76,7 +76,8 @@ def time_kernel(fn, iters=20, warm=3):
     """Average duration (s) of one launch group: `iters` launches captured into ONE hipGraph on the launch stream and the replay
     bracketed by HIP events on that stream.  (Round 2 timed eager launches from Python: the host gap between two dependent launches
     - 20-25 us of interpreter + dispatch per call - sat inside the bracket, 8 % of a 0.29 ms kernel; the replay leaves the ~2 us
-    dependent-launch floor, so the figure follows the rocprofv3 per-grid duration in profiles/r03_roofline_launch_durations.txt.)"""
+    dependent-launch floor, so the figure follows the rocprofv3 duration of the same launch in profiles/r04_roofline_launch_durations.txt, a kernel trace of
+    `scripts/kbench.py --only <layer>` in which every row is one of these launches and nothing else.)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -95,9 +96,9 @@ def time_kernel(fn, iters=20, warm=3):
 
 
 def kernel_rooflines(cg, N):
-    """The kernels that carry the step (time shares from profiles/r03_graph_replay_breakdown.txt), each timed in isolation with
+    """The kernels that carry the step (time shares from profiles/r04_eager_breakdown.txt), each timed in isolation with
     HIP events on the launch stream at the benchmarked batch, EXECUTED MFMA FLOPs per launch / duration against the fp32 MFMA
-    peak.  `traffic` / MFMA-pipe utilisation come from the committed PMC pass of the same launches (profiles/r03_pmc_kernels.json,
+    peak.  `traffic` / MFMA-pipe utilisation come from the committed PMC pass of the same launches (profiles/r04_pmc_kernels.json,
     scripts/pmc_kernels.sh; bench.py cannot run rocprofv3 on itself) and carry their source."""
     lib, stream = cg.tensor.lib(), cg.tensor.stream()
     out = []
@@ -141,7 +142,7 @@ def kernel_rooflines(cg, N):
     direct = 2.0 * N * 16 * 16 * 256 * 512 * 9
     entry("nn64x128", "igemm_nng_kernel<64,128,2,2,32> (gemm.hip; LDS-direct loads)",
           f"updateGradInput of upsample2 -> conv3x3 512->256 @8->16, batch {N}: one implicit GEMM, M={N * 64} K=4096 N=512",
-          2.0 * N * 64 * 4096 * 512, t, direct, "18 % of the step's kernel time (16 launches; profiles/r03_graph_replay_breakdown.txt)")
+          2.0 * N * 64 * 4096 * 512, t, direct, "19 % of the step's kernel time (16 launches; profiles/r04_eager_breakdown.txt)")
     # (2) igemm_tng_kernel<128,128> (LDS-direct loads): weight gradient of the same layer (4 phases, split over pixels) + its reduce kernels
     t = time_kernel(lambda: m.accGradParameters(xin, dy))
     entry("tn128x128", "igemm_tng_kernel<128,128,2,2> + wgrad_reduce_kernel<true> + bias_part_reduce_kernel (gemm.hip)",
@@ -329,13 +330,26 @@ def main():
         if not args.no_kernel_roofline and args.config == 2:
             try:
                 top = kernel_rooflines(cg, N)
-                res["roofline"] = top[0]          # the kernel with the largest share of the step
+                res["roofline"] = dict(top[0])    # the kernel with the largest share of the step
                 res["roofline_top"] = top
             except Exception as e:                # noqa: BLE001
                 sw = res["step_work"]
                 res["roofline"] = {"bound": "mfma", "kernel": "whole step (the live per-kernel timing failed: " + str(e)[:160] + ")",
                                    "achieved": sw["executed_tflops"], "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
                                    "frac": sw["executed_frac"], "traffic": None, "timed_live": False}
+        # the step-level block rides inside `roofline` too: the driver's parsed line then carries the kernel AND the step
+        sw = res["step_work"]
+        if isinstance(res.get("roofline"), dict):
+            res["roofline"]["step"] = {
+                "ms_per_step": ms, "executed_tflops": sw["executed_tflops"], "executed_frac": sw["executed_frac"],
+                "mfma_floor_ms": 1e3 * N * w["W_executed"] / PEAK_FP32_MFMA,     # the step's executed MFMA FLOPs at the fp32 MFMA peak
+                "direct_count_over_executed": w["W"] / w["W_executed"],
+                "note": "frac of the kernel block above = EXECUTED FLOPs of one launch / its duration / peak; the step's executed_frac is the "
+                        "same ratio over the whole step (all launches, all phases); direct-count figures (SURVEY.md 8d's numerator) are "
+                        "direct_count_over_executed times larger and are not utilisations",
+                "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.56, "D forward": 0.62, "D backward + Adam": 1.30,
+                                     "generator forward on N": 1.07, "D forward + data gradient (G step)": 1.15, "generator backward + Adam": 1.87},
+                "phases_source": "profiles/r04_eager_timeline.txt (one traced step, eager launches; tracer overhead included)"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baselines()
