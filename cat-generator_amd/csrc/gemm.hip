@@ -1823,6 +1823,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedJobTable t, 
     }
 }
 
+// KK == 1 (linear layers, the Winograd-domain products of winograd.hip): canonical gw[co][ci] += scale * sum_s part[s][ci][co] is a
+// TRANSPOSE of the partial planes.  The generic kernels above give a workgroup 32 consecutive partial elements and scatter them to
+// addresses Cin floats apart: 65 536 workgroups of 1 KB for the 16 Winograd products - 69 us alone, 295 us beside the data-gradient
+// chain (profiles/r04_eager_breakdown.txt).  Here: 32 x 32 tiles through LDS, 128-byte rows both ways, splits added in order.
+__global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ part, float* __restrict__ gw0, long gws, int Cin,
+                                                             int Cout, int S, long sstride, long gstride, float scale) {
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, group = blockIdx.z;
+    const float* pg = part + (long)group * gstride;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const long off = (long)(ci0 + r) * Cout + co0 + tx;
+        float s = 0.f;
+        for (int sp = 0; sp < S; ++sp) s += pg[(long)sp * sstride + off];      // fixed order
+        t[r][tx] = s;
+    }
+    __syncthreads();
+    float* gw = gw0 + (long)group * gws;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) gw[(long)(co0 + r) * Cin + ci0 + tx] += scale * t[tx][r];
+}
+
 // gb[c] += scale * sum_{s,p} bias_part[s*P+p][c]; 32 channels x 8 partial-sum lanes per workgroup
 // (S splits x P phases of one group; consecutive splits are `sstride` floats apart)
 __global__ __launch_bounds__(256) void bias_part_reduce_kernel(const float* bp, float* gb, int S, int P, long sstride,
@@ -2777,6 +2800,13 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
     const long relems = (long)KK * Cin * Cout;
     const long sstride = (long)ZP * wplane;                 // floats between consecutive splits
     const int kp = ups ? phase_kp(kH, padH) : 0;
+    static const bool treduce = [] { const char* e = getenv("CG_WGRAD_TREDUCE"); return !e || atoi(e) != 0; }();
+    if (treduce && strided && KK == 1 && !ups && !any_gb && Cin % 32 == 0 && Cout % 32 == 0 && g.nphase == 1) {
+        hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3(Cin / 32, Cout / 32, ngroups), dim3(256), 0, st, (const float*)ws, gw[0], gws_, Cin, Cout,
+                           p.splits, sstride, (long)g.nphase * wplane, scale);
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
     if ((long)rgrid.x * rgrid.y < cg::kNumCU) {
         RedJob job;
         memset(&job, 0, sizeof(job));

@@ -222,7 +222,7 @@ struct Net {
     bool fresh_allocs = false;                 // library-owned buffers were allocated + zeroed since the last device synchronise
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
-        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0;
+        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0, wgrad_lag = 1;
     long wino_min_tiles = 2048;
     std::string trace_log;
     const KTable* K = &kRealTable;
@@ -305,6 +305,7 @@ struct Compiler {
     bool failed = false;
     int pend[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // deferred weight-gradient reductions queued per stream index
     bool wg_used[4] = {false, false, false, false};   // the weight-gradient stream beside stream s has work to join
+    vector<std::function<void()>> wg_pending[4];      // option wgrad_lag: weight gradients held back until the next data-gradient GEMM of stream s
     bool acc_pass = false;        // compiling Module:backward (weight gradients deferred) rather than updateGradInput
 
     Compiler(Net* n, Prog* p) : net(n), pr(p) {}
@@ -1314,15 +1315,19 @@ struct Compiler {
                                       c.P(GG), c.P(ga1), c.P(ga2), c.P(g3), c.P(g4), c.P(gx));
         });
         if (acc) {
-            // weight gradients of the four layers on the GEMM path (grouped over the sibling branches), reductions deferred
-            wg_fork();
-            const int s_ = wg_enter();
+            // weight gradients of the four layers on the GEMM path (grouped over the sibling branches), reductions deferred; their
+            // gradOutputs come out of the launch above, so (without wgrad_lag) the fork sits behind it
+            if (!wg_lag()) wg_fork();
+            const long P_ = d.P;
+            MS* s0p = &s0;
+            wg_after_dgrad([this, k, G, N, S_, Cin, K3, P_, pooled, ga1, h1, ga2, h2, g3, h3, g4, n_, qv, s0p]() {
+            MS& s0 = *s0p;
             struct W { int li; Val x, dy; Geo g; };
             const W ws_[4] = {
                 {1, pooled, ga1, Geo{(int)N, (int)S_, (int)S_, (int)Cin, 16, 3, 3, 1, 1, 0}},
                 {3, h1, ga2, Geo{(int)N, (int)S_, (int)S_, 16, 16, 3, 3, 1, 1, 0}},
                 {7, h2, g3, Geo{(int)N, 1, 1, (int)K3, 64, 1, 1, 0, 0, 0}},
-                {9, h3, g4, Geo{(int)N, 1, 1, 64, d.P, 1, 1, 0, 0, 0}}};
+                {9, h3, g4, Geo{(int)N, 1, 1, 64, (int)P_, 1, 1, 0, 0, 0}}};
             for (int wi = 0; wi < 4; ++wi) {
                 const W wv = ws_[wi];
                 const bool defer = net->defer_wgrad;
@@ -1346,7 +1351,7 @@ struct Compiler {
                     return k->conv2d_wgrad_grouped(c.CS(), G, x, d_, gw, gb, GEO(wv.g), c.scale, c.W(), c.WB());
                 });
             }
-            wg_leave(s_);
+            });
         }
         vector<Val> outs = G == 1 ? vector<Val>{gx} : split(gx, G);
         for (int b = 0; b < G; ++b) S(*qs[b]).gin = outs[b];
@@ -1433,9 +1438,30 @@ struct Compiler {
         return s;
     }
     void wg_leave(int s) { cs = s; }
+    // Option wgrad_lag: a layer's weight-gradient launches are not issued where its gradOutput is complete but right in front of the
+    // NEXT data-gradient GEMM of the same stream (the layer in front of it), and at the end of the pass.  Forked at gradOutput, the
+    // weight-gradient GEMM of layer L outlives the data-gradient GEMM of L it runs beside, and the launch-bound kernels that follow on
+    // the chain (BN backward sums 35 -> 156 us, BN backward, split-K reductions) queue for the slots its workgroups hold; one layer
+    // later it starts together with the data gradient of L-1 and those kernels have the chip to themselves.
+    bool wg_lag() const { return wg_on() && net->wgrad_lag && net->world <= 1; }
+    void wg_before_dgrad() { if (wg_lag()) wg_release(); else wg_fork(); }   // call in front of a layer's data-gradient launch ...
+    void wg_after_dgrad(std::function<void()> f) {                             // ... and behind it, with the layer's weight-gradient launches
+        if (wg_lag()) { wg_pending[cs].push_back(std::move(f)); return; }
+        const int s_ = wg_enter(); f(); wg_leave(s_);
+    }
+    void wg_release() {   // on stream cs: fork here, issue what was held back
+        if (dry || cs >= 4 || wg_pending[cs].empty()) return;
+        vector<std::function<void()>> fs;
+        fs.swap(wg_pending[cs]);
+        wg_fork();
+        const int s_ = wg_enter();
+        for (auto& f : fs) f();
+        wg_leave(s_);
+    }
     void wg_join_all() {   // end of the pass: reductions still queued on the weight-gradient streams, then stream 0 waits for them
         if (dry) return;
         const int back = cs;
+        for (int s = 0; s < 4; ++s) { cs = s; wg_release(); }
         for (int s = 0; s < 4; ++s) {
             if (!wg_used[s]) continue;
             cs = 4 + s;
@@ -1744,9 +1770,9 @@ struct Compiler {
             return table_sum(m, gs);
         }
         case K_LINEAR: case K_CONV: {
-            if (acc) wg_fork();
+            if (acc) wg_before_dgrad();   // wgrad_lag: the layer behind this one starts its weight gradient beside THIS data gradient
             Val gi = dgrad(m, go);
-            if (acc) { const int s_ = wg_enter(); wgrad(m, go); wg_leave(s_); }
+            if (acc) { Mod* mp_ = &m; const Val go_ = go; wg_after_dgrad([this, mp_, go_]() { wgrad(*mp_, go_); }); }
             return gi;
         }
         case K_PRELU: {
@@ -2085,7 +2111,7 @@ struct Compiler {
             const Geo g = gin[0].g;
             ws_need(cg_conv2d_workspace_bytes_grouped(G, GEO(g)));
             vector<Mod*> ms_ = mods;
-            if (acc) wg_fork();
+            if (acc) wg_before_dgrad();
             emit([=](Run& c) {
                 const float *x[4], *w[4]; float* y[4];
                 for (int b = 0; b < G; ++b) { x[b] = c.P(gin[b].x); w[b] = wsel(ms_[b], gin[b].wsel); y[b] = c.P(gin[b].out); }
@@ -2094,7 +2120,12 @@ struct Compiler {
             vector<Val> outs;
             for (int b = 0; b < G; ++b) { S(*mods[b]).gin = gin[b].out; outs.push_back(gin[b].out); }
             if (acc) {
-                const int s_ = wg_enter();
+                const vector<Val> gouts_ = gouts;
+                Mod* m0p = &m0;
+                wg_after_dgrad([this, k, G, ms_, gouts_, m0p]() {
+                vector<Mod*> mods = ms_;
+                const vector<Val>& gouts = gouts_;
+                Mod& m0 = *m0p;
                 vector<PrepAcc> ap;
                 for (int b = 0; b < G; ++b) ap.push_back(prep_acc(*mods[b], gouts[b]));
                 const Geo ga = ap[0].g;
@@ -2113,7 +2144,7 @@ struct Compiler {
                     if (defer) return k->conv2d_wgrad_grouped_deferred(c.CS(), G, x, d_, gw, gb, GEO(ga), c.scale, wsp, wsb);
                     return k->conv2d_wgrad_grouped(c.CS(), G, x, d_, gw, gb, GEO(ga), c.scale, c.W(), c.WB());
                 });
-                wg_leave(s_);
+                });
             }
             return outs;
         }
@@ -2261,6 +2292,7 @@ void Compiler::bucket_done(int first_module) {
             if (pr->bucket_first[bi] != t) continue;
             // the bucket's weight gradients are on the weight-gradient stream (behind everything this stream has issued: fork here), maybe
             // still queued as deferred reductions; its collective starts from there
+            wg_release();
             wg_fork();
             const int s_ = wg_enter();
             flush_wgrad();
@@ -2438,7 +2470,7 @@ std::string prog_key(Net* n, int nd, const long* dims, int fmt) {
     k += "|o" + std::to_string(n->overlap_groups) + std::to_string(n->defer_wgrad) + std::to_string(n->winograd) + std::to_string(n->fusion) +
          std::to_string(n->stacking) + std::to_string(n->grouped) + std::to_string(n->share_pool) + std::to_string(n->sampler_shared) +
          std::to_string(n->view_fuse) + std::to_string(n->cat_fuse) + std::to_string(n->fuse_locnet) + std::to_string(n->head_fuse) +
-         std::to_string(n->wgrad_stream) + "m" +
+         std::to_string(n->wgrad_stream) + std::to_string(n->wgrad_lag) + "m" +
          std::to_string(n->wino_min_tiles);
     return k;
 }
@@ -2464,6 +2496,7 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_HEAD_FUSE"))) n->head_fuse = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_STREAM"))) n->wgrad_stream = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_PRIO"))) n->wgrad_prio = atoi(e);
+    if ((e = getenv("CG_WGRAD_LAG"))) n->wgrad_lag = atoi(e) != 0;
     *net = n;
     return 0;
 }
@@ -2488,7 +2521,7 @@ int cg_net_set_option(void* net, const char* name, long value) {
         {"overlap_groups", &n->overlap_groups}, {"defer_wgrad", &n->defer_wgrad}, {"winograd", &n->winograd}, {"share_pool", &n->share_pool},
         {"sampler_shared", &n->sampler_shared}, {"view_fuse", &n->view_fuse}, {"cat_fuse", &n->cat_fuse}, {"stacking", &n->stacking},
         {"grouped", &n->grouped}, {"fusion", &n->fusion}, {"fuse_locnet", &n->fuse_locnet}, {"pack_overlap", &n->pack_overlap},
-        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}};
+        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wgrad_lag", &n->wgrad_lag}};
     if (!strcmp(name, "trace")) {
         CG_REQUIRE(n->progs.empty(), "cg_net_set_option: trace must be chosen before the first pass");
         n->trace = value != 0; n->K = n->trace ? &kTraceTable : &kRealTable;

@@ -80,10 +80,19 @@ def test_segments_and_lockstep_branches_of_the_discriminator():
     lb = T.calls(b, "cg_locnet_backward")
     assert [a["ngroups"] for _, a in lb] == ["i:3", "i:1"]
     # each localisation backward is followed by the four weight gradients of its layers (conv1, conv2, linear1, linear2)
+    # (on the weight-gradient stream of the branch group's stream; option wgrad_lag holds them back until the next data-gradient GEMM
+    # of that stream - or the end of the pass - so they are found behind a later fork, not right behind the launch)
+    wl = [i for i, l in enumerate(b) if "cg_conv2d_wgrad_grouped_deferred" in l]
     for i, l in enumerate(b):
         if "cg_locnet_backward" in l:
-            assert b[i + 1].startswith("event|record|wgfork") and b[i + 2].startswith("event|wait|wgfork")
-            assert all("cg_conv2d_wgrad_grouped_deferred" in x for x in b[i + 3:i + 7])
+            G_ = l.split("|")[3]
+            mine = [j for j in wl if j > i and b[j].split("|")[3] == G_ and ("|i:16|i:16|" in b[j] or "|i:64|" in b[j])]
+            assert len(mine) >= 4, (l[:60], len(mine))
+    r_now = T.trace("D32_st3", 128, options=[("wgrad_lag", 0)])["backward"]
+    for i, l in enumerate(r_now):                    # wgrad_lag 0: fork right behind the launch, the four weight gradients follow at once
+        if "cg_locnet_backward" in l:
+            assert r_now[i + 1].startswith("event|record|wgfork") and r_now[i + 2].startswith("event|wait|wgfork")
+            assert all("cg_conv2d_wgrad_grouped_deferred" in x for x in r_now[i + 3:i + 7])
     # updateGradInput only (fevalG_on_D's pass through D, adversarial.lua:192-193): no weight gradient of any kind
     u = r["updateGradInput"]
     assert not [c for c in T.calls(u) if "wgrad" in c[0]]
@@ -257,16 +266,19 @@ def test_weight_gradients_run_beside_the_data_gradient_chain(which, N):
     b1, b0 = r1["backward"], r0["backward"]
     is_w = lambda l: l.startswith("call|cg_conv2d_wgrad") or l.startswith("call|cg_conv2d_ups2_wino_wgrad")
     # same launches, same arguments (workspace of the stream aside), same relative order within the weight gradients and within the rest
-    def strip(l):
-        f = l.split("|")
-        f[2] = "s"
-        return "|".join(f)
+    def strip(l):      # entry point + every scalar argument; streams and buffer names dropped (holding a launch back moves the allocation
+        f = l.split("|")   # order of its workspace, and with it the numbering of the regions)
+        return "|".join([f[0], f[1]] + [t for t in f[3:] if t[:2] in ("i:", "f:", "I:") and not t.startswith("u:")])
     calls1 = [l for l in T.canon(b1) if l.startswith("call|")]
     calls0 = [l for l in T.canon(b0) if l.startswith("call|")]
     nonflush = lambda ls: [strip(l) for l in ls if "wgrad_flush" not in l]
     assert sorted(nonflush(calls1)) == sorted(nonflush(calls0))
     assert [strip(l) for l in calls1 if not is_w(l)] == [strip(l) for l in calls0 if not is_w(l)]
-    assert nonflush([l for l in calls1 if is_w(l)]) == nonflush([l for l in calls0 if is_w(l)])
+    # the weight gradients keep their order PER STREAM (s4 + k carries what stream k carried in line); across streams the issue order
+    # moves, since a launch held back by wgrad_lag is issued in front of the next data-gradient GEMM of its own stream
+    on = lambda ls, st: nonflush([l for l in ls if is_w(l) and l.split("|")[2] == st])
+    for k_ in (0, 1):
+        assert on(T.canon(b1), "s%d" % (4 + k_)) == on(T.canon(b0), "s%d" % k_)
     # where they run
     w1 = [l.split("|")[2] for l in b1 if is_w(l)]
     assert w1 and set(w1) <= {"s4", "s5"} and not [l for l in b1 if l.startswith("call|") and not is_w(l) and l.split("|")[2] in ("s4", "s5")]
