@@ -1789,6 +1789,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* pa
     }
 }
 
+// KK == 1 (linear layers, the Winograd-domain products of winograd.hip): canonical gw[co][ci] += scale * sum_s part[s][ci][co] is a
+// TRANSPOSE of the partial planes.  The generic kernels above give a workgroup 32 consecutive partial elements and scatter them to
+// addresses Cin floats apart: 65 536 workgroups of 1 KB for the 16 Winograd products - 69 us alone, 295 us beside the data-gradient
+// chain (profiles/r04_eager_breakdown.txt).  Here: 32 x 32 tiles through LDS, 128-byte rows both ways, splits added in order.
+__device__ __forceinline__ void wgrad_reduce_t_tile(float (*t)[33], const float* __restrict__ pg, float* __restrict__ gw, int ci0, int co0,
+                                                    int Cin, int Cout, int S, long sstride, float scale) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const long off = (long)(ci0 + r) * Cout + co0 + tx;
+        float s = 0.f;
+        for (int sp = 0; sp < S; ++sp) s += pg[(long)sp * sstride + off];      // fixed order
+        t[r][tx] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) gw[(long)(co0 + r) * Cin + ci0 + tx] += scale * t[tx][r];
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ part, float* __restrict__ gw0, long gws, int Cin,
+                                                             int Cout, int S, long sstride, long gstride, float scale) {
+    __shared__ float t[32][33];
+    const int group = blockIdx.z;
+    wgrad_reduce_t_tile(t, part + (long)group * gstride, gw0 + (long)group * gws, blockIdx.x * 32, blockIdx.y * 32, Cin, Cout, S, sstride, scale);
+}
+
 // The same reduction for SEVERAL layers in one launch (cg_conv2d_wgrad_flush): the deferred form of cg_conv2d_wgrad* runs only
 // its GEMM and queues one RedJob; a dozen ~10 us reductions, each a short dependent chain, then overlap instead of queueing
 // up behind one another.  Workgroup b belongs to the job whose [block0, block0 + ngroups * (wblocks + bblocks)) holds b.
@@ -1798,6 +1823,7 @@ struct RedJob {
     long sstride, gstride, bsstride;
     int Cin, Cout, k, KK, pad, kp, S, P, ups, wblocks, bblocks, block0;
     float scale;
+    int tr;      // KK == 1, planes multiples of 32: the weight blocks are 32 x 32 transpose tiles (wgrad_reduce_t_tile), not 32-element runs
 };
 constexpr int kRedJobs = 20;
 struct RedJobTable { RedJob j[kRedJobs]; int n; };
@@ -1805,7 +1831,7 @@ struct RedJobTable { RedJob j[kRedJobs]; int n; };
 // A workgroup walks blocks b, b + gridDim.x, ... of the `total` 32-element blocks (round 4: the launch used to have one workgroup per
 // block - 31 000 of them for D's flush, each waiting for a slot of its own beside the GEMMs of the other queues; see ew_grid)
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedJobTable t, int total) {
-    __shared__ float sh[8][33];
+    __shared__ float sh[32][33];
     for (int b = (int)blockIdx.x; b < total; b += (int)gridDim.x) {
         int ji = 0;
         for (int q = 1; q < t.n; ++q)
@@ -1813,7 +1839,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedJobTable t, 
         const RedJob& J = t.j[ji];
         const int per = J.wblocks + J.bblocks;
         const int group = (b - J.block0) / per, bx = (b - J.block0) - group * per;
-        if (J.ups)
+        if (J.tr && bx < J.wblocks) {
+            const int nci = J.Cin / 32;
+            float* gw = J.rp.gws ? J.rp.gw0 + (long)group * J.rp.gws : sel4(group, J.rp.gw0, J.rp.gw1, J.rp.gw2, J.rp.gw3);
+            wgrad_reduce_t_tile(sh, J.part + (long)group * J.gstride, gw, (bx % nci) * 32, (bx / nci) * 32, J.Cin, J.Cout, J.S, J.sstride, J.scale);
+        } else if (J.ups)
             wgrad_reduce_small_body<true>(sh, bx, group, J.part, J.bias_part, J.rp, J.Cin, J.Cout, J.k, J.KK, J.pad, J.kp, J.S, J.P, J.scale,
                                           J.sstride, J.gstride, J.bsstride, J.wblocks);
         else
@@ -1821,29 +1851,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedJobTable t, 
                                            J.sstride, J.gstride, J.bsstride, J.wblocks);
         __syncthreads();   // the block's sums have been read out of `sh` before the next block overwrites them
     }
-}
-
-// KK == 1 (linear layers, the Winograd-domain products of winograd.hip): canonical gw[co][ci] += scale * sum_s part[s][ci][co] is a
-// TRANSPOSE of the partial planes.  The generic kernels above give a workgroup 32 consecutive partial elements and scatter them to
-// addresses Cin floats apart: 65 536 workgroups of 1 KB for the 16 Winograd products - 69 us alone, 295 us beside the data-gradient
-// chain (profiles/r04_eager_breakdown.txt).  Here: 32 x 32 tiles through LDS, 128-byte rows both ways, splits added in order.
-__global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ part, float* __restrict__ gw0, long gws, int Cin,
-                                                             int Cout, int S, long sstride, long gstride, float scale) {
-    __shared__ float t[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, group = blockIdx.z;
-    const float* pg = part + (long)group * gstride;
-#pragma unroll
-    for (int r = ty; r < 32; r += 8) {
-        const long off = (long)(ci0 + r) * Cout + co0 + tx;
-        float s = 0.f;
-        for (int sp = 0; sp < S; ++sp) s += pg[(long)sp * sstride + off];      // fixed order
-        t[r][tx] = s;
-    }
-    __syncthreads();
-    float* gw = gw0 + (long)group * gws;
-#pragma unroll
-    for (int r = ty; r < 32; r += 8) gw[(long)(co0 + r) * Cin + ci0 + tx] += scale * t[tx][r];
 }
 
 // gb[c] += scale * sum_{s,p} bias_part[s*P+p][c]; 32 channels x 8 partial-sum lanes per workgroup
@@ -2821,6 +2828,10 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
         job.ups = ups ? 1 : 0; job.scale = scale;
         job.sstride = sstride; job.gstride = (long)g.nphase * wplane; job.bsstride = (long)ZP * Cout;
         job.wblocks = cg::cdiv(relems, 32); job.bblocks = any_gb ? cg::cdiv(Cout, 32) : 0;
+        // a queued KK == 1 job (nn.Linear; D's 20480 -> 256 head is 5.2 M elements = 164 000 32-element blocks) reduces as transpose tiles
+        if (defer && treduce && KK == 1 && !ups && Cin % 32 == 0 && Cout % 32 == 0 && g.nphase == 1) {
+            job.tr = 1; job.wblocks = (Cin / 32) * (Cout / 32);
+        }
         return small_reduce(st, defer, job, ngroups);
     }
     for (int gi = 0; gi < ngroups; ++gi) {

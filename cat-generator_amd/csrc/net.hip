@@ -222,7 +222,7 @@ struct Net {
     bool fresh_allocs = false;                 // library-owned buffers were allocated + zeroed since the last device synchronise
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
-        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0, wgrad_lag = 1;
+        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0, wgrad_lag = 0;
     long wino_min_tiles = 2048;
     std::string trace_log;
     const KTable* K = &kRealTable;
@@ -1442,7 +1442,10 @@ struct Compiler {
     // NEXT data-gradient GEMM of the same stream (the layer in front of it), and at the end of the pass.  Forked at gradOutput, the
     // weight-gradient GEMM of layer L outlives the data-gradient GEMM of L it runs beside, and the launch-bound kernels that follow on
     // the chain (BN backward sums 35 -> 156 us, BN backward, split-K reductions) queue for the slots its workgroups hold; one layer
-    // later it starts together with the data gradient of L-1 and those kernels have the chip to themselves.
+    // later it starts together with the data gradient of L-1 and those kernels have the chip to themselves.  OFF by default: it also
+    // shifts the whole weight-gradient stream one layer back, and where that stream is as long as the chain (G32up-c: 0.92 ms beside
+    // 0.97 ms) its tail then sticks out behind the pass - same box 6.20 -> 6.46-6.61 ms per step for config #2, but 9.56 -> 9.25 ms for
+    // config #3 (G32up, two Winograd layers whose transforms sit on the chain); profiles/r04_sweeps.txt.
     bool wg_lag() const { return wg_on() && net->wgrad_lag && net->world <= 1; }
     void wg_before_dgrad() { if (wg_lag()) wg_release(); else wg_fork(); }   // call in front of a layer's data-gradient launch ...
     void wg_after_dgrad(std::function<void()> f) {                             // ... and behind it, with the layer's weight-gradient launches

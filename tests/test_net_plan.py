@@ -80,19 +80,20 @@ def test_segments_and_lockstep_branches_of_the_discriminator():
     lb = T.calls(b, "cg_locnet_backward")
     assert [a["ngroups"] for _, a in lb] == ["i:3", "i:1"]
     # each localisation backward is followed by the four weight gradients of its layers (conv1, conv2, linear1, linear2)
-    # (on the weight-gradient stream of the branch group's stream; option wgrad_lag holds them back until the next data-gradient GEMM
-    # of that stream - or the end of the pass - so they are found behind a later fork, not right behind the launch)
-    wl = [i for i, l in enumerate(b) if "cg_conv2d_wgrad_grouped_deferred" in l]
+    # (on the weight-gradient stream of the branch group's stream, forked right behind the launch that produces their gradOutputs)
     for i, l in enumerate(b):
         if "cg_locnet_backward" in l:
-            G_ = l.split("|")[3]
-            mine = [j for j in wl if j > i and b[j].split("|")[3] == G_ and ("|i:16|i:16|" in b[j] or "|i:64|" in b[j])]
-            assert len(mine) >= 4, (l[:60], len(mine))
-    r_now = T.trace("D32_st3", 128, options=[("wgrad_lag", 0)])["backward"]
-    for i, l in enumerate(r_now):                    # wgrad_lag 0: fork right behind the launch, the four weight gradients follow at once
+            assert b[i + 1].startswith("event|record|wgfork") and b[i + 2].startswith("event|wait|wgfork")
+            assert all("cg_conv2d_wgrad_grouped_deferred" in x for x in b[i + 3:i + 7])
+    # option wgrad_lag (off by default) holds a layer's weight gradients back until the next data-gradient GEMM of its stream - or the end
+    # of the pass - so they are found behind a LATER fork
+    r_lag = T.trace("D32_st3", 128, options=[("wgrad_lag", 1)])["backward"]
+    wl = [i for i, l in enumerate(r_lag) if "cg_conv2d_wgrad_grouped_deferred" in l]
+    for i, l in enumerate(r_lag):
         if "cg_locnet_backward" in l:
-            assert r_now[i + 1].startswith("event|record|wgfork") and r_now[i + 2].startswith("event|wait|wgfork")
-            assert all("cg_conv2d_wgrad_grouped_deferred" in x for x in r_now[i + 3:i + 7])
+            assert not r_lag[i + 1].startswith("event|record|wgfork")
+            G_ = l.split("|")[3]
+            assert len([j for j in wl if j > i and r_lag[j].split("|")[3] == G_]) >= 4
     # updateGradInput only (fevalG_on_D's pass through D, adversarial.lua:192-193): no weight gradient of any kind
     u = r["updateGradInput"]
     assert not [c for c in T.calls(u) if "wgrad" in c[0]]
@@ -254,14 +255,14 @@ def test_data_parallel_exchanges_sit_inside_the_plan():
         assert sum(1 for l in b[i0:i1] if l.startswith("call|")) >= 3
 
 
-@pytest.mark.parametrize("which,N", [("D32_st3", 128), ("G32up-c", 128), ("G32up", 256), ("D32_st3@64", 64)])
-def test_weight_gradients_run_beside_the_data_gradient_chain(which, N):
+@pytest.mark.parametrize("which,N,lag", [("D32_st3", 128, 0), ("G32up-c", 128, 0), ("G32up", 256, 0), ("D32_st3@64", 64, 0), ("D32_st3", 128, 1), ("G32up", 256, 1)])
+def test_weight_gradients_run_beside_the_data_gradient_chain(which, N, lag):
     """Option wgrad_stream (default on): Module:backward issues every accGradParameters launch - GEMM, Winograd-domain, the
     localisation nets' four, the deferred reductions - on stream 4 + s, forked from stream s where the layer's gradOutput is complete
     and joined into s0 once, at the end of the pass.  Nothing else changes: with the stream column and the fork / join events removed
     the plan IS the in-line plan (wgrad_stream 0, the configuration the golden sequences hold) up to the position of the launches
     that moved, and no data-gradient launch waits for a weight gradient."""
-    r1 = T.trace(which, N)
+    r1 = T.trace(which, N, options=[("wgrad_lag", lag)])
     r0 = T.trace(which, N, options=[("wgrad_stream", 0)])
     b1, b0 = r1["backward"], r0["backward"]
     is_w = lambda l: l.startswith("call|cg_conv2d_wgrad") or l.startswith("call|cg_conv2d_ups2_wino_wgrad")
