@@ -38,3 +38,4 @@ fi
 rm -rf gpurun_out/prof_${TAG}d
 echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/bench.err; echo "rc=$?"; cut -c1-300 gpurun_out/${TAG}_bench_line.json
 for c in 3 5; do timeout 300 python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline > gpurun_out/${TAG}_bench_config$c.json 2>/dev/null; cut -c1-200 gpurun_out/${TAG}_bench_config$c.json; done
+echo "== last switches, same box"; STEPS=40 bash scripts/gpu_ab_env.sh "X=0" "CG_COLREDUCE_WGS_PER_CU=2" "CG_WGRAD_STREAM=0" "CG_CONCAT_OVERLAP=0" "CG_LOCNET_V1=1" "CG_WGRAD_TREDUCE=0" "CG_EW_WGS_PER_CU=8" 2>&1 | tee gpurun_out/${TAG}_final_switches.txt
