@@ -347,9 +347,10 @@ def main():
                 "note": "frac of the kernel block above = EXECUTED FLOPs of one launch / its duration / peak; the step's executed_frac is the "
                         "same ratio over the whole step (all launches, all phases); direct-count figures (SURVEY.md 8d's numerator) are "
                         "direct_count_over_executed times larger and are not utilisations",
-                "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.56, "D forward": 0.62, "D backward + Adam": 1.30,
-                                     "generator forward on N": 1.07, "D forward + data gradient (G step)": 1.15, "generator backward + Adam": 1.87},
-                "phases_source": "profiles/r04_eager_timeline.txt (one traced step, eager launches; tracer overhead included)"}
+                "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.58, "D forward": 0.57, "D backward + Adam": 1.28,
+                                     "generator forward on N": 0.89, "D forward + data gradient (G step)": 1.19, "generator backward + Adam": 1.79},
+                "phases_source": "profiles/r04_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
+                                 "launches, 6.30 ms under the tracer; committed numbers, not measured in this run)"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baselines()
