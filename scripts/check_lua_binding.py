@@ -98,6 +98,36 @@ def check_blocks(path, src):
     return errs
 
 
+def check_brackets(path, raw, src):
+    """2b. ( [ { balance per file on the comment- / string-stripped text, an unterminated string or long bracket (the stripper runs to
+    the end of the file then), and characters Lua 5.1 has no token for."""
+    errs, stack = [], []
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for i, c in enumerate(src):
+        if c in "([{":
+            stack.append((c, src.count("\n", 0, i) + 1))
+        elif c in ")]}":
+            if not stack or stack[-1][0] != pairs[c]:
+                errs.append(f"{path}:{src.count(chr(10), 0, i) + 1}: unmatched `{c}`")
+                break
+            stack.pop()
+        elif c in "`$@!?\\" or (c == "|" ) or (c == "&"):
+            errs.append(f"{path}:{src.count(chr(10), 0, i) + 1}: `{c}` is not a Lua 5.1 token")
+    errs += [f"{path}:{l}: `{c}` is never closed" for c, l in stack[:3]]
+    # a string / long bracket that swallowed the rest of the file: the stripped text then ends in a run of blanks much longer than the raw tail
+    tail_raw = raw.rstrip()[-40:]
+    if tail_raw and not src.rstrip().endswith(tail_raw.strip()[-1:]) and not raw.rstrip().endswith(("]]", "]=]")) and src.rstrip()[-1:] != tail_raw[-1:]:
+        last = src.rstrip()
+        if len(raw.rstrip()) - len(last) > 200:
+            errs.append(f"{path}: a string or long bracket near line {last.count(chr(10)) + 1} is not terminated")
+    # `=` where `==` is needed inside a condition is a syntax error in Lua: if / elseif / while / until ... <single => ... then / do
+    for m in re.finditer(r"\b(if|elseif|while|until)\b([^\n]*?)\b(then|do)\b", src):
+        cond = m.group(2)
+        if re.search(r"(?<![=~<>])=(?!=)", cond) and "function" not in cond:
+            errs.append(f"{path}:{src.count(chr(10), 0, m.start()) + 1}: assignment inside a condition")
+    return errs
+
+
 def check_net_builder():
     """4. the planned executor's builder: lua/catgan/net.lua describes a module with the same (kind, iargs, fargs) as the executable
     twin cat-generator_amd/planned.py, and both use the kind numbers of csrc/net.hip's enum (the header documents them)."""
@@ -317,6 +347,7 @@ def main():
         raw = open(path).read()
         src = strip_lua(raw)
         errs += check_blocks(rel, src)
+        errs += check_brackets(rel, raw, src)
         for m in re.finditer(r"\bC\.(cg_\w+)", src):
             name = m.group(1)
             line = src.count("\n", 0, m.start()) + 1
