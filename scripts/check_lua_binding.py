@@ -98,6 +98,42 @@ def check_blocks(path, src):
     return errs
 
 
+def check_strings(path, raw):
+    """2c. a quoted string may not run over a line end (Lua 5.1), a long bracket / long comment must close."""
+    errs, i, n, line = [], 0, len(raw), 1
+    while i < n:
+        c = raw[i]
+        if raw.startswith("--", i):
+            m = re.match(r"--\[(=*)\[", raw[i:])
+            if m:
+                j = raw.find("]" + m.group(1) + "]", i)
+                if j < 0:
+                    errs.append(f"{path}:{line}: long comment is never closed"); break
+                line += raw.count("\n", i, j); i = j + 2 + len(m.group(1))
+            else:
+                j = raw.find("\n", i); i = n if j < 0 else j
+        elif c in "\"'":
+            j = i + 1
+            while j < n and raw[j] != c:
+                if raw[j] == "\n":
+                    errs.append(f"{path}:{line}: string is not terminated on its line"); break
+                j += 2 if raw[j] == "\\" else 1
+            if errs and errs[-1].endswith("on its line"):
+                break
+            i = j + 1
+        elif c == "[" and re.match(r"\[(=*)\[", raw[i:]):
+            m = re.match(r"\[(=*)\[", raw[i:])
+            j = raw.find("]" + m.group(1) + "]", i)
+            if j < 0:
+                errs.append(f"{path}:{line}: long bracket is never closed"); break
+            line += raw.count("\n", i, j); i = j + 2 + len(m.group(1))
+        else:
+            if c == "\n":
+                line += 1
+            i += 1
+    return errs
+
+
 def check_brackets(path, raw, src):
     """2b. ( [ { balance per file on the comment- / string-stripped text, an unterminated string or long bracket (the stripper runs to
     the end of the file then), and characters Lua 5.1 has no token for."""
@@ -348,6 +384,7 @@ def main():
         src = strip_lua(raw)
         errs += check_blocks(rel, src)
         errs += check_brackets(rel, raw, src)
+        errs += check_strings(rel, raw)
         for m in re.finditer(r"\bC\.(cg_\w+)", src):
             name = m.group(1)
             line = src.count("\n", 0, m.start()) + 1
