@@ -842,7 +842,13 @@ template <int S, int CIN> int launch_bwd(hipStream_t st, const LocBwd& a, int nb
     hipLaunchKernelGGL((locnet_bwd2_k<S, CIN>), dim3(nblk), dim3(NT2), lds, st, a);
     return 0;
 }
-inline bool has(int S, int Cin) { return (S == 16 && Cin == 3) || (S == 8 && Cin == 64); }
+// (16, 64) - the branch transformers of D32_st3 at 64x64 (config #5) - is instantiated and parity-clean but NOT selected: it needs
+// 131 / 118 KB of LDS and 260 VGPRs, i.e. one workgroup per CU for 192 samples, and the ten separate (grouped) launches it would
+// replace are faster: config #5 12.67 ms per step without, 12.81 with (profiles/r04_sweeps.txt).  CG_LOCNET_V2_1664=1 selects it.
+inline bool has(int S, int Cin) {
+    static const bool big = [] { const char* e = getenv("CG_LOCNET_V2_1664"); return e && atoi(e) != 0; }();
+    return (S == 16 && Cin == 3) || (S == 8 && Cin == 64) || (big && S == 16 && Cin == 64);
+}
 inline bool enabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("CG_LOCNET_V1"); v = (e && atoi(e) != 0) ? 0 : 1; }
@@ -862,6 +868,7 @@ extern "C" {
 // planes), the activations of one sample within LDS.
 int cg_locnet_supported(int S, int Cin, int P) {
     if (S < 8 || (S & (S - 1)) || Cin < 1 || P < 1 || P > 4) return 0;
+    if (v2::enabled() && v2::has(S, Cin)) return 1;     // the MFMA kernels bring their own (smaller) LDS plan
     const size_t lim = 160 * 1024 - 1024;   // the kernels' few static __shared__ words come out of the same 160 KB
     return fwd_lds_floats(S, Cin) * 4 <= lim && bwd_lds_floats(S, Cin) * 4 <= lim ? 1 : 0;
 }
@@ -883,7 +890,8 @@ int cg_locnet_forward(void* stream, int ngroups, int n_per_group, const float* x
     a.ur = use_rot ? 1 : 0; a.us = use_scale ? 1 : 0; a.ut = use_trans ? 1 : 0; a.slope = slope;
     a.pbuf = pooled; a.h1buf = h1; a.m2buf = m2; a.h2buf = h2; a.h3buf = h3; a.params = params; a.grid = grid;
     if (v2::enabled() && v2::has(S, Cin)) {   // the MFMA kernels (round 4)
-        const int rc = S == 16 ? v2::launch_fwd<16, 3>(cg::S(stream), a, ngroups * n_per_group) : v2::launch_fwd<8, 64>(cg::S(stream), a, ngroups * n_per_group);
+        const int nb = ngroups * n_per_group;
+        const int rc = S == 8 ? v2::launch_fwd<8, 64>(cg::S(stream), a, nb) : (Cin == 3 ? v2::launch_fwd<16, 3>(cg::S(stream), a, nb) : v2::launch_fwd<16, 64>(cg::S(stream), a, nb));
         if (rc) return rc;
         CG_LAUNCH_CHECK();
         return 0;
@@ -913,7 +921,8 @@ int cg_locnet_backward(void* stream, int ngroups, int n_per_group, const float* 
     a.h1buf = h1; a.m2buf = m2; a.h3buf = h3; a.params = params; a.ggrid = ggrid;
     a.ga1 = ga1; a.ga2 = ga2; a.g3 = g3; a.g4 = g4; a.gx = gx;
     if (v2::enabled() && v2::has(S, Cin)) {
-        const int rc = S == 16 ? v2::launch_bwd<16, 3>(cg::S(stream), a, ngroups * n_per_group) : v2::launch_bwd<8, 64>(cg::S(stream), a, ngroups * n_per_group);
+        const int nb = ngroups * n_per_group;
+        const int rc = S == 8 ? v2::launch_bwd<8, 64>(cg::S(stream), a, nb) : (Cin == 3 ? v2::launch_bwd<16, 3>(cg::S(stream), a, nb) : v2::launch_bwd<16, 64>(cg::S(stream), a, nb));
         if (rc) return rc;
         CG_LAUNCH_CHECK();
         return 0;

@@ -1394,6 +1394,7 @@ struct Compiler {
             emit([=](Run& c) { return c.net->trace ? (trace_note(c.net, "event|wait|fork|s" + std::to_string(sidx)), 0)
                                                     : (hipStreamWaitEvent((hipStream_t)c.S(sidx), c.net->fork_ev, 0) == hipSuccess ? 0 : 1); });
             thunks[t]();
+            wg_release();     // wgrad_lag: what the group still holds back starts here, in front of the group's join
             flush_wgrad();
             emit([=](Run& c) { return c.net->trace ? (trace_note(c.net, "event|record|join" + std::to_string(sidx) + "|s" + std::to_string(sidx)), 0)
                                                     : (hipEventRecord(c.net->side_ev[sidx - 1], (hipStream_t)c.S(sidx)) == hipSuccess ? 0 : 1); });
