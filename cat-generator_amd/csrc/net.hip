@@ -128,6 +128,7 @@ struct Mod {
     bool dirty_plain = true;
     float *wf_ph = nullptr, *wb_ph = nullptr;    // behind a folded 2x upsampling: phase-summed
     float *u_fwd = nullptr, *u_bwd = nullptr;    // Winograd-domain phase kernels
+    float* u22 = nullptr;                        // F(2x2,2x2) forward kernels of a 3x3 layer behind a folded upsampling
     bool wino = false, dirty_ups = true;
     bool is_gemm() const { return kind == K_LINEAR || kind == K_CONV; }
     bool is_act() const { return kind == K_PRELU || kind == K_LRELU; }
@@ -224,6 +225,7 @@ struct Net {
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
         cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0, wgrad_lag = 0;
     long wino_min_tiles = 2048;
+    int wino22 = 1;                            // F(2x2,2x2) forward for upsample2 -> conv3x3 above wino_min_tiles (option "winograd22")
     std::string trace_log;
     const KTable* K = &kRealTable;
     vector<void*> trace_streams;               // stream handle -> index in trace mode
@@ -513,6 +515,12 @@ struct Compiler {
 
     // ---------------------------------------------------------------------------------------- conv / linear preparation
     static bool can_fold_ups(const Mod& m) { return m.kH() == m.kW() && m.kH() % 2 == 1 && m.padH() == m.padW() && m.padH() == (m.kH() - 1) / 2; }
+    bool use_wino22(Mod& m, const Val& x) {   // F(2x2,2x2) forward for a lazily upsampled input: 3x3, pad 1, even low-res grid, planes % 128
+        if (!(net->winograd && net->wino22 && m.kind == K_CONV && x.ups && m.kH() == 3 && m.kW() == 3 && m.padH() == 1 && m.padW() == 1)) return false;
+        const long N = x.d[0], Hp = x.d[2] >> 1, Wp = x.d[3] >> 1;
+        if (N * Hp * Wp / 4 < net->wino_min_tiles) return false;
+        return cg_conv2d_ups2_wino22_supported((int)N, (int)Hp, (int)Wp, (int)m.ia[0], (int)m.ia[1]) != 0;
+    }
     bool use_wino(Mod& m, const Val& x) {   // Winograd path for a lazily upsampled input: 5x5, pad 2, even low-res grid, planes % 128
         if (!(net->winograd && m.kind == K_CONV && x.ups && m.kH() == 5 && m.kW() == 5 && m.padH() == 2 && m.padW() == 2)) return false;
         const long N = x.d[0], Hp = x.d[2] >> 1, Wp = x.d[3] >> 1;
@@ -1198,6 +1206,20 @@ struct Compiler {
             emit([=](Run& c) { return k->conv2d_ups2_wino_forward_stats(c.CS(), c.P(x), cp->u_fwd, cp->b, c.P(out), c.P(v), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)C,
                                                                        hp ? c.P(part) : nullptr); });
             S(conv).x = x; S(conv).out = out; S(conv).use_wino = true;
+        } else if (use_wino22(conv, x)) {
+            // forward in F(2x2,2x2); the layer's state is that of the phase-folded direct path, which its backward takes
+            Prep p = prep_fwd(conv, x);
+            const long N = x.d[0], Hp = x.d[2] >> 1, Wp = x.d[3] >> 1, Ci = conv.ia[0];
+            if (!dry && !conv.u22) { conv.u22 = (float*)alloc(cg_conv2d_ups2_wino22_u_floats((int)Ci, (int)C) * 4); conv.dirty_ups = true; }
+            out = p.out;
+            Val v = buf(conv, "wino22_v", {(long)cg_conv2d_ups2_wino22_v_floats((int)N, (int)Hp, (int)Wp, (int)Ci)});
+            rows = (long)cg_conv2d_ups2_wino_stats_rows((int)N, (int)Hp, (int)Wp, (int)Ci, (int)C);
+            if (rows) part = buf(bn, "stats_part", {rows, 2, C});
+            const bool hp = rows != 0;
+            Val px = p.x;
+            emit([=](Run& c) { return k->conv2d_ups2_wino22_forward_stats(c.CS(), c.P(px), cp->u22, cp->b, c.P(out), c.P(v), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)C,
+                                                                         hp ? c.P(part) : nullptr); });
+            S(conv).x = p.x; S(conv).out = p.out; S(conv).use_wino = false;
         } else {
             Prep p = prep_fwd(conv, x);
             rows = epilogue_ok(p.g) ? (long)cg_conv2d_stats_rows(GEO(p.g)) : 0;
@@ -2454,6 +2476,7 @@ int sync_packs(Net* n, Prog* pr, Run& c, int* join_before) {
         void* st = on_side ? c.S(1) : stream;
         if (n->K->pack_conv_weight_ups2(st, m.w, m.wf_ph, m.wb_ph, (int)m.ia[1], (int)m.ia[0], (int)m.kH(), (int)((m.kH() - 1) / 2))) return 1;
         if (m.wino && n->K->conv2d_ups2_wino_pack(st, m.wf_ph, m.wb_ph, m.u_fwd, m.u_bwd, (int)m.ia[1], (int)m.ia[0])) return 1;
+        if (m.u22 && n->K->conv2d_ups2_wino22_pack(st, m.wf_ph, m.u22, (int)m.ia[1], (int)m.ia[0])) return 1;
         if (on_side && (*join_before < 0 || fo < *join_before)) *join_before = fo;
         m.dirty_ups = false;
     }
@@ -2474,7 +2497,7 @@ std::string prog_key(Net* n, int nd, const long* dims, int fmt) {
     k += "|o" + std::to_string(n->overlap_groups) + std::to_string(n->defer_wgrad) + std::to_string(n->winograd) + std::to_string(n->fusion) +
          std::to_string(n->stacking) + std::to_string(n->grouped) + std::to_string(n->share_pool) + std::to_string(n->sampler_shared) +
          std::to_string(n->view_fuse) + std::to_string(n->cat_fuse) + std::to_string(n->fuse_locnet) + std::to_string(n->head_fuse) +
-         std::to_string(n->wgrad_stream) + std::to_string(n->wgrad_lag) + "m" +
+         std::to_string(n->wgrad_stream) + std::to_string(n->wgrad_lag) + std::to_string(n->wino22) + "m" +
          std::to_string(n->wino_min_tiles);
     return k;
 }
@@ -2501,6 +2524,7 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_WGRAD_STREAM"))) n->wgrad_stream = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_PRIO"))) n->wgrad_prio = atoi(e);
     if ((e = getenv("CG_WGRAD_LAG"))) n->wgrad_lag = atoi(e) != 0;
+    if ((e = getenv("CG_WINOGRAD22"))) n->wino22 = atoi(e) != 0;
     *net = n;
     return 0;
 }
@@ -2525,7 +2549,7 @@ int cg_net_set_option(void* net, const char* name, long value) {
         {"overlap_groups", &n->overlap_groups}, {"defer_wgrad", &n->defer_wgrad}, {"winograd", &n->winograd}, {"share_pool", &n->share_pool},
         {"sampler_shared", &n->sampler_shared}, {"view_fuse", &n->view_fuse}, {"cat_fuse", &n->cat_fuse}, {"stacking", &n->stacking},
         {"grouped", &n->grouped}, {"fusion", &n->fusion}, {"fuse_locnet", &n->fuse_locnet}, {"pack_overlap", &n->pack_overlap},
-        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wgrad_lag", &n->wgrad_lag}};
+        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wgrad_lag", &n->wgrad_lag}, {"winograd22", &n->wino22}};
     if (!strcmp(name, "trace")) {
         CG_REQUIRE(n->progs.empty(), "cg_net_set_option: trace must be chosen before the first pass");
         n->trace = value != 0; n->K = n->trace ? &kTraceTable : &kRealTable;

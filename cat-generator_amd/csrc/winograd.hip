@@ -141,6 +141,92 @@ __global__ __launch_bounds__(256) void wino_filter_transform_kernel(const float*
 }
 
 // ---------------------------------------------------------------------------
+// F(2x2,2x2) for nn.SpatialUpSamplingNearest(2) -> 3x3 convolution (models.lua:211-212; round 4).  After the phase folding, output
+// phase (a,b) is a 2x2-tap convolution of the low-res input whose window starts at row -1 + a, column -1 + b: per 2x2 tile of low-res
+// outputs and phase, 16 multiplies per channel pair; Winograd's minimal form needs 9 (y0 = (d0-d1) g0 + d1 (g0+g1), y1 = d1 (g0+g1) +
+// (d2-d1) g1 per axis: B^T = [1 -1 0; 0 1 0; 0 -1 1], G = [1 0; 1 1; 0 1], A^T = [1 1 0; 0 1 1] - all 0 / +-1, exact up to the
+// additions).  The four phases' 3x3 windows are the four 3x3 corners of ONE 4x4 patch (rows 2ti-1 .. 2ti+2), so the input transform
+// reads the patch once and writes 4 x 9 planes:  V[(p*9 + xi)][tile][c].  The GEMMs and the output transform are wino_gemm_g_kernel's
+// with 9 positions and V taken per phase.
+// One thread per (tile, channel quad): 16 float4 loads, 36 float4 stores.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino22_input_transform_kernel(const float* __restrict__ src, float* __restrict__ V, int N, int Hl,
+                                                                     int Wl, int C) {
+    const int cq_n = C >> 2;
+    const int tH = Hl >> 1, tW = Wl >> 1;
+    const long T = (long)N * tH * tW;
+    const long total = T * cq_n;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+        const int cq = (int)(idx % cq_n);
+        const long tile = idx / cq_n;
+        const int tj = (int)(tile % tW);
+        const int ti = (int)((tile / tW) % tH);
+        const long n = tile / ((long)tW * tH);
+        float4 d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int iy = 2 * ti - 1 + r, ix = 2 * tj - 1 + c;
+                const bool ok = iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
+                const int cy = min(max(iy, 0), Hl - 1), cx = min(max(ix, 0), Wl - 1);
+                const float4 q = ld4(src + ((n * Hl + cy) * (long)Wl + cx) * C + cq * 4);
+                d[r][c] = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        float* out = V + tile * C + cq * 4;
+        const long xs = T * C;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float4 t[3][4];   // B^T applied to rows a .. a+2, all four columns
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                t[0][c] = f4sub(d[a][c], d[a + 1][c]);
+                t[1][c] = d[a + 1][c];
+                t[2][c] = f4sub(d[a + 2][c], d[a + 1][c]);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const long pbase = (long)(a * 2 + b) * 9;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    *reinterpret_cast<float4*>(out + (pbase + i * 3 + 0) * xs) = f4sub(t[i][b], t[i][b + 1]);
+                    *reinterpret_cast<float4*>(out + (pbase + i * 3 + 1) * xs) = t[i][b + 1];
+                    *reinterpret_cast<float4*>(out + (pbase + i * 3 + 2) * xs) = f4sub(t[i][b + 2], t[i][b + 1]);
+                }
+            }
+        }
+    }
+}
+
+// U = G g_p G^T of the 2x2 phase kernels: src = wf_ph [p][tp = ry*2 + rx][ci][co] -> U[p][xi = i*3 + j][ci][co].
+__global__ __launch_bounds__(256) void wino22_filter_transform_kernel(const float* __restrict__ src, float* __restrict__ U, int rows,
+                                                                      int cols) {
+    const int cqn = cols >> 2;
+    const long plane = (long)rows * cols;
+    const long total = 4L * rows * cqn;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+        const int cq = (int)(idx % cqn);
+        const int row = (int)((idx / cqn) % rows);
+        const int p = (int)(idx / ((long)cqn * rows));
+        float4 g[2][2];
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+            for (int rx = 0; rx < 2; ++rx) g[ry][rx] = ld4(src + ((long)p * 4 + ry * 2 + rx) * plane + (long)row * cols + cq * 4);
+        float4 t[3][2];   // G g
+#pragma unroll
+        for (int rx = 0; rx < 2; ++rx) { t[0][rx] = g[0][rx]; t[1][rx] = f4add(g[0][rx], g[1][rx]); t[2][rx] = g[1][rx]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float* dst = U + (((long)p * 9 + i * 3) * rows + row) * cols + cq * 4;
+            *reinterpret_cast<float4*>(dst) = t[i][0];
+            *reinterpret_cast<float4*>(dst + plane) = f4add(t[i][0], t[i][1]);
+            *reinterpret_cast<float4*>(dst + 2 * plane) = t[i][1];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // The 16 GEMMs + output transform.  Block tile 64 tiles x 128 columns, K step 16, 4 waves of 32 x 64.
 // grid = (T/64 * Nc/128, 1, P).  LDS: A [k][m] XOR-swizzled, B [k][n], double buffered (same scheme as gemm.hip).
 // ---------------------------------------------------------------------------
@@ -155,6 +241,7 @@ struct WinoArgs {
     int Ho, Wo;
     float* stats;        // != null: column sums of y and y^2 per (phase, tile block, wave row): [rows][2][Nc] (see gemm.hip)
     int xcd;             // XCD-aware placement of the workgroups that share a V block (CG_XCD_SWIZZLE)
+    int vpp;             // 1: V holds NPOS planes PER PHASE ([P][NPOS][T][K], F(2x2,2x2)); 0: one set shared by the phases ([NPOS][T][K])
 };
 
 // NW waves per workgroup: 4 (wave tile 32x64) or 8 (wave tile 32x32: twice the waves per tile for latency hiding); BK = K step
@@ -412,7 +499,7 @@ __device__ __forceinline__ void wino_glds16(__amdgpu_buffer_rsrc_t r, float* lds
 #endif
 }
 
-template <int BK>
+template <int BK, int NPOS = 16>
 __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
     constexpr int BM = 64, BN = 128;
     constexpr int KV = BK / 4, RPW = 64 / KV, G2 = KV / 2;
@@ -448,9 +535,10 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
     const unsigned a_voff = (unsigned)(a_row * a.K + 4 * (a_pos ^ a_sw)) * 4u;
     const int b_kr = wave * 2 + (lane >> 5);                      // + 16 q
     const unsigned b_voff = (unsigned)(b_kr * a.Nc + n0 + 4 * (lane & 31)) * 4u;
-    const float* Up = a.U + (long)phase * 16 * a.K * a.Nc;
+    const float* Up = a.U + (long)phase * NPOS * a.K * a.Nc;
     __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc((void*)Up, 0, 0x7fffffff, 0x00020000);
     const long a_plane = (long)a.T * a.K;                         // V stride between xi (one plane < 2 GB: host check)
+    const float* Vp = a.V + (a.vpp ? (long)phase * NPOS * a_plane : 0L);
 
     // the next tile to request: (xi, k0), advanced by every dma_tile
     int nxi = 0, nk0 = 0;
@@ -459,7 +547,7 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
         float* A = buf ? As1 : As0;
         float* B = buf ? Bs1 : Bs0;
         if (AW == 8 || wave < AW) {
-            __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)(a.V + nxi * a_plane), 0, 0x7fffffff, 0x00020000);
+            __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)(Vp + nxi * a_plane), 0, 0x7fffffff, 0x00020000);
             wino_glds16(rsv, A + (wave % AW) * RPW * BK, a_voff, nk0 * 4);
         }
         const int sb = (nxi * a.K + nk0) * a.Nc * 4;
@@ -502,15 +590,17 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
-    for (int xi = 0; xi < 16; ++xi) {
+    for (int xi = 0; xi < NPOS; ++xi) {
         for (int kt = 0; kt < KT; kt += 2) {   // KT is even (host checks K % (2 BK) == 0)
             k_tile(std::integral_constant<int, 0>{}, true);
-            k_tile(std::integral_constant<int, 1>{}, !(kt + 2 == KT && xi == 15));
+            k_tile(std::integral_constant<int, 1>{}, !(kt + 2 == KT && xi == NPOS - 1));
         }
-        // M_xi complete: fold it into the four outputs, A^T = [1 1 1 0; 0 1 -1 -1]
-        const int xy = xi >> 2, xx = xi & 3;
-        const float cy0 = xy < 3 ? 1.f : 0.f, cy1 = xy == 0 ? 0.f : (xy == 1 ? 1.f : -1.f);
-        const float cx0 = xx < 3 ? 1.f : 0.f, cx1 = xx == 0 ? 0.f : (xx == 1 ? 1.f : -1.f);
+        // M_xi complete: fold it into the four outputs.  F(2x2,3x3): A^T = [1 1 1 0; 0 1 -1 -1];  F(2x2,2x2): A^T = [1 1 0; 0 1 1]
+        const int xy = NPOS == 16 ? xi >> 2 : xi / 3, xx = NPOS == 16 ? xi & 3 : xi - 3 * (xi / 3);
+        const float cy0 = NPOS == 16 ? (xy < 3 ? 1.f : 0.f) : (xy < 2 ? 1.f : 0.f);
+        const float cy1 = NPOS == 16 ? (xy == 0 ? 0.f : (xy == 1 ? 1.f : -1.f)) : (xy > 0 ? 1.f : 0.f);
+        const float cx0 = NPOS == 16 ? (xx < 3 ? 1.f : 0.f) : (xx < 2 ? 1.f : 0.f);
+        const float cx1 = NPOS == 16 ? (xx == 0 ? 0.f : (xx == 1 ? 1.f : -1.f)) : (xx > 0 ? 1.f : 0.f);
         const float c00 = cy0 * cx0, c01 = cy0 * cx1, c10 = cy1 * cx0, c11 = cy1 * cx1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -679,7 +769,7 @@ int cg_conv2d_ups2_wino_pack(void* stream, const float* wf_ph, const float* wb_p
 // their input transform; exported so that it can be timed / profiled in isolation).
 // dgrad == 0: v [16][T][Cin], u = u_fwd, y [N][2Hp][2Wp][Cout];  dgrad == 1: v [16][T][4*Cout], u = u_bwd, y [N][Hp][Wp][Cin].
 static int wino_gemm_launch(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
-                            int Cin, int Cout, int dgrad, float* stats);
+                            int Cin, int Cout, int dgrad, float* stats, int npos = 16);
 
 int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
                              int Cin, int Cout, int dgrad) {
@@ -693,13 +783,14 @@ size_t cg_conv2d_ups2_wino_stats_rows(int N, int Hp, int Wp, int Cin, int Cout) 
 }
 
 static int wino_gemm_launch(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
-                            int Cin, int Cout, int dgrad, float* stats) {
+                            int Cin, int Cout, int dgrad, float* stats, int npos) {
     CG_REQUIRE(v && u && y, "cg_conv2d_ups2_wino_gemm: null pointer");
     CG_REQUIRE(wino_dims_ok(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino_gemm: unsupported dimensions");
     const int T = N * (Hp / 2) * (Wp / 2);
     WinoArgs a;
     a.V = v; a.U = u; a.bias = bias; a.y = y; a.T = T; a.tH = Hp / 2; a.tW = Wp / 2; a.stats = stats;
     a.xcd = (int)cg::opt(cg::OPT_XCD_SWIZZLE);
+    a.vpp = npos == 9 ? 1 : 0;
     CG_REQUIRE(!stats || (!dgrad && cg::opt(cg::OPT_WINO_WAVES) != 4), "wino_gemm: statistics only on the 8-wave forward launch");
     if (dgrad) { a.K = 4 * Cout; a.Nc = Cin; a.so = 1; a.Ho = Hp; a.Wo = Wp; }
     else { a.K = Cin; a.Nc = Cout; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp; }
@@ -711,6 +802,13 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
     // LDS-direct loads (CG_WINO_GLDS): 8-wave geometry only; one xi plane of V must stay below the 2 GB a buffer offset reaches
     const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && nw != 4 && (long)T * a.K * 4L < 0x7fffffffL &&
                       16L * a.K * a.Nc * 4L < 0x7fffffffL;
+    if (npos == 9) {     // F(2x2,2x2): the LDS-direct-load kernel only (cg_conv2d_ups2_wino22_supported checks the same conditions)
+        CG_REQUIRE(glds && !dgrad, "wino_gemm: the 9-position form needs the LDS-direct-load kernel (CG_WINO_GLDS, 8 waves) and is forward only");
+        if (k32 && a.K % 64 == 0) hipLaunchKernelGGL((wino_gemm_g_kernel<32, 9>), grid, dim3(512), 0, cg::S(stream), a);
+        else hipLaunchKernelGGL((wino_gemm_g_kernel<16, 9>), grid, dim3(512), 0, cg::S(stream), a);
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
     if (glds && k32 && a.K % 64 == 0) { hipLaunchKernelGGL((wino_gemm_g_kernel<32>), grid, dim3(512), 0, cg::S(stream), a); CG_LAUNCH_CHECK(); return 0; }
     if (glds) { hipLaunchKernelGGL((wino_gemm_g_kernel<16>), grid, dim3(512), 0, cg::S(stream), a); CG_LAUNCH_CHECK(); return 0; }
     const bool quad = cg::opt(cg::OPT_WINO_QUAD) != 0 && nw != 4;
@@ -740,6 +838,38 @@ int cg_conv2d_ups2_wino_forward_stats(void* stream, const float* x_lo, const flo
 int cg_conv2d_ups2_wino_forward(void* stream, const float* x_lo, const float* u_fwd, const float* bias, float* y, float* v,
                                 int N, int Hp, int Wp, int Cin, int Cout) {
     return cg_conv2d_ups2_wino_forward_stats(stream, x_lo, u_fwd, bias, y, v, N, Hp, Wp, Cin, Cout, nullptr);
+}
+
+// ---- F(2x2,2x2): upsample2 -> conv 3x3 (pad 1), forward ----
+size_t cg_conv2d_ups2_wino22_supported(int N, int Hp, int Wp, int Cin, int Cout) {
+    if (!wino_dims_ok(N, Hp, Wp, Cin, Cout)) return 0;
+    const long T = (long)N * (Hp / 2) * (Wp / 2);
+    const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && cg::opt(cg::OPT_WINO_WAVES) != 4 && T * Cin * 4L < 0x7fffffffL &&
+                      16L * Cin * Cout * 4L < 0x7fffffffL;
+    return glds ? 1 : 0;
+}
+size_t cg_conv2d_ups2_wino22_v_floats(int N, int Hp, int Wp, int Cin) { return (size_t)36 * ((size_t)N * (Hp / 2) * (Wp / 2)) * Cin; }
+size_t cg_conv2d_ups2_wino22_u_floats(int Cin, int Cout) { return (size_t)4 * 9 * Cin * Cout; }
+
+int cg_conv2d_ups2_wino22_pack(void* stream, const float* wf_ph, float* u22, int Cout, int Cin) {
+    CG_REQUIRE(wf_ph && u22, "cg_conv2d_ups2_wino22_pack: null pointer");
+    CG_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "cg_conv2d_ups2_wino22_pack: channel counts must be multiples of 4");
+    const long total = 4L * Cin * (Cout / 4);
+    hipLaunchKernelGGL(wino22_filter_transform_kernel, dim3(cg::ew_grid(total)), dim3(256), 0, cg::S(stream), wf_ph, u22, Cin, Cout);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+// y[N][2Hp][2Wp][Cout] = bias + conv3x3(upsample2(x_lo)); v: scratch of cg_conv2d_ups2_wino22_v_floats floats; stats as
+// cg_conv2d_ups2_wino_forward_stats (same rows: cg_conv2d_ups2_wino_stats_rows).
+int cg_conv2d_ups2_wino22_forward_stats(void* stream, const float* x_lo, const float* u22, const float* bias, float* y, float* v,
+                                        int N, int Hp, int Wp, int Cin, int Cout, float* stats) {
+    CG_REQUIRE(x_lo && u22 && y && v, "cg_conv2d_ups2_wino22_forward: null pointer");
+    CG_REQUIRE(cg_conv2d_ups2_wino22_supported(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino22_forward: unsupported dimensions / options");
+    const int T = N * (Hp / 2) * (Wp / 2);
+    hipLaunchKernelGGL(wino22_input_transform_kernel, dim3(cg::ew_grid((long)T * (Cin / 4))), dim3(256), 0, cg::S(stream), x_lo, v, N, Hp, Wp, Cin);
+    CG_LAUNCH_CHECK();
+    return wino_gemm_launch(stream, v, u22, bias, y, N, Hp, Wp, Cin, Cout, 0, stats, 9);
 }
 
 // dx_lo[N][Hp][Wp][Cin] = gradient w.r.t. the low-res input (the upsampling's 2x2 block sum folded in);

@@ -127,6 +127,45 @@ def test_winograd_path_matches_direct_phase_path(cg):
         close(a, b, K=K, what=f"winograd vs direct: {what}")
 
 
+@pytest.mark.parametrize("N,Cin,H,Cout", [(2, 128, 8, 128), (3, 256, 6, 128), (32, 512, 8, 256)])
+def test_winograd22_forward_of_the_3x3_layers_behind_an_upsampling(cg, N, Cin, H, Cout):
+    """F(2x2,2x2) forward (cg_conv2d_ups2_wino22_*, csrc/winograd.hip; models.lua:211-212) through the C ABI against the ORACLE's
+    upsample -> conv3x3 and against the phase-folded direct kernel, incl. the batch-norm statistics partials of the epilogue and the
+    borders (zero padding on the low-res grid) - the last case is G's 512 -> 256 layer at a quarter of the benchmarked batch.  The
+    planned pass takes this path at >= 2048 tiles (whole-generator tests at batch 128 run it inside G)."""
+    tensor_mod = importlib.import_module("cat-generator_amd.tensor")
+    rs = np.random.RandomState(N + Cin)
+    L, st = cg.lib(), tensor_mod.stream()
+    xl = rs.randn(N, Cin, H, H).astype(f32)
+    w = (rs.randn(Cout, Cin, 3, 3) / np.sqrt(Cin * 9)).astype(f32); bias = rs.randn(Cout).astype(f32)
+    m = cg.nn.SpatialConvolution(Cin, Cout, 3, 3, 1, 1, 1)
+    m.weight.copy(w); m.bias.copy(bias)
+    up = cg.nn.SpatialUpSamplingNearest(2)
+    y_direct = m.forward(up.forward(cg.Tensor.from_numpy(xl))).numpy()       # packs m._wf_ph (the phase-summed kernels)
+    assert L.conv2d_ups2_wino22_supported(N, H, H, Cin, Cout) == 1
+    dev = m._wf_ph.device
+    u22 = torch.empty(L.conv2d_ups2_wino22_u_floats(Cin, Cout), dtype=torch.float32, device=dev)
+    assert L.conv2d_ups2_wino22_pack(st, m._wf_ph.data_ptr(), u22.data_ptr(), Cout, Cin) == 0
+    v = torch.empty(L.conv2d_ups2_wino22_v_floats(N, H, H, Cin), dtype=torch.float32, device=dev)
+    x_lo = torch.from_numpy(np.ascontiguousarray(xl.transpose(0, 2, 3, 1))).to(dev)        # NHWC low-res map
+    y = torch.full((N, 2 * H, 2 * H, Cout), float("nan"), dtype=torch.float32, device=dev)
+    rows = L.conv2d_ups2_wino_stats_rows(N, H, H, Cin, Cout)
+    part = torch.zeros((max(rows, 1), 2, Cout), dtype=torch.float32, device=dev)
+    b_dev = torch.from_numpy(bias).to(dev)
+    torch.cuda.synchronize()           # the torch-side fills above ran on torch's stream, the launch below on the library's
+    assert L.conv2d_ups2_wino22_forward_stats(st, x_lo.data_ptr(), u22.data_ptr(), b_dev.data_ptr(), y.data_ptr(), v.data_ptr(),
+                                              N, H, H, Cin, Cout, part.data_ptr() if rows else None) == 0
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().transpose(0, 3, 1, 2)
+    ref = O.conv2d_forward(O.UpSample2().forward(xl), w, bias, 1)
+    close(got, ref, K=Cin * 9, what="F(2x2,2x2) forward vs oracle")
+    close(got, y_direct, K=Cin * 9, what="F(2x2,2x2) forward vs the phase-folded kernel")
+    if rows:
+        p_ = part.cpu().numpy().astype(np.float64)
+        close(p_[:, 0].sum(0), ref.astype(np.float64).sum((0, 2, 3)), K=N * 4 * H * H, tol=5e-5, what="epilogue sum")
+        close(p_[:, 1].sum(0), (ref.astype(np.float64) ** 2).sum((0, 2, 3)), K=N * 4 * H * H, tol=5e-5, what="epilogue sum of squares")
+
+
 @pytest.mark.parametrize("N,i,o", [(128, 100, 8192), (6, 20480, 256), (5, 64, 4), (3, 256, 1), (64, 1024, 64)])
 def test_linear_fwd_bwd(cg, N, i, o):
     rs = np.random.RandomState(N + i + o)

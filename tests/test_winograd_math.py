@@ -80,3 +80,47 @@ def test_forward_and_gradients_match_direct_convolution():
     dup = np.array([[np.sum(dyp[i:i + 5, j:j + 5] * w[::-1, ::-1]) for j in range(2 * Hl)] for i in range(2 * Hl)])
     dx_ref = dup.reshape(Hl, 2, Hl, 2).sum(axis=(1, 3))
     np.testing.assert_allclose(dx, dx_ref, rtol=0, atol=1e-11)
+
+
+# ---- F(2x2,2x2): upsample2 -> conv3x3 (pad 1); csrc/winograd.hip wino22_* ------------------------------------------------------
+BT22 = np.array([[1, -1, 0], [0, 1, 0], [0, -1, 1]], dtype=np.float64)
+G22 = np.array([[1, 0], [1, 1], [0, 1]], dtype=np.float64)
+AT22 = np.array([[1, 1, 0], [0, 1, 1]], dtype=np.float64)
+
+
+def phase_kernels_3x3(w):
+    """w [3][3] (pad 1) -> g[p][2][2]: output phase (a, b) reads low-res rows -1 + a + {0, 1} (gemm.hip pack_weight_ups2)."""
+    g = np.zeros((4, 2, 2))
+    for p in range(4):
+        for dy in range(3):
+            for dx in range(3):
+                g[p, phase_map(p >> 1, dy, 1), phase_map(p & 1, dx, 1)] += w[dy, dx]
+    return g
+
+
+def test_f22_on_the_phases_of_an_upsampled_3x3_convolution():
+    """The minimal form (9 products per 2x2 tile and phase instead of 16) reproduces the direct convolution of the materialised
+    upsampled map; the four phases' 3x3 windows are the corners of ONE 4x4 low-res patch (rows 2ti-1 .. 2ti+2), and the output
+    transform's coefficients are the 0/1 pattern wino_gemm_g_kernel<.., 9> hard-codes: cy0 = (xi < 2), cy1 = (xi > 0)."""
+    rs = np.random.RandomState(3)
+    Hl = 6
+    x, w = rs.randn(Hl, Hl), rs.randn(3, 3)
+    up = np.pad(np.repeat(np.repeat(x, 2, 0), 2, 1), 1)
+    y_ref = np.array([[np.sum(up[i:i + 3, j:j + 3] * w) for j in range(2 * Hl)] for i in range(2 * Hl)])
+    g = phase_kernels_3x3(w)
+    xp = np.pad(x, 1)
+    y = np.zeros_like(y_ref)
+    for i in range(3):
+        assert AT22[0, i] == float(i < 2) and AT22[1, i] == float(i > 0)
+    for ti in range(Hl // 2):
+        for tj in range(Hl // 2):
+            patch = xp[2 * ti:2 * ti + 4, 2 * tj:2 * tj + 4]
+            for p in range(4):
+                a, b = p >> 1, p & 1
+                V = BT22 @ patch[a:a + 3, b:b + 3] @ BT22.T
+                U = G22 @ g[p] @ G22.T
+                Y = AT22 @ (U * V) @ AT22.T
+                for u in range(2):
+                    for v in range(2):
+                        y[2 * (2 * ti + u) + a, 2 * (2 * tj + v) + b] = Y[u, v]
+    np.testing.assert_allclose(y, y_ref, rtol=0, atol=1e-12)
