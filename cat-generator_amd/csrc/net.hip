@@ -128,7 +128,7 @@ struct Mod {
     bool dirty_plain = true;
     float *wf_ph = nullptr, *wb_ph = nullptr;    // behind a folded 2x upsampling: phase-summed
     float *u_fwd = nullptr, *u_bwd = nullptr;    // Winograd-domain phase kernels
-    float* u22 = nullptr;                        // F(2x2,2x2) forward kernels of a 3x3 layer behind a folded upsampling
+    float *u22 = nullptr, *u22b = nullptr;       // F(2x2,2x2) forward / data-gradient kernels of a 3x3 layer behind a folded upsampling
     bool wino = false, dirty_ups = true;
     bool is_gemm() const { return kind == K_LINEAR || kind == K_CONV; }
     bool is_act() const { return kind == K_PRELU || kind == K_LRELU; }
@@ -166,7 +166,7 @@ struct MS {
     bool skip = false;           // nn.View fused into the linear layer behind it
     long in_shape[4] = {0, 0, 0, 0}; int in_nd = 0;
     bool map_in = false; long mc = 0, mh = 0, mw = 0;        // nn.Linear consuming an NHWC map
-    bool use_wino = false;
+    bool use_wino = false, use_wino22 = false;
     bool fused = false; int fG = 0; Val fX, fmask; long fN = 0, fC = 0, fH = 0, fW = 0;   // act_pool segment state (on the activation)
     bool bn_fused = false; long bnM = 0, bnC = 0;            // gemm_bn_act segment state (on the batch-norm)
     double count = 0;            // BN: samples behind the statistics (x world under sync-BN)
@@ -225,7 +225,7 @@ struct Net {
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
         cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0, wgrad_lag = 0;
     long wino_min_tiles = 2048;
-    int wino22 = 1;                            // F(2x2,2x2) forward for upsample2 -> conv3x3 above wino_min_tiles (option "winograd22")
+    int wino22 = 3;                            // F(2x2,2x2) for upsample2 -> conv3x3 above wino_min_tiles: bit 0 forward, bit 1 data gradient (option "winograd22")
     std::string trace_log;
     const KTable* K = &kRealTable;
     vector<void*> trace_streams;               // stream handle -> index in trace mode
@@ -516,7 +516,7 @@ struct Compiler {
     // ---------------------------------------------------------------------------------------- conv / linear preparation
     static bool can_fold_ups(const Mod& m) { return m.kH() == m.kW() && m.kH() % 2 == 1 && m.padH() == m.padW() && m.padH() == (m.kH() - 1) / 2; }
     bool use_wino22(Mod& m, const Val& x) {   // F(2x2,2x2) forward for a lazily upsampled input: 3x3, pad 1, even low-res grid, planes % 128
-        if (!(net->winograd && net->wino22 && m.kind == K_CONV && x.ups && m.kH() == 3 && m.kW() == 3 && m.padH() == 1 && m.padW() == 1)) return false;
+        if (!(net->winograd && (net->wino22 & 1) && m.kind == K_CONV && x.ups && m.kH() == 3 && m.kW() == 3 && m.padH() == 1 && m.padW() == 1)) return false;
         const long N = x.d[0], Hp = x.d[2] >> 1, Wp = x.d[3] >> 1;
         if (N * Hp * Wp / 4 < net->wino_min_tiles) return false;
         return cg_conv2d_ups2_wino22_supported((int)N, (int)Hp, (int)Wp, (int)m.ia[0], (int)m.ia[1]) != 0;
@@ -639,7 +639,7 @@ struct Compiler {
                     s.x = x; s.out = out; s.use_wino = true;
                     return out;
                 }
-                s.use_wino = false;
+                s.use_wino = false; s.use_wino22 = false;
             }
             Prep p = prep_fwd(m, in);
             ws_need(cg_conv2d_workspace_bytes(GEO(p.g)));
@@ -918,7 +918,7 @@ struct Compiler {
                 return k->conv2d_forward_grouped(c.CS(), G, x, w, bi, y, GEO(g), c.W(), c.WB());
             });
             outs.clear();
-            for (int b = 0; b < G; ++b) { S(*mods[b]).x = preps[b].x; S(*mods[b]).out = preps[b].out; S(*mods[b]).use_wino = false; outs.push_back(preps[b].out); }
+            for (int b = 0; b < G; ++b) { S(*mods[b]).x = preps[b].x; S(*mods[b]).out = preps[b].out; S(*mods[b]).use_wino = false; S(*mods[b]).use_wino22 = false; outs.push_back(preps[b].out); }
             return outs;
         }
         case K_PRELU: {
@@ -1080,7 +1080,7 @@ struct Compiler {
             return k->conv2d_forward_ex(c.CS(), G, x, w, bi, y, GEO(g), code, slope, code == 1 ? al : nullptr, ya, nullptr, c.W(), c.WB());
         });
         for (int b = 0; b < G; ++b) {
-            MS& sc = S(*convs[b]); sc.x = preps[b].x; sc.out = preps[b].out; sc.use_wino = false;
+            MS& sc = S(*convs[b]); sc.x = preps[b].x; sc.out = preps[b].out; sc.use_wino = false; sc.use_wino22 = false;
             MS& sa = S(*acts[b]); sa.x = preps[b].out; sa.out = ys[b];
         }
         if (G > 1 && stackable(*acts[0])) {   // let the parameter-free activation run its backward as one stacked launch
@@ -1210,7 +1210,11 @@ struct Compiler {
             // forward in F(2x2,2x2); the layer's state is that of the phase-folded direct path, which its backward takes
             Prep p = prep_fwd(conv, x);
             const long N = x.d[0], Hp = x.d[2] >> 1, Wp = x.d[3] >> 1, Ci = conv.ia[0];
-            if (!dry && !conv.u22) { conv.u22 = (float*)alloc(cg_conv2d_ups2_wino22_u_floats((int)Ci, (int)C) * 4); conv.dirty_ups = true; }
+            if (!dry && !conv.u22) {
+                conv.u22 = (float*)alloc(cg_conv2d_ups2_wino22_u_floats((int)Ci, (int)C) * 4);
+                conv.u22b = (float*)alloc(cg_conv2d_ups2_wino22_u_floats((int)Ci, (int)C) * 4);
+                conv.dirty_ups = true;
+            }
             out = p.out;
             Val v = buf(conv, "wino22_v", {(long)cg_conv2d_ups2_wino22_v_floats((int)N, (int)Hp, (int)Wp, (int)Ci)});
             rows = (long)cg_conv2d_ups2_wino_stats_rows((int)N, (int)Hp, (int)Wp, (int)Ci, (int)C);
@@ -1219,9 +1223,10 @@ struct Compiler {
             Val px = p.x;
             emit([=](Run& c) { return k->conv2d_ups2_wino22_forward_stats(c.CS(), c.P(px), cp->u22, cp->b, c.P(out), c.P(v), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)C,
                                                                          hp ? c.P(part) : nullptr); });
-            S(conv).x = p.x; S(conv).out = p.out; S(conv).use_wino = false;
+            S(conv).x = p.x; S(conv).out = p.out; S(conv).use_wino = false; S(conv).use_wino22 = true;
         } else {
             Prep p = prep_fwd(conv, x);
+            S(conv).use_wino22 = false;
             rows = epilogue_ok(p.g) ? (long)cg_conv2d_stats_rows(GEO(p.g)) : 0;
             ws_need(cg_conv2d_workspace_bytes(GEO(p.g)));
             out = p.out;
@@ -1767,6 +1772,9 @@ struct Compiler {
             if (s.use_wino) {
                 Val vdy = buf(m, "wino_vdy", {(long)cg_conv2d_ups2_wino_v_floats((int)N, (int)Hp, (int)Wp, (int)(4 * Co))});
                 emit([=](Run& c) { return k->conv2d_ups2_wino_dgrad(c.CS(), c.P(dy), mp->u_bwd, c.P(lo), c.P(vdy), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
+            } else if (s.use_wino22 && (net->wino22 & 2) && mp->u22b) {
+                Val vdy = buf(m, "wino22_vdy", {(long)cg_conv2d_ups2_wino22_dgrad_v_floats((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co)});
+                emit([=](Run& c) { return k->conv2d_ups2_wino22_dgrad(c.CS(), c.P(dy), mp->u22b, c.P(lo), c.P(vdy), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
             } else {
                 ws_need(cg_conv2d_dgrad_ups2_workspace_bytes((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co, kk, pad));
                 emit([=](Run& c) { return k->conv2d_dgrad_ups2(c.CS(), c.P(dy), mp->wb_ph, c.P(lo), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co, kk, pad, c.W(), c.WB()); });
@@ -2476,7 +2484,7 @@ int sync_packs(Net* n, Prog* pr, Run& c, int* join_before) {
         void* st = on_side ? c.S(1) : stream;
         if (n->K->pack_conv_weight_ups2(st, m.w, m.wf_ph, m.wb_ph, (int)m.ia[1], (int)m.ia[0], (int)m.kH(), (int)((m.kH() - 1) / 2))) return 1;
         if (m.wino && n->K->conv2d_ups2_wino_pack(st, m.wf_ph, m.wb_ph, m.u_fwd, m.u_bwd, (int)m.ia[1], (int)m.ia[0])) return 1;
-        if (m.u22 && n->K->conv2d_ups2_wino22_pack(st, m.wf_ph, m.u22, (int)m.ia[1], (int)m.ia[0])) return 1;
+        if (m.u22 && n->K->conv2d_ups2_wino22_pack(st, m.wf_ph, m.wb_ph, m.u22, m.u22b, (int)m.ia[1], (int)m.ia[0])) return 1;
         if (on_side && (*join_before < 0 || fo < *join_before)) *join_before = fo;
         m.dirty_ups = false;
     }
@@ -2524,7 +2532,7 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_WGRAD_STREAM"))) n->wgrad_stream = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_PRIO"))) n->wgrad_prio = atoi(e);
     if ((e = getenv("CG_WGRAD_LAG"))) n->wgrad_lag = atoi(e) != 0;
-    if ((e = getenv("CG_WINOGRAD22"))) n->wino22 = atoi(e) != 0;
+    if ((e = getenv("CG_WINOGRAD22"))) n->wino22 = atoi(e);
     *net = n;
     return 0;
 }

@@ -198,7 +198,54 @@ __global__ __launch_bounds__(256) void wino22_input_transform_kernel(const float
     }
 }
 
-// U = G g_p G^T of the 2x2 phase kernels: src = wf_ph [p][tp = ry*2 + rx][ci][co] -> U[p][xi = i*3 + j][ci][co].
+// Data gradient of the same layers.  dx_lo[u][v] = sum_p sum_r dy_p[u - a + ry][v - b + rx] . g_p[1-ry][1-rx] over the phase
+// sub-lattices dy_p[i][j] = dy[2i+a][2j+b]: per phase a 2x2-tap correlation with the flipped kernel whose window starts at row u - a,
+// the four phases summed - one F(2x2,2x2) problem with the phases side by side along K (K = 4 Cout).
+// V[xi][tile][p*Cs + co] = B^T d B of the 3x3 patch (rows 2ti - a .. 2ti - a + 2 of sub-lattice p).  One thread per (tile, channel
+// quad): 9 float4 loads, 9 float4 stores.
+__global__ __launch_bounds__(256) void wino22_dy_input_transform_kernel(const float* __restrict__ dy, float* __restrict__ V, int N, int Hl,
+                                                                        int Wl, int Cs) {
+    const int C = 4 * Cs, cq_n = C >> 2;
+    const int tH = Hl >> 1, tW = Wl >> 1;
+    const long T = (long)N * tH * tW;
+    const long total = T * cq_n;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+        const int cq = (int)(idx % cq_n);
+        const long tile = idx / cq_n;
+        const int tj = (int)(tile % tW);
+        const int ti = (int)((tile / tW) % tH);
+        const long n = tile / ((long)tW * tH);
+        const int p = (cq * 4) / Cs, cs = cq * 4 - p * Cs;
+        const int pa = p >> 1, pb = p & 1;
+        float4 d[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int iy = 2 * ti - pa + r, ix = 2 * tj - pb + c;
+                const bool ok = iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
+                const int cy = min(max(iy, 0), Hl - 1), cx = min(max(ix, 0), Wl - 1);
+                const float4 q = ld4(dy + ((n * 2 * Hl + 2 * cy + pa) * (long)(2 * Wl) + 2 * cx + pb) * Cs + cs);
+                d[r][c] = ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        float4 t[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { t[0][c] = f4sub(d[0][c], d[1][c]); t[1][c] = d[1][c]; t[2][c] = f4sub(d[2][c], d[1][c]); }
+        float* out = V + tile * C + cq * 4;
+        const long xs = T * C;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            *reinterpret_cast<float4*>(out + (i * 3 + 0) * xs) = f4sub(t[i][0], t[i][1]);
+            *reinterpret_cast<float4*>(out + (i * 3 + 1) * xs) = t[i][1];
+            *reinterpret_cast<float4*>(out + (i * 3 + 2) * xs) = f4sub(t[i][2], t[i][1]);
+        }
+    }
+}
+
+// U = G g_p G^T of the 2x2 phase kernels.
+// FWD: src = wf_ph [p][tp = ry*2 + rx][ci][co] -> U[p][xi = i*3 + j][ci][co].
+// BWD: src = wb_ph [p][tp][co][ci] -> U[xi][p*Cout + co][ci] of the FLIPPED kernel (data-gradient operand: the four phases side by side along K).
+template <bool BWD>
 __global__ __launch_bounds__(256) void wino22_filter_transform_kernel(const float* __restrict__ src, float* __restrict__ U, int rows,
                                                                       int cols) {
     const int cqn = cols >> 2;
@@ -212,16 +259,21 @@ __global__ __launch_bounds__(256) void wino22_filter_transform_kernel(const floa
 #pragma unroll
         for (int ry = 0; ry < 2; ++ry)
 #pragma unroll
-            for (int rx = 0; rx < 2; ++rx) g[ry][rx] = ld4(src + ((long)p * 4 + ry * 2 + rx) * plane + (long)row * cols + cq * 4);
+            for (int rx = 0; rx < 2; ++rx) {
+                const int tp = BWD ? (1 - ry) * 2 + (1 - rx) : ry * 2 + rx;
+                g[ry][rx] = ld4(src + ((long)p * 4 + tp) * plane + (long)row * cols + cq * 4);
+            }
         float4 t[3][2];   // G g
 #pragma unroll
         for (int rx = 0; rx < 2; ++rx) { t[0][rx] = g[0][rx]; t[1][rx] = f4add(g[0][rx], g[1][rx]); t[2][rx] = g[1][rx]; }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            float* dst = U + (((long)p * 9 + i * 3) * rows + row) * cols + cq * 4;
+            float* dst = BWD ? U + ((long)(i * 3) * 4 * rows + (long)p * rows + row) * cols + cq * 4
+                             : U + (((long)p * 9 + i * 3) * rows + row) * cols + cq * 4;
+            const long xstep = BWD ? 4 * plane : plane;   // distance between neighbouring positions xi
             *reinterpret_cast<float4*>(dst) = t[i][0];
-            *reinterpret_cast<float4*>(dst + plane) = f4add(t[i][0], t[i][1]);
-            *reinterpret_cast<float4*>(dst + 2 * plane) = t[i][1];
+            *reinterpret_cast<float4*>(dst + xstep) = f4add(t[i][0], t[i][1]);
+            *reinterpret_cast<float4*>(dst + 2 * xstep) = t[i][1];
         }
     }
 }
@@ -242,6 +294,7 @@ struct WinoArgs {
     float* stats;        // != null: column sums of y and y^2 per (phase, tile block, wave row): [rows][2][Nc] (see gemm.hip)
     int xcd;             // XCD-aware placement of the workgroups that share a V block (CG_XCD_SWIZZLE)
     int vpp;             // 1: V holds NPOS planes PER PHASE ([P][NPOS][T][K], F(2x2,2x2)); 0: one set shared by the phases ([NPOS][T][K])
+    int kz;              // > 0 (wino_gemm_g_kernel, so == 1): blockIdx.z is a K slice of kz rows, its partial result goes to y + z * T*4*Nc
 };
 
 // NW waves per workgroup: 4 (wave tile 32x64) or 8 (wave tile 32x32: twice the waves per tile for latency hiding); BK = K step
@@ -525,7 +578,11 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
         tn = member - phase * ntn;
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int KT = a.K / BK;
+    const int Kext = a.kz ? a.kz : a.K;                           // K rows this workgroup walks, from row koff
+    const int koff = a.kz ? phase * a.kz : 0;
+    float* const yout = a.y + (a.kz ? (long)phase * a.T * 4 * a.Nc : 0L);
+    if (a.kz) phase = 0;
+    const int KT = Kext / BK;
 
     // ---- staging: lane -> (row, LDS quad position) of A, (k row, column quad) of B
     const int a_row_l = (wave % AW) * RPW + lane / KV;            // row of the tile block this lane brings (waves >= AW: unused)
@@ -548,13 +605,13 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
         float* B = buf ? Bs1 : Bs0;
         if (AW == 8 || wave < AW) {
             __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)(Vp + nxi * a_plane), 0, 0x7fffffff, 0x00020000);
-            wino_glds16(rsv, A + (wave % AW) * RPW * BK, a_voff, nk0 * 4);
+            wino_glds16(rsv, A + (wave % AW) * RPW * BK, a_voff, (koff + nk0) * 4);
         }
-        const int sb = (nxi * a.K + nk0) * a.Nc * 4;
+        const int sb = (nxi * a.K + koff + nk0) * a.Nc * 4;
 #pragma unroll
         for (int q = 0; q < BQ; ++q) wino_glds16(rsu, B + (16 * q + wave * 2) * BN, b_voff + (unsigned)(16 * q * a.Nc) * 4u, sb);
         nk0 += BK;
-        if (nk0 >= a.K) { nk0 = 0; ++nxi; }
+        if (nk0 >= Kext) { nk0 = 0; ++nxi; }
     };
 
     f32x16 accM, accY[4];
@@ -626,7 +683,7 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
         for (int o = 0; o < 4; ++o) {
             const int oy = (2 * ti + (o >> 1)) * a.so + pa, ox = (2 * tj + (o & 1)) * a.so + pb;
             const float v = accY[o][r] + bcol;
-            a.y[((n * a.Ho + oy) * (long)a.Wo + ox) * a.Nc + n0 + wn0 + l31] = v;
+            yout[((n * a.Ho + oy) * (long)a.Wo + ox) * a.Nc + n0 + wn0 + l31] = v;
             if (a.stats) { st1 += v; st2 += v * v; }
         }
     }
@@ -769,7 +826,7 @@ int cg_conv2d_ups2_wino_pack(void* stream, const float* wf_ph, const float* wb_p
 // their input transform; exported so that it can be timed / profiled in isolation).
 // dgrad == 0: v [16][T][Cin], u = u_fwd, y [N][2Hp][2Wp][Cout];  dgrad == 1: v [16][T][4*Cout], u = u_bwd, y [N][Hp][Wp][Cin].
 static int wino_gemm_launch(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
-                            int Cin, int Cout, int dgrad, float* stats, int npos = 16);
+                            int Cin, int Cout, int dgrad, float* stats, int npos = 16, int kslices = 1);
 
 int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
                              int Cin, int Cout, int dgrad) {
@@ -783,19 +840,22 @@ size_t cg_conv2d_ups2_wino_stats_rows(int N, int Hp, int Wp, int Cin, int Cout) 
 }
 
 static int wino_gemm_launch(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
-                            int Cin, int Cout, int dgrad, float* stats, int npos) {
+                            int Cin, int Cout, int dgrad, float* stats, int npos, int kslices) {
     CG_REQUIRE(v && u && y, "cg_conv2d_ups2_wino_gemm: null pointer");
     CG_REQUIRE(wino_dims_ok(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino_gemm: unsupported dimensions");
     const int T = N * (Hp / 2) * (Wp / 2);
     WinoArgs a;
     a.V = v; a.U = u; a.bias = bias; a.y = y; a.T = T; a.tH = Hp / 2; a.tW = Wp / 2; a.stats = stats;
     a.xcd = (int)cg::opt(cg::OPT_XCD_SWIZZLE);
-    a.vpp = npos == 9 ? 1 : 0;
+    a.vpp = npos == 9 && !dgrad ? 1 : 0;
+    a.kz = 0;
     CG_REQUIRE(!stats || (!dgrad && cg::opt(cg::OPT_WINO_WAVES) != 4), "wino_gemm: statistics only on the 8-wave forward launch");
     if (dgrad) { a.K = 4 * Cout; a.Nc = Cin; a.so = 1; a.Ho = Hp; a.Wo = Wp; }
     else { a.K = Cin; a.Nc = Cout; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp; }
     const int nw = (int)cg::opt(cg::OPT_WINO_WAVES), bk = (int)cg::opt(cg::OPT_WINO_BK);
-    const dim3 grid(cg::cdiv(T, 64) * (a.Nc / 128), 1, dgrad ? 1 : 4);
+    CG_REQUIRE(kslices <= 1 || (npos == 9 && dgrad && a.K % kslices == 0 && (a.K / kslices) % 64 == 0), "wino_gemm: K slices only on the 9-position data gradient");
+    if (kslices > 1) a.kz = a.K / kslices;
+    const dim3 grid(cg::cdiv(T, 64) * (a.Nc / 128), 1, dgrad ? (kslices > 1 ? kslices : 1) : 4);
     // K step 32 (half the barriers per MFMA) pays when the launch is at most ~one workgroup per CU - the data-gradient
     // geometry at batch 128 (0.53 -> 0.41 ms) - and costs 6 % when two workgroups per CU already hide each other's barriers
     const bool k32 = bk == 32 || (bk == 0 && (long)grid.x * grid.z <= cg::kNumCU * 3 / 2);
@@ -803,8 +863,8 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
     const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && nw != 4 && (long)T * a.K * 4L < 0x7fffffffL &&
                       16L * a.K * a.Nc * 4L < 0x7fffffffL;
     if (npos == 9) {     // F(2x2,2x2): the LDS-direct-load kernel only (cg_conv2d_ups2_wino22_supported checks the same conditions)
-        CG_REQUIRE(glds && !dgrad, "wino_gemm: the 9-position form needs the LDS-direct-load kernel (CG_WINO_GLDS, 8 waves) and is forward only");
-        if (k32 && a.K % 64 == 0) hipLaunchKernelGGL((wino_gemm_g_kernel<32, 9>), grid, dim3(512), 0, cg::S(stream), a);
+        CG_REQUIRE(glds, "wino_gemm: the 9-position form needs the LDS-direct-load kernel (CG_WINO_GLDS, 8 waves)");
+        if (k32 && (a.kz ? a.kz : a.K) % 64 == 0) hipLaunchKernelGGL((wino_gemm_g_kernel<32, 9>), grid, dim3(512), 0, cg::S(stream), a);
         else hipLaunchKernelGGL((wino_gemm_g_kernel<16, 9>), grid, dim3(512), 0, cg::S(stream), a);
         CG_LAUNCH_CHECK();
         return 0;
@@ -851,12 +911,19 @@ size_t cg_conv2d_ups2_wino22_supported(int N, int Hp, int Wp, int Cin, int Cout)
 size_t cg_conv2d_ups2_wino22_v_floats(int N, int Hp, int Wp, int Cin) { return (size_t)36 * ((size_t)N * (Hp / 2) * (Wp / 2)) * Cin; }
 size_t cg_conv2d_ups2_wino22_u_floats(int Cin, int Cout) { return (size_t)4 * 9 * Cin * Cout; }
 
-int cg_conv2d_ups2_wino22_pack(void* stream, const float* wf_ph, float* u22, int Cout, int Cin) {
-    CG_REQUIRE(wf_ph && u22, "cg_conv2d_ups2_wino22_pack: null pointer");
+int cg_conv2d_ups2_wino22_pack(void* stream, const float* wf_ph, const float* wb_ph, float* u_fwd, float* u_bwd, int Cout, int Cin) {
+    CG_REQUIRE((wf_ph && u_fwd) || (wb_ph && u_bwd), "cg_conv2d_ups2_wino22_pack: null pointer");
     CG_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "cg_conv2d_ups2_wino22_pack: channel counts must be multiples of 4");
-    const long total = 4L * Cin * (Cout / 4);
-    hipLaunchKernelGGL(wino22_filter_transform_kernel, dim3(cg::ew_grid(total)), dim3(256), 0, cg::S(stream), wf_ph, u22, Cin, Cout);
-    CG_LAUNCH_CHECK();
+    if (wf_ph && u_fwd) {
+        hipLaunchKernelGGL(wino22_filter_transform_kernel<false>, dim3(cg::ew_grid(4L * Cin * (Cout / 4))), dim3(256), 0, cg::S(stream), wf_ph,
+                           u_fwd, Cin, Cout);
+        CG_LAUNCH_CHECK();
+    }
+    if (wb_ph && u_bwd) {
+        hipLaunchKernelGGL(wino22_filter_transform_kernel<true>, dim3(cg::ew_grid(4L * Cout * (Cin / 4))), dim3(256), 0, cg::S(stream), wb_ph,
+                           u_bwd, Cout, Cin);
+        CG_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -870,6 +937,47 @@ int cg_conv2d_ups2_wino22_forward_stats(void* stream, const float* x_lo, const f
     hipLaunchKernelGGL(wino22_input_transform_kernel, dim3(cg::ew_grid((long)T * (Cin / 4))), dim3(256), 0, cg::S(stream), x_lo, v, N, Hp, Wp, Cin);
     CG_LAUNCH_CHECK();
     return wino_gemm_launch(stream, v, u22, bias, y, N, Hp, Wp, Cin, Cout, 0, stats, 9);
+}
+
+// The data gradient's launch has T/64 x Cin/128 workgroups - 128 on G's 512 -> 256 layer at batch 128, half the chip.  Below ~one
+// workgroup per CU the four phases (K slices of Cout rows) go to blockIdx.z, each writing a partial dx_lo behind V in the scratch, and
+// wino22_sum4_kernel adds them in a fixed order (CG_WINO22_KSPLIT = 0 / 1 forces the choice).
+static bool wino22_dgrad_split(int N, int Hp, int Wp, int Cin, int Cout) {
+    static const int force = [] { const char* e = getenv("CG_WINO22_KSPLIT"); return e ? atoi(e) : -1; }();
+    if (Cout % 64 != 0) return false;
+    if (force >= 0) return force != 0;
+    return (long)cg::cdiv(N * (Hp / 2) * (Wp / 2), 64) * (Cin / 128) < cg::kNumCU;
+}
+
+__global__ __launch_bounds__(256) void wino22_sum4_kernel(const float* __restrict__ part, float* __restrict__ out, long n4, long stride) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += gridDim.x * 256L) {
+        const float4 a = ld4(part + 4 * i), b = ld4(part + stride + 4 * i), c = ld4(part + 2 * stride + 4 * i), d = ld4(part + 3 * stride + 4 * i);
+        *reinterpret_cast<float4*>(out + 4 * i) = f4add(f4add(a, b), f4add(c, d));
+    }
+}
+
+size_t cg_conv2d_ups2_wino22_dgrad_v_floats(int N, int Hp, int Wp, int Cin, int Cout) {
+    const size_t T = (size_t)N * (Hp / 2) * (Wp / 2);
+    return 36 * T * Cout + (wino22_dgrad_split(N, Hp, Wp, Cin, Cout) ? 16 * T * Cin : 0);
+}
+
+// dx_lo[N][Hp][Wp][Cin] = gradient of upsample2 -> conv3x3 w.r.t. the low-res input; v_dy: scratch of cg_conv2d_ups2_wino22_dgrad_v_floats()
+// floats (9 planes x T x 4 Cout, + the four partial results when the K slices are split); u_bwd from cg_conv2d_ups2_wino22_pack.
+int cg_conv2d_ups2_wino22_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy, int N, int Hp, int Wp, int Cin,
+                                int Cout) {
+    CG_REQUIRE(dy && u_bwd && dx_lo && v_dy, "cg_conv2d_ups2_wino22_dgrad: null pointer");
+    CG_REQUIRE(cg_conv2d_ups2_wino22_supported(N, Hp, Wp, Cin, Cout) && (long)N * (Hp / 2) * (Wp / 2) * Cout * 16L < 0x7fffffffL,
+               "cg_conv2d_ups2_wino22_dgrad: unsupported dimensions / options");
+    const int T = N * (Hp / 2) * (Wp / 2);
+    hipLaunchKernelGGL(wino22_dy_input_transform_kernel, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, cg::S(stream), dy, v_dy, N, Hp, Wp, Cout);
+    CG_LAUNCH_CHECK();
+    if (!wino22_dgrad_split(N, Hp, Wp, Cin, Cout)) return wino_gemm_launch(stream, v_dy, u_bwd, nullptr, dx_lo, N, Hp, Wp, Cin, Cout, 1, nullptr, 9);
+    float* part = v_dy + (size_t)36 * T * Cout;
+    if (wino_gemm_launch(stream, v_dy, u_bwd, nullptr, part, N, Hp, Wp, Cin, Cout, 1, nullptr, 9, 4)) return 1;
+    const long n = (long)T * 4 * Cin;
+    hipLaunchKernelGGL(wino22_sum4_kernel, dim3(cg::ew_grid(n / 4)), dim3(256), 0, cg::S(stream), part, dx_lo, n / 4, n);
+    CG_LAUNCH_CHECK();
+    return 0;
 }
 
 // dx_lo[N][Hp][Wp][Cin] = gradient w.r.t. the low-res input (the upsampling's 2x2 block sum folded in);

@@ -225,14 +225,19 @@ int cg_conv2d_ups2_wino_forward_stats(void* stream, const float* x_lo, const flo
 /* F(2x2,2x2) for nn.SpatialUpSamplingNearest(2) -> 3x3 convolution (models.lua:211-212 at the full batch; round 4), FORWARD: the four
  * phases are 2x2-tap convolutions with windows one pixel apart - 9 multiplies per 2x2 low-res tile and phase instead of 16.  u22:
  * cg_conv2d_ups2_wino22_u_floats() floats from the phase-summed kernels (cg_pack_conv_weight_ups2's wf_ph); v: scratch of
- * cg_conv2d_ups2_wino22_v_floats() floats (4 phases x 9 planes); stats as cg_conv2d_ups2_wino_forward_stats.  The backward of such a
- * layer stays on the phase-folded direct kernels (cg_conv2d_dgrad_ups2 / cg_conv2d_wgrad with ups = 1). */
+ * cg_conv2d_ups2_wino22_v_floats() floats (4 phases x 9 planes); stats as cg_conv2d_ups2_wino_forward_stats.  The weight gradient of
+ * such a layer stays on the phase-folded direct kernel (cg_conv2d_wgrad with ups = 1). */
 size_t cg_conv2d_ups2_wino22_supported(int N, int Hp, int Wp, int Cin, int Cout);
 size_t cg_conv2d_ups2_wino22_v_floats(int N, int Hp, int Wp, int Cin);
 size_t cg_conv2d_ups2_wino22_u_floats(int Cin, int Cout);
-int cg_conv2d_ups2_wino22_pack(void* stream, const float* wf_ph, float* u22, int Cout, int Cin);
+int cg_conv2d_ups2_wino22_pack(void* stream, const float* wf_ph, const float* wb_ph, float* u_fwd, float* u_bwd, int Cout, int Cin);
 int cg_conv2d_ups2_wino22_forward_stats(void* stream, const float* x_lo, const float* u22, const float* bias, float* y,
                                         float* v, int N, int Hp, int Wp, int Cin, int Cout, float* stats);
+/* updateGradInput of the same layers: dx_lo[N][Hp][Wp][Cin] (the upsampling's 2x2 block sum folded in); v_dy: scratch of
+ * cg_conv2d_ups2_wino22_dgrad_v_floats() floats; u_bwd from cg_conv2d_ups2_wino22_pack (wb_ph: cg_pack_conv_weight_ups2). */
+size_t cg_conv2d_ups2_wino22_dgrad_v_floats(int N, int Hp, int Wp, int Cin, int Cout);
+int cg_conv2d_ups2_wino22_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy,
+                                int N, int Hp, int Wp, int Cin, int Cout);
 int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy,
                               int N, int Hp, int Wp, int Cin, int Cout);
 /* accGradParameters in the Winograd domain, from the v the forward wrote: gw_canonical[Cout][Cin][5][5] += scale*dW,

@@ -127,12 +127,15 @@ def test_winograd_path_matches_direct_phase_path(cg):
         close(a, b, K=K, what=f"winograd vs direct: {what}")
 
 
-@pytest.mark.parametrize("N,Cin,H,Cout", [(2, 128, 8, 128), (3, 256, 6, 128), (32, 512, 8, 256)])
-def test_winograd22_forward_of_the_3x3_layers_behind_an_upsampling(cg, N, Cin, H, Cout):
-    """F(2x2,2x2) forward (cg_conv2d_ups2_wino22_*, csrc/winograd.hip; models.lua:211-212) through the C ABI against the ORACLE's
+@pytest.mark.parametrize("N,Cin,H,Cout", [(2, 128, 8, 128), (3, 256, 6, 128), (32, 512, 8, 256), (64, 512, 16, 128)])
+def test_winograd22_of_the_3x3_layers_behind_an_upsampling(cg, N, Cin, H, Cout):
+    """F(2x2,2x2) forward and data gradient (cg_conv2d_ups2_wino22_*, csrc/winograd.hip; models.lua:211-212) through the C ABI against the ORACLE's
     upsample -> conv3x3 and against the phase-folded direct kernel, incl. the batch-norm statistics partials of the epilogue and the
-    borders (zero padding on the low-res grid) - the last case is G's 512 -> 256 layer at a quarter of the benchmarked batch.  The
-    planned pass takes this path at >= 2048 tiles (whole-generator tests at batch 128 run it inside G)."""
+    borders (zero padding on the low-res grid) - the third case is G's 512 -> 256 layer at a quarter of the benchmarked batch.  The
+    planned pass takes this path at >= 2048 tiles (whole-generator tests at batch 128 run it inside G).  The data gradient splits its
+    K slices over blockIdx.z below one workgroup per CU (the first three cases) and runs unsplit above (the last one, checked against
+    the phase-folded kernel only: its own parity with the oracle is test_conv_fwd_bwd's)."""
+    big = N * H * H * Cin * Cout >= 1 << 30
     tensor_mod = importlib.import_module("cat-generator_amd.tensor")
     rs = np.random.RandomState(N + Cin)
     L, st = cg.lib(), tensor_mod.stream()
@@ -145,7 +148,8 @@ def test_winograd22_forward_of_the_3x3_layers_behind_an_upsampling(cg, N, Cin, H
     assert L.conv2d_ups2_wino22_supported(N, H, H, Cin, Cout) == 1
     dev = m._wf_ph.device
     u22 = torch.empty(L.conv2d_ups2_wino22_u_floats(Cin, Cout), dtype=torch.float32, device=dev)
-    assert L.conv2d_ups2_wino22_pack(st, m._wf_ph.data_ptr(), u22.data_ptr(), Cout, Cin) == 0
+    u22b = torch.empty_like(u22)
+    assert L.conv2d_ups2_wino22_pack(st, m._wf_ph.data_ptr(), m._wb_ph.data_ptr(), u22.data_ptr(), u22b.data_ptr(), Cout, Cin) == 0
     v = torch.empty(L.conv2d_ups2_wino22_v_floats(N, H, H, Cin), dtype=torch.float32, device=dev)
     x_lo = torch.from_numpy(np.ascontiguousarray(xl.transpose(0, 2, 3, 1))).to(dev)        # NHWC low-res map
     y = torch.full((N, 2 * H, 2 * H, Cout), float("nan"), dtype=torch.float32, device=dev)
@@ -157,13 +161,26 @@ def test_winograd22_forward_of_the_3x3_layers_behind_an_upsampling(cg, N, Cin, H
                                               N, H, H, Cin, Cout, part.data_ptr() if rows else None) == 0
     torch.cuda.synchronize()
     got = y.cpu().numpy().transpose(0, 3, 1, 2)
-    ref = O.conv2d_forward(O.UpSample2().forward(xl), w, bias, 1)
+    ref = y_direct if big else O.conv2d_forward(O.UpSample2().forward(xl), w, bias, 1)
     close(got, ref, K=Cin * 9, what="F(2x2,2x2) forward vs oracle")
     close(got, y_direct, K=Cin * 9, what="F(2x2,2x2) forward vs the phase-folded kernel")
     if rows:
         p_ = part.cpu().numpy().astype(np.float64)
         close(p_[:, 0].sum(0), ref.astype(np.float64).sum((0, 2, 3)), K=N * 4 * H * H, tol=5e-5, what="epilogue sum")
         close(p_[:, 1].sum(0), (ref.astype(np.float64) ** 2).sum((0, 2, 3)), K=N * 4 * H * H, tol=5e-5, what="epilogue sum of squares")
+    # updateGradInput in the same form: the four phase sub-lattices of dy side by side along K, flipped kernels (cg_conv2d_ups2_wino22_dgrad)
+    dy = rs.randn(N, Cout, 2 * H, 2 * H).astype(f32)
+    gi_direct = up.updateGradInput(None, m.updateGradInput(up.output, cg.Tensor.from_numpy(dy))).numpy()
+    dy_dev = torch.from_numpy(np.ascontiguousarray(dy.transpose(0, 2, 3, 1))).to(dev)
+    vdy = torch.empty(L.conv2d_ups2_wino22_dgrad_v_floats(N, H, H, Cin, Cout), dtype=torch.float32, device=dev)
+    dx = torch.full((N, H, H, Cin), float("nan"), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    assert L.conv2d_ups2_wino22_dgrad(st, dy_dev.data_ptr(), u22b.data_ptr(), dx.data_ptr(), vdy.data_ptr(), N, H, H, Cin, Cout) == 0
+    torch.cuda.synchronize()
+    assert (L.conv2d_ups2_wino22_dgrad_v_floats(N, H, H, Cin, Cout) > 36 * N * (H // 2) ** 2 * Cout) == (not big)    # split / unsplit
+    gref = gi_direct if big else O.UpSample2().backward(O.conv2d_backward_data(dy, w, (N, Cin, 2 * H, 2 * H), 1))
+    close(dx.cpu().numpy().transpose(0, 3, 1, 2), gref, K=4 * Cout * 9, what="F(2x2,2x2) data gradient vs oracle")
+    close(dx.cpu().numpy().transpose(0, 3, 1, 2), gi_direct, K=4 * Cout * 9, what="F(2x2,2x2) data gradient vs the phase-folded kernel")
 
 
 @pytest.mark.parametrize("N,i,o", [(128, 100, 8192), (6, 20480, 256), (5, 64, 4), (3, 256, 1), (64, 1024, 64)])

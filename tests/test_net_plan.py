@@ -121,10 +121,16 @@ def test_generator_plan_uses_epilogue_statistics_and_winograd_at_the_benchmarked
     assert "cg_upsample2x_forward" not in f and "cg_prelu_forward" not in f
     b = [c[0] for c in T.calls(r["backward"])]
     assert b.count("cg_conv2d_ups2_wino_dgrad") == 1 and b.count("cg_conv2d_ups2_wino_wgrad") == 1
-    assert b.count("cg_conv2d_dgrad_ups2") == 2 and b.count("cg_bn_act_backward") == 3 and b[-1] == "cg_conv2d_wgrad_flush"
+    # the 512 -> 256 3x3 layer behind the 8x8 -> 16x16 upsampling: forward and data gradient in F(2x2,2x2), weight gradient direct
+    assert f.count("cg_conv2d_ups2_wino22_forward_stats") == 1 and b.count("cg_conv2d_ups2_wino22_dgrad") == 1
+    assert b.count("cg_conv2d_dgrad_ups2") == 1 and b.count("cg_bn_act_backward") == 3 and b[-1] == "cg_conv2d_wgrad_flush"
+    r22 = T.trace("G32up-c", 128, options=[("winograd22", 1)])     # bit 0 only: the forward alone
+    assert [c[0] for c in T.calls(r22["backward"])].count("cg_conv2d_dgrad_ups2") == 2
+    r20 = T.trace("G32up-c", 128, options=[("winograd22", 0)])
+    assert "cg_conv2d_ups2_wino22_forward_stats" not in [c[0] for c in T.calls(r20["forward"])]
     assert r["backward"][-2:] == ["event|record|wgjoin0|s4", "event|wait|wgjoin0|s0"]
     small = [c[0] for c in T.calls(T.trace("G32up-c", 8)["forward"])]
-    assert "cg_conv2d_ups2_wino_forward_stats" not in small        # below 2048 tiles the direct phase kernels run
+    assert "cg_conv2d_ups2_wino_forward_stats" not in small and "cg_conv2d_ups2_wino22_forward_stats" not in small   # below 2048 tiles the direct phase kernels run
 
 
 PTR_ARG = {"void*", "const void*", "float*", "const float*", "double*", "const double*", "int32_t*", "const int32_t*", "uint64_t*",
