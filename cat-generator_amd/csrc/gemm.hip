@@ -92,7 +92,7 @@ struct Geom {
 };
 
 constexpr int MAXG = 4;  // groups per launch: same geometry, separate tensors (D32_st3's identical branches)
-constexpr int kMaxStridedGroups = 16;   // ... or up to 16 equally spaced ones (cg_conv2d_wgrad_strided)
+constexpr int kMaxStridedGroups = 36;   // ... or up to 36 equally spaced ones (cg_conv2d_wgrad_strided: 16 planes of F(2x2,3x3), 4 x 9 of F(2x2,2x2))
 
 struct NNArgs {
     const float* x0; const float* x1; const float* x2; const float* x3;   // per group (no arrays: see TapDesc)
@@ -129,7 +129,7 @@ struct TNArgs {
     Geom g;
     int pchunk;         // pixels per split (multiple of BK)
     int xcd_swizzle;
-    long xgs, dgs;      // != 0: group g reads x0 + g * xgs / d0 + g * dgs (up to kMaxStridedGroups equally spaced groups: the 16
+    long xgs, dgs;      // != 0: group g reads x0 + g * xgs / d0 + g * dgs (up to kMaxStridedGroups equally spaced groups: the
                         // Winograd-domain weight-gradient GEMMs of winograd.hip in one launch), x1.. / d1.. unused
 };
 

@@ -225,7 +225,8 @@ struct Net {
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
         cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0, wgrad_lag = 0;
     long wino_min_tiles = 2048;
-    int wino22 = 3;                            // F(2x2,2x2) for upsample2 -> conv3x3 above wino_min_tiles: bit 0 forward, bit 1 data gradient (option "winograd22")
+    int wino22 = 3;                            // F(2x2,2x2) for upsample2 -> conv3x3 above wino_min_tiles: bit 0 forward, 1 data gradient, 2 weight gradient
+                                               // (option "winograd22"; the weight gradient is 292 -> 257 us alone but no gain in the step: off)
     std::string trace_log;
     const KTable* K = &kRealTable;
     vector<void*> trace_streams;               // stream handle -> index in trace mode
@@ -1742,6 +1743,16 @@ struct Compiler {
             emit([=](Run& c) { return k->conv2d_ups2_wino_wgrad(c.CS(), c.P(v), c.P(dy), mp->gw, mp->gb, (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co, c.scale, c.W(), c.WB()); });
             return;
         }
+        if (m.kind == K_CONV && s.x.ups && s.use_wino22 && (net->wino22 & 4)) {
+            // F(2x2,2x2)-domain weight gradient from the transformed input the forward of this batch left in wino22_v
+            Val dy = as_nhwc(go);
+            const Val& x = s.x;
+            const long N = x.d[0], Hp = x.d[2] >> 1, Wp = x.d[3] >> 1, Ci = m.ia[0], Co = m.ia[1];
+            Val v = buf(m, "wino22_v", {(long)cg_conv2d_ups2_wino22_v_floats((int)N, (int)Hp, (int)Wp, (int)Ci)});
+            ws_need(cg_conv2d_ups2_wino22_wgrad_workspace_bytes((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co));
+            emit([=](Run& c) { return k->conv2d_ups2_wino22_wgrad(c.CS(), c.P(v), c.P(dy), mp->gw, mp->gb, (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co, c.scale, c.W(), c.WB()); });
+            return;
+        }
         PrepAcc p = prep_acc(m, go);
         if (net->defer_wgrad && net->fusion) {
             const size_t need = std::max<size_t>(cg_conv2d_wgrad_workspace_bytes(GEO(p.g)), 4096);
@@ -2557,13 +2568,14 @@ int cg_net_set_option(void* net, const char* name, long value) {
         {"overlap_groups", &n->overlap_groups}, {"defer_wgrad", &n->defer_wgrad}, {"winograd", &n->winograd}, {"share_pool", &n->share_pool},
         {"sampler_shared", &n->sampler_shared}, {"view_fuse", &n->view_fuse}, {"cat_fuse", &n->cat_fuse}, {"stacking", &n->stacking},
         {"grouped", &n->grouped}, {"fusion", &n->fusion}, {"fuse_locnet", &n->fuse_locnet}, {"pack_overlap", &n->pack_overlap},
-        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wgrad_lag", &n->wgrad_lag}, {"winograd22", &n->wino22}};
+        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wgrad_lag", &n->wgrad_lag}};
     if (!strcmp(name, "trace")) {
         CG_REQUIRE(n->progs.empty(), "cg_net_set_option: trace must be chosen before the first pass");
         n->trace = value != 0; n->K = n->trace ? &kTraceTable : &kRealTable;
         return 0;
     }
     if (!strcmp(name, "winograd_min_tiles")) { n->wino_min_tiles = value; return 0; }
+    if (!strcmp(name, "winograd22")) { n->wino22 = (int)value; return 0; }     // bit mask: 1 forward, 2 data gradient, 4 weight gradient
     if (!strcmp(name, "fuse_locnet")) { n->fuse_locnet = (int)value; return 0; }   // 0 off, 1 every localisation branch, 2 ungrouped ones only
     for (auto& t : tab) if (!strcmp(name, t.nm)) { *t.p = value != 0; return 0; }
     return cg::fail("cg_net_set_option: unknown option %s", name);

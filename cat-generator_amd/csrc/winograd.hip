@@ -785,6 +785,78 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradient of upsample2 -> conv3x3 in the F(2x2,2x2) domain, from the V the forward left behind ([p][xi][T][Cin]):
+//   dM = A dY_p A^T per tile and phase (A = [1 0; 1 1; 0 1]) -> Mdy[p][xi][tile][Cout];  dU_{p,xi}^T [Cout][Cin] = Mdy^T V: 36 equally
+//   spaced TN GEMMs with K = T in ONE launch (9/16 of the direct kernel's multiplies);  G^T dU_p G (G^T = [1 1 0; 0 1 1]) is the 2x2 phase
+//   kernel's gradient, its taps scattered onto the canonical 3x3 taps like the direct path's reduce.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino22_dy_transform_kernel(const float* __restrict__ dy, float* __restrict__ Mdy, int N, int Hl, int Wl,
+                                                                  int Cout) {
+    const int cq_n = Cout;   // 4 phases x Cout / 4 quads
+    const int tH = Hl >> 1, tW = Wl >> 1;
+    const long T = (long)N * tH * tW;
+    const long total = T * cq_n;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+        const int cq = (int)(idx % cq_n);
+        const long tile = idx / cq_n;
+        const int tj = (int)(tile % tW);
+        const int ti = (int)((tile / tW) % tH);
+        const long n = tile / ((long)tW * tH);
+        const int p = (cq * 4) / Cout, co = cq * 4 - p * Cout;
+        const int pa = p >> 1, pb = p & 1;
+        float4 e[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+                e[u][v] = ld4(dy + ((n * 2 * Hl + 2 * (2 * ti + u) + pa) * (long)(2 * Wl) + 2 * (2 * tj + v) + pb) * Cout + co);
+        float4 r[3][2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) { r[0][v] = e[0][v]; r[1][v] = f4add(e[0][v], e[1][v]); r[2][v] = e[1][v]; }
+        float* out = Mdy + ((long)p * 9 * T + tile) * Cout + co;
+        const long xs = T * Cout;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            *reinterpret_cast<float4*>(out + (i * 3 + 0) * xs) = r[i][0];
+            *reinterpret_cast<float4*>(out + (i * 3 + 1) * xs) = f4add(r[i][0], r[i][1]);
+            *reinterpret_cast<float4*>(out + (i * 3 + 2) * xs) = r[i][1];
+        }
+    }
+}
+
+__device__ __host__ __forceinline__ int wino22_phase_map(int a, int d) { return ((a + d - 1) >> 1) - ((a - 1) >> 1); }
+
+// gw[co][ci][3][3] += scale * sum_p (G^T dU_p G)[map_p(dy,dx)];  dUt layout [p*9 + xi][co][ci].  One thread per (co, ci).
+__global__ __launch_bounds__(256) void wino22_wgrad_finish_kernel(const float* __restrict__ dUt, float* __restrict__ gw, int Cout, int Cin,
+                                                                  float scale) {
+    const long total = (long)Cout * Cin;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+        float acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float u[3][3];
+#pragma unroll
+            for (int xi = 0; xi < 9; ++xi) u[xi / 3][xi % 3] = dUt[((long)p * 9 + xi) * total + idx];
+            float t[2][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { t[0][c] = u[0][c] + u[1][c]; t[1][c] = u[1][c] + u[2][c]; }
+            float g[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) { g[r][0] = t[r][0] + t[r][1]; g[r][1] = t[r][1] + t[r][2]; }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] += g[wino22_phase_map(p >> 1, dy)][wino22_phase_map(p & 1, dx)];
+        }
+        float* dst = gw + idx * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dst[t] += scale * acc[t];
+    }
+}
+
 static bool wino_dims_ok(int N, int Hp, int Wp, int Cin, int Cout) {
     return N > 0 && Hp > 0 && Wp > 0 && (Hp & 1) == 0 && (Wp & 1) == 0 && Cin > 0 && Cout > 0 && Cin % 128 == 0 &&
            Cout % 128 == 0 /* K % 32, Nc % 128 for both GEMM geometries */ && (long)N * Hp * Wp * std::max(Cin, 4 * Cout) * 4L < (1L << 40);
@@ -1033,6 +1105,40 @@ int cg_conv2d_ups2_wino_wgrad(void* stream, const float* v, const float* dy, flo
     }
     hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(cg::ew_grid((long)Cout * Cin)), dim3(256), 0, st, dut, gw_canonical, Cout,
                        Cin, scale);
+    CG_LAUNCH_CHECK();
+    if (gb) return cg_bias_grad(stream, dy, gb, (long)N * 4 * Hp * Wp, Cout, scale, bws, wino_align(sizeof(double) * Cout));
+    return 0;
+}
+
+size_t cg_conv2d_ups2_wino22_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout) {
+    if (!wino_dims_ok(N, Hp, Wp, Cin, Cout)) return 0;
+    const size_t T = (size_t)N * (Hp / 2) * (Wp / 2);
+    return wino_align(36 * T * Cout * sizeof(float)) + wino_align((size_t)36 * Cout * Cin * sizeof(float)) + wino_align(sizeof(double) * Cout) +
+           cg_conv2d_wgrad_workspace_bytes_grouped(36, (int)T, 1, 1, Cin, Cout, 1, 1, 0, 0, 0);
+}
+
+// gw_canonical[Cout][Cin][3][3] += scale * dW, gb += scale * sum dy, from the transformed input v ([4][9][T][Cin]) the F(2x2,2x2) forward of
+// this batch left behind.
+int cg_conv2d_ups2_wino22_wgrad(void* stream, const float* v, const float* dy, float* gw_canonical, float* gb, int N, int Hp, int Wp, int Cin,
+                                int Cout, float scale, void* ws, size_t ws_bytes) {
+    CG_REQUIRE(v && dy && gw_canonical, "cg_conv2d_ups2_wino22_wgrad: null pointer");
+    CG_REQUIRE(wino_dims_ok(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino22_wgrad: unsupported dimensions");
+    const size_t need = cg_conv2d_ups2_wino22_wgrad_workspace_bytes(N, Hp, Wp, Cin, Cout);
+    CG_REQUIRE(ws && ws_bytes >= need && (uintptr_t)ws % 16 == 0, "cg_conv2d_ups2_wino22_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+    hipStream_t st = cg::S(stream);
+    const int T = N * (Hp / 2) * (Wp / 2);
+    char* base = (char*)ws;
+    float* mdy = (float*)base;                    base += wino_align((size_t)36 * T * Cout * sizeof(float));
+    float* dut = (float*)base;                    base += wino_align((size_t)36 * Cout * Cin * sizeof(float));
+    void* bws = base;                             base += wino_align(sizeof(double) * Cout);
+    void* tws = base;
+    const size_t tws_bytes = ws_bytes - (size_t)(base - (char*)ws);
+    hipLaunchKernelGGL(wino22_dy_transform_kernel, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, st, dy, mdy, N, Hp, Wp, Cout);
+    CG_LAUNCH_CHECK();
+    if (cg_memset_zero(stream, dut, (size_t)36 * Cout * Cin * sizeof(float))) return 1;
+    if (cg_conv2d_wgrad_strided(stream, 36, v, (long)T * Cin, mdy, (long)T * Cout, dut, (long)Cout * Cin, T, 1, 1, Cin, Cout, 1, 1, 0, 0, 0, 1.f,
+                                tws, tws_bytes)) return 1;
+    hipLaunchKernelGGL(wino22_wgrad_finish_kernel, dim3(cg::ew_grid((long)Cout * Cin)), dim3(256), 0, st, dut, gw_canonical, Cout, Cin, scale);
     CG_LAUNCH_CHECK();
     if (gb) return cg_bias_grad(stream, dy, gb, (long)N * 4 * Hp * Wp, Cout, scale, bws, wino_align(sizeof(double) * Cout));
     return 0;

@@ -225,8 +225,8 @@ int cg_conv2d_ups2_wino_forward_stats(void* stream, const float* x_lo, const flo
 /* F(2x2,2x2) for nn.SpatialUpSamplingNearest(2) -> 3x3 convolution (models.lua:211-212 at the full batch; round 4), FORWARD: the four
  * phases are 2x2-tap convolutions with windows one pixel apart - 9 multiplies per 2x2 low-res tile and phase instead of 16.  u22:
  * cg_conv2d_ups2_wino22_u_floats() floats from the phase-summed kernels (cg_pack_conv_weight_ups2's wf_ph); v: scratch of
- * cg_conv2d_ups2_wino22_v_floats() floats (4 phases x 9 planes); stats as cg_conv2d_ups2_wino_forward_stats.  The weight gradient of
- * such a layer stays on the phase-folded direct kernel (cg_conv2d_wgrad with ups = 1). */
+ * cg_conv2d_ups2_wino22_v_floats() floats (4 phases x 9 planes; what cg_conv2d_ups2_wino22_wgrad consumes later); stats as
+ * cg_conv2d_ups2_wino_forward_stats. */
 size_t cg_conv2d_ups2_wino22_supported(int N, int Hp, int Wp, int Cin, int Cout);
 size_t cg_conv2d_ups2_wino22_v_floats(int N, int Hp, int Wp, int Cin);
 size_t cg_conv2d_ups2_wino22_u_floats(int Cin, int Cout);
@@ -238,6 +238,11 @@ int cg_conv2d_ups2_wino22_forward_stats(void* stream, const float* x_lo, const f
 size_t cg_conv2d_ups2_wino22_dgrad_v_floats(int N, int Hp, int Wp, int Cin, int Cout);
 int cg_conv2d_ups2_wino22_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy,
                                 int N, int Hp, int Wp, int Cin, int Cout);
+/* accGradParameters of the same layers in the F(2x2,2x2) domain, from the v the forward of this batch wrote: gw_canonical[Cout][Cin][3][3] +=
+ * scale*dW, gb (may be NULL) += scale * sum dy.  36 equally spaced weight-gradient GEMMs in one launch (cg_conv2d_wgrad_strided) + G^T . G. */
+size_t cg_conv2d_ups2_wino22_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout);
+int cg_conv2d_ups2_wino22_wgrad(void* stream, const float* v, const float* dy, float* gw_canonical, float* gb,
+                                int N, int Hp, int Wp, int Cin, int Cout, float scale, void* ws, size_t ws_bytes);
 int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy,
                               int N, int Hp, int Wp, int Cin, int Cout);
 /* accGradParameters in the Winograd domain, from the v the forward wrote: gw_canonical[Cout][Cin][5][5] += scale*dW,

@@ -129,7 +129,7 @@ def test_winograd_path_matches_direct_phase_path(cg):
 
 @pytest.mark.parametrize("N,Cin,H,Cout", [(2, 128, 8, 128), (3, 256, 6, 128), (32, 512, 8, 256), (64, 512, 16, 128)])
 def test_winograd22_of_the_3x3_layers_behind_an_upsampling(cg, N, Cin, H, Cout):
-    """F(2x2,2x2) forward and data gradient (cg_conv2d_ups2_wino22_*, csrc/winograd.hip; models.lua:211-212) through the C ABI against the ORACLE's
+    """F(2x2,2x2) forward, data gradient and weight gradient (cg_conv2d_ups2_wino22_*, csrc/winograd.hip; models.lua:211-212) through the C ABI against the ORACLE's
     upsample -> conv3x3 and against the phase-folded direct kernel, incl. the batch-norm statistics partials of the epilogue and the
     borders (zero padding on the low-res grid) - the third case is G's 512 -> 256 layer at a quarter of the benchmarked batch.  The
     planned pass takes this path at >= 2048 tiles (whole-generator tests at batch 128 run it inside G).  The data gradient splits its
@@ -181,6 +181,25 @@ def test_winograd22_of_the_3x3_layers_behind_an_upsampling(cg, N, Cin, H, Cout):
     gref = gi_direct if big else O.UpSample2().backward(O.conv2d_backward_data(dy, w, (N, Cin, 2 * H, 2 * H), 1))
     close(dx.cpu().numpy().transpose(0, 3, 1, 2), gref, K=4 * Cout * 9, what="F(2x2,2x2) data gradient vs oracle")
     close(dx.cpu().numpy().transpose(0, 3, 1, 2), gi_direct, K=4 * Cout * 9, what="F(2x2,2x2) data gradient vs the phase-folded kernel")
+    # accGradParameters from the v the forward above left behind (cg_conv2d_ups2_wino22_wgrad): must ACCUMULATE, scaled
+    m.gradWeight.fill(1.0); m.gradBias.fill(1.0)
+    m.accGradParameters(up.output, cg.Tensor.from_numpy(dy), 0.5)
+    gw_direct, gb_direct = m.gradWeight.numpy(), m.gradBias.numpy()
+    gw_dev, gb_dev = torch.ones((Cout, Cin, 3, 3), dtype=torch.float32, device=dev), torch.ones(Cout, dtype=torch.float32, device=dev)
+    wsb = L.conv2d_ups2_wino22_wgrad_workspace_bytes(N, H, H, Cin, Cout)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    assert L.conv2d_ups2_wino22_wgrad(st, v.data_ptr(), dy_dev.data_ptr(), gw_dev.data_ptr(), gb_dev.data_ptr(), N, H, H, Cin, Cout, 0.5,
+                                      ws.data_ptr(), wsb) == 0
+    torch.cuda.synchronize()
+    P = N * 4 * H * H
+    if not big:
+        gw, gb = np.ones_like(w), np.ones_like(bias)
+        O.conv2d_backward_weight(O.UpSample2().forward(xl), dy, gw, gb, 1, 0.5)
+        close(gw_dev.cpu().numpy(), gw, K=P, tol=4e-5, what="F(2x2,2x2) gradWeight vs oracle")
+        close(gb_dev.cpu().numpy(), gb, K=P, tol=4e-5, what="gradBias vs oracle")
+    close(gw_dev.cpu().numpy(), gw_direct, K=P, tol=4e-5, what="F(2x2,2x2) gradWeight vs the phase-folded kernel")
+    close(gb_dev.cpu().numpy(), gb_direct, K=P, tol=4e-5, what="gradBias vs the phase-folded kernel")
 
 
 @pytest.mark.parametrize("N,i,o", [(128, 100, 8192), (6, 20480, 256), (5, 64, 4), (3, 256, 1), (64, 1024, 64)])

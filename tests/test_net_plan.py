@@ -121,11 +121,16 @@ def test_generator_plan_uses_epilogue_statistics_and_winograd_at_the_benchmarked
     assert "cg_upsample2x_forward" not in f and "cg_prelu_forward" not in f
     b = [c[0] for c in T.calls(r["backward"])]
     assert b.count("cg_conv2d_ups2_wino_dgrad") == 1 and b.count("cg_conv2d_ups2_wino_wgrad") == 1
-    # the 512 -> 256 3x3 layer behind the 8x8 -> 16x16 upsampling: forward and data gradient in F(2x2,2x2), weight gradient direct
-    assert f.count("cg_conv2d_ups2_wino22_forward_stats") == 1 and b.count("cg_conv2d_ups2_wino22_dgrad") == 1
+    # the 512 -> 256 3x3 layer behind the 8x8 -> 16x16 upsampling: forward and data gradient in F(2x2,2x2); the weight gradient in that
+    # domain (from the V the forward left behind) is option bit 2, off by default (no gain in the step)
+    assert f.count("cg_conv2d_ups2_wino22_forward_stats") == 1 and b.count("cg_conv2d_ups2_wino22_dgrad") == 1 and "cg_conv2d_ups2_wino22_wgrad" not in b
+    r7 = T.trace("G32up-c", 128, options=[("winograd22", 7)])
+    v_fwd = [a for n_, a in T.calls(r7["forward"]) if n_ == "cg_conv2d_ups2_wino22_forward_stats"][0]["v"]
+    assert [a for n_, a in T.calls(r7["backward"]) if n_ == "cg_conv2d_ups2_wino22_wgrad"][0]["v"] == v_fwd
     assert b.count("cg_conv2d_dgrad_ups2") == 1 and b.count("cg_bn_act_backward") == 3 and b[-1] == "cg_conv2d_wgrad_flush"
     r22 = T.trace("G32up-c", 128, options=[("winograd22", 1)])     # bit 0 only: the forward alone
-    assert [c[0] for c in T.calls(r22["backward"])].count("cg_conv2d_dgrad_ups2") == 2
+    b22 = [c[0] for c in T.calls(r22["backward"])]
+    assert b22.count("cg_conv2d_dgrad_ups2") == 2 and "cg_conv2d_ups2_wino22_wgrad" not in b22
     r20 = T.trace("G32up-c", 128, options=[("winograd22", 0)])
     assert "cg_conv2d_ups2_wino22_forward_stats" not in [c[0] for c in T.calls(r20["forward"])]
     assert r["backward"][-2:] == ["event|record|wgjoin0|s4", "event|wait|wgjoin0|s0"]
@@ -255,7 +260,7 @@ def test_data_parallel_exchanges_sit_inside_the_plan():
         # complete gradients: the deferred reductions flushed, or the layer's own immediate (Winograd-domain) weight gradient
         # (on the weight-gradient stream s4, which first takes up everything s0 has issued: BN / PReLU gradients of the bucket)
         prev = [l for l in b[:i] if not l.startswith("event|")][-1]
-        assert "cg_conv2d_wgrad_flush|s4" in prev or "cg_conv2d_ups2_wino_wgrad|s4" in prev or prev.startswith("hook|")
+        assert "cg_conv2d_wgrad_flush|s4" in prev or "cg_conv2d_ups2_wino_wgrad|s4" in prev or "cg_conv2d_ups2_wino22_wgrad|s4" in prev or prev.startswith("hook|")
         assert b[i - 1] == "event|wait|wgfork0|s4" or "cg_conv2d_wgrad_flush|s4" in b[i - 1]
     for (i0, _), (i1, _) in zip(buckets, buckets[1:]):                                   # the next layer's backward runs under the bucket
         assert sum(1 for l in b[i0:i1] if l.startswith("call|")) >= 3
@@ -271,7 +276,7 @@ def test_weight_gradients_run_beside_the_data_gradient_chain(which, N, lag):
     r1 = T.trace(which, N, options=[("wgrad_lag", lag)])
     r0 = T.trace(which, N, options=[("wgrad_stream", 0)])
     b1, b0 = r1["backward"], r0["backward"]
-    is_w = lambda l: l.startswith("call|cg_conv2d_wgrad") or l.startswith("call|cg_conv2d_ups2_wino_wgrad")
+    is_w = lambda l: l.startswith("call|cg_conv2d_wgrad") or l.startswith("call|cg_conv2d_ups2_wino_wgrad") or l.startswith("call|cg_conv2d_ups2_wino22_wgrad")
     # same launches, same arguments (workspace of the stream aside), same relative order within the weight gradients and within the rest
     def strip(l):      # entry point + every scalar argument; streams and buffer names dropped (holding a launch back moves the allocation
         f = l.split("|")   # order of its workspace, and with it the numbering of the regions)
