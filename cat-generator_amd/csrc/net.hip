@@ -223,7 +223,7 @@ struct Net {
     bool fresh_allocs = false;                 // library-owned buffers were allocated + zeroed since the last device synchronise
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
-        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0, wgrad_lag = 0;
+        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0, wgrad_lag = 0, wgrad_cu_quarters = 0;
     long wino_min_tiles = 2048;
     int wino22 = 3;                            // F(2x2,2x2) for upsample2 -> conv3x3 above wino_min_tiles: bit 0 forward, 1 data gradient, 2 weight gradient
                                                // (option "winograd22"; the weight gradient is 292 -> 257 us alone but no gain in the step: off)
@@ -2403,6 +2403,15 @@ int ensure_streams(Net* n, int nstreams) {
             int least = 0, greatest = 0;
             CG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
             CG_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, idx >= 4 ? least : greatest));
+        } else if (idx >= 4 && n->wgrad_cu_quarters > 0 && n->wgrad_cu_quarters < 4) {
+            // experiment switch (CG_WGRAD_CU_QUARTERS = 1..3): the weight-gradient streams on a CU mask that leaves (4 - q) / 4 of every XCD's CUs
+            // to the data-gradient chain (bit i kept if ((i >> 3) & 3) < q: a quarter of each XCD under either numbering of the mask bits)
+            uint32_t mask[8];
+            for (int w = 0; w < 8; ++w) {
+                mask[w] = 0;
+                for (int b = 0; b < 32; ++b) if ((((w * 32 + b) >> 3) & 3) < n->wgrad_cu_quarters) mask[w] |= 1u << b;
+            }
+            CG_HIP(hipExtStreamCreateWithCUMask(&s, 8, mask));
         } else
             CG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         CG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2542,6 +2551,7 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_HEAD_FUSE"))) n->head_fuse = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_STREAM"))) n->wgrad_stream = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_PRIO"))) n->wgrad_prio = atoi(e);
+    if ((e = getenv("CG_WGRAD_CU_QUARTERS"))) n->wgrad_cu_quarters = atoi(e);
     if ((e = getenv("CG_WGRAD_LAG"))) n->wgrad_lag = atoi(e) != 0;
     if ((e = getenv("CG_WINOGRAD22"))) n->wino22 = atoi(e);
     *net = n;
