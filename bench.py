@@ -45,18 +45,23 @@ CONFIGS = {   # BASELINE.json configs (index + 1)
 def step_work(cfg, N):
     """Forward FLOPs per image (2 x MAC) of the generator and the discriminator, direct count and as
     EXECUTED by the engine: a 3x3 (5x5) convolution behind nn.SpatialUpSamplingNearest(2) runs as four phase convolutions
-    with 2x2 (3x3) taps on the low-res grid (16/36 resp. 36/100 of the MACs), and the 5x5 layers' phases run as Winograd
-    F(2x2,3x3) (16/36 of those) when the Winograd path takes them (planes % 128 == 0, >= 2048 tiles)."""
+    with 2x2 (3x3) taps on the low-res grid (16/36 resp. 36/100 of the MACs), the 5x5 layers' phases run as Winograd
+    F(2x2,3x3) (16/36 of those) and the 3x3 layers' forward / data gradient as F(2x2,2x2) (9/16 of those) when the Winograd
+    paths take them (planes % 128 == 0, >= 2048 tiles)."""
     C, s = cfg["ch"], cfg["size"]
     conv = lambda ci, co, k, ho: 2.0 * ci * co * k * k * ho * ho
     lin = lambda i, o: 2.0 * i * o
 
     def ups(ci, co, k, ho, n):
+        """(direct, executed) MACs x 2 of one layer behind an upsampling; `executed` is the per-image average over the 3.5 passes a step
+        makes through the generator (forward on N/2, forward on N, data gradient, weight gradient), since round 4 not the same for all."""
         d = conv(ci, co, k, ho)
-        if k == 3:
-            return d, d * 16 / 36
-        wino = ci % 128 == 0 and co % 128 == 0 and n * (ho // 2) ** 2 // 4 >= 2048
-        return d, d * 36 / 100 * (16 / 36 if wino else 1.0)
+        big = lambda m: ci % 128 == 0 and co % 128 == 0 and m * (ho // 2) ** 2 // 4 >= 2048      # Winograd paths: planes % 128, >= 2048 tiles
+        if k == 3:      # F(2x2,2x2): forward and data gradient at 9/16 of the phase-folded MACs, the weight gradient stays phase-folded
+            f = lambda m: 16 / 36 * (9 / 16 if big(m) else 1.0)
+            return d, d * (0.5 * f(n // 2) + f(n) + f(n) + 16 / 36) / 3.5
+        f = lambda m: 36 / 100 * (16 / 36 if big(m) else 1.0)
+        return d, d * (0.5 * f(n // 2) + 3 * f(n)) / 3.5
 
     if cfg["gen"] == "G32up-c":
         b = s // 8
@@ -96,7 +101,7 @@ def time_kernel(fn, iters=20, warm=3):
 
 
 def kernel_rooflines(cg, N):
-    """The kernels that carry the step (time shares from profiles/r04_eager_breakdown.txt), each timed in isolation with
+    """The kernels that carry the step, in the order of their share of its kernel time (profiles/r04_eager_breakdown.txt), each timed in isolation with
     HIP events on the launch stream at the benchmarked batch, EXECUTED MFMA FLOPs per launch / duration against the fp32 MFMA
     peak.  `traffic` / MFMA-pipe utilisation come from the committed PMC pass of the same launches (profiles/r04_pmc_kernels.json,
     scripts/pmc_kernels.sh; bench.py cannot run rocprofv3 on itself) and carry their source."""
@@ -133,39 +138,66 @@ def kernel_rooflines(cg, N):
         dy = cg.Tensor(torch.rand(n * ho * ho * co, device="cuda") - 0.5, (n, co, ho, ho), "nhwc")
         xin = cg.nn.SpatialUpSamplingNearest(2).forward(x) if ups else x
         m.forward(xin)
-        return m, xin, dy
+        return m, xin, dy, x
 
-    # (1) igemm_nng_kernel<64,128,2,2,32> (LDS-direct loads): largest launch = data gradient of G's 512->256 3x3 layer behind the 2x
-    #     upsampling (models.lua:211-212), one GEMM over the 4 phases' taps: M = N*8*8, K = 16 taps * 256, Cout = 512
-    m, xin, dy = conv(512, 256, 3, 8, N, 1)
-    t = time_kernel(lambda: m.updateGradInput(xin, dy))
+    E = lambda n: torch.empty(int(n), dtype=torch.float32, device="cuda")
+    # (1) igemm_tng_kernel<128,128,2,2> (LDS-direct loads), 16 % of the step's kernel time in 6 launches: largest direct launch = weight
+    #     gradient of G's 512->256 3x3 layer behind the 2x upsampling (models.lua:211-212): 4 phases x 4 taps, pixels split 8 ways.
+    #     Timed: the GEMM ALONE (cg_conv2d_wgrad_gemm: partial sums left in the workspace); the launch group with its reductions rides along
+    m, xin, dy, x = conv(512, 256, 3, 8, N, 1)
+    geom = (N, 8, 8, 512, 256, 3, 3, 1, 1, 1)
+    wsb = lib.conv2d_wgrad_workspace_bytes(*geom)
+    ws = torch.empty(max(int(wsb), 16), dtype=torch.uint8, device="cuda")
+    t = time_kernel(lambda: lib.conv2d_wgrad_gemm(stream, x.ptr, dy.ptr, *geom, ws.data_ptr(), wsb))
+    t_group = time_kernel(lambda: m.accGradParameters(xin, dy))
     direct = 2.0 * N * 16 * 16 * 256 * 512 * 9
+    entry("tn128x128", "igemm_tng_kernel<128,128,2,2> (gemm.hip; LDS-direct loads)",
+          f"weight-gradient GEMM of upsample2 -> conv3x3 512->256 @8->16, batch {N}: 4 phases x [2048 x {N * 64}]^T.[{N * 64} x 256], pixels split 8 ways",
+          2.0 * N * 64 * 4 * 2048 * 256, t, direct, "16 % of the step's kernel time (6 launches; profiles/r04_eager_breakdown.txt)",
+          {"launch_group_ms": 1e3 * t_group, "launch_group": "accGradParameters of the layer = this GEMM + wgrad_reduce_kernel<true> + bias_part_reduce_kernel"})
+    # (2) igemm_nng_kernel<64,128,2,2,32> (LDS-direct loads), 14 % in 15 launches (round 3's dominant kernel; its largest launch then, the data
+    #     gradient of the layer above, now runs in F(2x2,2x2) - entry 5): largest launch now = forward of G's first convolution behind the
+    #     4x4 -> 8x8 upsampling (models.lua:205-206), one GEMM per phase: M = N*16, K = 4 taps * 512, Cout = 512
+    m1, x1in, dy1, _ = conv(512, 512, 3, 4, N, 1)
+    t = time_kernel(lambda: m1.updateOutput(x1in))
     entry("nn64x128", "igemm_nng_kernel<64,128,2,2,32> (gemm.hip; LDS-direct loads)",
-          f"updateGradInput of upsample2 -> conv3x3 512->256 @8->16, batch {N}: one implicit GEMM, M={N * 64} K=4096 N=512",
-          2.0 * N * 64 * 4096 * 512, t, direct, "19 % of the step's kernel time (16 launches; profiles/r04_eager_breakdown.txt)")
-    # (2) igemm_tng_kernel<128,128> (LDS-direct loads): weight gradient of the same layer (4 phases, split over pixels) + its reduce kernels
-    t = time_kernel(lambda: m.accGradParameters(xin, dy))
-    entry("tn128x128", "igemm_tng_kernel<128,128,2,2> + wgrad_reduce_kernel<true> + bias_part_reduce_kernel (gemm.hip)",
-          f"accGradParameters of the same layer, batch {N}: launch GROUP (TN GEMM + deterministic split reduce)",
-          2.0 * N * 64 * 4 * 2048 * 256, t, direct, "11 % (9 launches)", {"timed": "launch group, not the GEMM kernel alone"})
+          f"updateOutput of upsample2 -> conv3x3 512->512 @4->8, batch {N}: 4 phases x [{N * 16} x 2048].[2048 x 512]",
+          2.0 * N * 16 * 4 * 2048 * 512, t, 2.0 * N * 8 * 8 * 512 * 512 * 9, "14 % (15 launches)")
     # (3) igemm_nn_kernel<128,64,...,16>: D's 64->64 3x3 convolution at 32x32 (models.lua:648)
-    m2, x2, dy2 = conv(64, 64, 3, 32, N, 0)
+    m2, x2, dy2, _ = conv(64, 64, 3, 32, N, 0)
     t = time_kernel(lambda: m2.updateOutput(x2))
     f2 = 2.0 * N * 32 * 32 * 64 * 64 * 9
     entry("nn128x64", "igemm_nn_kernel<128,64,2,2,true,true,16> (gemm.hip)",
-          f"updateOutput of conv3x3 64->64 @32x32, batch {N}: M={N * 1024} K=576 N=64", f2, t, f2, "8.5 % (8 launches)")
-    # (4) wino_gemm_g_kernel<16>: the 16 Winograd-domain GEMMs + in-register output transform of G's upsample2 -> conv5x5
-    m3, x3, dy3 = conv(256, 128, 5, 16, N, 1)
+          f"updateOutput of conv3x3 64->64 @32x32, batch {N}: M={N * 1024} K=576 N=64", f2, t, f2, "8 % (8 launches)")
+    # (4) wino_gemm_g_kernel<16,16>: the 16 Winograd-domain GEMMs + in-register output transform of G's upsample2 -> conv5x5
+    m3, x3, dy3, _ = conv(256, 128, 5, 16, N, 1)
     if getattr(m3, "_wino", False):
         y = m3.output
         v = m3._get("wino_v", (lib.conv2d_ups2_wino_v_floats(N, 16, 16, 256),))
         t = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(cg.tensor.stream(), v.ptr, m3._u_fwd.data_ptr(), m3.bias.ptr, y.ptr, N, 16, 16, 256, 128, 0))
         d3 = 2.0 * N * 32 * 32 * 128 * 256 * 25
-        entry("wino_g16", "wino_gemm_g_kernel<16> (winograd.hip; LDS-direct loads)",
+        entry("wino_g16", "wino_gemm_g_kernel<16,16> (winograd.hip; LDS-direct loads)",
               f"forward of upsample2 -> conv5x5 256->128 @16->32 (models.lua:217-218), batch {N}: 4 phases x 16 GEMMs [tiles x 256].[256 x 128]",
-              d3 * 36 / 100 * 16 / 36, t, d3, "9 % (3 launches of the two wino_gemm variants)",
+              d3 * 36 / 100 * 16 / 36, t, d3, "8 % (3 launches of the two 16-position wino_gemm_g variants)",
               {"layer_ms": {"fwd": 1e3 * time_kernel(lambda: m3.updateOutput(x3)), "dgrad": 1e3 * time_kernel(lambda: m3.updateGradInput(x3, dy3)),
                             "wgrad": 1e3 * time_kernel(lambda: m3.accGradParameters(x3, dy3))}})
+    # (5) round 4: F(2x2,2x2) on G's 512->256 3x3 layer (the layer of entry 1): forward = input transform + 4 phases x 9 GEMMs, data gradient =
+    #     dy transform + 9 GEMMs over K = 4*256 in four K slices + fixed-order sum - launch GROUPS through the C ABI, as the planned pass issues them
+    if lib.conv2d_ups2_wino22_supported(N, 8, 8, 512, 256):
+        u22, u22b = E(lib.conv2d_ups2_wino22_u_floats(512, 256)), E(lib.conv2d_ups2_wino22_u_floats(512, 256))
+        lib.conv2d_ups2_wino22_pack(stream, m._wf_ph.data_ptr(), m._wb_ph.data_ptr(), u22.data_ptr(), u22b.data_ptr(), 256, 512)
+        v22, vdy = E(lib.conv2d_ups2_wino22_v_floats(N, 8, 8, 512)), E(lib.conv2d_ups2_wino22_dgrad_v_floats(N, 8, 8, 512, 256))
+        rows = lib.conv2d_ups2_wino_stats_rows(N, 8, 8, 512, 256)
+        part, y22, g22 = E(max(int(rows), 1) * 2 * 256), E(N * 16 * 16 * 256), E(N * 8 * 8 * 512)
+        tf = time_kernel(lambda: lib.conv2d_ups2_wino22_forward_stats(stream, x.ptr, u22.data_ptr(), m.bias.ptr, y22.data_ptr(), v22.data_ptr(), N, 8, 8, 512, 256,
+                                                                      part.data_ptr() if rows else None))
+        tb = time_kernel(lambda: lib.conv2d_ups2_wino22_dgrad(stream, dy.ptr, u22b.data_ptr(), g22.data_ptr(), vdy.data_ptr(), N, 8, 8, 512, 256))
+        f22 = 2.0 * (N * 16) * 4 * 9 * 512 * 256
+        entry("wino22_fwd", "wino22_input_transform_kernel + wino_gemm_g_kernel<32,9> (winograd.hip; LDS-direct loads)",
+              f"forward of upsample2 -> conv3x3 512->256 @8->16 in F(2x2,2x2), batch {N}: 4 phases x 9 GEMMs [{N * 16} tiles x 512].[512 x 256]",
+              f22, tf, direct, "5 % with the data gradient (2 + 3 launches)",
+              {"timed": "launch group (transform + GEMMs)", "direct_kernel_ms": 1e3 * time_kernel(lambda: m.updateOutput(xin)),
+               "dgrad_group_ms": 1e3 * tb, "dgrad_direct_kernel_ms": 1e3 * time_kernel(lambda: m.updateGradInput(xin, dy))})
     return out
 
 

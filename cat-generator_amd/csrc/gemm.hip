@@ -2664,7 +2664,7 @@ int small_reduce(hipStream_t st, bool defer, const RedJob& job, int ngroups) {
 
 int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* const* dy, float* const* gw, float* const* gb, int N,
                int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes,
-               bool defer, long xgs = 0, long dgs = 0, long gws = 0);
+               bool defer, long xgs = 0, long dgs = 0, long gws = 0, bool gemm_only = false);
 }  // namespace
 
 int cg_conv2d_wgrad_grouped(void* stream, int ngroups, const float* const* x, const float* const* dy, float* const* gw,
@@ -2691,6 +2691,16 @@ int cg_conv2d_wgrad_strided(void* stream, int ngroups, const float* x, long x_st
     CG_REQUIRE(ngroups >= 1 && ngroups <= kMaxStridedGroups, "cg_conv2d_wgrad_strided: 1..%d groups per launch", kMaxStridedGroups);
     return wgrad_impl(stream, ngroups, &x, &dy, &gw, nullptr, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups, scale, ws, ws_bytes, false,
                       x_stride, dy_stride, gw_stride);
+}
+
+// The weight-gradient GEMM alone: the split partial sums [splits][phases][taps*Cin][Cout] are left in ws, nothing is reduced into a
+// gradient (exported so that the kernel can be timed / profiled in isolation - bench.py's roofline entry; not part of a training step).
+int cg_conv2d_wgrad_gemm(void* stream, const float* x, const float* dy, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH,
+                         int padW, int ups, void* ws, size_t ws_bytes) {
+    CG_REQUIRE(x && dy && ws, "cg_conv2d_wgrad_gemm: null pointer");
+    CG_REQUIRE(!skinny_ok(1, Cin, Cout, kH, kW, padH, padW, ups), "cg_conv2d_wgrad_gemm: this geometry runs the skinny kernel, not the GEMM");
+    float* gw = (float*)ws;   // never written: the reduction is skipped
+    return wgrad_impl(stream, 1, &x, &dy, &gw, nullptr, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups, 1.f, ws, ws_bytes, false, 0, 0, 0, true);
 }
 
 int cg_conv2d_wgrad_pending(void* stream, int* njobs) {
@@ -2731,7 +2741,7 @@ int cg_conv2d_wgrad_flush(void* stream) {
 namespace {
 int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* const* dy, float* const* gw, float* const* gb, int N,
                int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes,
-               bool defer, long xgs, long dgs, long gws_) {
+               bool defer, long xgs, long dgs, long gws_, bool gemm_only) {
     CG_REQUIRE(x && dy && gw, "cg_conv2d_wgrad: null pointer");
     const bool strided = xgs != 0;     // equally spaced groups: only x[0] / dy[0] / gw[0] are pointers
     CG_REQUIRE(ngroups >= 1 && ngroups <= (strided ? kMaxStridedGroups : MAXG), "cg_conv2d_wgrad: 1..%d groups per launch", strided ? kMaxStridedGroups : MAXG);
@@ -2799,6 +2809,7 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
     else if (p.tc.bm == 64 && p.tc.bn == 64) launch_tn<64, 64, 2, 2>(a, grid, st, veca, vecb);
     else launch_tn<128, 32, 4, 1>(a, grid, st, veca, vecb);
     CG_LAUNCH_CHECK();
+    if (gemm_only) return 0;   // cg_conv2d_wgrad_gemm: the partial sums stay in ws
     const int KK = kH * kW;
     int ci_t = KK == 1 ? 64 : 8;
     while (ci_t > 1 && (size_t)KK * ci_t * 33 * sizeof(float) > 60000) ci_t >>= 1;

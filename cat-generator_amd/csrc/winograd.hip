@@ -1013,24 +1013,28 @@ int cg_conv2d_ups2_wino22_forward_stats(void* stream, const float* x_lo, const f
 
 // The data gradient's launch has T/64 x Cin/128 workgroups - 128 on G's 512 -> 256 layer at batch 128, half the chip.  Below ~one
 // workgroup per CU the four phases (K slices of Cout rows) go to blockIdx.z, each writing a partial dx_lo behind V in the scratch, and
-// wino22_sum4_kernel adds them in a fixed order (CG_WINO22_KSPLIT = 0 / 1 forces the choice).
-static bool wino22_dgrad_split(int N, int Hp, int Wp, int Cin, int Cout) {
+// wino22_sum_kernel adds them in a fixed order (CG_WINO22_KSPLIT = 0 / 1 forces the choice, 2 = two slices of two phases).
+static int wino22_dgrad_slices(int N, int Hp, int Wp, int Cin, int Cout) {   // 1 (unsplit), 2 or 4 K slices
     static const int force = [] { const char* e = getenv("CG_WINO22_KSPLIT"); return e ? atoi(e) : -1; }();
-    if (Cout % 64 != 0) return false;
-    if (force >= 0) return force != 0;
-    return (long)cg::cdiv(N * (Hp / 2) * (Wp / 2), 64) * (Cin / 128) < cg::kNumCU;
+    if (Cout % 64 != 0) return 1;
+    if (force >= 0) return force == 2 ? 2 : (force ? 4 : 1);
+    return (long)cg::cdiv(N * (Hp / 2) * (Wp / 2), 64) * (Cin / 128) < cg::kNumCU ? 4 : 1;
 }
 
-__global__ __launch_bounds__(256) void wino22_sum4_kernel(const float* __restrict__ part, float* __restrict__ out, long n4, long stride) {
+extern "C++" template <int S>
+__global__ __launch_bounds__(256) void wino22_sum_kernel(const float* __restrict__ part, float* __restrict__ out, long n4, long stride) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += gridDim.x * 256L) {
-        const float4 a = ld4(part + 4 * i), b = ld4(part + stride + 4 * i), c = ld4(part + 2 * stride + 4 * i), d = ld4(part + 3 * stride + 4 * i);
-        *reinterpret_cast<float4*>(out + 4 * i) = f4add(f4add(a, b), f4add(c, d));
+        const float4 a = ld4(part + 4 * i), b = ld4(part + stride + 4 * i);
+        float4 r = f4add(a, b);
+        if (S == 4) r = f4add(r, f4add(ld4(part + 2 * stride + 4 * i), ld4(part + 3 * stride + 4 * i)));
+        *reinterpret_cast<float4*>(out + 4 * i) = r;
     }
 }
 
 size_t cg_conv2d_ups2_wino22_dgrad_v_floats(int N, int Hp, int Wp, int Cin, int Cout) {
     const size_t T = (size_t)N * (Hp / 2) * (Wp / 2);
-    return 36 * T * Cout + (wino22_dgrad_split(N, Hp, Wp, Cin, Cout) ? 16 * T * Cin : 0);
+    const int sl = wino22_dgrad_slices(N, Hp, Wp, Cin, Cout);
+    return 36 * T * Cout + (sl > 1 ? (size_t)sl * 4 * T * Cin : 0);
 }
 
 // dx_lo[N][Hp][Wp][Cin] = gradient of upsample2 -> conv3x3 w.r.t. the low-res input; v_dy: scratch of cg_conv2d_ups2_wino22_dgrad_v_floats()
@@ -1043,11 +1047,13 @@ int cg_conv2d_ups2_wino22_dgrad(void* stream, const float* dy, const float* u_bw
     const int T = N * (Hp / 2) * (Wp / 2);
     hipLaunchKernelGGL(wino22_dy_input_transform_kernel, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, cg::S(stream), dy, v_dy, N, Hp, Wp, Cout);
     CG_LAUNCH_CHECK();
-    if (!wino22_dgrad_split(N, Hp, Wp, Cin, Cout)) return wino_gemm_launch(stream, v_dy, u_bwd, nullptr, dx_lo, N, Hp, Wp, Cin, Cout, 1, nullptr, 9);
+    const int sl = wino22_dgrad_slices(N, Hp, Wp, Cin, Cout);
+    if (sl == 1) return wino_gemm_launch(stream, v_dy, u_bwd, nullptr, dx_lo, N, Hp, Wp, Cin, Cout, 1, nullptr, 9);
     float* part = v_dy + (size_t)36 * T * Cout;
-    if (wino_gemm_launch(stream, v_dy, u_bwd, nullptr, part, N, Hp, Wp, Cin, Cout, 1, nullptr, 9, 4)) return 1;
+    if (wino_gemm_launch(stream, v_dy, u_bwd, nullptr, part, N, Hp, Wp, Cin, Cout, 1, nullptr, 9, sl)) return 1;
     const long n = (long)T * 4 * Cin;
-    hipLaunchKernelGGL(wino22_sum4_kernel, dim3(cg::ew_grid(n / 4)), dim3(256), 0, cg::S(stream), part, dx_lo, n / 4, n);
+    if (sl == 4) hipLaunchKernelGGL(wino22_sum_kernel<4>, dim3(cg::ew_grid(n / 4)), dim3(256), 0, cg::S(stream), part, dx_lo, n / 4, n);
+    else hipLaunchKernelGGL(wino22_sum_kernel<2>, dim3(cg::ew_grid(n / 4)), dim3(256), 0, cg::S(stream), part, dx_lo, n / 4, n);
     CG_LAUNCH_CHECK();
     return 0;
 }

@@ -164,6 +164,10 @@ int cg_conv2d_wgrad_grouped_deferred(void* stream, int ngroups, const float* con
                             float* const* gw_canonical, float* const* gb, int N, int Hp, int Wp, int Cin, int Cout,
                             int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes);
 int cg_conv2d_wgrad_flush(void* stream);
+/* The weight-gradient GEMM of cg_conv2d_wgrad alone (split partial sums left in ws, cg_conv2d_wgrad_workspace_bytes; no gradient is
+ * written): exported for timing / profiling the kernel in isolation (bench.py's roofline entry), not used by a training step. */
+int cg_conv2d_wgrad_gemm(void* stream, const float* x, const float* dy, int N, int Hp, int Wp, int Cin, int Cout,
+                         int kH, int kW, int padH, int padW, int ups, void* ws, size_t ws_bytes);
 int cg_conv2d_wgrad_pending(void* stream, int* njobs);
 /* Up to 16 weight gradients of ONE geometry whose tensors are equally spaced in memory (group g: x + g*x_stride, dy + g*dy_stride,
  * gw + g*gw_stride, strides in floats) as one GEMM launch + one reduction: the 16 Winograd-domain products of the upsample2 -> 5x5

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-layer GEMM micro-benchmark: every conv/linear shape of G32up-c and D32_st3 at batch N (fwd, dgrad, wgrad),
-timed with HIP events on the launch stream.  Usage: python scripts/kbench.py [N] [--quick]"""
+timed with HIP events on the launch stream.  Usage: python scripts/kbench.py [N] [--quick] [--only a,b] [--pass fwd|dgrad|wgrad]
+(--pass: launch only that pass of a convolution, so that a kernel trace / counter pass of the command holds ONE kind of launch)"""
 import importlib
 import os
 import sys
@@ -10,6 +11,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 cg = importlib.import_module("cat-generator_amd")
+
+
+PASS = sys.argv[sys.argv.index("--pass") + 1] if "--pass" in sys.argv else None
 
 
 def tk(fn, iters=10, warm=2):
@@ -33,10 +37,8 @@ def conv_case(name, N, Cin, H, Cout, k, ups):
     xin = cg.nn.SpatialUpSamplingNearest(2).forward(x) if ups else x
     m.forward(xin)
     flop = 2.0 * N * Ho * Ho * Cout * Cin * k * k
-    r = {}
-    r["fwd"] = tk(lambda: m.updateOutput(xin))
-    r["dgrad"] = tk(lambda: m.updateGradInput(xin, dy))
-    r["wgrad"] = tk(lambda: m.accGradParameters(xin, dy))
+    fns = {"fwd": lambda: m.updateOutput(xin), "dgrad": lambda: m.updateGradInput(xin, dy), "wgrad": lambda: m.accGradParameters(xin, dy)}
+    r = {p: (tk(fns[p]) if PASS in (None, p) else float("inf")) for p in ("fwd", "dgrad", "wgrad")}
     return name, flop, r
 
 
