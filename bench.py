@@ -148,7 +148,7 @@ def kernel_rooflines(cg, N):
     geom = (N, 8, 8, 512, 256, 3, 3, 1, 1, 1)
     wsb = lib.conv2d_wgrad_workspace_bytes(*geom)
     ws = torch.empty(max(int(wsb), 16), dtype=torch.uint8, device="cuda")
-    t = time_kernel(lambda: lib.conv2d_wgrad_gemm(stream, x.ptr, dy.ptr, *geom, ws.data_ptr(), wsb))
+    t = time_kernel(lambda: lib.conv2d_wgrad_gemm(cg.tensor.stream(), x.ptr, dy.ptr, *geom, ws.data_ptr(), wsb))
     t_group = time_kernel(lambda: m.accGradParameters(xin, dy))
     direct = 2.0 * N * 16 * 16 * 256 * 512 * 9
     entry("tn128x128", "igemm_tng_kernel<128,128,2,2> (gemm.hip; LDS-direct loads)",
@@ -189,9 +189,9 @@ def kernel_rooflines(cg, N):
         v22, vdy = E(lib.conv2d_ups2_wino22_v_floats(N, 8, 8, 512)), E(lib.conv2d_ups2_wino22_dgrad_v_floats(N, 8, 8, 512, 256))
         rows = lib.conv2d_ups2_wino_stats_rows(N, 8, 8, 512, 256)
         part, y22, g22 = E(max(int(rows), 1) * 2 * 256), E(N * 16 * 16 * 256), E(N * 8 * 8 * 512)
-        tf = time_kernel(lambda: lib.conv2d_ups2_wino22_forward_stats(stream, x.ptr, u22.data_ptr(), m.bias.ptr, y22.data_ptr(), v22.data_ptr(), N, 8, 8, 512, 256,
+        tf = time_kernel(lambda: lib.conv2d_ups2_wino22_forward_stats(cg.tensor.stream(), x.ptr, u22.data_ptr(), m.bias.ptr, y22.data_ptr(), v22.data_ptr(), N, 8, 8, 512, 256,
                                                                       part.data_ptr() if rows else None))
-        tb = time_kernel(lambda: lib.conv2d_ups2_wino22_dgrad(stream, dy.ptr, u22b.data_ptr(), g22.data_ptr(), vdy.data_ptr(), N, 8, 8, 512, 256))
+        tb = time_kernel(lambda: lib.conv2d_ups2_wino22_dgrad(cg.tensor.stream(), dy.ptr, u22b.data_ptr(), g22.data_ptr(), vdy.data_ptr(), N, 8, 8, 512, 256))
         f22 = 2.0 * (N * 16) * 4 * 9 * 512 * 256
         entry("wino22_fwd", "wino22_input_transform_kernel + wino_gemm_g_kernel<32,9> (winograd.hip; LDS-direct loads)",
               f"forward of upsample2 -> conv3x3 512->256 @8->16 in F(2x2,2x2), batch {N}: 4 phases x 9 GEMMs [{N * 16} tiles x 512].[512 x 256]",
@@ -379,10 +379,10 @@ def main():
                 "note": "frac of the kernel block above = EXECUTED FLOPs of one launch / its duration / peak; the step's executed_frac is the "
                         "same ratio over the whole step (all launches, all phases); direct-count figures (SURVEY.md 8d's numerator) are "
                         "direct_count_over_executed times larger and are not utilisations",
-                "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.58, "D forward": 0.57, "D backward + Adam": 1.28,
-                                     "generator forward on N": 0.89, "D forward + data gradient (G step)": 1.19, "generator backward + Adam": 1.79},
+                "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.56, "D forward": 0.57, "D backward + Adam": 1.26,
+                                     "generator forward on N": 0.83, "D forward + data gradient (G step)": 1.19, "generator backward + Adam": 1.71},
                 "phases_source": "profiles/r04_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
-                                 "launches, 6.30 ms under the tracer; committed numbers, not measured in this run)"}
+                                 "launches, 6.12 ms under the tracer; committed numbers, not measured in this run)"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baselines()
