@@ -223,7 +223,10 @@ struct Net {
     bool fresh_allocs = false;                 // library-owned buffers were allocated + zeroed since the last device synchronise
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
-        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0, wgrad_lag = 0, wgrad_cu_quarters = 0;
+        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0, wgrad_lag = 0, wgrad_cu_quarters = 0,
+        wino_dsplit = 1,       // the F(2x2,3x3) data gradient in K slices when its unsplit launch is <= one workgroup per CU (cg_conv2d_ups2_wino_dgrad_split)
+        early_flush = 0;       // 1: the reductions queued on a weight-gradient stream start before the LAST localisation net's four GEMMs, not behind
+                               // them (measured: no difference, 6.00-6.05 ms either way - profiles/r04_sweeps.txt; off)
     long wino_min_tiles = 2048;
     int wino22 = 3;                            // F(2x2,2x2) for upsample2 -> conv3x3 above wino_min_tiles: bit 0 forward, 1 data gradient, 2 weight gradient
                                                // (option "winograd22"; the weight gradient is 292 -> 257 us alone but no gain in the step: off)
@@ -1336,6 +1339,14 @@ struct Compiler {
         Val ga1 = buf(q0, "loc.ga1", {G * N, 16, S_, S_}, NHWC), ga2 = buf(q0, "loc.ga2", {G * N, 16, S_, S_}, NHWC), g3 = buf(q0, "loc.g3", {G * N, 64}),
             g4 = buf(q0, "loc.g4", {G * N, d.P}), gx = buf(q0, "loc.gx", {G * N, Cin, 2 * S_, 2 * S_}, NHWC);
         Net* n_ = net; vector<Mod*> qv = qs; const LocDesc dd = d;
+        if (acc && G == 1 && net->early_flush && wg_on() && !wg_lag() && wg_used[cs] && pend[4 + cs]) {
+            // the ungrouped transformer is the first module of D (models.lua:645): its four weight-gradient GEMMs end the pass, and the
+            // batched reduction of everything queued before them (D's 64 -> 64 layer in 256 pixel splits: 38 MB of partial sums) would
+            // otherwise wait for them and run alone on the chip, 43 us behind the last data-gradient launch.  Issued here it runs beside
+            // the chain's sampler / localisation backward, and the final flush holds four small jobs.
+            const int back = cs;
+            cs = 4 + back; flush_wgrad(); cs = back;
+        }
         emit([=](Run& c) {
             const float* w[48];
             loc_weights(qv, n_, w);
@@ -1782,7 +1793,12 @@ struct Compiler {
             const int kk = (int)m.kH(), pad = (int)m.padH();
             if (s.use_wino) {
                 Val vdy = buf(m, "wino_vdy", {(long)cg_conv2d_ups2_wino_v_floats((int)N, (int)Hp, (int)Wp, (int)(4 * Co))});
-                emit([=](Run& c) { return k->conv2d_ups2_wino_dgrad(c.CS(), c.P(dy), mp->u_bwd, c.P(lo), c.P(vdy), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
+                const long np = net->wino_dsplit ? (long)cg_conv2d_ups2_wino_dgrad_part_floats((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co) : 0;
+                if (np) {
+                    Val part = buf(m, "wino_dpart", {np});
+                    emit([=](Run& c) { return k->conv2d_ups2_wino_dgrad_split(c.CS(), c.P(dy), mp->u_bwd, c.P(lo), c.P(vdy), c.P(part), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
+                } else
+                    emit([=](Run& c) { return k->conv2d_ups2_wino_dgrad(c.CS(), c.P(dy), mp->u_bwd, c.P(lo), c.P(vdy), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
             } else if (s.use_wino22 && (net->wino22 & 2) && mp->u22b) {
                 Val vdy = buf(m, "wino22_vdy", {(long)cg_conv2d_ups2_wino22_dgrad_v_floats((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co)});
                 emit([=](Run& c) { return k->conv2d_ups2_wino22_dgrad(c.CS(), c.P(dy), mp->u22b, c.P(lo), c.P(vdy), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
@@ -2525,7 +2541,7 @@ std::string prog_key(Net* n, int nd, const long* dims, int fmt) {
     k += "|o" + std::to_string(n->overlap_groups) + std::to_string(n->defer_wgrad) + std::to_string(n->winograd) + std::to_string(n->fusion) +
          std::to_string(n->stacking) + std::to_string(n->grouped) + std::to_string(n->share_pool) + std::to_string(n->sampler_shared) +
          std::to_string(n->view_fuse) + std::to_string(n->cat_fuse) + std::to_string(n->fuse_locnet) + std::to_string(n->head_fuse) +
-         std::to_string(n->wgrad_stream) + std::to_string(n->wgrad_lag) + std::to_string(n->wino22) + "m" +
+         std::to_string(n->wgrad_stream) + std::to_string(n->wgrad_lag) + std::to_string(n->wino22) + std::to_string(n->wino_dsplit) + std::to_string(n->early_flush) + "m" +
          std::to_string(n->wino_min_tiles);
     return k;
 }
@@ -2552,6 +2568,8 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_WGRAD_STREAM"))) n->wgrad_stream = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_PRIO"))) n->wgrad_prio = atoi(e);
     if ((e = getenv("CG_WGRAD_CU_QUARTERS"))) n->wgrad_cu_quarters = atoi(e);
+    if ((e = getenv("CG_WINO_DSPLIT"))) n->wino_dsplit = atoi(e) != 0;
+    if ((e = getenv("CG_EARLY_FLUSH"))) n->early_flush = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_LAG"))) n->wgrad_lag = atoi(e) != 0;
     if ((e = getenv("CG_WINOGRAD22"))) n->wino22 = atoi(e);
     *net = n;
@@ -2578,7 +2596,8 @@ int cg_net_set_option(void* net, const char* name, long value) {
         {"overlap_groups", &n->overlap_groups}, {"defer_wgrad", &n->defer_wgrad}, {"winograd", &n->winograd}, {"share_pool", &n->share_pool},
         {"sampler_shared", &n->sampler_shared}, {"view_fuse", &n->view_fuse}, {"cat_fuse", &n->cat_fuse}, {"stacking", &n->stacking},
         {"grouped", &n->grouped}, {"fusion", &n->fusion}, {"fuse_locnet", &n->fuse_locnet}, {"pack_overlap", &n->pack_overlap},
-        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wgrad_lag", &n->wgrad_lag}};
+        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wgrad_lag", &n->wgrad_lag}, {"wino_dsplit", &n->wino_dsplit},
+        {"early_flush", &n->early_flush}};
     if (!strcmp(name, "trace")) {
         CG_REQUIRE(n->progs.empty(), "cg_net_set_option: trace must be chosen before the first pass");
         n->trace = value != 0; n->K = n->trace ? &kTraceTable : &kRealTable;

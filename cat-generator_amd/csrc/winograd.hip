@@ -925,7 +925,7 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
     if (dgrad) { a.K = 4 * Cout; a.Nc = Cin; a.so = 1; a.Ho = Hp; a.Wo = Wp; }
     else { a.K = Cin; a.Nc = Cout; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp; }
     const int nw = (int)cg::opt(cg::OPT_WINO_WAVES), bk = (int)cg::opt(cg::OPT_WINO_BK);
-    CG_REQUIRE(kslices <= 1 || (npos == 9 && dgrad && a.K % kslices == 0 && (a.K / kslices) % 64 == 0), "wino_gemm: K slices only on the 9-position data gradient");
+    CG_REQUIRE(kslices <= 1 || (dgrad && a.K % kslices == 0 && (a.K / kslices) % 64 == 0), "wino_gemm: K slices only on the data gradient, in multiples of 64 rows");
     if (kslices > 1) a.kz = a.K / kslices;
     const dim3 grid(cg::cdiv(T, 64) * (a.Nc / 128), 1, dgrad ? (kslices > 1 ? kslices : 1) : 4);
     // K step 32 (half the barriers per MFMA) pays when the launch is at most ~one workgroup per CU - the data-gradient
@@ -941,7 +941,8 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
         CG_LAUNCH_CHECK();
         return 0;
     }
-    if (glds && k32 && a.K % 64 == 0) { hipLaunchKernelGGL((wino_gemm_g_kernel<32>), grid, dim3(512), 0, cg::S(stream), a); CG_LAUNCH_CHECK(); return 0; }
+    CG_REQUIRE(kslices <= 1 || glds, "wino_gemm: K slices need the LDS-direct-load kernel (CG_WINO_GLDS, 8 waves)");
+    if (glds && k32 && (a.kz ? a.kz : a.K) % 64 == 0) { hipLaunchKernelGGL((wino_gemm_g_kernel<32>), grid, dim3(512), 0, cg::S(stream), a); CG_LAUNCH_CHECK(); return 0; }
     if (glds) { hipLaunchKernelGGL((wino_gemm_g_kernel<16>), grid, dim3(512), 0, cg::S(stream), a); CG_LAUNCH_CHECK(); return 0; }
     const bool quad = cg::opt(cg::OPT_WINO_QUAD) != 0 && nw != 4;
     if (quad && k32 && a.K % 64 == 0) hipLaunchKernelGGL((wino_gemm_kernel<8, 32, true>), grid, dim3(512), 0, cg::S(stream), a);
@@ -1070,6 +1071,41 @@ int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd,
                        4 * Cout, Cout);
     CG_LAUNCH_CHECK();
     return cg_conv2d_ups2_wino_gemm(stream, v_dy, u_bwd, nullptr, dx_lo, N, Hp, Wp, Cin, Cout, 1);
+}
+
+// The same data gradient with its K rows (the four phases' channels) in 2 or 4 slices over blockIdx.z and a fixed-order sum of the partial
+// results: the unsplit launch has T/64 x Cin/128 workgroups, which leaves most of the chip idle where Cin is 128 (G32up's first 5x5 layer).  part: cg_conv2d_ups2_wino_dgrad_part_floats() floats (0 = keep the unsplit launch; CG_WINO_DGRAD_KSLICES = 1 / 2 / 4 forces).
+static int wino_dgrad_slices(int N, int Hp, int Wp, int Cin, int Cout) {
+    static const int force = [] { const char* e = getenv("CG_WINO_DGRAD_KSLICES"); return e ? atoi(e) : 0; }();
+    const long T = (long)N * (Hp / 2) * (Wp / 2);
+    const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && cg::opt(cg::OPT_WINO_WAVES) != 4 && T * 4L * Cout * 4L < 0x7fffffffL &&
+                      16L * 4L * Cout * Cin * 4L < 0x7fffffffL;
+    if (!glds || !wino_dims_ok(N, Hp, Wp, Cin, Cout)) return 1;
+    // workgroups of the unsplit launch: at one per CU or more it stays (G32up-c's layer at batch 128: 256, splitting measured +0.5 % on the
+    // step), below that 2 or 4 slices (G32up's 128 -> 256 layer at batch 256: 64 workgroups -> 4 slices, config #3 9.52 -> 9.25 ms)
+    const long wgs = (long)cg::cdiv((int)T, 64) * (Cin / 128);
+    int sl = force == 1 || force == 2 || force == 4 ? force : (wgs >= cg::kNumCU ? 1 : (wgs * 2 >= cg::kNumCU ? 2 : 4));
+    while (sl > 1 && (4 * Cout / sl) % 64 != 0) sl >>= 1;
+    return sl;
+}
+size_t cg_conv2d_ups2_wino_dgrad_part_floats(int N, int Hp, int Wp, int Cin, int Cout) {
+    const int sl = wino_dgrad_slices(N, Hp, Wp, Cin, Cout);
+    return sl > 1 ? (size_t)sl * N * Hp * Wp * Cin : 0;
+}
+int cg_conv2d_ups2_wino_dgrad_split(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy, float* part, int N, int Hp,
+                                    int Wp, int Cin, int Cout) {
+    const int sl = wino_dgrad_slices(N, Hp, Wp, Cin, Cout);
+    if (sl <= 1 || !part) return cg_conv2d_ups2_wino_dgrad(stream, dy, u_bwd, dx_lo, v_dy, N, Hp, Wp, Cin, Cout);
+    CG_REQUIRE(dy && u_bwd && dx_lo && v_dy, "cg_conv2d_ups2_wino_dgrad_split: null pointer");
+    const int T = N * (Hp / 2) * (Wp / 2);
+    hipLaunchKernelGGL(wino_input_transform_kernel<1>, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, cg::S(stream), dy, v_dy, N, Hp, Wp, 4 * Cout, Cout);
+    CG_LAUNCH_CHECK();
+    if (wino_gemm_launch(stream, v_dy, u_bwd, nullptr, part, N, Hp, Wp, Cin, Cout, 1, nullptr, 16, sl)) return 1;
+    const long n = (long)T * 4 * Cin;
+    if (sl == 4) hipLaunchKernelGGL(wino22_sum_kernel<4>, dim3(cg::ew_grid(n / 4)), dim3(256), 0, cg::S(stream), part, dx_lo, n / 4, n);
+    else hipLaunchKernelGGL(wino22_sum_kernel<2>, dim3(cg::ew_grid(n / 4)), dim3(256), 0, cg::S(stream), part, dx_lo, n / 4, n);
+    CG_LAUNCH_CHECK();
+    return 0;
 }
 
 static size_t wino_align(size_t b) { return (b + 255) / 256 * 256; }

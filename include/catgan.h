@@ -249,6 +249,12 @@ int cg_conv2d_ups2_wino22_wgrad(void* stream, const float* v, const float* dy, f
                                 int N, int Hp, int Wp, int Cin, int Cout, float scale, void* ws, size_t ws_bytes);
 int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy,
                               int N, int Hp, int Wp, int Cin, int Cout);
+/* The same data gradient with its K rows (the four phases' channels) in 2 or 4 slices over the launch's z dimension and a fixed-order sum
+ * of the partial results (round 4: the unsplit launch of G's 5x5 layer is one workgroup per CU).  part: scratch of
+ * cg_conv2d_ups2_wino_dgrad_part_floats() floats; 0 floats / part == NULL = the unsplit launch above. */
+size_t cg_conv2d_ups2_wino_dgrad_part_floats(int N, int Hp, int Wp, int Cin, int Cout);
+int cg_conv2d_ups2_wino_dgrad_split(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy, float* part,
+                                    int N, int Hp, int Wp, int Cin, int Cout);
 /* accGradParameters in the Winograd domain, from the v the forward wrote: gw_canonical[Cout][Cin][5][5] += scale*dW,
  * gb (may be NULL) += scale * sum dy.  16 plain weight-gradient GEMMs (cg_conv2d_wgrad_grouped) + G^T . G. */
 size_t cg_conv2d_ups2_wino_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout);

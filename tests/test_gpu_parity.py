@@ -120,6 +120,19 @@ def test_winograd_path_matches_direct_phase_path(cg):
             gi = up.updateGradInput(None, m.backward(up.output, dy)).numpy()
             assert bool(getattr(m, "_wino", False)) == wino
             res[wino] = (y, gi, m.gradWeight.numpy(), m.gradBias.numpy())
+            if wino:   # the planner's form of the data gradient: K rows in slices over blockIdx.z + fixed-order sum (cg_conv2d_ups2_wino_dgrad_split)
+                L, st = cg.lib(), importlib.import_module("cat-generator_amd.tensor").stream()
+                npart = L.conv2d_ups2_wino_dgrad_part_floats(N, H, H, Cin, Cout)
+                assert npart == 4 * N * H * H * Cin                      # 8 workgroups unsplit: four slices
+                dev = m._u_bwd.device
+                part = torch.empty(npart, dtype=torch.float32, device=dev)
+                vdy = torch.empty(L.conv2d_ups2_wino_v_floats(N, H, H, 4 * Cout), dtype=torch.float32, device=dev)
+                dxs = torch.full((N, H, H, Cin), float("nan"), dtype=torch.float32, device=dev)
+                dyn = cg.nn.as_nhwc(dy)
+                torch.cuda.synchronize()
+                assert L.conv2d_ups2_wino_dgrad_split(st, dyn.ptr, m._u_bwd.data_ptr(), dxs.data_ptr(), vdy.data_ptr(), part.data_ptr(), N, H, H, Cin, Cout) == 0
+                torch.cuda.synchronize()
+                close(dxs.cpu().numpy().transpose(0, 3, 1, 2), gi, K=4 * Cout * 9, what="winograd data gradient in K slices vs unsplit")
         finally:
             cg.nn.SpatialConvolution.winograd = True
     for a, b, K, what in zip(res[True], res[False], (Cin * 9, 4 * Cout * 9, N * 4 * H * H, N * 4 * H * H),
