@@ -635,8 +635,14 @@ class SpatialConvolution(_GemmLayer):
             k, pad = self.kH, self.padH
             if self._use_wino(x):
                 vdy = self._get("wino_vdy", (lib().conv2d_ups2_wino_v_floats(N, Hp, Wp, 4 * self.nOutputPlane),))
-                lib().conv2d_ups2_wino_dgrad(stream(), dy.ptr, self._u_bwd.data_ptr(), lo.ptr, vdy.ptr, N, Hp, Wp,
-                                             self.nInputPlane, self.nOutputPlane)
+                npart = lib().conv2d_ups2_wino_dgrad_part_floats(N, Hp, Wp, self.nInputPlane, self.nOutputPlane)
+                if npart:    # below one workgroup per CU: K slices over blockIdx.z + fixed-order sum (winograd.hip)
+                    part = self._get("wino_dpart", (npart,))
+                    lib().conv2d_ups2_wino_dgrad_split(stream(), dy.ptr, self._u_bwd.data_ptr(), lo.ptr, vdy.ptr, part.ptr, N, Hp, Wp,
+                                                       self.nInputPlane, self.nOutputPlane)
+                else:
+                    lib().conv2d_ups2_wino_dgrad(stream(), dy.ptr, self._u_bwd.data_ptr(), lo.ptr, vdy.ptr, N, Hp, Wp,
+                                                 self.nInputPlane, self.nOutputPlane)
                 self.gradInput = Tensor(lo.t, (N, self.nInputPlane, Hl, Wl), "nhwc", 1)
                 return self.gradInput
             ws, wsb = WS.get(lib().conv2d_dgrad_ups2_workspace_bytes(N, Hp, Wp, self.nInputPlane, self.nOutputPlane, k, pad))
