@@ -124,3 +124,45 @@ def test_f22_on_the_phases_of_an_upsampled_3x3_convolution():
                     for v in range(2):
                         y[2 * (2 * ti + u) + a, 2 * (2 * tj + v) + b] = Y[u, v]
     np.testing.assert_allclose(y, y_ref, rtol=0, atol=1e-12)
+
+
+def test_f22_data_gradient_and_weight_gradient_of_an_upsampled_3x3_convolution():
+    """The backward forms csrc/winograd.hip runs for the same layer.  Data gradient (wino22_dy_input_transform_kernel + the 9-position GEMMs
+    over K = 4 Cout): dx[u][v] = sum_p sum_r dy_p[u - a + ry][v - b + rx] . g_p[1-ry][1-rx] on the phase sub-lattices dy_p = dy[a::2, b::2] -
+    per phase F(2x2,2x2) with the FLIPPED 2x2 kernel on the 3x3 window that starts at row 2ti - a, the four phases summed.  Weight gradient
+    (wino22_dy_transform_kernel, 36 products, wino22_wgrad_finish_kernel): dU_p = sum_tiles V_p . (A dY_p A^T), A = [1 0; 1 1; 0 1];
+    dg_p = G^T dU_p G; the phase taps scatter onto the canonical 3x3 taps through the same map that folded them."""
+    rs = np.random.RandomState(4)
+    Hl = 6
+    x, w = rs.randn(Hl, Hl), rs.randn(3, 3)
+    dy = rs.randn(2 * Hl, 2 * Hl)
+    g = phase_kernels_3x3(w)
+    # reference: adjoint of (upsample -> conv3x3 pad 1)
+    dyp = np.pad(dy, 1)
+    dup = np.array([[np.sum(dyp[i:i + 3, j:j + 3] * w[::-1, ::-1]) for j in range(2 * Hl)] for i in range(2 * Hl)])
+    dx_ref = dup.reshape(Hl, 2, Hl, 2).sum(axis=(1, 3))
+    up = np.pad(np.repeat(np.repeat(x, 2, 0), 2, 1), 1)
+    dw_ref = np.array([[np.sum(up[i:i + 2 * Hl, j:j + 2 * Hl] * dy) for j in range(3)] for i in range(3)])
+    dx = np.zeros((Hl, Hl))
+    dg = np.zeros((4, 2, 2))
+    xp = np.pad(x, 1)
+    A = AT22.T
+    for p in range(4):
+        a, b = p >> 1, p & 1
+        sub = dy[a::2, b::2]                                   # [Hl][Hl]
+        subp = np.pad(sub, ((a, 2 - a), (b, 2 - b)))           # window of tile ti starts at sub-lattice row 2ti - a
+        U = G22 @ g[p][::-1, ::-1] @ G22.T
+        for ti in range(Hl // 2):
+            for tj in range(Hl // 2):
+                V = BT22 @ subp[2 * ti:2 * ti + 3, 2 * tj:2 * tj + 3] @ BT22.T
+                dx[2 * ti:2 * ti + 2, 2 * tj:2 * tj + 2] += AT22 @ (U * V) @ AT22.T
+                Vx = BT22 @ xp[2 * ti + a:2 * ti + a + 3, 2 * tj + b:2 * tj + b + 3] @ BT22.T     # the forward's V of this phase
+                dM = A @ sub[2 * ti:2 * ti + 2, 2 * tj:2 * tj + 2] @ A.T
+                dg[p] += G22.T @ (Vx * dM) @ G22
+    np.testing.assert_allclose(dx, dx_ref, rtol=0, atol=1e-11)
+    dw = np.zeros((3, 3))
+    for p in range(4):
+        for ddy in range(3):
+            for ddx in range(3):
+                dw[ddy, ddx] += dg[p, phase_map(p >> 1, ddy, 1), phase_map(p & 1, ddx, 1)]
+    np.testing.assert_allclose(dw, dw_ref, rtol=0, atol=1e-11)
