@@ -472,7 +472,14 @@ function Conv:updateGradInput(input, gradOutput)
       local lo = self:_buf('gin_lo', { N, self.nInputPlane, Hp, Wp }, 'nhwc')
       if self:_use_wino(x) then
          local vdy = self:_buf('wino_vdy', { tonumber(C.cg_conv2d_ups2_wino_v_floats(N, Hp, Wp, 4 * self.nOutputPlane)) })
-         check(C.cg_conv2d_ups2_wino_dgrad(S(), dy.ptr, self._u_bwd.ptr, lo.ptr, vdy.ptr, N, Hp, Wp, self.nInputPlane, self.nOutputPlane))
+         -- below one workgroup per CU: K slices over blockIdx.z + fixed-order sum (csrc/winograd.hip); 0 floats = the unsplit launch
+         local npart = tonumber(C.cg_conv2d_ups2_wino_dgrad_part_floats(N, Hp, Wp, self.nInputPlane, self.nOutputPlane))
+         if npart > 0 then
+            local part = self:_buf('wino_dpart', { npart })
+            check(C.cg_conv2d_ups2_wino_dgrad_split(S(), dy.ptr, self._u_bwd.ptr, lo.ptr, vdy.ptr, part.ptr, N, Hp, Wp, self.nInputPlane, self.nOutputPlane))
+         else
+            check(C.cg_conv2d_ups2_wino_dgrad(S(), dy.ptr, self._u_bwd.ptr, lo.ptr, vdy.ptr, N, Hp, Wp, self.nInputPlane, self.nOutputPlane))
+         end
       else
          local ws, wsb = workspace(C.cg_conv2d_dgrad_ups2_workspace_bytes(N, Hp, Wp, self.nInputPlane, self.nOutputPlane, self.kH, self.padH))
          check(C.cg_conv2d_dgrad_ups2(S(), dy.ptr, self._wb_ph.ptr, lo.ptr, N, Hp, Wp, self.nInputPlane, self.nOutputPlane, self.kH, self.padH, ws, wsb))
