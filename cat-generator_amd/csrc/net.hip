@@ -1486,7 +1486,11 @@ struct Compiler {
     // shifts the whole weight-gradient stream one layer back, and where that stream is as long as the chain (G32up-c: 0.92 ms beside
     // 0.97 ms) its tail then sticks out behind the pass - same box 6.20 -> 6.46-6.61 ms per step for config #2, but 9.56 -> 9.25 ms for
     // config #3 (G32up, two Winograd layers whose transforms sit on the chain); profiles/r04_sweeps.txt.
-    bool wg_lag() const { return wg_on() && net->wgrad_lag && net->world <= 1; }
+    bool net_has_sampler() const { for (auto& m : net->mods) if (m && m->kind == K_SAMPLER) return true; return false; }
+    bool wg_lag() const {   // option value 2 / 3 (experiment): only nets with / without a spatial transformer (D / G)
+        if (!(wg_on() && net->wgrad_lag && net->world <= 1)) return false;
+        return net->wgrad_lag == 1 || (net->wgrad_lag == 2) == net_has_sampler();
+    }
     void wg_before_dgrad() { if (wg_lag()) wg_release(); else wg_fork(); }   // call in front of a layer's data-gradient launch ...
     void wg_after_dgrad(std::function<void()> f) {                             // ... and behind it, with the layer's weight-gradient launches
         if (wg_lag()) { wg_pending[cs].push_back(std::move(f)); return; }
@@ -2570,7 +2574,7 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_WGRAD_CU_QUARTERS"))) n->wgrad_cu_quarters = atoi(e);
     if ((e = getenv("CG_WINO_DSPLIT"))) n->wino_dsplit = atoi(e) != 0;
     if ((e = getenv("CG_EARLY_FLUSH"))) n->early_flush = atoi(e) != 0;
-    if ((e = getenv("CG_WGRAD_LAG"))) n->wgrad_lag = atoi(e) != 0;
+    if ((e = getenv("CG_WGRAD_LAG"))) n->wgrad_lag = atoi(e);
     if ((e = getenv("CG_WINOGRAD22"))) n->wino22 = atoi(e);
     *net = n;
     return 0;
