@@ -702,9 +702,13 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
 //   Mdy[xi][tile][p*Cout+co]; then dU_xi = V_xi^T Mdy_xi (plain TN GEMMs), and G^T dU G maps back to the 3x3 phase
 //   kernels, whose taps are scattered onto the canonical 5x5 taps exactly like the direct path's reduce.
 // ---------------------------------------------------------------------------
+// bpart != null (host: the grid's stride is a multiple of the channel quads, so a thread keeps its quad): the kernel also leaves the column
+// sums of the dy it reads - the gradBias partials - per workgroup in bpart[gridDim.x][4*Cout] (wino_bias_finish_kernel adds them in a fixed
+// order): dy is read once for both, where cg_bias_grad was a second 67 MB pass on the weight-gradient stream (59 us in the step).
 __global__ __launch_bounds__(256) void wino_dy_transform_kernel(const float* __restrict__ dy, float* __restrict__ Mdy, int N,
-                                                                int Hl, int Wl, int Cout) {
+                                                                int Hl, int Wl, int Cout, float* __restrict__ bpart) {
     const int C = 4 * Cout, cq_n = C >> 2;
+    float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int tH = Hl >> 1, tW = Wl >> 1;
     const long T = (long)N * tH * tW;
     const long total = T * cq_n;
@@ -722,6 +726,7 @@ __global__ __launch_bounds__(256) void wino_dy_transform_kernel(const float* __r
 #pragma unroll
             for (int v = 0; v < 2; ++v)
                 e[u][v] = ld4(dy + ((n * 2 * Hl + 2 * (2 * ti + u) + pa) * (long)(2 * Wl) + 2 * (2 * tj + v) + pb) * Cout + co);
+        bacc = f4add(bacc, f4add(f4add(e[0][0], e[0][1]), f4add(e[1][0], e[1][1])));
         float4 r[4][2];
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
@@ -739,6 +744,41 @@ __global__ __launch_bounds__(256) void wino_dy_transform_kernel(const float* __r
             *reinterpret_cast<float4*>(out + (xy * 4 + 2) * xs) = f4sub(r[xy][0], r[xy][1]);
             *reinterpret_cast<float4*>(out + (xy * 4 + 3) * xs) = make_float4(-r[xy][1].x, -r[xy][1].y, -r[xy][1].z, -r[xy][1].w);
         }
+    }
+    if (bpart) {
+        // threads t and t + cq_n of a workgroup hold the same channel quad when cq_n < 256 (256 % cq_n == 0: host check)
+        __shared__ float4 shb[256];
+        shb[threadIdx.x] = bacc;
+        __syncthreads();
+        const int cq = (int)((blockIdx.x * 256L + threadIdx.x) % cq_n);
+        if (cq_n >= 256) *reinterpret_cast<float4*>(bpart + (long)blockIdx.x * C + cq * 4) = bacc;
+        else if ((int)threadIdx.x < cq_n) {
+            float4 t = shb[threadIdx.x];
+            for (int j = threadIdx.x + cq_n; j < 256; j += cq_n) t = f4add(t, shb[j]);
+            *reinterpret_cast<float4*>(bpart + (long)blockIdx.x * C + cq * 4) = t;
+        }
+    }
+}
+
+// gb[co] += scale * sum over workgroups b and phases p of bpart[b][p*Cout + co]: one workgroup per 32 channels, 8 row lanes, fp64, fixed order
+__global__ __launch_bounds__(256) void wino_bias_finish_kernel(const float* __restrict__ bpart, int nblocks, int Cout, float* __restrict__ gb,
+                                                               float scale) {
+    __shared__ double sh[8][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int co = blockIdx.x * 32 + cl;
+    double a = 0.0;
+    if (co < Cout)
+        for (int b = rl; b < nblocks; b += 8) {
+            const float* row = bpart + (long)b * 4 * Cout + co;
+            a += ((double)row[0] + (double)row[Cout]) + ((double)row[2 * Cout] + (double)row[3 * Cout]);
+        }
+    sh[rl][cl] = a;
+    __syncthreads();
+    if (rl == 0 && co < Cout) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += sh[r][cl];
+        gb[co] += scale * (float)t;
     }
 }
 
@@ -1114,7 +1154,8 @@ size_t cg_conv2d_ups2_wino_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin,
     if (!wino_dims_ok(N, Hp, Wp, Cin, Cout)) return 0;
     const size_t T = (size_t)N * (Hp / 2) * (Wp / 2);
     return wino_align(16 * T * 4 * Cout * sizeof(float)) + wino_align((size_t)16 * 4 * Cout * Cin * sizeof(float)) +
-           wino_align(sizeof(double) * Cout) +
+           wino_align(std::max(sizeof(double) * Cout, (size_t)cg::kNumCU * 8 * 4 * Cout * sizeof(float))) +   // gradBias: cg_bias_grad's scratch / the dy transform's partials
+
            cg_conv2d_wgrad_workspace_bytes_grouped(16, (int)T, 1, 1, Cin, 4 * Cout, 1, 1, 0, 0, 0);
 }
 
@@ -1132,10 +1173,21 @@ int cg_conv2d_ups2_wino_wgrad(void* stream, const float* v, const float* dy, flo
     char* base = (char*)ws;
     float* mdy = (float*)base;                    base += wino_align((size_t)16 * T * C4 * sizeof(float));
     float* dut = (float*)base;                    base += wino_align((size_t)16 * C4 * Cin * sizeof(float));
-    void* bws = base;                             base += wino_align(sizeof(double) * Cout);
+    const size_t bws_bytes = wino_align(std::max(sizeof(double) * Cout, (size_t)cg::kNumCU * 8 * 4 * Cout * sizeof(float)));
+    void* bws = base;                             base += bws_bytes;
     void* tws = base;
     const size_t tws_bytes = ws_bytes - (size_t)(base - (char*)ws);
-    hipLaunchKernelGGL(wino_dy_transform_kernel, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, st, dy, mdy, N, Hp, Wp, Cout);
+    // gradBias from the dy this transform reads anyway (CG_WINO_BIAS_FUSE=1; OFF by default: parity-clean, but the step measured 6.07 -> 6.11 ms
+    // with it - the separate 59 us pass is not on the pass's critical path, the longer transform is; profiles/r04_sweeps.txt): the grid's stride
+    // must be a multiple of the channel quads (Cout per pixel group) so that a thread keeps its quad, and a workgroup's threads share quads evenly
+    static const bool bias_fuse = [] { const char* e = getenv("CG_WINO_BIAS_FUSE"); return e && atoi(e) != 0; }();
+    int tgrid = (int)cg::ew_grid((long)T * Cout);
+    const int cqn = Cout;
+    bool fuse = gb && bias_fuse && (256 % cqn == 0 || cqn % 256 == 0);
+    if (fuse && cqn > 256) { const int m = cqn / 256; tgrid = tgrid / m * m; fuse = tgrid > 0; }
+    if (fuse && (size_t)tgrid * 4 * Cout * sizeof(float) > bws_bytes) fuse = false;
+    if (!fuse) tgrid = (int)cg::ew_grid((long)T * Cout);
+    hipLaunchKernelGGL(wino_dy_transform_kernel, dim3(tgrid), dim3(256), 0, st, dy, mdy, N, Hp, Wp, Cout, fuse ? (float*)bws : nullptr);
     CG_LAUNCH_CHECK();
     CG_HIP(hipMemsetAsync(dut, 0, (size_t)16 * C4 * Cin * sizeof(float), st));
     // 16 TN GEMMs dU_xi^T[pco][ci] = sum_tile Mdy_xi[tile][pco] V_xi[tile][ci]: the planes of V, Mdy and dU are equally spaced, so all
@@ -1148,6 +1200,11 @@ int cg_conv2d_ups2_wino_wgrad(void* stream, const float* v, const float* dy, flo
     hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(cg::ew_grid((long)Cout * Cin)), dim3(256), 0, st, dut, gw_canonical, Cout,
                        Cin, scale);
     CG_LAUNCH_CHECK();
+    if (fuse) {
+        hipLaunchKernelGGL(wino_bias_finish_kernel, dim3(cg::cdiv(Cout, 32)), dim3(256), 0, st, (const float*)bws, tgrid, Cout, gb, scale);
+        CG_LAUNCH_CHECK();
+        return 0;
+    }
     if (gb) return cg_bias_grad(stream, dy, gb, (long)N * 4 * Hp * Wp, Cout, scale, bws, wino_align(sizeof(double) * Cout));
     return 0;
 }
