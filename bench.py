@@ -4,9 +4,9 @@ G32up-c / D32_st3 at 32x32 RGB, batch 128 per GPU (BASELINE.json configs[1]; N G
 configs[3] at N=8).  Synthetic data resident in HBM: real images U[0,1), noise U(-1,1), engine-generated
 dropout masks, parameters initialised as weight-init.lua + Torch7 defaults.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus 8 --steps 20 --warmup 5
+        bench.py --gpus 8 --steps 50 --warmup 10
     python bench.py --config 3        # BASELINE configs[2]: G32up, grayscale, batch 256
     python bench.py --config 5        # per-GPU share of configs[4]: G32up-c scaled to 64x64, 64 images per GPU
 
@@ -100,20 +100,23 @@ def time_kernel(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def kernel_rooflines(cg, N):
-    """The kernels that carry the step, in the order of their share of its kernel time (profiles/r04_eager_breakdown.txt), each timed in isolation with
-    HIP events on the launch stream at the benchmarked batch, EXECUTED MFMA FLOPs per launch / duration against the fp32 MFMA
-    peak.  `traffic` / MFMA-pipe utilisation come from the committed PMC pass of the same launches (profiles/r04_pmc_kernels.json,
-    scripts/pmc_kernels.sh; bench.py cannot run rocprofv3 on itself) and carry their source."""
+def kernel_rooflines(cg, cfg, N):
+    """The kernels that carry the step of configuration `cfg` (profiles/r05_breakdown_config*.txt), each timed in isolation with
+    HIP events on the launch stream at the benchmarked batch: EXECUTED MFMA FLOPs per launch / duration against the fp32 MFMA
+    peak.  The FIRST entry is the configuration's dominant kernel.  `traffic` / MFMA-pipe utilisation come from the committed PMC
+    pass of the same launches where one exists (profiles/*_pmc_kernels.json, scripts/pmc_kernels.sh: config 2 only; bench.py
+    cannot run rocprofv3 on itself) and carry their source; `traffic_over_algorithmic` prices them against STRICT algorithmic
+    bytes (every input and output of the launch once)."""
     lib, stream = cg.tensor.lib(), cg.tensor.stream()
     out = []
     pmc = {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-    except Exception:
-        pass
+    if cfg is CONFIGS[2]:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+        except Exception:
+            pass
 
-    def entry(key, kernel, what, flop, t, direct=None, share=None, extra=None):
+    def entry(key, kernel, what, flop, t, direct=None, share=None, extra=None, alg_bytes=None):
         e = {"bound": "mfma", "kernel": kernel, "launch": what, "flop_per_launch": flop, "launch_ms": 1e3 * t,
              "achieved": flop / t / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s", "frac": flop / t / PEAK_FP32_MFMA,
              "traffic": None}
@@ -121,12 +124,16 @@ def kernel_rooflines(cg, N):
             e["flop_per_launch_direct_count"] = direct
         if share:
             e["step_time_share_profiled"] = share
+        if alg_bytes:
+            e["algorithmic_bytes_strict"] = alg_bytes
         p_ = pmc.get(key)
         if p_:
             e["traffic"] = p_.get("hbm_bytes_per_launch_corrected")
             e["mfma_pipe_util_pmc"] = p_.get("mfma_pipe_util")
             e["valu_per_mfma_pmc"] = p_.get("valu_per_mfma")
             e["pmc_source"] = p_.get("source", "profiles/" + PMC_FILE)
+            if alg_bytes and e["traffic"]:
+                e["traffic_over_algorithmic"] = e["traffic"] / alg_bytes
         if extra:
             e.update(extra)
         out.append(e)
@@ -141,80 +148,109 @@ def kernel_rooflines(cg, N):
         return m, xin, dy, x
 
     E = lambda n: torch.empty(int(n), dtype=torch.float32, device="cuda")
-    # (1) igemm_tng_kernel<128,128,2,2> (LDS-direct loads), 16 % of the step's kernel time in 6 launches: largest direct launch = weight
-    #     gradient of G's 512->256 3x3 layer behind the 2x upsampling (models.lua:211-212): 4 phases x 4 taps, pixels split 8 ways.
-    #     Timed: the GEMM ALONE (cg_conv2d_wgrad_gemm: partial sums left in the workspace); the launch group with its reductions rides along
-    m, xin, dy, x = conv(512, 256, 3, 8, N, 1)
-    geom = (N, 8, 8, 512, 256, 3, 3, 1, 1, 1)
+    s = cfg["size"]
+
+    def d_conv2():
+        # igemm_nn_kernel<128,64,...,16>: D's 64->64 3x3 convolution at full resolution (models.lua:648)
+        m2, x2, dy2, _ = conv(64, 64, 3, s, N, 0)
+        t = time_kernel(lambda: m2.updateOutput(x2))
+        f2 = 2.0 * N * s * s * 64 * 64 * 9
+        entry("nn128x64", "igemm_nn_kernel<128,64,2,2,true,true,16> (gemm.hip)",
+              f"updateOutput of conv3x3 64->64 @{s}x{s}, batch {N}: M={N * s * s} K=576 N=64", f2, t, f2, None,
+              alg_bytes=4.0 * (2 * N * s * s * 64 + 576 * 64))
+
+    def wino5(ci, co, h, first):
+        # wino_gemm_g_kernel<*,16>: the 16 Winograd-domain GEMMs + in-register output transform of an upsample2 -> conv5x5 layer
+        m3, x3, dy3, _ = conv(ci, co, 5, h, N, 1)
+        if not getattr(m3, "_wino", False):
+            return
+        y = m3.output
+        v = m3._get("wino_v", (lib.conv2d_ups2_wino_v_floats(N, h, h, ci),))
+        t = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(cg.tensor.stream(), v.ptr, m3._u_fwd.data_ptr(), m3.bias.ptr, y.ptr, N, h, h, ci, co, 0))
+        d3 = 2.0 * N * (2 * h) ** 2 * co * ci * 25
+        tiles = N * h * h // 4 * 4          # 2x2-output tiles per phase x 4 phases
+        entry("wino_g16" if first else None, "wino_gemm_g_kernel<*,16> (winograd.hip; LDS-direct loads)",
+              f"forward GEMMs of upsample2 -> conv5x5 {ci}->{co} @{h}->{2 * h}, batch {N}: 4 phases x 16 GEMMs [tiles x {ci}].[{ci} x {co}] + output transform",
+              d3 * 36 / 100 * 16 / 36, t, d3, None,
+              {"layer_ms": {"fwd": 1e3 * time_kernel(lambda: m3.updateOutput(x3)), "dgrad": 1e3 * time_kernel(lambda: m3.updateGradInput(x3, dy3)),
+                            "wgrad": 1e3 * time_kernel(lambda: m3.accGradParameters(x3, dy3))}},
+              alg_bytes=4.0 * (16 * tiles * ci + 4 * 16 * ci * co + N * (2 * h) ** 2 * co))
+
+    if cfg["gen"] != "G32up-c":
+        # G32up (configs[2]): two upsample2 -> conv5x5 layers (models.lua:145,150), both in F(2x2,3x3); the 256->128 layer at 16->32 carries
+        # 80 % of F_G, its forward GEMM launch is the configuration's dominant kernel
+        wino5(256, 128, 16, True)
+        wino5(128, 256, 8, False)
+        d_conv2()
+        return out
+
+    b = s // 8            # G32up-c: 4x4 at 32x32, 8x8 at 64x64 (models.lua:196-228 scaled)
+    h2 = 2 * b
+    # (1) igemm_tng_kernel<128,128,2,2> (LDS-direct loads): largest direct launch = weight gradient of G's 512->256 3x3 layer behind the
+    #     2x upsampling (models.lua:211-212): 4 phases x 4 taps, pixels split.  Timed: the GEMM ALONE (cg_conv2d_wgrad_gemm: partial
+    #     sums left in the workspace); the launch group with its reductions rides along
+    m, xin, dy, x = conv(512, 256, 3, h2, N, 1)
+    geom = (N, h2, h2, 512, 256, 3, 3, 1, 1, 1)
     wsb = lib.conv2d_wgrad_workspace_bytes(*geom)
     ws = torch.empty(max(int(wsb), 16), dtype=torch.uint8, device="cuda")
     t = time_kernel(lambda: lib.conv2d_wgrad_gemm(cg.tensor.stream(), x.ptr, dy.ptr, *geom, ws.data_ptr(), wsb))
     t_group = time_kernel(lambda: m.accGradParameters(xin, dy))
-    direct = 2.0 * N * 16 * 16 * 256 * 512 * 9
+    direct = 2.0 * N * (2 * h2) ** 2 * 256 * 512 * 9
+    px = N * h2 * h2
     entry("tn128x128", "igemm_tng_kernel<128,128,2,2> (gemm.hip; LDS-direct loads)",
-          f"weight-gradient GEMM of upsample2 -> conv3x3 512->256 @8->16, batch {N}: 4 phases x [2048 x {N * 64}]^T.[{N * 64} x 256], pixels split 8 ways",
-          2.0 * N * 64 * 4 * 2048 * 256, t, direct, "16 % of the step's kernel time (6 launches; profiles/r04_eager_breakdown.txt)",
-          {"launch_group_ms": 1e3 * t_group, "launch_group": "accGradParameters of the layer = this GEMM + wgrad_reduce_kernel<true> + bias_part_reduce_kernel"})
-    # (2) igemm_nng_kernel<64,128,2,2,32> (LDS-direct loads), 14 % in 15 launches (round 3's dominant kernel; its largest launch then, the data
-    #     gradient of the layer above, now runs in F(2x2,2x2) - entry 5): largest launch now = forward of G's first convolution behind the
-    #     4x4 -> 8x8 upsampling (models.lua:205-206), one GEMM per phase: M = N*16, K = 4 taps * 512, Cout = 512
-    m1, x1in, dy1, _ = conv(512, 512, 3, 4, N, 1)
+          f"weight-gradient GEMM of upsample2 -> conv3x3 512->256 @{h2}->{2 * h2}, batch {N}: 4 phases x [2048 x {px}]^T.[{px} x 256], pixels split",
+          2.0 * px * 4 * 2048 * 256, t, direct, "16 % of the step's kernel time at config 2 (6 launches; profiles/r04_eager_breakdown.txt)",
+          {"launch_group_ms": 1e3 * t_group, "launch_group": "accGradParameters of the layer = this GEMM + wgrad_reduce_kernel<true> + bias_part_reduce_kernel"},
+          alg_bytes=4.0 * (px * 512 + 4 * px * 256 + 9 * 512 * 256))
+    # (2) igemm_nng_kernel<64,128,2,2,32> (LDS-direct loads): forward of G's first convolution behind the first upsampling
+    #     (models.lua:205-206), one GEMM per phase: M = N*b*b, K = 4 taps * 512, Cout = 512
+    m1, x1in, dy1, _ = conv(512, 512, 3, b, N, 1)
     t = time_kernel(lambda: m1.updateOutput(x1in))
     entry("nn64x128", "igemm_nng_kernel<64,128,2,2,32> (gemm.hip; LDS-direct loads)",
-          f"updateOutput of upsample2 -> conv3x3 512->512 @4->8, batch {N}: 4 phases x [{N * 16} x 2048].[2048 x 512]",
-          2.0 * N * 16 * 4 * 2048 * 512, t, 2.0 * N * 8 * 8 * 512 * 512 * 9, "14 % (15 launches)")
-    # (3) igemm_nn_kernel<128,64,...,16>: D's 64->64 3x3 convolution at 32x32 (models.lua:648)
-    m2, x2, dy2, _ = conv(64, 64, 3, 32, N, 0)
-    t = time_kernel(lambda: m2.updateOutput(x2))
-    f2 = 2.0 * N * 32 * 32 * 64 * 64 * 9
-    entry("nn128x64", "igemm_nn_kernel<128,64,2,2,true,true,16> (gemm.hip)",
-          f"updateOutput of conv3x3 64->64 @32x32, batch {N}: M={N * 1024} K=576 N=64", f2, t, f2, "8 % (8 launches)")
-    # (4) wino_gemm_g_kernel<16,16>: the 16 Winograd-domain GEMMs + in-register output transform of G's upsample2 -> conv5x5
-    m3, x3, dy3, _ = conv(256, 128, 5, 16, N, 1)
-    if getattr(m3, "_wino", False):
-        y = m3.output
-        v = m3._get("wino_v", (lib.conv2d_ups2_wino_v_floats(N, 16, 16, 256),))
-        t = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(cg.tensor.stream(), v.ptr, m3._u_fwd.data_ptr(), m3.bias.ptr, y.ptr, N, 16, 16, 256, 128, 0))
-        d3 = 2.0 * N * 32 * 32 * 128 * 256 * 25
-        entry("wino_g16", "wino_gemm_g_kernel<16,16> (winograd.hip; LDS-direct loads)",
-              f"forward of upsample2 -> conv5x5 256->128 @16->32 (models.lua:217-218), batch {N}: 4 phases x 16 GEMMs [tiles x 256].[256 x 128]",
-              d3 * 36 / 100 * 16 / 36, t, d3, "8 % (3 launches of the two 16-position wino_gemm_g variants)",
-              {"layer_ms": {"fwd": 1e3 * time_kernel(lambda: m3.updateOutput(x3)), "dgrad": 1e3 * time_kernel(lambda: m3.updateGradInput(x3, dy3)),
-                            "wgrad": 1e3 * time_kernel(lambda: m3.accGradParameters(x3, dy3))}})
-    # (5) round 4: F(2x2,2x2) on G's 512->256 3x3 layer (the layer of entry 1): forward = input transform + 4 phases x 9 GEMMs, data gradient =
-    #     dy transform + 9 GEMMs over K = 4*256 in four K slices + fixed-order sum - launch GROUPS through the C ABI, as the planned pass issues them
-    if lib.conv2d_ups2_wino22_supported(N, 8, 8, 512, 256):
+          f"updateOutput of upsample2 -> conv3x3 512->512 @{b}->{2 * b}, batch {N}: 4 phases x [{N * b * b} x 2048].[2048 x 512]",
+          2.0 * N * b * b * 4 * 2048 * 512, t, 2.0 * N * (2 * b) ** 2 * 512 * 512 * 9, "14 % at config 2 (15 launches)",
+          alg_bytes=4.0 * (N * b * b * 512 + 4 * 2048 * 512 + N * (2 * b) ** 2 * 512))
+    # (3) D's 64->64 3x3 convolution, (4) the Winograd GEMMs of G's upsample2 -> conv5x5 (models.lua:217-218)
+    d_conv2()
+    wino5(256, 128, 4 * b, True)
+    # (5) F(2x2,2x2) on G's 512->256 3x3 layer (the layer of entry 1): forward = input transform + 4 phases x 9 GEMMs, data gradient =
+    #     dy transform + 9 GEMMs over K = 4*256 in K slices + fixed-order sum - launch GROUPS through the C ABI, as the planned pass issues them
+    if lib.conv2d_ups2_wino22_supported(N, h2, h2, 512, 256):
         u22, u22b = E(lib.conv2d_ups2_wino22_u_floats(512, 256)), E(lib.conv2d_ups2_wino22_u_floats(512, 256))
         lib.conv2d_ups2_wino22_pack(stream, m._wf_ph.data_ptr(), m._wb_ph.data_ptr(), u22.data_ptr(), u22b.data_ptr(), 256, 512)
-        v22, vdy = E(lib.conv2d_ups2_wino22_v_floats(N, 8, 8, 512)), E(lib.conv2d_ups2_wino22_dgrad_v_floats(N, 8, 8, 512, 256))
-        rows = lib.conv2d_ups2_wino_stats_rows(N, 8, 8, 512, 256)
-        part, y22, g22 = E(max(int(rows), 1) * 2 * 256), E(N * 16 * 16 * 256), E(N * 8 * 8 * 512)
-        tf = time_kernel(lambda: lib.conv2d_ups2_wino22_forward_stats(cg.tensor.stream(), x.ptr, u22.data_ptr(), m.bias.ptr, y22.data_ptr(), v22.data_ptr(), N, 8, 8, 512, 256,
+        v22, vdy = E(lib.conv2d_ups2_wino22_v_floats(N, h2, h2, 512)), E(lib.conv2d_ups2_wino22_dgrad_v_floats(N, h2, h2, 512, 256))
+        rows = lib.conv2d_ups2_wino_stats_rows(N, h2, h2, 512, 256)
+        part, y22, g22 = E(max(int(rows), 1) * 2 * 256), E(N * (2 * h2) ** 2 * 256), E(px * 512)
+        tf = time_kernel(lambda: lib.conv2d_ups2_wino22_forward_stats(cg.tensor.stream(), x.ptr, u22.data_ptr(), m.bias.ptr, y22.data_ptr(), v22.data_ptr(), N, h2, h2, 512, 256,
                                                                       part.data_ptr() if rows else None))
-        tb = time_kernel(lambda: lib.conv2d_ups2_wino22_dgrad(cg.tensor.stream(), dy.ptr, u22b.data_ptr(), g22.data_ptr(), vdy.data_ptr(), N, 8, 8, 512, 256))
-        f22 = 2.0 * (N * 16) * 4 * 9 * 512 * 256
+        tb = time_kernel(lambda: lib.conv2d_ups2_wino22_dgrad(cg.tensor.stream(), dy.ptr, u22b.data_ptr(), g22.data_ptr(), vdy.data_ptr(), N, h2, h2, 512, 256))
+        f22 = 2.0 * (px // 4) * 4 * 9 * 512 * 256
         entry("wino22_fwd", "wino22_input_transform_kernel + wino_gemm_g_kernel<32,9> (winograd.hip; LDS-direct loads)",
-              f"forward of upsample2 -> conv3x3 512->256 @8->16 in F(2x2,2x2), batch {N}: 4 phases x 9 GEMMs [{N * 16} tiles x 512].[512 x 256]",
-              f22, tf, direct, "5 % with the data gradient (2 + 3 launches)",
+              f"forward of upsample2 -> conv3x3 512->256 @{h2}->{2 * h2} in F(2x2,2x2), batch {N}: 4 phases x 9 GEMMs [{px // 4} tiles x 512].[512 x 256]",
+              f22, tf, direct, "5 % with the data gradient at config 2 (2 + 3 launches)",
               {"timed": "launch group (transform + GEMMs)", "direct_kernel_ms": 1e3 * time_kernel(lambda: m.updateOutput(xin)),
-               "dgrad_group_ms": 1e3 * tb, "dgrad_direct_kernel_ms": 1e3 * time_kernel(lambda: m.updateGradInput(xin, dy))})
+               "dgrad_group_ms": 1e3 * tb, "dgrad_direct_kernel_ms": 1e3 * time_kernel(lambda: m.updateGradInput(xin, dy))},
+              alg_bytes=4.0 * (px * 512 + 36 * 512 * 256 + 4 * px * 256))
     return out
 
 
-def cpu_baselines():
-    """CPU baselines on this box's host cores, bounded samples, timed in this run.
-    Headline = the METRIC's configuration, configs[1] (batch 128), on all usable cores: the oracle (a port: im2col blocked over
-    output pixels + register-tiled SGEMM + OpenMP over the samples of a batch, the algorithm class of THNN SpatialConvolutionMM)
-    and PyTorch-CPU eager on the same graphs (oracle/torch_ref.py: oneDNN / MKL, the best CPU library available here) - the
-    FASTER of the two is `value`, `kind` / `sample` say which.  `others` keeps configs[0] (batch 16) at the reference's default
-    4 threads (train.lua:39) and at one thread per sample, for both."""
+def cpu_baselines(cfg):
+    """CPU baselines on this box's host cores, bounded samples, timed in this run, at the METRIC's configuration.
+    `value` / `kind: "port"` = the oracle (a port of the reference's algorithm class: im2col blocked over output pixels +
+    register-tiled SGEMM + OpenMP over the samples of a batch, i.e. THNN SpatialConvolutionMM), at the faster of two thread counts.
+    `others` carries PyTorch-CPU eager on the same graphs (oracle/torch_ref.py: oneDNN / MKL - `kind: "library"`, neither the
+    reference nor the port: the best CPU library available here, usually faster than the port) and, for configs[1], the
+    reference's own plumbing case configs[0] (batch 16) at its default 4 threads (train.lua:39)."""
     from oracle import oracle as O
     from oracle import torch_ref as TR
     nproc = os.cpu_count() or 1
     rs = np.random.RandomState(0)
+    C, S_, NB = cfg["ch"], cfg["size"], cfg["batch"]
+    mk_g = (lambda rng: O.create_G32up_c(C, 100, rng, base=S_ // 8)) if cfg["gen"] == "G32up-c" else (lambda rng: O.create_G32up(C, 100, rng))
+    names = f"{cfg['gen']}/D32_st3 at {S_}x{S_}x{C}"
 
     def batch(n):
-        return (rs.rand(n // 2, 3, 32, 32).astype(np.float32), (rs.rand(n // 2, 100) * 2 - 1).astype(np.float32),
+        return (rs.rand(n // 2, C, S_, S_).astype(np.float32), (rs.rand(n // 2, 100) * 2 - 1).astype(np.float32),
                 (rs.rand(n, 100) * 2 - 1).astype(np.float32))
 
     def run(T, n, budget_s, max_steps):
@@ -231,27 +267,30 @@ def cpu_baselines():
     def port(n, threads, budget_s, max_steps, note):
         O.set_num_threads(threads)
         rng = O.RNG(1)
-        steps, dt = run(O.Trainer(O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng)), n, budget_s, max_steps)
+        steps, dt = run(O.Trainer(mk_g(rng), O.create_D32_st3(C, S_, rng)), n, budget_s, max_steps)
         return {"value": n * steps / dt, "unit": "images/sec", "cores": O.num_threads(), "nproc": nproc, "kind": "port", "batch": n,
-                "sample": f"{steps} G+D steps of G32up-c/D32_st3 at batch {n} after 1 warm-up, oracle/ (C: im2col in L2-sized blocks + "
+                "sample": f"{steps} G+D steps of {names} at batch {n} after 1 warm-up, oracle/ (C: im2col in L2-sized blocks + "
                           f"SGEMM, OpenMP {O.num_threads()} threads{note}), {dt:.1f} s"}
 
     def torch_cpu(n, threads, budget_s, max_steps):
         torch.set_num_threads(threads)
         rng = O.RNG(1)
-        steps, dt = run(TR.TorchTrainer(O.create_G32up_c(3, 100, rng), O.create_D32_st3(3, 32, rng)), n, budget_s, max_steps)
-        return {"value": n * steps / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "nproc": nproc, "kind": "port", "batch": n,
-                "sample": f"{steps} G+D steps at batch {n} after 1 warm-up, PyTorch-CPU eager ({torch.__version__}, autograd, "
-                          f"{torch.get_num_threads()} threads) on the same graphs (oracle/torch_ref.py), {dt:.1f} s"}
+        steps, dt = run(TR.TorchTrainer(mk_g(rng), O.create_D32_st3(C, S_, rng)), n, budget_s, max_steps)
+        return {"value": n * steps / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "nproc": nproc, "kind": "library", "batch": n,
+                "sample": f"{steps} G+D steps of {names} at batch {n} after 1 warm-up, PyTorch-CPU eager ({torch.__version__}, autograd, "
+                          f"{torch.get_num_threads()} threads) on the same graphs (oracle/torch_ref.py) - a CPU LIBRARY, not the port, "
+                          f"not the reference, {dt:.1f} s"}
 
-    NB = CONFIGS[2]["batch"]                     # the metric's batch: 128
     wide = min(nproc, NB)                        # the port's loops are parallel over the samples of a batch
-    head = [port(NB, wide, 12.0, 3, ", one per sample" if wide == NB else ", all cores"),
-            torch_cpu(NB, min(nproc, 128), 12.0, 3)]
-    others = [port(16, min(nproc, 4), 4.0, 3, ", the reference's default --threads"), port(16, min(nproc, 16), 4.0, 6, ", one per sample"),
-              torch_cpu(16, min(nproc, 64), 4.0, 6)]
-    best = dict(max(head, key=lambda r: r["value"]))      # headline: the fastest CPU path at the metric's configuration
-    best["config"] = "configs[1]: batch 128 (the metric's configuration)"
+    mid = min(nproc, 32)
+    head = [port(NB, wide, 8.0, 2, ", one per sample" if wide == NB else ", all cores")]
+    if mid != wide:
+        head.append(port(NB, mid, 8.0, 2, ""))
+    others = [torch_cpu(NB, min(nproc, 128), 8.0, 2)]
+    if cfg is CONFIGS[2]:
+        others += [port(16, min(nproc, 4), 4.0, 3, ", configs[0] = the reference's plumbing case at its default --threads")]
+    best = dict(max(head, key=lambda r: r["value"]))
+    best["config"] = cfg["name"]
     best["others"] = [r for r in head if r["sample"] != best["sample"]] + others
     return best
 
@@ -259,8 +298,8 @@ def cpu_baselines():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config number (1-based)")
     ap.add_argument("--batch-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -321,8 +360,14 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()
-        for _ in range(args.steps):
+        marks = []                     # one event per block of ~K/5 steps INSIDE the timed region (exactly K steps are timed): the spread of the line
+        blk = max(1, args.steps // 5)
+        for i in range(args.steps):
             step()
+            if (i + 1) % blk == 0 and i + 1 < args.steps:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append((i + 1, ev))
         e1.record()
         torch.cuda.synchronize()
     cg.parallel.barrier()
@@ -358,10 +403,14 @@ def main():
                           "direct_count_tflops": per_gpu * w["W"] / 1e12, "peak_tflops": PEAK_FP32_MFMA / 1e12},
             "event_ms_per_step": e0.elapsed_time(e1) / args.steps, "finite": finite,
         }
+        pts = [(0, e0)] + marks + [(args.steps, e1)]
+        blocks = [pa[1].elapsed_time(pb[1]) / (pb[0] - pa[0]) for pa, pb in zip(pts[:-1], pts[1:])]
+        res["spread"] = {"ms_per_step_blocks": [round(v, 4) for v in blocks], "min": min(blocks), "max": max(blocks),
+                         "note": f"HIP-event time of consecutive blocks of {blk} steps inside the one timed region of {args.steps} steps"}
         # The headline numbers above are complete; the two legs below are measured live and must never cost the driver its line.
-        if not args.no_kernel_roofline and args.config == 2:
+        if not args.no_kernel_roofline:
             try:
-                top = kernel_rooflines(cg, N)
+                top = kernel_rooflines(cg, cfg, N)
                 res["roofline"] = dict(top[0])    # the kernel with the largest share of the step
                 res["roofline_top"] = top
             except Exception as e:                # noqa: BLE001
@@ -379,13 +428,16 @@ def main():
                 "note": "frac of the kernel block above = EXECUTED FLOPs of one launch / its duration / peak; the step's executed_frac is the "
                         "same ratio over the whole step (all launches, all phases); direct-count figures (SURVEY.md 8d's numerator) are "
                         "direct_count_over_executed times larger and are not utilisations",
-                "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.56, "D forward": 0.57, "D backward + Adam": 1.26,
-                                     "generator forward on N": 0.83, "D forward + data gradient (G step)": 1.19, "generator backward + Adam": 1.71},
-                "phases_source": "profiles/r04_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
-                                 "launches, 6.12 ms under the tracer; committed numbers, not measured in this run)"}
+                }
+            if args.config == 2:
+                res["roofline"]["step"].update({
+                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.56, "D forward": 0.57, "D backward + Adam": 1.26,
+                                         "generator forward on N": 0.83, "D forward + data gradient (G step)": 1.19, "generator backward + Adam": 1.71},
+                    "phases_source": "profiles/r04_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
+                                     "launches, 6.12 ms under the tracer; committed numbers, not measured in this run)"})
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baselines()
+                res["cpu_baseline"] = cpu_baselines(cfg)
             except Exception as e:                # noqa: BLE001
                 res["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": "failed: " + str(e)[:160]}
         sys.stdout.flush()
