@@ -33,6 +33,13 @@ DEFAULT_OPT = dict(  # train.lua:15-49
     # beside the generator's GEMMs the launch-bound kernels of D's chain queue for slots, and what the overlap wins
     # they lose: same box 6.32 / 6.33 with, 6.29 / 6.29 ms without (config #3: 9.64 / 9.54); CG_CONCURRENT_G=1 switches it back on
     concurrent_g_forward=os.environ.get("CG_CONCURRENT_G", "0") != "0",
+    # Round 5: BOTH generator forwards of an iteration - the D-step's fake images on N/2 noise rows (adversarial.lua:232-233)
+    # and the G-step's pass on N rows (:185) - read the same G parameters (G moves at :262 only), so the second one starts at the head of
+    # the iteration on a side stream, beside the first, instead of after D's update: two serial chains of GEMM -> statistics ->
+    # normalise -> transform fill each other's launch gaps.  Result-neutral: the G-step's noise is drawn from the position it has in
+    # the reference's order (behind the D-step's dropout masks), the side pass leaves the batch-norm running statistics alone and
+    # they are moved after the join, in the reference's order (cg_net_apply_running).  CG_CONCURRENT_G_BOTH=0 switches it off.
+    concurrent_g_both=os.environ.get("CG_CONCURRENT_G_BOTH", "1") != "0",
 )
 
 
@@ -72,6 +79,7 @@ class State:
         self.keep_outputs = False  # tests: snapshot D's output before the G-step reuses the buffer
         self.device_rng = False    # draw the real-batch indices on the device (required under hipGraph replay)
         self._side = None          # side HIP stream + fork/join events for the concurrent G-step forward
+        self._d_draws = {}         # batch -> counter-stream draws of MODEL_D:forward (learned in the first iteration)
 
 
 def mean(t):
@@ -118,6 +126,9 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         S.GRAD_PARAMETERS_D.zero()
         targets = buf["targets_D"]
         outputs = S.MODEL_D.forward(inputs)
+        pd = getattr(S.MODEL_D, "_pnet", None)
+        if pd and pd[1] is not None and getattr(S.MODEL_D, "_planned_last", False):
+            S._d_draws[N] = pd[1].last_draws     # counter-stream draws of D's forward at this batch: static per plan
         f = S.CRITERION.forward(outputs, targets)
         df_do = S.CRITERION.backward(outputs, targets)
         S.MODEL_D.backward(inputs, df_do)   # planned: weight-gradient reductions deferred and flushed inside cg_net_backward
@@ -160,6 +171,14 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         samples = st.pop("samples_pre", None)
         if "join" in st:  # the forward ran on the side stream: join before anything consumes it
             torch.cuda.current_stream().wait_event(st.pop("join"))
+        if st.pop("both", False):
+            # the side pass left the running statistics alone: move them now, behind the fake-image pass's update (the reference's order)
+            S.MODEL_G._pnet[1].apply_running()
+            off = st.pop("noise_off", None)
+            if off is not None:
+                r = rng()
+                assert r.offset == off, "the G-step's noise was drawn from the wrong position of the counter stream"
+                r.take(st["noiseInputs"].nElement())
         if samples is None:
             samples = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
         outputs = S.MODEL_D.forward(samples)
@@ -203,7 +222,33 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         lib().gather_rows(stream(), trainData.pool.ptr, buf["idx"].data_ptr(), inputs.ptr, half, rowlen)
         # (1.2) sampled data
         noise = nn.to_device(noise_D) if noise_D is not None else nn_utils.stepNoiseInputs(S, half)
+        both = _both_forwards_ok(S, N)
+        if both:
+            if S._side is None:
+                S._side = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
+            side, ev_fork, ev_join = S._side
+            ev_fork.record()
+            side.wait_event(ev_fork)
         samples = nn.as_nhwc(nn_utils.createImagesFromNoise(S, noise, False))
+        if both:
+            # the G-step's forward, issued behind the fake-image pass on the side stream: its plan (the N-row one) becomes the net's last
+            # forward, which is what MODEL_G:backward continues
+            pn = S.MODEL_G._pnet[1]
+            r = rng()
+            with torch.cuda.stream(side):
+                if noise_G is not None:
+                    st["noiseInputs"] = nn.to_device(noise_G)
+                else:
+                    st["noise_off"] = r.offset + S._d_draws[N]       # behind the D-step's dropout masks (drawn by MODEL_D:forward below)
+                    st["noiseInputs"] = nn_utils.stepNoiseInputsAt(S, N, st["noise_off"])
+                pn.set_defer_running(True)
+                try:
+                    st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
+                finally:
+                    pn.set_defer_running(False)
+                ev_join.record()
+            st["join"] = ev_join
+            st["both"] = True
         lib().memcpy_d2d(stream(), inputs.ptr + half * rowlen * 4, samples.ptr, half * rowlen * 4)
         S._last_fake = samples.clone() if S.keep_outputs else samples
         # Fork: the G-step's generator forward (fresh noise) depends only on G's parameters, not on anything the
@@ -257,6 +302,18 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         if S.keep_outputs:
             S._last["gG"] = S.GRAD_PARAMETERS_G.clone()
     return st["doTrainD"]
+
+
+def _both_forwards_ok(S, N):
+    """Both generator forwards of the iteration side by side (OPT.concurrent_g_both)?  Single rank (a second pass would put its sync-BN
+    collectives on the communicator of the first), one D and one G iteration, planned generator, and D's draw count at this batch known
+    from an earlier iteration (the first iteration of a run goes one after the other)."""
+    OPT = S.OPT
+    G = S.MODEL_G
+    return bool(OPT.get("concurrent_g_both", False) and not OPT.get("concurrent_g_forward", False) and has_gpu() and nn.planned
+                and parallel.world_size() == 1 and OPT["D_iterations"] == 1 and OPT["G_iterations"] == 1 and N in S._d_draws
+                and type(G) is nn.Sequential and getattr(G, "_pnet", None) and G._pnet[1] is not None and getattr(G, "_planned_last", False)
+                and OPT["batchSize"] >= N)
 
 
 def _bucketable(G):

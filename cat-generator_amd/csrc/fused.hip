@@ -345,6 +345,21 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_k(const float* __restri
     }
 }
 
+// The running-statistics half of bn_act_fwd_v4k / bn_forward alone, from the same fp64 sums and with the same arithmetic: a pass
+// that ran with running_mean == NULL (two generator forwards side by side, adversarial.py) applies its update afterwards, in the
+// reference's order (nn.SpatialBatchNormalization updateOutput, models.lua:207).
+__global__ __launch_bounds__(256) void bn_running_update_k(const double* __restrict__ sums, double count, float momentum, float* running_mean,
+                                                           float* running_var, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / count;
+    double var = sums[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+}
+
 // training-mode batch-norm + PReLU in one pass; every thread owns one channel quad (the grid stride is a multiple of C/4),
 // derives its mean / invstd from the fp64 sums exactly as bn_prepare_k does; workgroup 0 also writes save_mean /
 // save_invstd and moves the running statistics.
@@ -754,6 +769,13 @@ int cg_drop_linear_sigmoid_backward(void* stream, const float* dp, const float* 
 int cg_bn_stats_finalize(void* stream, const float* partials, long rows, int C, double* sums) {
     CG_REQUIRE(partials && sums && rows > 0 && rows < (1L << 30) && C > 0, "cg_bn_stats_finalize: bad args");
     hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cg::cdiv(2L * C, 16)), dim3(256), 0, cg::S(stream), partials, (int)rows, C, sums);
+    CG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cg_bn_running_update(void* stream, const double* sums, double count, int C, float momentum, float* running_mean, float* running_var) {
+    CG_REQUIRE(sums && running_mean && running_var && C > 0 && count > 0, "cg_bn_running_update: bad args");
+    hipLaunchKernelGGL(bn_running_update_k, dim3(cg::cdiv((long)C, 256)), dim3(256), 0, cg::S(stream), sums, count, momentum, running_mean, running_var, C);
     CG_LAUNCH_CHECK();
     return 0;
 }

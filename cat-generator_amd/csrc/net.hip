@@ -199,6 +199,9 @@ struct Prog {
     vector<std::pair<float*, long>> buckets;   // gradient buckets of the root Sequential (first module index order)
     vector<int> bucket_first;
     std::map<int, int> ups_first_op;           // module id of a layer behind a folded upsampling -> index of its first forward op
+    struct BnRun { Mod* bn; Val sums; double cnt; long C; float mom; };
+    vector<BnRun> bn_runs;                     // training-mode batch-norms of the forward pass (cg_net_apply_running)
+    bool running_pending = false;
 };
 
 typedef void* (*alloc_fn_t)(void* user, size_t bytes);
@@ -220,6 +223,8 @@ struct Net {
     vector<void*> owned;
     vector<Region> regions;
     bool params_dirty = true;
+    bool pack_inflight = false;               // sync_packs forked a re-packing that a LATER pass on another stream may still have to wait for
+    int defer_running = 0;                     // run-time switch: batch-norm forwards leave the running statistics to cg_net_apply_running
     bool fresh_allocs = false;                 // library-owned buffers were allocated + zeroed since the last device synchronise
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
@@ -689,8 +694,10 @@ struct Compiler {
                 emit_allreduce_sum(sums, 2 * C, 1);
                 const double cnt = (double)Mr * dp_factor();
                 s.count = cnt;
-                emit([=](Run& c) { return k->bn_forward(c.CS(), c.P(x), c.P(out), mp->w, mp->b, (const double*)c.P(sums), cnt, Mr, (int)C, eps, mom,
-                                                        mp->rmean, mp->rvar, c.P(sm), c.P(sv)); });
+                emit([=](Run& c) { const bool df = c.net->defer_running != 0;
+                                   return k->bn_forward(c.CS(), c.P(x), c.P(out), mp->w, mp->b, (const double*)c.P(sums), cnt, Mr, (int)C, eps, mom,
+                                                        df ? nullptr : mp->rmean, df ? nullptr : mp->rvar, c.P(sm), c.P(sv)); });
+                if (!dry) pr->bn_runs.push_back({mp, sums, cnt, C, mom});
             }
             s.x = x; s.out = out; s.bn_fused = false;
             return out;
@@ -1254,8 +1261,10 @@ struct Compiler {
         S(bn).count = cnt;
         Val y = buf_like(act, "out", out, NHWC);
         const float eps = bn.fa[0], mom = bn.fa[1];
-        emit([=](Run& c) { return k->bn_act_forward(c.CS(), c.P(out), c.P(y), bp->w, bp->b, (const double*)c.P(sums), cnt, Mr, (int)C, eps, mom, bp->rmean, bp->rvar,
-                                                    c.P(sm), c.P(sv), ap->w); });
+        emit([=](Run& c) { const bool df = c.net->defer_running != 0;
+                           return k->bn_act_forward(c.CS(), c.P(out), c.P(y), bp->w, bp->b, (const double*)c.P(sums), cnt, Mr, (int)C, eps, mom, df ? nullptr : bp->rmean,
+                                                    df ? nullptr : bp->rvar, c.P(sm), c.P(sv), ap->w); });
+        if (!dry) pr->bn_runs.push_back({bp, sums, cnt, C, mom});
         MS& sb = S(bn); sb.x = out; sb.out = Val(); sb.bn_fused = true; sb.bnM = Mr; sb.bnC = C;
         MS& sa = S(act); sa.x = Val(); sa.out = y;
         return y;
@@ -2531,6 +2540,7 @@ int sync_packs(Net* n, Prog* pr, Run& c, int* join_before) {
     if (forked) {
         if (n->trace) trace_note(n, "event|record|packs|s1");
         else if (hipEventRecord(n->pack_ev, c.st[1]) != hipSuccess) return cg::fail("cg_net: hipEventRecord failed");
+        n->pack_inflight = true;
     }
     g_cur_net = nullptr;
     return 0;
@@ -2607,6 +2617,7 @@ int cg_net_set_option(void* net, const char* name, long value) {
         n->trace = value != 0; n->K = n->trace ? &kTraceTable : &kRealTable;
         return 0;
     }
+    if (!strcmp(name, "defer_running")) { n->defer_running = value != 0; return 0; }   // run-time switch, plans unchanged
     if (!strcmp(name, "winograd_min_tiles")) { n->wino_min_tiles = value; return 0; }
     if (!strcmp(name, "winograd22")) { n->wino22 = (int)value; return 0; }     // bit mask: 1 forward, 2 data gradient, 4 weight gradient
     if (!strcmp(name, "fuse_locnet")) { n->fuse_locnet = (int)value; return 0; }   // 0 off, 1 every localisation branch, 2 ungrouped ones only
@@ -2733,9 +2744,13 @@ int cg_net_forward(void* net, void* stream, const float* x, int nd, const long* 
     fill_run(n, pr, c, stream);
     int join_before = -1;
     if (sync_packs(n, pr, c, &join_before)) return 1;
+    // another pass of this net (on another stream) may have the re-packing in flight: wait for it before the first launch
+    if (join_before < 0 && n->pack_inflight && !n->trace && hipStreamWaitEvent(c.st[0], n->pack_ev, 0) != hipSuccess)
+        return cg::fail("cg_net_forward: hipStreamWaitEvent failed");
     c.x = x; c.seed = rng_seed; c.roff = rng_offset; c.rbase = rng_base;
     if (run_ops(n, pr->fwd, c, join_before)) return 1;
     n->last = pr;
+    pr->running_pending = n->defer_running != 0 && !pr->bn_runs.empty();
     if (draws) *draws = (uint64_t)pr->draws;
     if (y) *y = c.P(pr->out);
     if (ynd) *ynd = pr->out.nd;
@@ -2787,12 +2802,28 @@ int cg_net_backward(void* net, void* stream, const float* x, const float* gy, in
     Run c;
     fill_run(n, pr, c, stream);
     c.x = x; c.gy = gy; c.scale = scale;
+    n->pack_inflight = false;      // every forward pass since the last re-packing has waited for it
     if (run_ops(n, pr->bwd[acc], c)) return 1;
     const Val& gi = pr->gin[acc];
     if (gx) *gx = c.P(gi);
     if (gnd) *gnd = gi.nd;
     if (gdims) for (int i = 0; i < 4; ++i) gdims[i] = gi.d[i];
     if (gfmt) *gfmt = gi.fmt + 2 * gi.ups;
+    return 0;
+}
+
+int cg_net_apply_running(void* net, void* stream) {
+    Net* n = NET(net);
+    CG_REQUIRE(n, "cg_net_apply_running: null net");
+    Prog* pr = n->last;
+    if (!pr || !pr->running_pending) return 0;
+    pr->running_pending = false;
+    g_cur_net = n;
+    for (auto& b : pr->bn_runs) {
+        if (!b.bn->rmean || !b.bn->rvar) continue;
+        if (n->K->bn_running_update(stream, (const double*)b.sums.p, b.cnt, (int)b.C, b.mom, b.bn->rmean, b.bn->rvar)) { g_cur_net = nullptr; return 1; }
+    }
+    g_cur_net = nullptr;
     return 0;
 }
 

@@ -29,10 +29,22 @@ def stepNoiseInputs(S, N):
     return _fill_noise(t)
 
 
-def _fill_noise(t):
+def _fill_noise(t, offset=None):
+    """offset: an explicit position of the counter stream (the caller reserves it and advances the generator itself)."""
     r = rng()
-    lib().rng_uniform_dev(stream(), t.ptr, t.nElement(), -1.0, 1.0, r.seed, r.take(t.nElement()), r.base_ptr())
+    lib().rng_uniform_dev(stream(), t.ptr, t.nElement(), -1.0, 1.0, r.seed, r.take(t.nElement()) if offset is None else int(offset), r.base_ptr())
     return t
+
+
+def stepNoiseInputsAt(S, N, offset):
+    """stepNoiseInputs with the draws taken from `offset` of the counter stream instead of its current position: the G-step's noise
+    drawn ahead of time (adversarial.iteration runs both generator forwards side by side) at the position it has in the reference's
+    order - behind the D-step's dropout masks."""
+    cache = S.__dict__.setdefault("_noise_bufs", {})
+    t = cache.get(N)
+    if t is None:
+        t = cache[N] = Tensor.empty((N, S.OPT["noiseDim"]))
+    return _fill_noise(t, offset)
 
 
 def createImagesFromNoise(S, noiseInputs, outputAsList=False, *_):

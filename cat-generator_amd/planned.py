@@ -251,6 +251,7 @@ class PlannedNet:
         self.L.net_forward(self.h, stream(), x.ptr, len(x.shape), dims, 1 if x.fmt == "nhwc" else 0, r.seed, r.offset, r.base_ptr(),
                            ctypes.addressof(draws), ctypes.byref(y), ctypes.byref(ynd), ydims, ctypes.byref(yfmt))
         r.offset += draws.value
+        self.last_draws = int(draws.value)      # static per plan: a host may reserve the stream positions behind this pass ahead of time
         self._x = x
         if self.trace:
             return Tensor(torch.empty(0), tuple(int(ydims[i]) for i in range(ynd.value)), "nhwc" if yfmt.value & 1 else "plain")
@@ -264,6 +265,14 @@ class PlannedNet:
         if self.trace:
             return Tensor(torch.empty(0), tuple(int(gdims[i]) for i in range(gnd.value)), "nhwc" if gfmt.value & 1 else "plain")
         return self._wrap(gx.value, gnd.value, gdims, gfmt.value)
+
+    def set_defer_running(self, on):
+        """cg_net_set_option "defer_running": the following forward passes leave the batch-norm running statistics to apply_running()."""
+        self.L.net_set_option(self.h, b"defer_running", int(bool(on)))
+
+    def apply_running(self):
+        """Apply the running-statistics update of the most recent deferred forward pass, on the current stream."""
+        self.L.net_apply_running(self.h, stream())
 
     def finish_buckets(self):
         """Join the gradient-bucket all-reduces cg_net_backward started (bucket_overlap): device-side wait, no host sync."""

@@ -321,6 +321,10 @@ int cg_bn_forward_eval(void* stream, const float* x, float* y, const float* gamm
  * sums[0..C) = sum_rows partials[r][0][c], sums[C..2C) = sum_rows partials[r][1][c] (fp64, fixed order) - the same
  * quantities cg_bn_stats produces from a pass over x; a data-parallel host all-reduces `sums` next (sync-BN). */
 int cg_bn_stats_finalize(void* stream, const float* partials, long rows, int C, double* sums);
+/* The running-statistics update of nn.SpatialBatchNormalization:updateOutput (models.lua:207; momentum 0.1, unbiased variance) ALONE,
+ * from the fp64 sums of a pass that was run with running_mean == running_var == NULL: same arithmetic as cg_bn_forward /
+ * cg_bn_act_forward, so a deferred update is bit-identical to an in-line one (cg_net_apply_running uses it). */
+int cg_bn_running_update(void* stream, const double* sums, double count, int C, float momentum, float* running_mean, float* running_var);
 /* cg_bn_forward followed by cg_prelu_forward (models.lua:207-208) in one pass: y = prelu(bn(x)); alpha == NULL: no
  * activation.  The normalised tensor is not materialised: the backward below recomputes it from x. */
 int cg_bn_act_forward(void* stream, const float* x, float* y, const float* gamma, const float* beta,
@@ -571,7 +575,13 @@ int cg_comm_sync(void* comm);
  * cg_net_backward: continues the most recent forward.  gy = gradOutput in layout gy_fmt; acc != 0: Module:backward (gradInput +
  *   accGradParameters with `scale`), acc == 0: Module:updateGradInput only (fevalG_on_D's pass through D, adversarial.lua:192-193).
  *   gfmt: 0 row-major, 1 NHWC.
- * cg_net_module_state: .output (which 0) / .gradInput (1) / dropout mask (2) of one module after a pass (NULL when fused away). */
+ * cg_net_module_state: .output (which 0) / .gradInput (1) / dropout mask (2) of one module after a pass (NULL when fused away).
+ * cg_net_set_option "defer_running" 1 (a RUN-time switch, no re-planning): training-mode batch-norm layers of the following forward
+ *   passes leave running_mean / running_var alone; cg_net_apply_running(net, stream) then applies the update of the most recent
+ *   such pass (cg_bn_running_update per layer, bit-identical to the in-line update).  For a host that runs two forward passes of one
+ *   net side by side on two streams - the generator's fake-image pass and the G-step's pass, adversarial.lua:232-233 and :185, which
+ *   read the same parameters - and still wants the running statistics moved in the reference's order.  A pass that did not re-pack
+ *   the weights itself waits (device-side) for a re-packing another pass of the net has in flight. */
 int cg_net_create(void** net);
 int cg_net_destroy(void* net);
 int cg_net_set_option(void* net, const char* name, long value);
@@ -588,6 +598,7 @@ int cg_net_forward(void* net, void* stream, const float* x, int nd, const long* 
                    const uint64_t* rng_base, uint64_t* draws, float** y, int* ynd, long* ydims, int* yfmt);
 int cg_net_backward(void* net, void* stream, const float* x, const float* gy, int gy_fmt, int acc, float scale, float** gx, int* gnd,
                     long* gdims, int* gfmt);
+int cg_net_apply_running(void* net, void* stream);
 int cg_net_buckets(void* net, int* nbuckets);
 int cg_net_module_state(void* net, int id, int which, float** ptr, int* nd, long* dims, int* fmt);
 int cg_net_stats(void* net, long* nprograms, long* nlaunch_fwd, long* nlaunch_bwd, size_t* bytes);

@@ -607,6 +607,37 @@ def test_generator_forward_beside_the_discriminator_update_is_result_neutral(cg)
     np.testing.assert_array_equal(d0, d1)
 
 
+def test_both_generator_forwards_side_by_side_are_result_neutral(cg):
+    """OPT.concurrent_g_both (round 5; both generator forwards of an iteration side by side from its head, adversarial.lua:232-233 and :185
+    read the same G parameters) is a schedule, not arithmetic - WITHOUT injecting anything: the G-step's noise is drawn ahead of time at
+    the position it has in the reference's order (behind the D-step's dropout masks), the side pass defers its batch-norm running
+    statistics and they are moved after the join (cg_net_apply_running), behind the fake-image pass's.  Four iterations (the first one
+    runs one after the other either way: D's draw count is learned there) give the same bits in the parameters of G and D, in the
+    running statistics and in the position of the counter stream."""
+    N = 16
+
+    def run(both):
+        cg.manual_seed(47)
+        G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
+        S = cg.adversarial.State(dict(batchSize=N, concurrent_g_both=both, seed=3), G, D)
+        data = cg.adversarial.TrainData(np.random.RandomState(6).rand(64, 3, 32, 32).astype(f32))
+        for _ in range(4):
+            cg.adversarial.iteration(S, data, N)
+        torch.cuda.synchronize()
+        bns = [m for m in G.listModules() if type(m).__name__ == "SpatialBatchNormalization"]
+        assert len(bns) == 3
+        used = bool(getattr(S, "_d_draws", None)) and both
+        return (S.PARAMETERS_G.numpy(), S.PARAMETERS_D.numpy(), [b.running_mean.numpy() for b in bns], [b.running_var.numpy() for b in bns],
+                cg.tensor.rng().offset, used)
+    g0, d0, rm0, rv0, o0, _ = run(False)
+    g1, d1, rm1, rv1, o1, used = run(True)
+    assert used and o0 == o1
+    np.testing.assert_array_equal(g0, g1)
+    np.testing.assert_array_equal(d0, d1)
+    for a, b in zip(rm0 + rv0, rm1 + rv1):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_graph_replay_matches_eager(cg):
     """hipGraph replay of the iteration vs eager launches: same parameters (to drift tolerance) after 3 steps (device-side RNG/Adam
     counters make the replay advance its mask / noise / index streams and step counts exactly like eager mode)."""
