@@ -172,8 +172,6 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         if "join" in st:  # the forward ran on the side stream: join before anything consumes it
             torch.cuda.current_stream().wait_event(st.pop("join"))
         if st.pop("both", False):
-            # the side pass left the running statistics alone: move them now, behind the fake-image pass's update (the reference's order)
-            S.MODEL_G._pnet[1].apply_running()
             off = st.pop("noise_off", None)
             if off is not None:
                 r = rng()
@@ -231,6 +229,8 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
             side.wait_event(ev_fork)
         samples = nn.as_nhwc(nn_utils.createImagesFromNoise(S, noise, False))
         if both:
+            ev_a = S._side_a = getattr(S, "_side_a", None) or torch.cuda.Event()
+            ev_a.record()      # the fake-image pass (and with it its running-statistics update) is complete on the step's stream
             # the G-step's forward, issued behind the fake-image pass on the side stream: its plan (the N-row one) becomes the net's last
             # forward, which is what MODEL_G:backward continues
             pn = S.MODEL_G._pnet[1]
@@ -246,6 +246,10 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
                     st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
                 finally:
                     pn.set_defer_running(False)
+                # the side pass left the running statistics alone: move them here, off the step's chain, but behind the fake-image pass's
+                # update (the reference's order, adversarial.lua:232 then :185)
+                side.wait_event(ev_a)
+                pn.apply_running()
                 ev_join.record()
             st["join"] = ev_join
             st["both"] = True
