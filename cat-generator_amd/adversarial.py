@@ -223,7 +223,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         both = _both_forwards_ok(S, N)
         if both:
             if S._side is None:
-                S._side = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
+                S._side = (_side_stream(), torch.cuda.Event(), torch.cuda.Event())
             side, ev_fork, ev_join = S._side
             ev_fork.record()
             side.wait_event(ev_fork)
@@ -306,6 +306,17 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         if S.keep_outputs:
             S._last["gG"] = S.GRAD_PARAMETERS_G.clone()
     return st["doTrainD"]
+
+
+def _side_stream():
+    """The host's side stream for the G-step's generator forward, on a hardware queue of its own choice (cg_stream_on_queue: the runtime
+    serves all streams from four hardware queues, and a torch.cuda.Stream() lands on whichever is next in creation order - possibly the
+    step's own, where nothing overlaps: +0.2 ms per step).  Any class but 0 measures the same (profiles/r05_queue_classes.txt); CG_QMAP_T
+    overrides."""
+    import ctypes
+    h = ctypes.c_void_p()
+    lib().stream_on_queue(stream(), int(os.environ.get("CG_QMAP_T", "2")), 7, ctypes.byref(h))
+    return torch.cuda.ExternalStream(h.value)
 
 
 def _both_forwards_ok(S, N):

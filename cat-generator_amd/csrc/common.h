@@ -41,9 +41,9 @@ constexpr int kNumCU = 256;  // MI355X: 8 XCDs x 32 CUs
 // Tunables (cg_set_option / cg_get_option, catgan.h).  Default = the environment variable of the same name if set,
 // else the built-in value; cg_set_option overrides both at run time (tests force every kernel variant this way).
 enum Opt {
-    OPT_SPLIT_TARGET, OPT_SPLIT_MINK, OPT_TN_SMAX, OPT_TN_TARGET, OPT_SKINNY, OPT_GEMM_SLOW, OPT_GEMM_BK32,
-    OPT_COLREDUCE_WGS_PER_CU, OPT_WINO_WAVES, OPT_WINO_BK, OPT_NN_TILE, OPT_TN_TILE, OPT_NN_SPLITS, OPT_TN_SPLITS,
-    OPT_EPILOGUE_STATS, OPT_SAMPLER_ATOMICS, OPT_XCD_SWIZZLE, OPT_NN_QUAD, OPT_TN_QUAD, OPT_WINO_QUAD, OPT_NN_PF, OPT_NN_GLDS, OPT_TN_GLDS, OPT_WINO_GLDS, OPT_EW_WGS_PER_CU, OPT_COUNT
+    OPT_SPLIT_TARGET, OPT_SPLIT_MINK, OPT_TN_SMAX, OPT_TN_TARGET, OPT_SKINNY, OPT_GEMM_BK32,
+    OPT_COLREDUCE_WGS_PER_CU, OPT_WINO_BK, OPT_NN_TILE, OPT_TN_TILE, OPT_NN_SPLITS, OPT_TN_SPLITS,
+    OPT_EPILOGUE_STATS, OPT_XCD_SWIZZLE, OPT_NN_GLDS, OPT_TN_GLDS, OPT_WINO_GLDS, OPT_EW_WGS_PER_CU, OPT_COUNT
 };
 long opt(Opt o);
 
@@ -57,6 +57,16 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // first appears inside a capture takes a pooled block without allocating).
 constexpr size_t kColScratchBytes = 8u << 20;
 void* col_scratch(hipStream_t stream);   // nullptr + cg::fail() on error
+// ---- hardware queues (round 5).  The HIP runtime serves ALL streams of a process from GPU_MAX_HW_QUEUES = 4 hardware queues,
+// assigned in creation order; two streams of one queue run back to back whatever the dependency graph says, and WHICH streams share a
+// queue decides how much of a plan's overlap exists (measured: +-10 % per step between creation orders; one extra stream created by
+// the library once moved the host's side stream onto the main stream's queue, +2.7 %; more than 4 queues is far worse - 8: 7.4 ms,
+// 5: 11 ms per step against 5.9, the queues then time-slice the chip).  So side streams are not created where they are needed: they
+// come out of one pool whose streams are CLASSIFIED, once, by a timing probe against the caller's stream (two spinning kernels on a
+// pair of streams: together they take one kernel's time on different queues, two on the same), and a plan asks for "the k-th stream of
+// queue class c": class 0 = the caller's own queue, 1..3 = the other three, numbered in the order the probe meets them.
+hipStream_t queue_stream(hipStream_t ref, int cls, int slot);   // nullptr + cg::fail() on error
+int queue_class(hipStream_t ref, hipStream_t s);                // class of a pool stream (or of ref itself: 0); -1 unknown
 // Drop every weight-gradient reduction still queued by cg_conv2d_wgrad_*_deferred (any stream): a pass that failed half way must not
 // leave partial sums behind for the next flush to add to a gradient.
 void wgrad_discard_all();

@@ -806,9 +806,7 @@ int cg_bn_act_backward_stats(void* stream, const float* x, const float* dy, cons
     const int qb = C >= 128 ? 32 : 16;
     const int cblocks = cg::cdiv(C / 4, qb);
     const int cmul = (int)cg::opt(cg::OPT_COLREDUCE_WGS_PER_CU);
-    // experiment switch CG_BNBWD_WGS_DIV = d: 1/d workgroup per CU (fewer slots to wait for beside another queue's GEMM, longer loops each)
-    static const int wdiv = [] { const char* e = getenv("CG_BNBWD_WGS_DIV"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 16 ? v : 1; }();
-    long chunks = std::max(1L, std::min((M + 63) / 64, (long)cg::kNumCU * cmul / cblocks / wdiv));
+    long chunks = std::max(1L, std::min((M + 63) / 64, (long)cg::kNumCU * cmul / cblocks));
     const long rows_per_block = ((M + chunks - 1) / chunks + 3) / 4 * 4;
     chunks = (M + rows_per_block - 1) / rows_per_block;
     const dim3 grid(cblocks, (unsigned)chunks);

@@ -25,8 +25,8 @@
 // accumulators; LDS tiles are double buffered, one barrier per K tile.  How a K tile gets into LDS:
 //   * igemm_nn_kernel / igemm_tn_kernel (register staging): both operands K-major in LDS ([k][m] XOR-swizzled, [k][n]),
 //     a fragment read is one conflict-free ds_read_b32 per operand per MFMA; the next tile's global loads are issued
-//     before the current tile's MFMAs and stored to LDS behind them.  Variants kept for A/B: QUAD (k-quad tiles,
-//     ds_read_b128 fragments), PF = 2 (loads two tiles ahead).
+//     before the current tile's MFMAs and stored to LDS behind them.  (The k-quad LDS layouts, the loads two tiles ahead and the
+//     quad weight-gradient kernel of rounds 2-4 lost every A/B they were in and were removed in round 5: profiles/NOTES_r01_r02.md.)
 //   * igemm_nng_kernel / igemm_tng_kernel (LDS-direct loads, buffer_load_dwordx4 ... lds): the default where the
 //     geometry allows (round 2: the ablation builds below located the loop's loss in the register -> LDS staging).
 #include "common.h"
@@ -43,11 +43,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;
-// Ablation builds (scripts/build_exp.sh, timing only - results are garbage): -DCG_EXP=<bits> removes from the K loop of
-// igemm_nn_kernel 1 = the global loads, 2 = the LDS stores, 4 = the barriers, 8 = the MFMAs.
-#ifndef CG_EXP
-#define CG_EXP 0
-#endif
 constexpr unsigned OOB = 0x80000000u;
 // -DCG_TRACE (scripts/build_exp.sh trace): every igemm_nn_kernel workgroup records 100 MHz timestamps at its start, behind
 // the prologue (first tile in LDS), behind the K loop and at its end, plus the hardware id of the CU it ran on, into the
@@ -226,25 +221,9 @@ __device__ __forceinline__ void nn_store_lean(const f32x16 (&acc)[MI][NI], const
 // NN: Y[m][n] = sum_k A(m,k) * W[k][n]
 // ---------------------------------------------------------------------------
 //
-// QUAD (FAST && VECB only): the LDS tiles hold k QUADS - As[k/4][m][4], Bs[k/4][n][4] - so that one ds_read_b128 hands a
-// lane its operand values of FOUR MFMA steps (the kernel above reads one ds_read_b32 per operand per step and waits for
-// it: the ISA showed `ds_read2_b32 ; s_waitcnt lgkmcnt(0) ; 2 x v_mfma` sixteen times per K tile, i.e. the LDS latency
-// exposed once per 128 MFMA cycles).  Within a group of 8 k the half-wave h = lane / 32 takes quad h, MFMA step s
-// multiplies A[m][8g + 4h + s] with B[8g + 4h + s][n] - a permutation of the k order, the same for both operands.
-//   A: the gathered float4 (4 consecutive channels of a pixel) IS a quad: one ds_write_b128 instead of four transposed
-//      ds_write_b32; slot (kq, m ^ swz(kq)) keeps the 8 lanes of a store group (8 quads of one pixel, or 4 quads of two)
-//      on 8 distinct 16-byte bank slots, and a fragment read (16 lanes = 16 rows at fixed kq) a permutation of all 16.
-//   B: a thread loads the 4 x 4 block (rows 4kq..4kq+3, columns n..n+3) and stores its register transpose as four
-//      quads; slot (kq, n ^ ((n >> 3) & 3)) does the same for the weights.
-//
-// PF = 2: the global loads run TWO K tiles ahead of the MFMAs (two sets of staging registers; tile t + 2 is requested at the
-// start of tile t and stored to LDS at the end of tile t + 1).  The per-workgroup timeline (scripts/wg_trace.py) showed the K
-// loop at 74 % of its MFMA time with two workgroups per CU and 58 % with one: a K tile's MFMAs last 0.85 us, less than a
-// load that misses the XCD's L2, so with a distance of one tile every wave waited for its loads once per tile.
-template <int BM, int BN, int WM, int WN, bool FAST, bool VECB, int BK, bool QUAD = false, int PF = 1>
-__global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void igemm_nn_kernel(NNArgs a) {
+template <int BM, int BN, int WM, int WN, bool FAST, bool VECB, int BK>
+__global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(!QUAD || (FAST && VECB), "the quad layout exists for the buffer-load path only");
     constexpr int MI = BM / WM / 32;
     constexpr int NI = BN / WN / 32;
     static_assert(MI >= 1 && NI >= 1, "wave tile >= 32x32");
@@ -259,9 +238,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void i
     static_assert(BM % ARPP == 0 && AROWS >= 1, "BM multiple of rows-per-pass");
     constexpr int NVEC = BN / 4;
     constexpr int BRPP = 256 / NVEC;  // B rows per pass
-    constexpr int BPASS = QUAD ? 4 : (BK + BRPP - 1) / BRPP;
-    constexpr int NBLK = KV * NVEC;   // QUAD: 4 x 4 blocks of the B tile, one per thread of the first NBLK threads
-    static_assert(!QUAD || NBLK <= 256, "one B block per thread");
+    constexpr int BPASS = (BK + BRPP - 1) / BRPP;
 
     __shared__ __attribute__((aligned(16))) float smem[2 * A_TILE + 2 * B_TILE];
     float* As = smem;
@@ -307,11 +284,10 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void i
         r_oy[p] = oy; r_ox[p] = ox;
         rowb[p] = ((n * g.Hs + oy * g.td.ss) * g.Ws + ox * g.td.ss) * g.Cin;
     }
-    const int b_nv = tid % NVEC, b_kr = tid / NVEC;   // QUAD: b_kr is the k quad of the thread's 4 x 4 block
-    const bool b_on = !QUAD || tid < NBLK;
+    const int b_nv = tid % NVEC, b_kr = tid / NVEC;
 
-    float4 aregs[PF][AROWS];
-    float4 bregs[PF][BPASS];
+    float4 areg[AROWS];
+    float4 breg[BPASS];
 
     // ---- FAST-path state -------------------------------------------------------------------------------
     unsigned long long cur[AROWS];     // tap-validity mask of each row, shifted so bit 0 = next tile's tap
@@ -358,30 +334,25 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void i
         rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wph, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int q = 0; q < BPASS; ++q) {
-            const int kr = QUAD ? 4 * b_kr + q : b_kr + q * BRPP;
+            const int kr = b_kr + q * BRPP;
             const int n = n0 + 4 * b_nv;
-            bvoff[q] = (b_on && kr < BK && n < g.Cout) ? (unsigned)(kr * g.Cout + n) * 4u : OOB;
+            bvoff[q] = (kr < BK && n < g.Cout) ? (unsigned)(kr * g.Cout + n) * 4u : OOB;
         }
     }
 
-    // live == false (PF == 2 only: a tile behind the last one): the loads are still issued, at the out-of-range offset that
-    // returns 0 - the K loop then has no branch around its loads and the compiler's vmcnt bookkeeping stays exact (with a
-    // conditional load it waited for the newest tile's loads before storing the older one, which undid the prefetch)
-    auto load_tile = [&](int k0, auto setc, bool live = true) {
-        float4 (&areg)[AROWS] = aregs[decltype(setc)::value];
-        float4 (&breg)[BPASS] = bregs[decltype(setc)::value];
+    auto load_tile = [&](int k0) {
         if (FAST) {
             // (tapi, ci0, toff) describe this tile; all SGPR arithmetic
-            const int soff = live ? (toff - minoff + ci0) * 4 : 0;
+            const int soff = (toff - minoff + ci0) * 4;
 #pragma unroll
             for (int p = 0; p < AROWS; ++p) {
-                const unsigned voff = (live && ((unsigned)cur[p] & 1u)) ? rowbytes[p] : OOB;
+                const unsigned voff = ((unsigned)cur[p] & 1u) ? rowbytes[p] : OOB;
                 areg[p] = bufld4(rsx, voff, soff);
             }
             if (VECB) {
-                const int sb = live ? k0 * g.Cout * 4 : 0;
+                const int sb = k0 * g.Cout * 4;
 #pragma unroll
-                for (int q = 0; q < BPASS; ++q) breg[q] = bufld4(rsw, live ? bvoff[q] : OOB, sb);
+                for (int q = 0; q < BPASS; ++q) breg[q] = bufld4(rsw, bvoff[q], sb);
             }
             ci0 += BK;
             if (ci0 >= g.Cin) {
@@ -440,50 +411,10 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void i
 
     // the LDS double-buffer index is a compile-time constant everywhere (the K loop is unrolled by two), so that every
     // ds_read / ds_write address is a loop-invariant register plus an immediate offset - no address VALU in the loop
-    // QUAD: loop-invariant slot indices (16-byte units) of the stores and of the fragment reads
-    int qa_st[AROWS], qb_st[4], qa_rd[KV / 2 > 0 ? KV / 2 : 1], qb_rd = 0;
-    if (QUAD) {
-        constexpr int SH = KV == 8 ? 0 : 1;   // 8 quads of one pixel per store group, or 4 quads of two pixels
-#pragma unroll
-        for (int p = 0; p < AROWS; ++p) qa_st[p] = a_kv * BM + ((a_r + ARPP * p) ^ ((a_kv & 7) << SH));
-        const int sb = (b_nv >> 1) & 3;       // ((4 b_nv + i) >> 3) & 3
-#pragma unroll
-        for (int i = 0; i < 4; ++i) qb_st[i] = b_kr * BN + 4 * b_nv + (i ^ sb);
-#pragma unroll
-        for (int gq = 0; gq < KV / 2; ++gq) {
-            const int kq = 2 * gq + h;
-            qa_rd[gq] = kq * BM + wm0 + (l31 ^ ((kq & 7) << SH));
-        }
-        qb_rd = h * BN + wn0 + (l31 ^ ((l31 >> 3) & 3));
-    }
-
-    auto store_tile = [&](auto bufc, auto setc) {
+    auto store_tile = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        float4 (&areg)[AROWS] = aregs[decltype(setc)::value];
-        float4 (&breg)[BPASS] = bregs[decltype(setc)::value];
         float* A = As + buf * A_TILE;
         float* B = Bs + buf * B_TILE;
-        if (QUAD) {
-            float4* A4 = reinterpret_cast<float4*>(A);
-            float4* B4 = reinterpret_cast<float4*>(B);
-#pragma unroll
-            for (int p = 0; p < AROWS; ++p) A4[qa_st[p]] = areg[p];
-            // pin the 16 loaded values HERE: without it the register coalescer builds the transposed quads with moves
-            // right behind the buffer loads, i.e. waits for the global loads before the tile's MFMAs instead of after
-            float4 tb4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                tb4[q] = breg[q];
-                asm volatile("" : "+v"(tb4[q].x), "+v"(tb4[q].y), "+v"(tb4[q].z), "+v"(tb4[q].w));
-            }
-            if (NBLK == 256 || b_on) {
-                B4[qb_st[0]] = make_float4(tb4[0].x, tb4[1].x, tb4[2].x, tb4[3].x);
-                B4[qb_st[1]] = make_float4(tb4[0].y, tb4[1].y, tb4[2].y, tb4[3].y);
-                B4[qb_st[2]] = make_float4(tb4[0].z, tb4[1].z, tb4[2].z, tb4[3].z);
-                B4[qb_st[3]] = make_float4(tb4[0].w, tb4[1].w, tb4[2].w, tb4[3].w);
-            }
-            return;
-        }
 #pragma unroll
         for (int p = 0; p < AROWS; ++p) {
             const int rs = (a_r + ARPP * p) ^ a_swizzle<BK>(a_kv);
@@ -507,59 +438,17 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    using Set0 = std::integral_constant<int, 0>;
     CG_STAMP(6);   // trace builds: end of the integer set-up (tile origin, tap-validity masks, descriptors)
     if (T > 0) {
-        load_tile(ks, Set0{});
-        store_tile(std::integral_constant<int, 0>{}, Set0{});
-        if (PF == 2) load_tile(ks + BK, std::integral_constant<int, PF - 1>{}, T > 1);
+        load_tile(ks);
+        store_tile(std::integral_constant<int, 0>{});
     }
     __syncthreads();
     CG_STAMP(1);
 
     auto k_tile = [&](auto bufc, int t) {
         constexpr int buf = decltype(bufc)::value;
-        // PF == 1: request tile t + 1 into the only register set; PF == 2: request tile t + 2 into set `buf` (its previous
-        // content, tile t, went to LDS one tile ago) - tile t + 1 waits in set buf ^ 1 for the store at the end of this tile
-        using LoadSet = std::integral_constant<int, PF == 2 ? buf : 0>;
-        using StoreSet = std::integral_constant<int, PF == 2 ? (buf ^ 1) : 0>;
-        if (PF == 2) load_tile(ks + (t + PF) * BK, LoadSet{}, t + PF < T);
-        else if (!(CG_EXP & 1) && t + PF < T) load_tile(ks + (t + PF) * BK, LoadSet{});
-        if (QUAD) {
-            const float4* A4 = reinterpret_cast<const float4*>(As + buf * A_TILE);
-            const float4* B4 = reinterpret_cast<const float4*>(Bs + buf * B_TILE);
-            constexpr int G2 = KV / 2;
-            // hand-placed schedule (sched_barrier(0) = nothing crosses): the fragments of group g + 2 are requested before
-            // the 4 MI NI MFMAs of group g are issued, so a wave waits for the LDS once per K tile (for groups 0 / 1 behind
-            // the barrier) instead of once per MFMA pair; the transposing moves of the B store stay behind the MFMAs
-            float4 af[G2][MI], bf[G2][NI];
-            auto frag = [&](int gq) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[gq][i] = A4[qa_rd[gq] + i * 32];
-#pragma unroll
-                for (int j = 0; j < NI; ++j) bf[gq][j] = B4[qb_rd + gq * 2 * BN + j * 32];
-            };
-            __builtin_amdgcn_sched_barrier(0);
-            frag(0);
-            if (G2 > 1) frag(1);
-#pragma unroll
-            for (int gq = 0; gq < G2; ++gq) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (gq + 2 < G2) frag(gq + 2);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int sidx = 0; sidx < 4; ++sidx)
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int j = 0; j < NI; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af[gq][i], sidx), f4c(bf[gq][j], sidx), acc[i][j], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < T) store_tile(std::integral_constant<int, buf ^ 1>{}, StoreSet{});
-            __syncthreads();
-            return;
-        }
+        if (t + 1 < T) load_tile(ks + (t + 1) * BK);   // tile t + 1 into the staging registers, stored to LDS behind this tile's MFMAs
         const float* A = As + buf * A_TILE + wm0;
         const float* B = Bs + buf * B_TILE + wn0 + l31;
 #pragma unroll
@@ -572,23 +461,11 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void i
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    if (CG_EXP & 8) { asm volatile("" :: "v"(av[i]), "v"(bv[j])); continue; }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (!(CG_EXP & 2) && t + 1 < T) store_tile(std::integral_constant<int, buf ^ 1>{}, StoreSet{});
-        if (!(CG_EXP & 4)) __syncthreads();
-        else asm volatile("" ::: "memory");
+        if (t + 1 < T) store_tile(std::integral_constant<int, buf ^ 1>{});
+        __syncthreads();
     };
-    if (PF == 2) {   // whole pairs first, then the odd tile: no branch between the two halves of the loop body
-        int t = 0;
-        for (; t + 1 < T; t += 2) {
-            k_tile(std::integral_constant<int, 0>{}, t);
-            k_tile(std::integral_constant<int, 1>{}, t + 1);
-        }
-        if (t < T) k_tile(std::integral_constant<int, 0>{}, t);
-    } else
     for (int t = 0; t < T; t += 2) {
         k_tile(std::integral_constant<int, 0>{}, t);
         if (t + 1 < T) k_tile(std::integral_constant<int, 1>{}, t + 1);
@@ -670,7 +547,7 @@ __global__ __launch_bounds__(256, (BK == 16 && !QUAD && PF == 1) ? 4 : 2) void i
 //      consecutive bytes.  A lane whose tap falls into the padding asks for the out-of-range offset and its quad is
 //      written as zeros (checked on the hardware: tools/glds_test.hip).
 //   B: [k][n] as in igemm_nn_kernel (a wave instruction = 64 / (BN/4) consecutive weight rows), ds_read_b32 fragments.
-// MFMA step (g, s) multiplies A[m][8g + 4h + s] with B[8g + 4h + s][n] (h = lane / 32), the k order of the QUAD kernels.
+// MFMA step (g, s) multiplies A[m][8g + 4h + s] with B[8g + 4h + s][n] (h = lane / 32).
 // FAST && VECB geometries only (Cin % BK == 0, 16-byte aligned operands, Cout % 4 == 0); prologue and epilogue as above.
 // ---------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int BK>
@@ -1250,246 +1127,12 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// TN with quad LDS tiles (see the QUAD note above igemm_nn_kernel): the reduction index is the pixel, so a quad is
-// 4 consecutive PIXELS of one column - As[p/4][k][4], Bs[p/4][n][4].  A thread loads a 4 x 4 block (4 pixel rows x one
-// float4 of channels) per operand and stores its register transpose as four ds_write_b128; a fragment read is one
-// ds_read_b128 per operand per FOUR MFMA steps.  Only the lean addressing of igemm_tn_kernel is implemented (the host
-// checks): 16-byte aligned channel quads, a source tensor with the grid's geometry, a reduction range of whole K tiles,
-// and either a power-of-two grid with HWg >= BKT (a K tile never straddles two images) or a 1 x 1 kernel without padding
-// (`flat`: every row is valid and rows are simply consecutive - the linear layers and the Winograd-domain GEMMs).
-// ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int BKT>
-__global__ __launch_bounds__(256, 2) void igemm_tnq_kernel(TNArgs a, int flat) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    constexpr int MI = BM / WM / 32;
-    constexpr int NI = BN / WN / 32;
-    constexpr int PQ = BKT / 4, G2 = PQ / 2;
-    constexpr int AVEC = BM / 4, BVEC = BN / 4;
-    constexpr int NA = PQ * AVEC, NB = PQ * BVEC;     // 4 x 4 blocks per operand tile
-    static_assert(NA <= 256 && NB <= 256, "one block per thread and operand");
-    constexpr bool SPLIT_THREADS = NA + NB <= 256;    // disjoint thread ranges stage A and B
-    constexpr int A_TILE = BKT * BM, B_TILE = BKT * BN;
-
-    __shared__ __attribute__((aligned(16))) float smem[2 * A_TILE + 2 * B_TILE];
-    float* As = smem;
-    float* Bs = smem + 2 * A_TILE;
-
-    const Geom& g = a.g;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm0 = (wave / WN) * (BM / WM);
-    const int wn0 = (wave % WN) * (BN / WN);
-
-    const int ntn = (g.Cout + BN - 1) / BN;
-    int bid = blockIdx.x, split = blockIdx.y;
-    if ((a.xcd_swizzle & 2) && (gridDim.y & 7) == 0) {   // XCD = pixel chunk, see igemm_tn_kernel
-        const int L = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, s8 = (int)gridDim.y >> 3;
-        split = (L & 7) + 8 * ((L >> 3) % s8);
-        bid = (L >> 3) / s8;
-    } else if ((a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) {
-        bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-    }
-    const int tn = ntn == 1 ? 0 : bid % ntn, tm = ntn == 1 ? bid : bid / ntn;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int zz = blockIdx.z;
-    const int group = g.nphase == 1 ? zz : (g.nphase == 4 ? zz >> 2 : zz / g.nphase);
-    const int phase = zz - group * g.nphase, pa = phase >> 1, pb = phase & 1;
-    const float* gx = a.xgs ? a.x0 + (long)group * a.xgs : sel4(group, a.x0, a.x1, a.x2, a.x3);
-    const float* gdy = a.dgs ? a.d0 + (long)group * a.dgs : sel4(group, a.d0, a.d1, a.d2, a.d3);
-    const int ps = split * a.pchunk;
-    const int pend = min(g.M, ps + a.pchunk);
-    const int T = (pend - ps) / BKT;
-
-    // ---- staging: thread -> (pixel quad, column quad) of each operand
-    const bool a_on = tid < NA;
-    const int tb = SPLIT_THREADS ? tid - NA : tid;
-    const bool b_on = tb >= 0 && tb < NB;
-    const int a_cq = tid % AVEC, a_pq = tid / AVEC;
-    const int b_cq = (b_on ? tb : 0) % BVEC, b_pq = (b_on ? tb : 0) / BVEC;
-    const bool lin_out = g.so == 1 && g.nphase == 1;
-    const int HWg = g.Hg * g.Wg;
-
-    int l_minoff = 0, c_ty = 0, c_tx = 0, c_off = 0;
-    bool c_ok;
-    {
-        const int mm = m0 + 4 * a_cq;
-        c_ok = a_on && mm < g.Ktot;
-        const int mc = c_ok ? mm : 0;
-        const int tap = mc / g.Cin;
-        int off;
-        tap_decode(g, tap, pa, pb, c_ty, c_tx, off);
-        c_off = off + (mc - tap * g.Cin);
-        l_minoff = sel4(phase, g.minoff0, g.minoff1, g.minoff2, g.minoff3);   // host-computed (finish_geom)
-    }
-    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(gx + l_minoff), 0, 0x7fffffff, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)gdy, 0, 0x7fffffff, 0x00020000);
-    const bool b_nok = b_on && n0 + 4 * b_cq < g.Cout;
-    int l_ay[4], l_ax[4];
-    unsigned l_avoff[4], l_bvoff[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int kra = 4 * a_pq + q, krb = 4 * b_pq + q;
-        const bool wide = flat || g.Wg >= BKT;
-        const int kyo = wide ? 0 : (kra >> g.lgW), kxo = flat ? 0 : (wide ? kra : (kra & (g.Wg - 1)));
-        l_ay[q] = kyo + c_ty;
-        l_ax[q] = kxo + c_tx;
-        l_avoff[q] = c_ok ? (unsigned)(kra * g.Cin + c_off - l_minoff) * 4u : OOB;
-        const int byo = wide ? 0 : (krb >> g.lgW), bxo = wide ? krb : (krb & (g.Wg - 1));
-        const int rel = lin_out ? krb * g.Cout : (byo * g.so * g.Wout + bxo * g.so) * g.Cout;
-        l_bvoff[q] = b_nok ? (unsigned)(rel + n0 + 4 * b_cq) * 4u : OOB;
-    }
-
-    float4 areg[4], breg[4];
-    const bool do_bias = a.bias_part != nullptr && tm == 0;
-    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    auto load_tile = [&](int p0) {
-        const int r0 = flat ? 0 : (p0 & (HWg - 1));
-        const int oyb = flat ? 0 : (r0 >> g.lgW), oxb = flat ? 0 : (r0 & (g.Wg - 1));
-        const int soa = p0 * g.Cin * 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool ok = (unsigned)(oyb + l_ay[q]) < (unsigned)g.Hv && (unsigned)(oxb + l_ax[q]) < (unsigned)g.Wv;
-            areg[q] = bufld4(rsx, ok ? l_avoff[q] : OOB, soa);
-        }
-        int sob;
-        if (lin_out) sob = p0 * g.Cout * 4;
-        else {
-            const int nimg = p0 >> g.lgHW;
-            sob = (((nimg * g.Hout + oyb * g.so + pa) * g.Wout + oxb * g.so + pb) * g.Cout) * 4;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) breg[q] = bufld4(rsd, l_bvoff[q], sob);
-    };
-
-    // loop-invariant slot indices (16-byte units): column c of pixel quad pq lives at pq * LD + (c ^ ((c >> 3) & 3))
-    int qa_st[4], qb_st[4];
-    {
-        const int sa = (a_cq >> 1) & 3, sb = (b_cq >> 1) & 3;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            qa_st[i] = a_pq * BM + 4 * a_cq + (i ^ sa);
-            qb_st[i] = b_pq * BN + 4 * b_cq + (i ^ sb);
-        }
-    }
-    const int lsw = l31 ^ ((l31 >> 3) & 3);
-    const int qa_rd = h * BM + wm0 + lsw, qb_rd = h * BN + wn0 + lsw;
-
-    auto store_tile = [&](auto bufc) {
-        constexpr int buf = decltype(bufc)::value;
-        float4* A4 = reinterpret_cast<float4*>(As + buf * A_TILE);
-        float4* B4 = reinterpret_cast<float4*>(Bs + buf * B_TILE);
-        // pin the loaded values here (see igemm_nn_kernel): the transposing moves must not drag the wait for the global loads
-        // in front of the MFMAs
-        float4 ta[4], tb4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ta[q] = areg[q]; tb4[q] = breg[q];
-            asm volatile("" : "+v"(ta[q].x), "+v"(ta[q].y), "+v"(ta[q].z), "+v"(ta[q].w));
-            asm volatile("" : "+v"(tb4[q].x), "+v"(tb4[q].y), "+v"(tb4[q].z), "+v"(tb4[q].w));
-        }
-        if (NA == 256 || a_on) {
-            A4[qa_st[0]] = make_float4(ta[0].x, ta[1].x, ta[2].x, ta[3].x);
-            A4[qa_st[1]] = make_float4(ta[0].y, ta[1].y, ta[2].y, ta[3].y);
-            A4[qa_st[2]] = make_float4(ta[0].z, ta[1].z, ta[2].z, ta[3].z);
-            A4[qa_st[3]] = make_float4(ta[0].w, ta[1].w, ta[2].w, ta[3].w);
-        }
-        if (NB == 256 || b_on) {
-            B4[qb_st[0]] = make_float4(tb4[0].x, tb4[1].x, tb4[2].x, tb4[3].x);
-            B4[qb_st[1]] = make_float4(tb4[0].y, tb4[1].y, tb4[2].y, tb4[3].y);
-            B4[qb_st[2]] = make_float4(tb4[0].z, tb4[1].z, tb4[2].z, tb4[3].z);
-            B4[qb_st[3]] = make_float4(tb4[0].w, tb4[1].w, tb4[2].w, tb4[3].w);
-            if (do_bias) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { bsum.x += tb4[q].x; bsum.y += tb4[q].y; bsum.z += tb4[q].z; bsum.w += tb4[q].w; }
-            }
-        }
-    };
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    if (T > 0) {
-        load_tile(ps);
-        store_tile(std::integral_constant<int, 0>{});
-    }
-    __syncthreads();
-
-    auto k_tile = [&](auto bufc, int t) {
-        constexpr int buf = decltype(bufc)::value;
-        if (t + 1 < T) load_tile(ps + (t + 1) * BKT);
-        const float4* A4 = reinterpret_cast<const float4*>(As + buf * A_TILE);
-        const float4* B4 = reinterpret_cast<const float4*>(Bs + buf * B_TILE);
-        float4 af[G2][MI], bf[G2][NI];
-        auto frag = [&](int gq) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[gq][i] = A4[qa_rd + gq * 2 * BM + i * 32];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bf[gq][j] = B4[qb_rd + gq * 2 * BN + j * 32];
-        };
-        __builtin_amdgcn_sched_barrier(0);
-        frag(0);
-        if (G2 > 1) frag(1);
-#pragma unroll
-        for (int gq = 0; gq < G2; ++gq) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (gq + 2 < G2) frag(gq + 2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af[gq][i], sidx), f4c(bf[gq][j], sidx), acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < T) store_tile(std::integral_constant<int, buf ^ 1>{});
-        __syncthreads();
-    };
-    for (int t = 0; t < T; t += 2) {
-        k_tile(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < T) k_tile(std::integral_constant<int, 1>{}, t + 1);
-    }
-
-    if (do_bias) {  // all waves are past the loop's final barrier: reuse the A tile as scratch
-        float* red = smem;
-        if (b_on) *reinterpret_cast<float4*>(red + b_pq * BN + 4 * b_cq) = bsum;
-        __syncthreads();
-        if (tid < BN && n0 + tid < g.Cout) {
-            float t = 0.f;
-#pragma unroll
-            for (int r = 0; r < PQ; ++r) t += red[r * BN + tid];
-            a.bias_part[(long)(split * (a.ngroups * g.nphase) + zz) * g.Cout + n0 + tid] = t;
-        }
-    }
-    float* pout = a.part + (long)(split * (a.ngroups * g.nphase) + zz) * g.Ktot * g.Cout;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn0 + j * 32 + l31;
-        if (n >= g.Cout) continue;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < g.Ktot) pout[(long)m * g.Cout + n] = acc[i][j][r];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // TN with LDS-direct loads (see igemm_nng_kernel): both operands are pixel rows of consecutive channels, i.e. already the
 // K-major [pixel][column] tiles the MFMA fragments are read from, so a wave instruction simply drops 64 / (BM / 4) pixel
 // rows of 4 BM bytes into place (no swizzle, ds_read_b32 fragments exactly as in igemm_tn_kernel).  Lean addressing only
-// (the host checks, tnq_kstep): power-of-two grid with HWg >= 16 or the flat rows of a 1 x 1 kernel, whole K tiles.
+// (the host checks, tng_ok): 16-byte aligned channel quads, a source tensor with the grid's geometry, a reduction range of whole K
+// tiles, and either a power-of-two grid with HWg >= 16 (a K tile never straddles two images) or a 1 x 1 kernel without padding
+// (`flat`: every row is valid and rows are simply consecutive - the linear layers and the Winograd-domain GEMMs).
 // ---------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int flat) {
@@ -2228,12 +1871,6 @@ static int pick_splits(long tiles, long kiters) {
 template <int BM, int BN, int WM, int WN>
 static void launch_nn(const NNArgs& a, dim3 grid, hipStream_t st, bool fast, bool vecb, bool bk32) {
     if (fast && vecb) {
-        const long quad = cg::opt(cg::OPT_NN_QUAD);   // 0 off, 1 on with the K steps of the b32 kernels, 2 K step 32 wherever it divides
-        if (quad) {
-            if (bk32 && (BM == 64 || quad >= 2)) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, 32, true>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, 16, true>), grid, dim3(256), 0, st, a);
-            return;
-        }
         // LDS-direct loads (igemm_nng_kernel).  CG_NN_GLDS = 1: the 64-row tiles at K step 32 (a pixel's 128 consecutive
         // bytes per 8 lanes; measured inside the replayed step 2.43 -> 1.91 ms for the 64x128 tile), 2: K step 32 for every
         // tile whose Cin allows it, 3: K step 16 as well (64-byte runs per pixel: slower than the register path in the step)
@@ -2244,11 +1881,6 @@ static void launch_nn(const NNArgs& a, dim3 grid, hipStream_t st, bool fast, boo
         }
         if (glds >= 3) {
             hipLaunchKernelGGL((igemm_nng_kernel<BM, BN, WM, WN, 16>), grid, dim3(256), 0, st, a);
-            return;
-        }
-        if (cg::opt(cg::OPT_NN_PF) >= 2) {   // global loads two K tiles ahead
-            if (BM == 64 && bk32) hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, (BM == 64 ? 32 : 16), false, 2>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nn_kernel<BM, BN, WM, WN, true, true, 16, false, 2>), grid, dim3(256), 0, st, a);
             return;
         }
         // 64-row tiles do only 8-16 MFMAs per wave per K step of 16: give them 32 so the per-tile work
@@ -2269,34 +1901,20 @@ static void launch_tn(const TNArgs& a, dim3 grid, hipStream_t st, bool veca, boo
     else hipLaunchKernelGGL((igemm_tn_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, a);
 }
 
-// quad-tile weight-gradient kernel (igemm_tnq_kernel): 0 = not eligible, else the K step (pixels per tile)
-static int tnq_kstep(const Geom& g, int pchunk, bool veca, bool vecb) {
-    long mode = cg::opt(cg::OPT_TN_QUAD);
-    const bool glds = cg::opt(cg::OPT_TN_GLDS) != 0;   // igemm_tng_kernel: same eligibility at K step 16; returns -16
-    if (glds) mode = 1;
-    if (!mode || !veca || !vecb) return 0;
+// LDS-direct weight-gradient kernel (igemm_tng_kernel, K step 16): lean addressing only
+static bool tng_ok(const Geom& g, int pchunk, bool veca, bool vecb) {
+    if (!cg::opt(cg::OPT_TN_GLDS) || !veca || !vecb) return false;
     const bool lin_src = g.td.ss == 1 && g.Hs == g.Hg && g.Ws == g.Wg;
     const bool lin_out = g.so == 1 && g.nphase == 1;
-    if (!lin_src) return 0;
+    if (!lin_src || g.M % 16 || pchunk % 16) return false;
     const bool flat = g.ntaps == 1 && g.td.r0y0 == 0 && g.td.r0x0 == 0 && lin_out;
-    const int HWg = g.Hg * g.Wg;
-    for (int bkt = (mode >= 2 ? 32 : 16); bkt >= 16; bkt >>= 1) {
-        if (g.M % bkt || pchunk % bkt) continue;
-        if (flat || (g.lgW >= 0 && g.lgHW >= 0 && HWg >= bkt && (lin_out || g.so == 2))) return glds ? -bkt : bkt;
-    }
-    return 0;
+    return flat || (g.lgW >= 0 && g.lgHW >= 0 && g.Hg * g.Wg >= 16 && (lin_out || g.so == 2));
 }
-static bool tnq_flat(const Geom& g) { return g.ntaps == 1 && g.td.r0y0 == 0 && g.td.r0x0 == 0 && g.so == 1 && g.nphase == 1; }
+static bool tng_flat(const Geom& g) { return g.ntaps == 1 && g.td.r0y0 == 0 && g.td.r0x0 == 0 && g.so == 1 && g.nphase == 1; }
 
 template <int BM, int BN, int WM, int WN>
-static void launch_tnq(const TNArgs& a, dim3 grid, hipStream_t st, int bkt) {
-    const int flat = tnq_flat(a.g) ? 1 : 0;
-    if (bkt < 0) {   // LDS-direct loads, K step 16
-        hipLaunchKernelGGL((igemm_tng_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, a, flat);
-        return;
-    }
-    if (bkt == 32) hipLaunchKernelGGL((igemm_tnq_kernel<BM, BN, WM, WN, 32>), grid, dim3(256), 0, st, a, flat);
-    else hipLaunchKernelGGL((igemm_tnq_kernel<BM, BN, WM, WN, 16>), grid, dim3(256), 0, st, a, flat);
+static void launch_tng(const TNArgs& a, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((igemm_tng_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, a, tng_flat(a.g) ? 1 : 0);
 }
 
 static int ilog2_exact(int v) {
@@ -2416,7 +2034,6 @@ static TNPlan plan_tn(const Geom& g, int ngroups) {
     else
     while (tiles * s < (long)tgt * cg::kNumCU && piters / (s * 2) >= 8 && s < smax) s *= 2;
     p.pchunk = cg::cdiv(piters, s) * BK;
-    if (cg::opt(cg::OPT_TN_QUAD) >= 2) p.pchunk = cg::cdiv(p.pchunk, 32) * 32;   // whole K tiles of 32 pixels
     p.splits = cg::cdiv(g.M, p.pchunk);
     return p;
 }
@@ -2503,7 +2120,7 @@ static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const
         CG_REQUIRE(ngroups == 1 && p.splits == 1, "%s: epilogue statistics need a single-group, unsplit launch", who);
         a.stats = ep->stats;
     }
-    const bool fast = (g.Cin % BK == 0) && al && cg::opt(cg::OPT_GEMM_SLOW) == 0;
+    const bool fast = (g.Cin % BK == 0) && al;
     const bool vecb = (g.Cout % 4 == 0) && alw;
     const bool bk32 = cg::opt(cg::OPT_GEMM_BK32) != 0 && (g.Cin % 32 == 0) && (p.kchunk % 32 == 0);
     dim3 grid(cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, g.nphase * ngroups);
@@ -2617,12 +2234,21 @@ int cg_conv2d_dgrad_ups2(void* stream, const float* dy, const float* wb_ph, floa
     return run_nn(cg::S(stream), g, 1, &dy, &wb_ph, nullptr, &dx_lo, ws, ws_bytes, "cg_conv2d_dgrad_ups2");
 }
 
-size_t cg_conv2d_wgrad_workspace_bytes_grouped(int ngroups, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW,
-                                               int padH, int padW, int ups) {
+static size_t wgrad_ws_bytes_groups(int ngroups, int maxg, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups) {
     Geom g;
-    if (ngroups < 1 || ngroups > kMaxStridedGroups || conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;   // > MAXG: cg_conv2d_wgrad_strided
+    if (ngroups < 1 || ngroups > maxg || conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
     const size_t reg = tn_ws_bytes(g, plan_tn(g, ngroups), ngroups);
     return skinny_ok(ngroups, Cin, Cout, kH, kW, padH, padW, ups) ? std::max(reg, skinny_wgrad_ws_bytes(Cin, Cout)) : reg;
+}
+// The size query doubles as the capability check of the entry point it belongs to (0 = this launch does not exist): <= MAXG groups of
+// separate tensors for cg_conv2d_wgrad_grouped / _deferred, <= kMaxStridedGroups equally spaced ones for cg_conv2d_wgrad_strided.
+size_t cg_conv2d_wgrad_workspace_bytes_grouped(int ngroups, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW,
+                                               int padH, int padW, int ups) {
+    return wgrad_ws_bytes_groups(ngroups, MAXG, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups);
+}
+size_t cg_conv2d_wgrad_workspace_bytes_strided(int ngroups, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW,
+                                               int padH, int padW, int ups) {
+    return wgrad_ws_bytes_groups(ngroups, kMaxStridedGroups, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups);
 }
 size_t cg_conv2d_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW,
                                        int ups) {
@@ -2634,13 +2260,10 @@ namespace {
 std::mutex g_red_mu;
 std::unordered_map<hipStream_t, std::vector<RedJob>> g_red_queue;
 
-// workgroups of a partial-sum reduction launch: CG_RED_WGS_PER_CU per CU, default 0 = one workgroup per 32-element block.  Unlike the
-// grid-stride element-wise kernels (cg::ew_grid) these do NOT gain from fewer, longer-lived workgroups: same box 6.32 (0) / 6.38 (8) /
-// 6.40 (32) ms per step - a block is a short dependent chain (strided partial loads -> LDS -> one add), so walking blocks serialises latency
-long red_cap() {
-    static const long per_cu = [] { const char* e = getenv("CG_RED_WGS_PER_CU"); return e ? atol(e) : 0L; }();
-    return per_cu > 0 ? per_cu * cg::kNumCU : 0x7fffffffL;
-}
+// Workgroups of a partial-sum reduction launch: one per 32-element block.  Unlike the grid-stride element-wise kernels (cg::ew_grid)
+// these do NOT gain from fewer, longer-lived workgroups (round 4, same box: 6.32 / 6.38 / 6.40 ms per step at 0 / 8 / 32 per CU): a
+// block is a short dependent chain (strided partial loads -> LDS -> one add), so walking blocks serialises latency.
+long red_cap() { return 0x7fffffffL; }
 
 int small_reduce(hipStream_t st, bool defer, const RedJob& job, int ngroups) {
     if (defer) {
@@ -2683,7 +2306,7 @@ int cg_conv2d_wgrad_grouped_deferred(void* stream, int ngroups, const float* con
 // dy + g*dy_stride (floats) and accumulates into gw + g*gw_stride - in one GEMM launch and one reduction.  What the Winograd-domain
 // weight gradient of winograd.hip is: 16 independent [tiles x Cin]^T [tiles x 4 Cout] products, one per transform position
 // (four launches of four groups through cg_conv2d_wgrad_grouped before round 4).  No bias gradients.  Workspace:
-// cg_conv2d_wgrad_workspace_bytes_grouped(ngroups, ...).
+// cg_conv2d_wgrad_workspace_bytes_strided(ngroups, ...).
 int cg_conv2d_wgrad_strided(void* stream, int ngroups, const float* x, long x_stride, const float* dy, long dy_stride, float* gw,
                             long gw_stride, int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups,
                             float scale, void* ws, size_t ws_bytes) {
@@ -2795,13 +2418,12 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
     a.bias_part = any_gb ? (float*)ws + (size_t)p.splits * ZP * wplane : nullptr;
     hipStream_t st = cg::S(stream);
     dim3 grid(cg::cdiv(g.Ktot, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, ZP);
-    const int bkt = tnq_kstep(g, p.pchunk, veca, vecb);
-    if (bkt) {
-        if (p.tc.bm == 128 && p.tc.bn == 128) launch_tnq<128, 128, 2, 2>(a, grid, st, bkt);
-        else if (p.tc.bm == 64 && p.tc.bn == 128) launch_tnq<64, 128, 2, 2>(a, grid, st, bkt);
-        else if (p.tc.bm == 128 && p.tc.bn == 64) launch_tnq<128, 64, 2, 2>(a, grid, st, bkt);
-        else if (p.tc.bm == 64 && p.tc.bn == 64) launch_tnq<64, 64, 2, 2>(a, grid, st, bkt);
-        else launch_tnq<128, 32, 4, 1>(a, grid, st, bkt);
+    if (tng_ok(g, p.pchunk, veca, vecb)) {
+        if (p.tc.bm == 128 && p.tc.bn == 128) launch_tng<128, 128, 2, 2>(a, grid, st);
+        else if (p.tc.bm == 64 && p.tc.bn == 128) launch_tng<64, 128, 2, 2>(a, grid, st);
+        else if (p.tc.bm == 128 && p.tc.bn == 64) launch_tng<128, 64, 2, 2>(a, grid, st);
+        else if (p.tc.bm == 64 && p.tc.bn == 64) launch_tng<64, 64, 2, 2>(a, grid, st);
+        else launch_tng<128, 32, 4, 1>(a, grid, st);
     }
     else if (p.tc.bm == 128 && p.tc.bn == 128) launch_tn<128, 128, 2, 2>(a, grid, st, veca, vecb);
     else if (p.tc.bm == 64 && p.tc.bn == 128) launch_tn<64, 128, 2, 2>(a, grid, st, veca, vecb);
@@ -2818,8 +2440,7 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
     const long relems = (long)KK * Cin * Cout;
     const long sstride = (long)ZP * wplane;                 // floats between consecutive splits
     const int kp = ups ? phase_kp(kH, padH) : 0;
-    static const bool treduce = [] { const char* e = getenv("CG_WGRAD_TREDUCE"); return !e || atoi(e) != 0; }();
-    if (treduce && strided && KK == 1 && !ups && !any_gb && Cin % 32 == 0 && Cout % 32 == 0 && g.nphase == 1) {
+    if (strided && KK == 1 && !ups && !any_gb && Cin % 32 == 0 && Cout % 32 == 0 && g.nphase == 1) {
         hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3(Cin / 32, Cout / 32, ngroups), dim3(256), 0, st, (const float*)ws, gw[0], gws_, Cin, Cout,
                            p.splits, sstride, (long)g.nphase * wplane, scale);
         CG_LAUNCH_CHECK();
@@ -2840,7 +2461,7 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
         job.sstride = sstride; job.gstride = (long)g.nphase * wplane; job.bsstride = (long)ZP * Cout;
         job.wblocks = cg::cdiv(relems, 32); job.bblocks = any_gb ? cg::cdiv(Cout, 32) : 0;
         // a queued KK == 1 job (nn.Linear; D's 20480 -> 256 head is 5.2 M elements = 164 000 32-element blocks) reduces as transpose tiles
-        if (defer && treduce && KK == 1 && !ups && Cin % 32 == 0 && Cout % 32 == 0 && g.nphase == 1) {
+        if (defer && KK == 1 && !ups && Cin % 32 == 0 && Cout % 32 == 0 && g.nphase == 1) {
             job.tr = 1; job.wblocks = (Cin / 32) * (Cout / 32);
         }
         return small_reduce(st, defer, job, ngroups);

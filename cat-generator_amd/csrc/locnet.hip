@@ -419,7 +419,7 @@ __global__ __launch_bounds__(NT) void locnet_bwd_k(LocBwd a) {
 //     sample (global load -> pool -> conv -> conv -> pool -> 2 linear layers -> grid) hide under the others';
 //   * the 16 K3 x 64 linear layer streams its rows as 16-byte loads, 4-8 rows in flight per wave, against register-held input.
 // Buffers, layouts and entry points are unchanged (the weight gradients stay on the GEMM path); sums re-associate within fp32
-// (K-steps of 4 input planes accumulate in tap order).  cg_set_option("CG_LOCNET_V1") / environment CG_LOCNET_V1=1 selects the VALU kernels.
+// (K-steps of 4 input planes accumulate in tap order).  The round-3 VALU kernels remain the fallback for the geometries v2::has() does not list.
 namespace v2 {
 
 constexpr int NW = 4, NT2 = 64 * NW;
@@ -842,18 +842,11 @@ template <int S, int CIN> int launch_bwd(hipStream_t st, const LocBwd& a, int nb
     hipLaunchKernelGGL((locnet_bwd2_k<S, CIN>), dim3(nblk), dim3(NT2), lds, st, a);
     return 0;
 }
-// (16, 64) - the branch transformers of D32_st3 at 64x64 (config #5) - is instantiated and parity-clean but NOT selected: it needs
+// (16, 64) - the branch transformers of D32_st3 at 64x64 (config #5) - was parity-clean in round 4 but is NOT instantiated: it needs
 // 131 / 118 KB of LDS and 260 VGPRs, i.e. one workgroup per CU for 192 samples, and the ten separate (grouped) launches it would
-// replace are faster: config #5 12.67 ms per step without, 12.81 with (profiles/r04_sweeps.txt).  CG_LOCNET_V2_1664=1 selects it.
-inline bool has(int S, int Cin) {
-    static const bool big = [] { const char* e = getenv("CG_LOCNET_V2_1664"); return e && atoi(e) != 0; }();
-    return (S == 16 && Cin == 3) || (S == 8 && Cin == 64) || (big && S == 16 && Cin == 64);
-}
-inline bool enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("CG_LOCNET_V1"); v = (e && atoi(e) != 0) ? 0 : 1; }
-    return v != 0;
-}
+// replace are faster: config #5 12.67 ms per step without, 12.81 with (profiles/r04_sweeps.txt).
+inline bool has(int S, int Cin) { return (S == 16 && Cin == 3) || (S == 8 && Cin == 64); }
+inline bool enabled() { return true; }
 
 }  // namespace v2
 
@@ -891,7 +884,7 @@ int cg_locnet_forward(void* stream, int ngroups, int n_per_group, const float* x
     a.pbuf = pooled; a.h1buf = h1; a.m2buf = m2; a.h2buf = h2; a.h3buf = h3; a.params = params; a.grid = grid;
     if (v2::enabled() && v2::has(S, Cin)) {   // the MFMA kernels (round 4)
         const int nb = ngroups * n_per_group;
-        const int rc = S == 8 ? v2::launch_fwd<8, 64>(cg::S(stream), a, nb) : (Cin == 3 ? v2::launch_fwd<16, 3>(cg::S(stream), a, nb) : v2::launch_fwd<16, 64>(cg::S(stream), a, nb));
+        const int rc = S == 8 ? v2::launch_fwd<8, 64>(cg::S(stream), a, nb) : v2::launch_fwd<16, 3>(cg::S(stream), a, nb);
         if (rc) return rc;
         CG_LAUNCH_CHECK();
         return 0;
@@ -922,7 +915,7 @@ int cg_locnet_backward(void* stream, int ngroups, int n_per_group, const float* 
     a.ga1 = ga1; a.ga2 = ga2; a.g3 = g3; a.g4 = g4; a.gx = gx;
     if (v2::enabled() && v2::has(S, Cin)) {
         const int nb = ngroups * n_per_group;
-        const int rc = S == 8 ? v2::launch_bwd<8, 64>(cg::S(stream), a, nb) : (Cin == 3 ? v2::launch_bwd<16, 3>(cg::S(stream), a, nb) : v2::launch_bwd<16, 64>(cg::S(stream), a, nb));
+        const int rc = S == 8 ? v2::launch_bwd<8, 64>(cg::S(stream), a, nb) : v2::launch_bwd<16, 3>(cg::S(stream), a, nb);
         if (rc) return rc;
         CG_LAUNCH_CHECK();
         return 0;

@@ -223,15 +223,14 @@ struct Net {
     vector<void*> owned;
     vector<Region> regions;
     bool params_dirty = true;
+    int qmap[8] = {-1, 0, 0, 0, 0, 0, 0, 0};  // hardware-queue class of stream index t (ensure_streams)
     bool pack_inflight = false;               // sync_packs forked a re-packing that a LATER pass on another stream may still have to wait for
     int defer_running = 0;                     // run-time switch: batch-norm forwards leave the running statistics to cg_net_apply_running
     bool fresh_allocs = false;                 // library-owned buffers were allocated + zeroed since the last device synchronise
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
-        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_prio = 0, wgrad_lag = 0, wgrad_cu_quarters = 0,
-        wino_dsplit = 1,       // the F(2x2,3x3) data gradient in K slices when its unsplit launch is <= one workgroup per CU (cg_conv2d_ups2_wino_dgrad_split)
-        early_flush = 0;       // 1: the reductions queued on a weight-gradient stream start before the LAST localisation net's four GEMMs, not behind
-                               // them (measured: no difference, 6.00-6.05 ms either way - profiles/r04_sweeps.txt; off)
+        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_lag = 0,
+        wino_dsplit = 1;       // the F(2x2,3x3) data gradient in K slices when its unsplit launch is <= one workgroup per CU (cg_conv2d_ups2_wino_dgrad_split)
     long wino_min_tiles = 2048;
     int wino22 = 3;                            // F(2x2,2x2) for upsample2 -> conv3x3 above wino_min_tiles: bit 0 forward, 1 data gradient, 2 weight gradient
                                                // (option "winograd22"; the weight gradient is 292 -> 257 us alone but no gain in the step: off)
@@ -1348,14 +1347,6 @@ struct Compiler {
         Val ga1 = buf(q0, "loc.ga1", {G * N, 16, S_, S_}, NHWC), ga2 = buf(q0, "loc.ga2", {G * N, 16, S_, S_}, NHWC), g3 = buf(q0, "loc.g3", {G * N, 64}),
             g4 = buf(q0, "loc.g4", {G * N, d.P}), gx = buf(q0, "loc.gx", {G * N, Cin, 2 * S_, 2 * S_}, NHWC);
         Net* n_ = net; vector<Mod*> qv = qs; const LocDesc dd = d;
-        if (acc && G == 1 && net->early_flush && wg_on() && !wg_lag() && wg_used[cs] && pend[4 + cs]) {
-            // the ungrouped transformer is the first module of D (models.lua:645): its four weight-gradient GEMMs end the pass, and the
-            // batched reduction of everything queued before them (D's 64 -> 64 layer in 256 pixel splits: 38 MB of partial sums) would
-            // otherwise wait for them and run alone on the chip, 43 us behind the last data-gradient launch.  Issued here it runs beside
-            // the chain's sampler / localisation backward, and the final flush holds four small jobs.
-            const int back = cs;
-            cs = 4 + back; flush_wgrad(); cs = back;
-        }
         emit([=](Run& c) {
             const float* w[48];
             loc_weights(qv, n_, w);
@@ -1767,7 +1758,8 @@ struct Compiler {
             emit([=](Run& c) { return k->conv2d_ups2_wino_wgrad(c.CS(), c.P(v), c.P(dy), mp->gw, mp->gb, (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co, c.scale, c.W(), c.WB()); });
             return;
         }
-        if (m.kind == K_CONV && s.x.ups && s.use_wino22 && (net->wino22 & 4)) {
+        if (m.kind == K_CONV && s.x.ups && s.use_wino22 && (net->wino22 & 4) &&
+            cg_conv2d_ups2_wino22_wgrad_supported((int)s.x.d[0], (int)(s.x.d[2] >> 1), (int)(s.x.d[3] >> 1), (int)m.ia[0], (int)m.ia[1])) {
             // F(2x2,2x2)-domain weight gradient from the transformed input the forward of this batch left in wino22_v
             Val dy = as_nhwc(go);
             const Val& x = s.x;
@@ -1812,7 +1804,7 @@ struct Compiler {
                     emit([=](Run& c) { return k->conv2d_ups2_wino_dgrad_split(c.CS(), c.P(dy), mp->u_bwd, c.P(lo), c.P(vdy), c.P(part), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
                 } else
                     emit([=](Run& c) { return k->conv2d_ups2_wino_dgrad(c.CS(), c.P(dy), mp->u_bwd, c.P(lo), c.P(vdy), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
-            } else if (s.use_wino22 && (net->wino22 & 2) && mp->u22b) {
+            } else if (s.use_wino22 && (net->wino22 & 2) && mp->u22b && cg_conv2d_ups2_wino22_dgrad_supported((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co)) {
                 Val vdy = buf(m, "wino22_vdy", {(long)cg_conv2d_ups2_wino22_dgrad_v_floats((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co)});
                 emit([=](Run& c) { return k->conv2d_ups2_wino22_dgrad(c.CS(), c.P(dy), mp->u22b, c.P(lo), c.P(vdy), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
             } else {
@@ -2420,31 +2412,41 @@ int settle_allocs(Net* n) {
     return 0;
 }
 
-int ensure_streams(Net* n, int nstreams) {
+// Side streams come out of the process-wide pool of streams classified by hardware queue (cg::queue_stream, common.h): stream index t of
+// a plan runs on queue class kQueueOf[t] relative to the caller's stream - [1..3] the branch groups' streams, [4 + s] the weight-gradient
+// stream beside stream s.  Measured on the batch-128 step (profiles/r05_queue_classes.txt; one box, ms per step): what must overlap has to
+// sit on DIFFERENT queues - a weight-gradient stream or the host's side stream on the step's own queue costs 0.2-0.4 ms - and beyond that
+// the choice is flat within 0.03 ms; D's best was its chain's weight gradients on the branch stream's queue and the branch's on a third
+// (5.91 against 5.95-6.2 for the other fifteen).  CG_QMAP="c1,..,c7[;next net's list]" overrides the table per net in creation order.
+static const int kQueueOf[8] = {0, 1, 2, 3, 1, 3, 2, 1};
+int ensure_streams(Net* n, int nstreams, void* ref) {
     if (n->trace) return 0;
-    while ((int)n->side.size() < nstreams - 1) {
-        hipStream_t s; hipEvent_t e;
-        const int idx = (int)n->side.size() + 1;
-        // experiment switches (CG_WGRAD_PRIO; profiles/r04_wgrad_stream_ab.txt): 1 = the weight-gradient streams at the LOWEST priority
-        // (measured: 11.1 ms per step against 6.8 - the low-priority queue's waves appear to be context-switched out whenever the
-        // other queues have work); 2 = the branch groups' side streams at the HIGHEST priority instead (the caller does the same for its own)
-        if ((idx >= 4 && n->wgrad_prio == 1) || (idx < 4 && n->wgrad_prio == 2)) {
-            int least = 0, greatest = 0;
-            CG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            CG_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, idx >= 4 ? least : greatest));
-        } else if (idx >= 4 && n->wgrad_cu_quarters > 0 && n->wgrad_cu_quarters < 4) {
-            // experiment switch (CG_WGRAD_CU_QUARTERS = 1..3): the weight-gradient streams on a CU mask that leaves (4 - q) / 4 of every XCD's CUs
-            // to the data-gradient chain (bit i kept if ((i >> 3) & 3) < q: a quarter of each XCD under either numbering of the mask bits)
-            uint32_t mask[8];
-            for (int w = 0; w < 8; ++w) {
-                mask[w] = 0;
-                for (int b = 0; b < 32; ++b) if ((((w * 32 + b) >> 3) & 3) < n->wgrad_cu_quarters) mask[w] |= 1u << b;
+    if ((int)n->side.size() < nstreams - 1) {
+        static int netno = 0;
+        static int slots[4] = {0, 0, 0, 0};
+        if (n->qmap[0] < 0) {
+            for (int t = 0; t < 8; ++t) n->qmap[t] = kQueueOf[t];
+            const char* e = getenv("CG_QMAP");
+            if (e) {
+                const char* q = e;
+                for (int i = 0; i < netno && q; ++i) { q = strchr(q, ';'); if (q) ++q; }
+                for (int t = 1; t < 8 && q && *q && *q != ';'; ++t) {
+                    n->qmap[t] = atoi(q) & 3;
+                    while (*q && *q != ',' && *q != ';') ++q;
+                    if (*q == ',') ++q;
+                }
             }
-            CG_HIP(hipExtStreamCreateWithCUMask(&s, 8, mask));
-        } else
-            CG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        CG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        n->side.push_back(s); n->side_ev.push_back(e);
+            ++netno;
+        }
+        while ((int)n->side.size() < nstreams - 1) {
+            const int t = (int)n->side.size() + 1;
+            const int c = n->qmap[t & 7];
+            hipStream_t s = cg::queue_stream((hipStream_t)ref, c, slots[c]++);
+            if (!s) return 1;
+            hipEvent_t e;
+            CG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            n->side.push_back(s); n->side_ev.push_back(e);
+        }
     }
     for (int t = 0; t < 4 && nstreams > 4; ++t)
         if (!n->wg_fork_ev[t]) {
@@ -2555,7 +2557,7 @@ std::string prog_key(Net* n, int nd, const long* dims, int fmt) {
     k += "|o" + std::to_string(n->overlap_groups) + std::to_string(n->defer_wgrad) + std::to_string(n->winograd) + std::to_string(n->fusion) +
          std::to_string(n->stacking) + std::to_string(n->grouped) + std::to_string(n->share_pool) + std::to_string(n->sampler_shared) +
          std::to_string(n->view_fuse) + std::to_string(n->cat_fuse) + std::to_string(n->fuse_locnet) + std::to_string(n->head_fuse) +
-         std::to_string(n->wgrad_stream) + std::to_string(n->wgrad_lag) + std::to_string(n->wino22) + std::to_string(n->wino_dsplit) + std::to_string(n->early_flush) + "m" +
+         std::to_string(n->wgrad_stream) + std::to_string(n->wgrad_lag) + std::to_string(n->wino22) + std::to_string(n->wino_dsplit) + "m" +
          std::to_string(n->wino_min_tiles);
     return k;
 }
@@ -2580,10 +2582,7 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_PACK_OVERLAP"))) n->pack_overlap = atoi(e) != 0;
     if ((e = getenv("CG_HEAD_FUSE"))) n->head_fuse = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_STREAM"))) n->wgrad_stream = atoi(e) != 0;
-    if ((e = getenv("CG_WGRAD_PRIO"))) n->wgrad_prio = atoi(e);
-    if ((e = getenv("CG_WGRAD_CU_QUARTERS"))) n->wgrad_cu_quarters = atoi(e);
     if ((e = getenv("CG_WINO_DSPLIT"))) n->wino_dsplit = atoi(e) != 0;
-    if ((e = getenv("CG_EARLY_FLUSH"))) n->early_flush = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_LAG"))) n->wgrad_lag = atoi(e);
     if ((e = getenv("CG_WINOGRAD22"))) n->wino22 = atoi(e);
     *net = n;
@@ -2594,7 +2593,7 @@ int cg_net_destroy(void* net) {
     Net* n = NET(net);
     if (!n) return 0;
     for (void* p : n->owned) { if (n->trace) free(p); else (void)hipFree(p); }
-    for (auto s : n->side) (void)hipStreamDestroy(s);
+    // n->side: pool streams (cg::queue_stream), not ours to destroy
     for (auto e : n->side_ev) (void)hipEventDestroy(e);
     if (n->fork_ev) (void)hipEventDestroy(n->fork_ev);
     if (n->pack_ev) { (void)hipEventDestroy(n->pack_fork_ev); (void)hipEventDestroy(n->pack_ev); }
@@ -2610,8 +2609,7 @@ int cg_net_set_option(void* net, const char* name, long value) {
         {"overlap_groups", &n->overlap_groups}, {"defer_wgrad", &n->defer_wgrad}, {"winograd", &n->winograd}, {"share_pool", &n->share_pool},
         {"sampler_shared", &n->sampler_shared}, {"view_fuse", &n->view_fuse}, {"cat_fuse", &n->cat_fuse}, {"stacking", &n->stacking},
         {"grouped", &n->grouped}, {"fusion", &n->fusion}, {"fuse_locnet", &n->fuse_locnet}, {"pack_overlap", &n->pack_overlap},
-        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wgrad_lag", &n->wgrad_lag}, {"wino_dsplit", &n->wino_dsplit},
-        {"early_flush", &n->early_flush}};
+        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wgrad_lag", &n->wgrad_lag}, {"wino_dsplit", &n->wino_dsplit}};
     if (!strcmp(name, "trace")) {
         CG_REQUIRE(n->progs.empty(), "cg_net_set_option: trace must be chosen before the first pass");
         n->trace = value != 0; n->K = n->trace ? &kTraceTable : &kRealTable;
@@ -2735,7 +2733,7 @@ int cg_net_forward(void* net, void* stream, const float* x, int nd, const long* 
         CG_REQUIRE(!pr->out.is_tab, "cg_net_forward: the root module returns a table");
         pr->out = C.materialise(pr->out);
         pr->draws = C.rng;
-        if (ensure_streams(n, std::max(pr->nstreams, n->pack_overlap && pr->ups_first_op.size() >= 2 ? 2 : 1))) return 1;
+        if (ensure_streams(n, std::max(pr->nstreams, n->pack_overlap && pr->ups_first_op.size() >= 2 ? 2 : 1), stream)) return 1;
         if (settle_allocs(n)) return 1;
         it = n->progs.emplace(key, std::move(pr)).first;
     }
@@ -2796,7 +2794,7 @@ int cg_net_backward(void* net, void* stream, const float* x, const float* gy, in
         CG_REQUIRE(!gi.is_tab, "cg_net_backward: the root module's gradInput is a table");
         pr->gin[acc] = gi;
         pr->have_bwd[acc] = true;
-        if (ensure_streams(n, pr->nstreams)) return 1;
+        if (ensure_streams(n, pr->nstreams, stream)) return 1;
         if (settle_allocs(n)) return 1;
     }
     Run c;

@@ -24,16 +24,16 @@ namespace {
 struct OptDef { const char* name; long dflt; };
 // order = enum Opt (common.h)
 const OptDef kOptDefs[OPT_COUNT] = {
-    {"CG_SPLIT_TARGET", 1}, {"CG_SPLIT_MINK", 8}, {"CG_TN_SMAX", 256}, {"CG_TN_TARGET", 3}, {"CG_SKINNY", 1},
-    {"CG_GEMM_SLOW", 0}, {"CG_GEMM_BK32", 1}, {"CG_COLREDUCE_WGS_PER_CU", 1}, {"CG_WINO_WAVES", 8}, {"CG_WINO_BK", 0},
-    {"CG_NN_TILE", 0}, {"CG_TN_TILE", 0}, {"CG_NN_SPLITS", 0}, {"CG_TN_SPLITS", 0}, {"CG_EPILOGUE_STATS", 1},
-    {"CG_SAMPLER_ATOMICS", 0}, {"CG_XCD_SWIZZLE", 3}, {"CG_NN_QUAD", 0}, {"CG_TN_QUAD", 0}, {"CG_WINO_QUAD", 0}, {"CG_NN_PF", 1}, {"CG_NN_GLDS", 1}, {"CG_TN_GLDS", 1}, {"CG_WINO_GLDS", 1}, {"CG_EW_WGS_PER_CU", 4},
+    {"CG_SPLIT_TARGET", 1}, {"CG_SPLIT_MINK", 8}, {"CG_TN_SMAX", 256}, {"CG_TN_TARGET", 3}, {"CG_SKINNY", 1}, {"CG_GEMM_BK32", 1},
+    {"CG_COLREDUCE_WGS_PER_CU", 1}, {"CG_WINO_BK", 0}, {"CG_NN_TILE", 0}, {"CG_TN_TILE", 0}, {"CG_NN_SPLITS", 0}, {"CG_TN_SPLITS", 0},
+    {"CG_EPILOGUE_STATS", 1}, {"CG_XCD_SWIZZLE", 3}, {"CG_NN_GLDS", 1}, {"CG_TN_GLDS", 1}, {"CG_WINO_GLDS", 1}, {"CG_EW_WGS_PER_CU", 4},
 };
 long g_opt_val[OPT_COUNT];
 int g_opt_state[OPT_COUNT];   // 0 = not read yet, 1 = default / environment, 2 = set through the ABI
 }  // namespace
 
 }  // namespace cg
+#include <chrono>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -58,19 +58,118 @@ void* col_scratch(hipStream_t stream) {
     }
     if (!capturing && (int)pool.size() <= kReserve) {
         char* p = nullptr;
-        // the memset runs on the null stream, which non-blocking streams do not wait for: finish it before any kernel draws a ticket
-        if (hipMalloc((void**)&p, kColScratchBytes * kPool) != hipSuccess || hipMemset(p, 0, kColScratchBytes * kPool) != hipSuccess ||
-            hipDeviceSynchronize() != hipSuccess) {
-            cg::fail("column reduce: cannot allocate %zu bytes of scratch", kColScratchBytes * kPool);
-            return nullptr;
-        }
-        for (int i = kPool - 1; i >= 0; --i) pool.insert(pool.begin(), p + (size_t)i * kColScratchBytes);   // older blocks go first
+        // ANOTHER stream of the process may be inside a graph capture right now (a plan's side / weight-gradient streams make
+        // refills frequent): allocation, a memset and a synchronisation are "potentially unsafe" calls that a capture in global mode
+        // forbids to every thread - so the refill runs with this thread's capture mode relaxed, and the memset is not on the null stream
+        // (which would drag a capturing blocking stream in).  Nothing here touches the capturing stream's work; the blocks are handed
+        // out only to streams that are not capturing.
+        // No stream of its own for the memset: HIP maps streams onto a handful of hardware queues in creation order, and one more stream
+        // moved the training host's side stream onto the main stream's queue (round 5: both generator forwards ran back to back, +2.7 %
+        // per step).  The memset goes on the REQUESTING stream - not capturing, we checked - and only that stream is waited for.
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        const bool ok = hipMalloc((void**)&p, kColScratchBytes * kPool) == hipSuccess &&
+                        hipMemsetAsync(p, 0, kColScratchBytes * kPool, stream) == hipSuccess &&   // finished before any kernel draws a ticket
+                        hipStreamSynchronize(stream) == hipSuccess;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (!ok) {
+            (void)hipGetLastError();
+            if (pool.empty()) { cg::fail("column reduce: cannot allocate %zu bytes of scratch", kColScratchBytes * kPool); return nullptr; }
+        } else
+            for (int i = kPool - 1; i >= 0; --i) pool.insert(pool.begin(), p + (size_t)i * kColScratchBytes);   // older blocks go first
     }
     void* blk = pool.back();
     pool.pop_back();
     blocks[stream] = blk;
     return blk;
 }
+namespace {
+__global__ void queue_probe_spin_k(unsigned long long ticks, int* sink) {   // wall_clock64: 100 MHz, independent of the shader clock
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) { }
+    if (ticks == ~0ull) *sink = 1;
+}
+struct QueuePool {
+    std::vector<hipStream_t> s;
+    std::unordered_map<hipStream_t, std::vector<int>> cls;   // per reference stream: class of every pool stream
+    std::mutex mu;
+};
+QueuePool& qpool() { static QueuePool p; return p; }
+constexpr int kQueuePool = 24;
+
+// milliseconds for one spinning kernel on a (and one on b, if b != a's sentinel) to finish
+double probe_pair(hipStream_t a, hipStream_t b, bool both, unsigned long long ticks) {
+    (void)hipStreamSynchronize(a);
+    if (both) (void)hipStreamSynchronize(b);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(queue_probe_spin_k, dim3(1), dim3(64), 0, a, ticks, (int*)nullptr);
+    if (both) hipLaunchKernelGGL(queue_probe_spin_k, dim3(1), dim3(64), 0, b, ticks, (int*)nullptr);
+    (void)hipStreamSynchronize(a);
+    if (both) (void)hipStreamSynchronize(b);
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+bool same_queue(hipStream_t a, hipStream_t b) {
+    const unsigned long long ticks = 30000;   // 0.3 ms
+    int votes = 0;
+    for (int r = 0; r < 3; ++r) {
+        const double one = probe_pair(a, a, false, ticks), two = probe_pair(a, b, true, ticks);
+        if (two > 1.6 * one) ++votes;
+    }
+    return votes >= 2;
+}
+}  // namespace
+
+int queue_classify(hipStream_t ref) {     // fills qpool().cls[ref]; caller holds the lock
+    QueuePool& p = qpool();
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (ref && hipStreamIsCapturing(ref, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+        return cg::fail("queue_stream: a stream's hardware queue cannot be probed inside a graph capture (run one pass on it before cg_graph_begin)");
+    while ((int)p.s.size() < kQueuePool) {
+        hipStream_t q;
+        if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) return cg::fail("queue_stream: hipStreamCreate failed");
+        p.s.push_back(q);
+    }
+    std::vector<int> c(p.s.size(), -1);
+    std::vector<hipStream_t> rep;           // representative of class 1, 2, 3
+    for (size_t i = 0; i < p.s.size(); ++i) {
+        if (same_queue(ref, p.s[i])) { c[i] = 0; continue; }
+        for (size_t k = 0; k < rep.size() && c[i] < 0; ++k)
+            if (same_queue(rep[k], p.s[i])) c[i] = (int)k + 1;
+        if (c[i] < 0) { rep.push_back(p.s[i]); c[i] = (int)rep.size(); }
+    }
+    (void)hipGetLastError();
+    p.cls[ref] = c;
+    return 0;
+}
+
+hipStream_t queue_stream(hipStream_t ref, int cls, int slot) {
+    QueuePool& p = qpool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (!p.cls.count(ref) && queue_classify(ref)) return nullptr;
+    const std::vector<int>& c = p.cls[ref];
+    int nclass = 0;
+    for (int v : c) nclass = std::max(nclass, v + 1);
+    if (nclass < 2) { cg::fail("queue_stream: the probe found one hardware queue only"); return nullptr; }
+    cls = cls % nclass;                     // fewer than four queues (GPU_MAX_HW_QUEUES < 4): wrap
+    int seen = 0;
+    hipStream_t last = nullptr;
+    for (size_t i = 0; i < c.size(); ++i)
+        if (c[i] == cls) { last = p.s[i]; if (seen++ == slot) return p.s[i]; }
+    if (last) return last;                  // more roles than pool streams of this class: share the last one
+    cg::fail("queue_stream: no pool stream on hardware queue class %d", cls);
+    return nullptr;
+}
+
+int queue_class(hipStream_t ref, hipStream_t s) {
+    if (s == ref) return 0;
+    QueuePool& p = qpool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    auto it = p.cls.find(ref);
+    if (it == p.cls.end()) return -1;
+    for (size_t i = 0; i < p.s.size(); ++i) if (p.s[i] == s) return it->second[i];
+    return -1;
+}
+
 unsigned long g_opt_epoch = 1;   // bumped by cg_set_option: compiled plans (net.hip) re-derive workspace sizes / dispatch-dependent rows
 long opt(Opt o) {
     if (g_opt_state[o] == 0) {
@@ -1232,6 +1331,13 @@ int cg_stream_create(void** stream) {
     CG_REQUIRE(stream, "null");
     hipStream_t s; CG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *stream = (void*)s; return 0;
 }
+int cg_stream_on_queue(void* ref_stream, int queue_class, int slot, void** stream) {
+    CG_REQUIRE(stream && queue_class >= 0 && slot >= 0, "cg_stream_on_queue: bad arguments");
+    hipStream_t s = cg::queue_stream(cg::S(ref_stream), queue_class, slot);
+    if (!s) return 1;
+    *stream = (void*)s;
+    return 0;
+}
 int cg_stream_destroy(void* stream) { CG_HIP(hipStreamDestroy(cg::S(stream))); return 0; }
 int cg_stream_sync(void* stream) { CG_HIP(hipStreamSynchronize(cg::S(stream))); return 0; }
 
@@ -1586,7 +1692,7 @@ int sampler_backward(void* stream, const float* img, const float* grid, const fl
                      int Hi, int Wi, int C, int Ho, int Wo) {
     const long P = (long)Ho * Wo, Q = (long)Hi * Wi;
     const size_t shb = ((size_t)5 * P + 2 * ((size_t)(Hi + 1) * (Wi + 1)) + 1) * 4;
-    if (cg::opt(cg::OPT_SAMPLER_ATOMICS) == 0 && shb <= 150 * 1024 && C <= 256 && N > 0) {   // deterministic gather form
+    if (shb <= 150 * 1024 && C <= 256 && N > 0) {   // deterministic gather form
         const bool v4 = C % 4 == 0 && al16(img) && al16(gout) && al16(gimg);
         const int units = v4 ? C / 4 : C;                  // lane-sized channel units per pixel
         int G = 4;

@@ -297,18 +297,16 @@ struct WinoArgs {
     int kz;              // > 0 (wino_gemm_g_kernel, so == 1): blockIdx.z is a K slice of kz rows, its partial result goes to y + z * T*4*Nc
 };
 
-// NW waves per workgroup: 4 (wave tile 32x64) or 8 (wave tile 32x32: twice the waves per tile for latency hiding); BK = K step
-// QUAD: k-quad LDS tiles read with ds_read_b128, one read per operand per four MFMA steps (see igemm_nn_kernel in gemm.hip:
-// same slots, swizzles and hand-placed schedule; V rows are stored as they are loaded, U goes in as register-transposed
-// 4 x 4 blocks held by the first KV * 32 threads).
-template <int NW, int BK, bool QUAD = false>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? ((QUAD && BK == 32) ? 2 : 4) : 2) void wino_gemm_kernel(WinoArgs a) {
+// The register-staged form (8 waves, wave tile 32 x 32; BK = K step): the fallback of wino_gemm_g_kernel below for tensors whose
+// planes a buffer descriptor cannot span, and the reference the LDS-direct kernels are tested against.  (The 4-wave and k-quad
+// instances of rounds 2-4 never won an A/B and were removed in round 5.)
+template <int NW, int BK>
+__global__ __launch_bounds__(64 * NW, 4) void wino_gemm_kernel(WinoArgs a) {
+    static_assert(NW == 8, "8 waves per workgroup");
     constexpr int BM = 64, BN = 128, NI = 8 / NW, NT = 64 * NW;
     constexpr int KV = BK / 4;                 // float4 per A row per K tile
     constexpr int BQ = BK * 32 / NT;           // B float4 per thread (1 or 2), NT/32 rows apart
-    static_assert(BM * KV <= NT && (QUAD || BQ == 1 || BQ == 2), "staging layout");
-    constexpr int NBLK = KV * 32;              // QUAD: 4 x 4 blocks of the B tile
-    static_assert(!QUAD || NBLK <= NT, "one B block per thread");
+    static_assert(BM * KV <= NT && (BQ == 1 || BQ == 2), "staging layout");
     constexpr int A_TILE = BK * BM, B_TILE = BK * BN;
     __shared__ __attribute__((aligned(16))) float smem[2 * A_TILE + 2 * B_TILE];
     float* As = smem;
@@ -343,66 +341,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((QUAD && BK == 32) ? 2 : 4) : 2
     const long a_xi = (long)a.T * a.K;            // V stride between xi
     const long b_half = (long)(NT / 32) * a.Nc;   // second B float4: k row + NT/32
     float4 areg, breg0, breg1;
-    // QUAD staging of B: thread -> block (k quad tid >> 5, column quad tid & 31), rows 4 * (tid >> 5) + q
-    const bool bq_on = QUAD && tid < NBLK;
-    const float* Bq = a.U + (long)phase * 16 * a.K * a.Nc + (long)(4 * (bq_on ? b_kr : 0)) * a.Nc + n0 + 4 * b_nv;
-    float4 bq[4];
     // running operand pointers: U is contiguous over (xi, k), V jumps to the next xi plane after the last K tile
     const float* Ac = Ap;
     const float* Bc = Bp;
     const long b_step = (long)BK * a.Nc;
     const long a_jump = a_xi - a.K + BK;
-    auto load_b_quad = [&]() {
-        if (NBLK == NT || bq_on) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bq[q] = ld4(Bq + (long)q * a.Nc);
-        }
-    };
     auto load_next = [&](bool last_kt) {
         Ac += last_kt ? a_jump : (long)BK;
         Bc += b_step;
         if (BM * KV == NT || a_thr) areg = ld4(Ac);
-        if (QUAD) { Bq += b_step; load_b_quad(); return; }
         breg0 = ld4(Bc);
         if (BQ == 2) breg1 = ld4(Bc + b_half);
     };
-    // QUAD slot indices (16-byte units), all loop invariants
-    constexpr int SH = KV == 8 ? 0 : 1;
-    const int qa_st = a_kv * BM + (a_r ^ ((a_kv & 7) << SH));
-    int qb_st[4], qa_rd[KV / 2];
-    {
-        const int sb = (b_nv >> 1) & 3;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) qb_st[i] = b_kr * BN + 4 * b_nv + (i ^ sb);
-#pragma unroll
-        for (int gq = 0; gq < KV / 2; ++gq) {
-            const int kq = 2 * gq + h;
-            qa_rd[gq] = kq * BM + wm0 + (l31 ^ ((kq & 7) << SH));
-        }
-    }
-    const int qb_rd = h * BN + wn0 + (l31 ^ ((l31 >> 3) & 3));
     const int a_so = a_r ^ (BK == 32 ? ((a_kv & 7) << 2) : ((a_kv & 3) << 3));   // see a_swizzle in gemm.hip
     auto store_tile = [&](int buf) {
         float* A = As + buf * A_TILE;
         float* B = Bs + buf * B_TILE;
-        if (QUAD) {
-            float4* A4 = reinterpret_cast<float4*>(A);
-            float4* B4 = reinterpret_cast<float4*>(B);
-            if (BM * KV == NT || a_thr) A4[qa_st] = areg;
-            float4 tb4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {   // pinned here so that the transposing moves stay behind the MFMAs
-                tb4[q] = bq[q];
-                asm volatile("" : "+v"(tb4[q].x), "+v"(tb4[q].y), "+v"(tb4[q].z), "+v"(tb4[q].w));
-            }
-            if (NBLK == NT || bq_on) {
-                B4[qb_st[0]] = make_float4(tb4[0].x, tb4[1].x, tb4[2].x, tb4[3].x);
-                B4[qb_st[1]] = make_float4(tb4[0].y, tb4[1].y, tb4[2].y, tb4[3].y);
-                B4[qb_st[2]] = make_float4(tb4[0].z, tb4[1].z, tb4[2].z, tb4[3].z);
-                B4[qb_st[3]] = make_float4(tb4[0].w, tb4[1].w, tb4[2].w, tb4[3].w);
-            }
-            return;
-        }
         if (BM * KV == NT || a_thr) {
             A[(4 * a_kv + 0) * BM + a_so] = areg.x;
             A[(4 * a_kv + 1) * BM + a_so] = areg.y;
@@ -424,49 +378,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((QUAD && BK == 32) ? 2 : 4) : 2
         }
 
     areg = ld4(Ac);
-    if (QUAD) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        load_b_quad();
-    } else {
-        breg0 = ld4(Bc);
-        breg1 = ld4(Bc + b_half);
-    }
+    breg0 = ld4(Bc);
+    breg1 = ld4(Bc + b_half);
     store_tile(0);
     __syncthreads();
     // one K tile from LDS buffer BUF (compile-time, so every ds_read offset is an immediate)
     auto k_tile = [&](auto bufc, bool more, bool last_kt) {
         constexpr int BUF = decltype(bufc)::value;
         if (more) load_next(last_kt);
-        if (QUAD) {
-            constexpr int G2 = KV / 2;
-            const float4* A4 = reinterpret_cast<const float4*>(As + BUF * A_TILE);
-            const float4* B4 = reinterpret_cast<const float4*>(Bs + BUF * B_TILE);
-            float4 af[G2], bf[G2][NI];
-            auto frag = [&](int gq) {
-                af[gq] = A4[qa_rd[gq]];
-#pragma unroll
-                for (int j = 0; j < NI; ++j) bf[gq][j] = B4[qb_rd + gq * 2 * BN + j * 32];
-            };
-            __builtin_amdgcn_sched_barrier(0);
-            frag(0);
-            if (G2 > 1) frag(1);
-#pragma unroll
-            for (int gq = 0; gq < G2; ++gq) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (gq + 2 < G2) frag(gq + 2);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int sidx = 0; sidx < 4; ++sidx)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        accM[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf4c(af[gq], sidx), wf4c(bf[gq][j], sidx), accM[j], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) store_tile(BUF ^ 1);
-            __syncthreads();
-            return;
-        }
         const float* A = As + BUF * A_TILE + wm0;
         const float* B = Bs + BUF * B_TILE + wn0 + l31;
 #pragma unroll
@@ -947,7 +866,7 @@ int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const
 
 // rows of the [rows][2][Cout] statistics buffer cg_conv2d_ups2_wino_forward_stats fills
 size_t cg_conv2d_ups2_wino_stats_rows(int N, int Hp, int Wp, int Cin, int Cout) {
-    if (!wino_dims_ok(N, Hp, Wp, Cin, Cout) || cg::opt(cg::OPT_EPILOGUE_STATS) == 0 || cg::opt(cg::OPT_WINO_WAVES) == 4) return 0;
+    if (!wino_dims_ok(N, Hp, Wp, Cin, Cout) || cg::opt(cg::OPT_EPILOGUE_STATS) == 0) return 0;
     return (size_t)4 * cg::cdiv((long)N * (Hp / 2) * (Wp / 2), 64) * 2;
 }
 
@@ -961,34 +880,30 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
     a.xcd = (int)cg::opt(cg::OPT_XCD_SWIZZLE);
     a.vpp = npos == 9 && !dgrad ? 1 : 0;
     a.kz = 0;
-    CG_REQUIRE(!stats || (!dgrad && cg::opt(cg::OPT_WINO_WAVES) != 4), "wino_gemm: statistics only on the 8-wave forward launch");
+    CG_REQUIRE(!stats || !dgrad, "wino_gemm: statistics only on the forward launch");
     if (dgrad) { a.K = 4 * Cout; a.Nc = Cin; a.so = 1; a.Ho = Hp; a.Wo = Wp; }
     else { a.K = Cin; a.Nc = Cout; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp; }
-    const int nw = (int)cg::opt(cg::OPT_WINO_WAVES), bk = (int)cg::opt(cg::OPT_WINO_BK);
+    const int bk = (int)cg::opt(cg::OPT_WINO_BK);
     CG_REQUIRE(kslices <= 1 || (dgrad && a.K % kslices == 0 && (a.K / kslices) % 64 == 0), "wino_gemm: K slices only on the data gradient, in multiples of 64 rows");
     if (kslices > 1) a.kz = a.K / kslices;
     const dim3 grid(cg::cdiv(T, 64) * (a.Nc / 128), 1, dgrad ? (kslices > 1 ? kslices : 1) : 4);
     // K step 32 (half the barriers per MFMA) pays when the launch is at most ~one workgroup per CU - the data-gradient
     // geometry at batch 128 (0.53 -> 0.41 ms) - and costs 6 % when two workgroups per CU already hide each other's barriers
     const bool k32 = bk == 32 || (bk == 0 && (long)grid.x * grid.z <= cg::kNumCU * 3 / 2);
-    // LDS-direct loads (CG_WINO_GLDS): 8-wave geometry only; one xi plane of V must stay below the 2 GB a buffer offset reaches
-    const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && nw != 4 && (long)T * a.K * 4L < 0x7fffffffL &&
+    // LDS-direct loads (CG_WINO_GLDS): one xi plane of V must stay below the 2 GB a buffer offset reaches
+    const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && (long)T * a.K * 4L < 0x7fffffffL &&
                       16L * a.K * a.Nc * 4L < 0x7fffffffL;
     if (npos == 9) {     // F(2x2,2x2): the LDS-direct-load kernel only (cg_conv2d_ups2_wino22_supported checks the same conditions)
-        CG_REQUIRE(glds, "wino_gemm: the 9-position form needs the LDS-direct-load kernel (CG_WINO_GLDS, 8 waves)");
+        CG_REQUIRE(glds, "wino_gemm: the 9-position form needs the LDS-direct-load kernel (CG_WINO_GLDS)");
         if (k32 && (a.kz ? a.kz : a.K) % 64 == 0) hipLaunchKernelGGL((wino_gemm_g_kernel<32, 9>), grid, dim3(512), 0, cg::S(stream), a);
         else hipLaunchKernelGGL((wino_gemm_g_kernel<16, 9>), grid, dim3(512), 0, cg::S(stream), a);
         CG_LAUNCH_CHECK();
         return 0;
     }
-    CG_REQUIRE(kslices <= 1 || glds, "wino_gemm: K slices need the LDS-direct-load kernel (CG_WINO_GLDS, 8 waves)");
+    CG_REQUIRE(kslices <= 1 || glds, "wino_gemm: K slices need the LDS-direct-load kernel (CG_WINO_GLDS)");
     if (glds && k32 && (a.kz ? a.kz : a.K) % 64 == 0) { hipLaunchKernelGGL((wino_gemm_g_kernel<32>), grid, dim3(512), 0, cg::S(stream), a); CG_LAUNCH_CHECK(); return 0; }
     if (glds) { hipLaunchKernelGGL((wino_gemm_g_kernel<16>), grid, dim3(512), 0, cg::S(stream), a); CG_LAUNCH_CHECK(); return 0; }
-    const bool quad = cg::opt(cg::OPT_WINO_QUAD) != 0 && nw != 4;
-    if (quad && k32 && a.K % 64 == 0) hipLaunchKernelGGL((wino_gemm_kernel<8, 32, true>), grid, dim3(512), 0, cg::S(stream), a);
-    else if (quad) hipLaunchKernelGGL((wino_gemm_kernel<8, 16, true>), grid, dim3(512), 0, cg::S(stream), a);
-    else if (nw == 4) hipLaunchKernelGGL((wino_gemm_kernel<4, 16>), grid, dim3(256), 0, cg::S(stream), a);
-    else if (k32 && a.K % 64 == 0) hipLaunchKernelGGL((wino_gemm_kernel<8, 32>), grid, dim3(512), 0, cg::S(stream), a);
+    if (k32 && a.K % 64 == 0) hipLaunchKernelGGL((wino_gemm_kernel<8, 32>), grid, dim3(512), 0, cg::S(stream), a);
     else hipLaunchKernelGGL((wino_gemm_kernel<8, 16>), grid, dim3(512), 0, cg::S(stream), a);
     CG_LAUNCH_CHECK();
     return 0;
@@ -1017,9 +932,19 @@ int cg_conv2d_ups2_wino_forward(void* stream, const float* x_lo, const float* u_
 size_t cg_conv2d_ups2_wino22_supported(int N, int Hp, int Wp, int Cin, int Cout) {
     if (!wino_dims_ok(N, Hp, Wp, Cin, Cout)) return 0;
     const long T = (long)N * (Hp / 2) * (Wp / 2);
-    const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && cg::opt(cg::OPT_WINO_WAVES) != 4 && T * Cin * 4L < 0x7fffffffL &&
+    const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && T * Cin * 4L < 0x7fffffffL &&
                       16L * Cin * Cout * 4L < 0x7fffffffL;
     return glds ? 1 : 0;
+}
+// the limits cg_conv2d_ups2_wino22_dgrad / _wgrad apply on top of the forward's (a planner that only asked the forward's
+// question would compile the forward and fail in Module:backward for a large batch x Cout)
+size_t cg_conv2d_ups2_wino22_dgrad_supported(int N, int Hp, int Wp, int Cin, int Cout) {
+    return cg_conv2d_ups2_wino22_supported(N, Hp, Wp, Cin, Cout) && (long)N * (Hp / 2) * (Wp / 2) * Cout * 16L < 0x7fffffffL ? 1 : 0;
+}
+size_t cg_conv2d_ups2_wino22_wgrad_supported(int N, int Hp, int Wp, int Cin, int Cout) {
+    if (!cg_conv2d_ups2_wino22_supported(N, Hp, Wp, Cin, Cout)) return 0;
+    const long T = (long)N * (Hp / 2) * (Wp / 2);
+    return T * Cout * 4L < 0x7fffffffL && T * Cin * 4L < 0x7fffffffL && 36L * Cin * Cout * 4L < 0x7fffffffL ? 1 : 0;
 }
 size_t cg_conv2d_ups2_wino22_v_floats(int N, int Hp, int Wp, int Cin) { return (size_t)36 * ((size_t)N * (Hp / 2) * (Wp / 2)) * Cin; }
 size_t cg_conv2d_ups2_wino22_u_floats(int Cin, int Cout) { return (size_t)4 * 9 * Cin * Cout; }
@@ -1054,11 +979,9 @@ int cg_conv2d_ups2_wino22_forward_stats(void* stream, const float* x_lo, const f
 
 // The data gradient's launch has T/64 x Cin/128 workgroups - 128 on G's 512 -> 256 layer at batch 128, half the chip.  Below ~one
 // workgroup per CU the four phases (K slices of Cout rows) go to blockIdx.z, each writing a partial dx_lo behind V in the scratch, and
-// wino22_sum_kernel adds them in a fixed order (CG_WINO22_KSPLIT = 0 / 1 forces the choice, 2 = two slices of two phases).
-static int wino22_dgrad_slices(int N, int Hp, int Wp, int Cin, int Cout) {   // 1 (unsplit), 2 or 4 K slices
-    static const int force = [] { const char* e = getenv("CG_WINO22_KSPLIT"); return e ? atoi(e) : -1; }();
+// wino22_sum_kernel adds them in a fixed order.
+static int wino22_dgrad_slices(int N, int Hp, int Wp, int Cin, int Cout) {   // 1 (unsplit) or 4 K slices
     if (Cout % 64 != 0) return 1;
-    if (force >= 0) return force == 2 ? 2 : (force ? 4 : 1);
     return (long)cg::cdiv(N * (Hp / 2) * (Wp / 2), 64) * (Cin / 128) < cg::kNumCU ? 4 : 1;
 }
 
@@ -1083,8 +1006,7 @@ size_t cg_conv2d_ups2_wino22_dgrad_v_floats(int N, int Hp, int Wp, int Cin, int 
 int cg_conv2d_ups2_wino22_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy, int N, int Hp, int Wp, int Cin,
                                 int Cout) {
     CG_REQUIRE(dy && u_bwd && dx_lo && v_dy, "cg_conv2d_ups2_wino22_dgrad: null pointer");
-    CG_REQUIRE(cg_conv2d_ups2_wino22_supported(N, Hp, Wp, Cin, Cout) && (long)N * (Hp / 2) * (Wp / 2) * Cout * 16L < 0x7fffffffL,
-               "cg_conv2d_ups2_wino22_dgrad: unsupported dimensions / options");
+    CG_REQUIRE(cg_conv2d_ups2_wino22_dgrad_supported(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino22_dgrad: unsupported dimensions / options");
     const int T = N * (Hp / 2) * (Wp / 2);
     hipLaunchKernelGGL(wino22_dy_input_transform_kernel, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, cg::S(stream), dy, v_dy, N, Hp, Wp, Cout);
     CG_LAUNCH_CHECK();
@@ -1114,11 +1036,11 @@ int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd,
 }
 
 // The same data gradient with its K rows (the four phases' channels) in 2 or 4 slices over blockIdx.z and a fixed-order sum of the partial
-// results: the unsplit launch has T/64 x Cin/128 workgroups, which leaves most of the chip idle where Cin is 128 (G32up's first 5x5 layer).  part: cg_conv2d_ups2_wino_dgrad_part_floats() floats (0 = keep the unsplit launch; CG_WINO_DGRAD_KSLICES = 1 / 2 / 4 forces).
+// results: the unsplit launch has T/64 x Cin/128 workgroups, which leaves most of the chip idle where Cin is 128 (G32up's first 5x5 layer).  part: cg_conv2d_ups2_wino_dgrad_part_floats() floats (0 = keep the unsplit launch).
 static int wino_dgrad_slices(int N, int Hp, int Wp, int Cin, int Cout) {
-    static const int force = [] { const char* e = getenv("CG_WINO_DGRAD_KSLICES"); return e ? atoi(e) : 0; }();
+    const int force = 0;
     const long T = (long)N * (Hp / 2) * (Wp / 2);
-    const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && cg::opt(cg::OPT_WINO_WAVES) != 4 && T * 4L * Cout * 4L < 0x7fffffffL &&
+    const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && T * 4L * Cout * 4L < 0x7fffffffL &&
                       16L * 4L * Cout * Cin * 4L < 0x7fffffffL;
     if (!glds || !wino_dims_ok(N, Hp, Wp, Cin, Cout)) return 1;
     // workgroups of the unsplit launch: at one per CU or more it stays (G32up-c's layer at batch 128: 256, splitting measured +0.5 % on the
@@ -1156,7 +1078,7 @@ size_t cg_conv2d_ups2_wino_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin,
     return wino_align(16 * T * 4 * Cout * sizeof(float)) + wino_align((size_t)16 * 4 * Cout * Cin * sizeof(float)) +
            wino_align(std::max(sizeof(double) * Cout, (size_t)cg::kNumCU * 8 * 4 * Cout * sizeof(float))) +   // gradBias: cg_bias_grad's scratch / the dy transform's partials
 
-           cg_conv2d_wgrad_workspace_bytes_grouped(16, (int)T, 1, 1, Cin, 4 * Cout, 1, 1, 0, 0, 0);
+           cg_conv2d_wgrad_workspace_bytes_strided(16, (int)T, 1, 1, Cin, 4 * Cout, 1, 1, 0, 0, 0);
 }
 
 // gw_canonical[Cout][Cin][5][5] += scale * dW, gb += scale * sum dy, from the transformed input v the forward left behind.
@@ -1177,22 +1099,16 @@ int cg_conv2d_ups2_wino_wgrad(void* stream, const float* v, const float* dy, flo
     void* bws = base;                             base += bws_bytes;
     void* tws = base;
     const size_t tws_bytes = ws_bytes - (size_t)(base - (char*)ws);
-    // gradBias from the dy this transform reads anyway (CG_WINO_BIAS_FUSE=1; OFF by default: parity-clean, but the step measured 6.07 -> 6.11 ms
-    // with it - the separate 59 us pass is not on the pass's critical path, the longer transform is; profiles/r04_sweeps.txt): the grid's stride
-    // must be a multiple of the channel quads (Cout per pixel group) so that a thread keeps its quad, and a workgroup's threads share quads evenly
-    static const bool bias_fuse = [] { const char* e = getenv("CG_WINO_BIAS_FUSE"); return e && atoi(e) != 0; }();
-    int tgrid = (int)cg::ew_grid((long)T * Cout);
-    const int cqn = Cout;
-    bool fuse = gb && bias_fuse && (256 % cqn == 0 || cqn % 256 == 0);
-    if (fuse && cqn > 256) { const int m = cqn / 256; tgrid = tgrid / m * m; fuse = tgrid > 0; }
-    if (fuse && (size_t)tgrid * 4 * Cout * sizeof(float) > bws_bytes) fuse = false;
-    if (!fuse) tgrid = (int)cg::ew_grid((long)T * Cout);
+    // (gradBias partial sums from this transform - it reads every dy anyway - were parity-clean but cost the step 0.6 % in round 4: the
+    // separate 59 us pass is not on the pass's critical path, the longer transform is; the kernel keeps the argument, nobody passes it)
+    const bool fuse = false;
+    const int tgrid = (int)cg::ew_grid((long)T * Cout);
     hipLaunchKernelGGL(wino_dy_transform_kernel, dim3(tgrid), dim3(256), 0, st, dy, mdy, N, Hp, Wp, Cout, fuse ? (float*)bws : nullptr);
     CG_LAUNCH_CHECK();
     CG_HIP(hipMemsetAsync(dut, 0, (size_t)16 * C4 * Cin * sizeof(float), st));
     // 16 TN GEMMs dU_xi^T[pco][ci] = sum_tile Mdy_xi[tile][pco] V_xi[tile][ci]: the planes of V, Mdy and dU are equally spaced, so all
-    // 16 run as ONE launch + one reduction (CG_WINO_WGRAD_GROUPS=4: four launches of four, the form of rounds 1-3)
-    static const int groups_per_launch = [] { const char* e = getenv("CG_WINO_WGRAD_GROUPS"); const int v = e ? atoi(e) : 16; return v == 4 ? 4 : 16; }();
+    // 16 run as ONE launch + one reduction (rounds 1-3: four launches of four)
+    const int groups_per_launch = 16;
     for (int q = 0; q < 16; q += groups_per_launch) {
         if (cg_conv2d_wgrad_strided(stream, groups_per_launch, v + q * (long)T * Cin, (long)T * Cin, mdy + q * (long)T * C4, (long)T * C4,
                                     dut + q * (long)C4 * Cin, (long)C4 * Cin, T, 1, 1, Cin, C4, 1, 1, 0, 0, 0, 1.f, tws, tws_bytes)) return 1;
@@ -1213,7 +1129,7 @@ size_t cg_conv2d_ups2_wino22_wgrad_workspace_bytes(int N, int Hp, int Wp, int Ci
     if (!wino_dims_ok(N, Hp, Wp, Cin, Cout)) return 0;
     const size_t T = (size_t)N * (Hp / 2) * (Wp / 2);
     return wino_align(36 * T * Cout * sizeof(float)) + wino_align((size_t)36 * Cout * Cin * sizeof(float)) + wino_align(sizeof(double) * Cout) +
-           cg_conv2d_wgrad_workspace_bytes_grouped(36, (int)T, 1, 1, Cin, Cout, 1, 1, 0, 0, 0);
+           cg_conv2d_wgrad_workspace_bytes_strided(36, (int)T, 1, 1, Cin, Cout, 1, 1, 0, 0, 0);
 }
 
 // gw_canonical[Cout][Cin][3][3] += scale * dW, gb += scale * sum dy, from the transformed input v ([4][9][T][Cin]) the F(2x2,2x2) forward of
@@ -1221,7 +1137,7 @@ size_t cg_conv2d_ups2_wino22_wgrad_workspace_bytes(int N, int Hp, int Wp, int Ci
 int cg_conv2d_ups2_wino22_wgrad(void* stream, const float* v, const float* dy, float* gw_canonical, float* gb, int N, int Hp, int Wp, int Cin,
                                 int Cout, float scale, void* ws, size_t ws_bytes) {
     CG_REQUIRE(v && dy && gw_canonical, "cg_conv2d_ups2_wino22_wgrad: null pointer");
-    CG_REQUIRE(wino_dims_ok(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino22_wgrad: unsupported dimensions");
+    CG_REQUIRE(cg_conv2d_ups2_wino22_wgrad_supported(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino22_wgrad: unsupported dimensions / options");
     const size_t need = cg_conv2d_ups2_wino22_wgrad_workspace_bytes(N, Hp, Wp, Cin, Cout);
     CG_REQUIRE(ws && ws_bytes >= need && (uintptr_t)ws % 16 == 0, "cg_conv2d_ups2_wino22_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
     hipStream_t st = cg::S(stream);

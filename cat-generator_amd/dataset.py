@@ -207,18 +207,31 @@ class AsyncLoader:
         if self.host_all:
             import warnings
             warnings.warn(f"AsyncLoader: {self.Ws}x{self.Hs} sources are more than 6x the {width}x{height} target: scaling on the host")
-        self.nbytes = self.count * self.Hs * self.Ws * 3
+        # host_all: nothing is scaled on the device, so no 8-bit staging / device buffer of the (large) SOURCE size exists at all - the
+        # worker writes the finished fp32 NHWC rows into a pinned buffer of the POOL's size and one asynchronous copy moves them
+        # (the u8 path would pin count x Hs x Ws x 3 bytes per slot for images it never uploads).  Otherwise: the u8
+        # staging, plus a pinned fp32 side buffer of the pool's size for the odd-sized images that take the host path.
+        self.row = height * width * self.C * 4
+        self.nbytes = self.count * self.row if self.host_all else self.count * self.Hs * self.Ws * 3
         self.copy_stream = ctypes.c_void_p()
         self.L.stream_create(ctypes.byref(self.copy_stream))
         self.slots = []
+        f32p = ctypes.POINTER(ctypes.c_float)
         for _ in range(self.depth):
-            host, dev_u8, ev_ready, ev_free = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+            host, dev_u8, ev_ready, ev_free, side = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
             self.L.host_alloc(ctypes.byref(host), self.nbytes)
-            self.L.malloc(ctypes.byref(dev_u8), self.nbytes)
             self.L.event_create(ctypes.byref(ev_ready)); self.L.event_create(ctypes.byref(ev_free))
             pool = Tensor.empty((self.count, self.C, height, width), "nhwc")
-            staging = np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_uint8)), shape=(self.count, self.Hs, self.Ws, 3))
-            self.slots.append(dict(host=host, staging=staging, dev_u8=dev_u8, ready=ev_ready, free=ev_free, pool=pool, n=0, used=False))
+            if self.host_all:
+                staging = np.ctypeslib.as_array(ctypes.cast(host, f32p), shape=(self.count, height, width, self.C))
+                patch = None
+            else:
+                self.L.malloc(ctypes.byref(dev_u8), self.nbytes)
+                staging = np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_uint8)), shape=(self.count, self.Hs, self.Ws, 3))
+                self.L.host_alloc(ctypes.byref(side), self.count * self.row)
+                patch = np.ctypeslib.as_array(ctypes.cast(side, f32p), shape=(self.count, height, width, self.C))
+            self.slots.append(dict(host=host, staging=staging, dev_u8=dev_u8, side=side, patch=patch, ready=ev_ready, free=ev_free, pool=pool,
+                                   n=0, used=False))
         self.k = 0
         self._thread = None
         self._err = None
@@ -228,7 +241,7 @@ class AsyncLoader:
         files = _prefetch_pick(self.count)   # on the caller's thread: the generator's draws stay in program order
         slot["n"] = len(files)
         if slot["used"]:
-            self.L.event_sync(slot["ready"])   # its previous upload has left the pinned buffer (long ago; costs nothing)
+            self.L.event_sync(slot["ready"])   # its previous upload has left the pinned buffers (long ago; costs nothing)
 
         slot["patches"] = []
 
@@ -239,9 +252,13 @@ class AsyncLoader:
                     if self.host_all or im.shape[:2] != (self.Hs, self.Ws):
                         # loadRandomImages' arithmetic for this one image: /255 -> image.scale -> colour space, as NHWC rows
                         img = image_scale(im.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0), width, height)
-                        img = rgbToColorSpace(img[None], colorSpace)[0]
-                        slot["patches"].append((i, np.ascontiguousarray(img.transpose(1, 2, 0))))
-                        slot["staging"][i] = 0
+                        img = rgbToColorSpace(img[None], colorSpace)[0].transpose(1, 2, 0)
+                        if self.host_all:
+                            slot["staging"][i] = img
+                        else:
+                            slot["patch"][i] = img         # pinned: the copy below needs no synchronisation
+                            slot["patches"].append(i)
+                            slot["staging"][i] = 0
                     else:
                         slot["staging"][i] = im
             except Exception as e:   # surfaced by next()
@@ -253,13 +270,13 @@ class AsyncLoader:
         L, cs, n = self.L, self.copy_stream, slot["n"]
         if slot["used"]:
             L.stream_wait_event(cs, slot["free"])      # the training stream has finished reading this pool
-        L.memcpy_h2d(cs, slot["dev_u8"], slot["host"], n * self.Hs * self.Ws * 3)
-        L.images_u8_scale_to_f32(cs, slot["dev_u8"], slot["pool"].ptr, n, self.Hs, self.Ws, height, width, 1 if colorSpace == "y" else 0)
-        if slot["patches"]:       # images scaled on the host (another source size): over the rows the kernel produced from zeros
-            row = height * width * self.C * 4
-            for i, arr in slot["patches"]:
-                L.memcpy_h2d(cs, slot["pool"].ptr + i * row, arr.ctypes.data, row)
-            L.stream_sync(cs)     # pageable sources: they must outlive the copies
+        if self.host_all:
+            L.memcpy_h2d(cs, slot["pool"].ptr, slot["host"], n * self.row)
+        else:
+            L.memcpy_h2d(cs, slot["dev_u8"], slot["host"], n * self.Hs * self.Ws * 3)
+            L.images_u8_scale_to_f32(cs, slot["dev_u8"], slot["pool"].ptr, n, self.Hs, self.Ws, height, width, 1 if colorSpace == "y" else 0)
+            for i in slot["patches"]:     # images scaled on the host (another source size): over the rows the kernel produced from zeros
+                L.memcpy_h2d(cs, slot["pool"].ptr + i * self.row, slot["side"].value + i * self.row, self.row)
             slot["patches"] = []
         L.event_record(slot["ready"], cs)
 
@@ -287,7 +304,11 @@ class AsyncLoader:
             self._thread.join()
         self.L.stream_sync(self.copy_stream)
         for s_ in self.slots:
-            self.L.host_free(s_["host"]); self.L.free(s_["dev_u8"])
+            self.L.host_free(s_["host"])
+            if s_["dev_u8"]:
+                self.L.free(s_["dev_u8"])
+            if s_["side"]:
+                self.L.host_free(s_["side"])
             self.L.event_destroy(s_["ready"]); self.L.event_destroy(s_["free"])
         self.L.stream_destroy(self.copy_stream)
         self.slots = []

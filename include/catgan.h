@@ -44,12 +44,12 @@ extern "C" {
  * utils/nn_utils.lua:638-643). */
 int         cg_abi_version(void);
 const char* cg_last_error(void);
-/* Tunables of the kernel dispatch (block tiles, split-K targets, Winograd variants ...), named like the environment
- * variables that set their defaults (CG_NN_TILE, CG_TN_TILE = bm*1000+bn; CG_NN_SPLITS, CG_TN_SPLITS; CG_GEMM_BK32;
- * CG_WINO_BK; CG_WINO_WAVES; CG_SKINNY; CG_GEMM_SLOW; CG_SPLIT_TARGET; CG_SPLIT_MINK; CG_TN_SMAX; CG_TN_TARGET;
- * CG_COLREDUCE_WGS_PER_CU; CG_EPILOGUE_STATS; CG_SAMPLER_ATOMICS; CG_XCD_SWIZZLE; how a K tile reaches the MFMAs in the GEMM
- * kernels: CG_NN_GLDS (0..3) / CG_TN_GLDS / CG_WINO_GLDS = LDS-direct loads, CG_NN_QUAD / CG_TN_QUAD / CG_WINO_QUAD = k-quad LDS layout with
- * ds_read_b128 fragments, CG_NN_PF = 2 loads two K tiles ahead).
+/* Tunables of the kernel dispatch, named like the environment variables that set their defaults - 18 since the round-5 pruning:
+ * block tiles CG_NN_TILE / CG_TN_TILE (bm*1000+bn) and splits CG_NN_SPLITS / CG_TN_SPLITS / CG_SPLIT_TARGET / CG_SPLIT_MINK / CG_TN_SMAX /
+ * CG_TN_TARGET; K step CG_GEMM_BK32 / CG_WINO_BK; CG_SKINNY; CG_EPILOGUE_STATS; CG_XCD_SWIZZLE; grid caps CG_COLREDUCE_WGS_PER_CU /
+ * CG_EW_WGS_PER_CU; and how a K tile reaches the MFMAs: CG_NN_GLDS (0..3) / CG_TN_GLDS / CG_WINO_GLDS = LDS-direct loads (default)
+ * or the register-staged kernels (0).  Removed after losing every A/B of rounds 2-4: the k-quad LDS layouts, loads two tiles ahead,
+ * the 4-wave Winograd GEMM, the sampler's atomic backward as an option, CG_GEMM_SLOW.
  * value == -1 restores the default.  Results never depend on them beyond
  * fp32 re-association; the parity tests use them to run every compiled kernel variant against the oracle. */
 int cg_set_option(const char* name, long value);
@@ -63,6 +63,13 @@ int cg_memcpy_d2h(void* stream, void* dst, const void* src, size_t bytes);
 int cg_memcpy_d2d(void* stream, void* dst, const void* src, size_t bytes);
 int cg_memset_zero(void* stream, void* dst, size_t bytes);
 int cg_stream_create(void** stream);
+/* A side stream on a chosen HARDWARE QUEUE.  The HIP runtime serves every stream of a process from four hardware queues, assigned
+ * in creation order; two streams of one queue run back to back whatever the events between them say, so which queue a side stream
+ * lands on decides whether its work overlaps with the caller's at all (csrc/common.h has the measurements).  queue_class 0 = the
+ * queue of ref_stream itself, 1..3 = the other three (numbered by a one-off timing probe); slot picks among the pool's streams of
+ * that class.  The stream belongs to the library: do NOT pass it to cg_stream_destroy.  Not callable for the first time inside a
+ * graph capture. */
+int cg_stream_on_queue(void* ref_stream, int queue_class, int slot, void** stream);
 int cg_stream_destroy(void* stream);
 int cg_stream_sync(void* stream);
 /* Input pipeline (dataset.lua:123-170, adversarial.lua:225-230): page-locked host buffers, so that cg_memcpy_h2d on a copy
@@ -172,7 +179,11 @@ int cg_conv2d_wgrad_pending(void* stream, int* njobs);
 /* Up to 16 weight gradients of ONE geometry whose tensors are equally spaced in memory (group g: x + g*x_stride, dy + g*dy_stride,
  * gw + g*gw_stride, strides in floats) as one GEMM launch + one reduction: the 16 Winograd-domain products of the upsample2 -> 5x5
  * layer's accGradParameters (models.lua:217-218; cg_conv2d_ups2_wino_wgrad below), which ran as four 4-group launches before.  No
- * bias gradient.  Workspace: cg_conv2d_wgrad_workspace_bytes_grouped(ngroups, ...) (ngroups <= 16 there for this entry point). */
+ * bias gradient.  Up to 36 groups (the 4 x 9 planes of F(2x2,2x2)).  Workspace: cg_conv2d_wgrad_workspace_bytes_strided(ngroups, ...);
+ * each size query is the capability check of ITS entry point: the _grouped one returns 0 above 4 groups (separate tensors), this one
+ * above 36. */
+size_t cg_conv2d_wgrad_workspace_bytes_strided(int ngroups, int N, int Hp, int Wp, int Cin, int Cout,
+                                               int kH, int kW, int padH, int padW, int ups);
 int cg_conv2d_wgrad_strided(void* stream, int ngroups, const float* x, long x_stride, const float* dy, long dy_stride,
                             float* gw_canonical, long gw_stride, int N, int Hp, int Wp, int Cin, int Cout,
                             int kH, int kW, int padH, int padW, int ups, float scale, void* ws, size_t ws_bytes);
@@ -232,6 +243,10 @@ int cg_conv2d_ups2_wino_forward_stats(void* stream, const float* x_lo, const flo
  * cg_conv2d_ups2_wino22_v_floats() floats (4 phases x 9 planes; what cg_conv2d_ups2_wino22_wgrad consumes later); stats as
  * cg_conv2d_ups2_wino_forward_stats. */
 size_t cg_conv2d_ups2_wino22_supported(int N, int Hp, int Wp, int Cin, int Cout);
+/* ... and whether the data-gradient / weight-gradient launches below take the same geometry (their scratch adds limits of its own):
+ * ask before choosing the path, fall back to cg_conv2d_dgrad_ups2 / cg_conv2d_wgrad otherwise. */
+size_t cg_conv2d_ups2_wino22_dgrad_supported(int N, int Hp, int Wp, int Cin, int Cout);
+size_t cg_conv2d_ups2_wino22_wgrad_supported(int N, int Hp, int Wp, int Cin, int Cout);
 size_t cg_conv2d_ups2_wino22_v_floats(int N, int Hp, int Wp, int Cin);
 size_t cg_conv2d_ups2_wino22_u_floats(int Cin, int Cout);
 int cg_conv2d_ups2_wino22_pack(void* stream, const float* wf_ph, const float* wb_ph, float* u_fwd, float* u_bwd, int Cout, int Cin);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The localisation launches alone (cg_locnet_forward / _backward, csrc/locnet.hip) at batch N: the first transformer (1 group, S 16,
 3 planes) and the three branch transformers (3 groups on a shared [N,16,16,64] map, S 8), timed with HIP events around `iters`
-back-to-back launches.  CG_LOCNET_V1=1 selects the round-3 VALU kernels (same-box A/B: run the script twice).
+back-to-back launches.
     python scripts/locbench.py [N] [iters]"""
 import ctypes
 import importlib
@@ -62,6 +62,5 @@ def case(name, G, S, Cin, P, ur, us, ut, shared):
     print(f"{name}: forward {out[0]:7.1f} us  backward {out[1]:7.1f} us   (G {G} x N {N}, S {S}, Cin {Cin}; checksum {chk:.6e})")
 
 
-print("CG_LOCNET_V1 =", os.environ.get("CG_LOCNET_V1", "0"))
 case("first transformer  ", 1, 16, 3, 1, 1, 0, 0, False)
 case("branch transformers", 3, 8, 64, 4, 1, 1, 1, True)

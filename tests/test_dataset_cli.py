@@ -175,6 +175,24 @@ def test_async_loader_pools_equal_the_blocking_loader(tmp_path, cs):
         for e in range(2):
             np.testing.assert_array_equal(cg.nn.as_nhwc(ld.next()).numpy(), mixed_ref[e])
         ld.close()
+        # sources more than 6x the target (the device kernel's box loop stops there): every image takes the host path; since round 5 the
+        # loader then pins an fp32 buffer of the POOL's size instead of an 8-bit one of the source size, and uploads it in one copy
+        big = tmp_path / "big"
+        os.makedirs(str(big))
+        for k in range(5):
+            Image.fromarray(rs.randint(0, 256, size=(200, 208, 3)).astype(np.uint8)).save(os.path.join(str(big), f"b{k}.jpg"), quality=95)
+        ds.setDirs([str(big)])
+        ds.seed(13)
+        big_ref = [ds.loadRandomImages(4).scaled for _ in range(3)]
+        ds.seed(13)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ld = ds.AsyncLoader(4)
+        assert ld.host_all and ld.nbytes == 4 * 32 * 32 * (1 if cs == "y" else 3) * 4
+        for e in range(3):
+            np.testing.assert_array_equal(cg.nn.as_nhwc(ld.next()).numpy(), big_ref[e])
+        ld.close()
     finally:
         ds.colorSpace = "rgb"
 

@@ -230,16 +230,13 @@ NN_TILES = [128128, 64128, 128064, 64064, 128032]
 @pytest.mark.parametrize("tile", NN_TILES)
 @pytest.mark.parametrize("bk32", [0, 1])
 @pytest.mark.parametrize("splits", [0, 3])
-@pytest.mark.parametrize("stage", ["b32", "quad", "pf2", "glds"])
+@pytest.mark.parametrize("stage", ["b32", "glds"])
 def test_forced_nn_tile_variants(cg, tile, bk32, splits, stage):
-    """igemm_nn_kernel<BM,BN,...,BK,QUAD,PF> / igemm_nng_kernel<BM,BN,..,BK> for every block tile, K step 16 / 32, with and
+    """igemm_nn_kernel<BM,BN,...,BK> / igemm_nng_kernel<BM,BN,..,BK> for every block tile, K step 16 / 32, with and
     without split-K (+ reduce kernel), on plain, upsample-folded (4 phases) and folded data-gradient (4 tap groups)
     geometries; ragged M and Cout.  How a K tile reaches the MFMAs: b32 = registers -> transposed LDS tile -> ds_read_b32
-    fragments; quad = k-quad LDS layout with ds_read_b128 fragments (CG_NN_QUAD=2: K step 32 for every tile when bk32; 1
-    takes it for the 64-row tiles only - a subset of these instances); pf2 = b32 with the global loads two tiles ahead;
-    glds = LDS-direct loads (buffer_load ... lds)."""
-    how = {"b32": dict(CG_NN_GLDS=0), "quad": dict(CG_NN_GLDS=0, CG_NN_QUAD=2), "pf2": dict(CG_NN_GLDS=0, CG_NN_PF=2),
-           "glds": dict(CG_NN_GLDS=3)}[stage]
+    fragments (the fallback family); glds = LDS-direct loads (buffer_load ... lds)."""
+    how = {"b32": dict(CG_NN_GLDS=0), "glds": dict(CG_NN_GLDS=3)}[stage]
     with options(cg, CG_NN_TILE=tile, CG_GEMM_BK32=bk32, CG_NN_SPLITS=splits, CG_SKINNY=0, **how):
         run_conv(cg, 3, 64, 10, 6, 72, 3, 0, seed=tile % 97)          # ragged M = 180, Cout = 72
         run_conv(cg, 2, 32, 8, 8, 128, 3, 1, seed=tile % 89, wino=False)
@@ -296,14 +293,12 @@ def run_linear(cg, N, i, o, seed=0):
 
 @pytest.mark.parametrize("tile", NN_TILES)
 @pytest.mark.parametrize("splits", [0, 5])
-@pytest.mark.parametrize("stage", ["b32", "quad16", "quad32", "glds"])
+@pytest.mark.parametrize("stage", ["b32", "glds"])
 def test_forced_tn_tile_variants(cg, tile, splits, stage):
-    """igemm_tn_kernel<BM,BN> / igemm_tnq_kernel<BM,BN,BKT> / igemm_tng_kernel<BM,BN> (weight gradient) for every block tile,
-    default and forced pixel splits; the lean power-of-two addressing (16x16 grid, and the 4 phases of a folded upsampling),
-    the generic one (10x6 grid: always the b32 kernel) and the flat rows of a linear layer.  quad16 / quad32: the pixel-quad
-    LDS layout with K steps of 16 / 32 pixels; glds: LDS-direct loads."""
-    how = {"b32": dict(CG_TN_GLDS=0), "quad16": dict(CG_TN_GLDS=0, CG_TN_QUAD=1), "quad32": dict(CG_TN_GLDS=0, CG_TN_QUAD=2),
-           "glds": dict(CG_TN_GLDS=1)}[stage]
+    """igemm_tn_kernel<BM,BN> / igemm_tng_kernel<BM,BN> (weight gradient) for every block tile, default and forced pixel splits;
+    the lean power-of-two addressing (16x16 grid, and the 4 phases of a folded upsampling), the generic one (10x6 grid: always
+    the b32 kernel) and the flat rows of a linear layer.  glds: LDS-direct loads."""
+    how = {"b32": dict(CG_TN_GLDS=0), "glds": dict(CG_TN_GLDS=1)}[stage]
     with options(cg, CG_TN_TILE=tile, CG_TN_SPLITS=splits, CG_SKINNY=0, **how):
         run_conv(cg, 3, 64, 10, 6, 72, 3, 0, seed=tile % 97, check_dgrad=False)
         run_conv(cg, 2, 64, 16, 16, 64, 3, 0, seed=tile % 89, check_dgrad=False)
@@ -312,28 +307,24 @@ def test_forced_tn_tile_variants(cg, tile, splits, stage):
 
 
 def test_generic_gather_variants(cg):
-    """The non-FAST (scalar gather) and non-vector-B template instances: Cin % 16 != 0, Cout % 4 != 0, and the FAST path
-    switched off (CG_GEMM_SLOW) on an aligned shape."""
+    """The non-FAST (scalar gather) and non-vector-B template instances: Cin % 16 != 0, Cout % 4 != 0."""
     run_conv(cg, 2, 24, 8, 8, 10, 3, 0, seed=1)
     run_conv(cg, 2, 16, 8, 8, 10, 3, 0, seed=2)
-    with options(cg, CG_GEMM_SLOW=1):
-        run_conv(cg, 2, 64, 8, 8, 64, 3, 0, seed=3)
+    run_conv(cg, 2, 24, 8, 8, 64, 3, 0, seed=3)
 
 
-@pytest.mark.parametrize("waves,bk,stage", [(8, 16, "b32"), (8, 32, "b32"), (4, 16, "b32"), (8, 16, "quad"), (8, 32, "quad"),
-                                            (8, 16, "glds"), (8, 32, "glds")])
-def test_forced_winograd_variants(cg, waves, bk, stage):
-    """wino_gemm_kernel<8,16>, <8,32>, <4,16>, the k-quad instances <8,16,true>, <8,32,true> and the LDS-direct-load kernels
-    wino_gemm_g_kernel<16>, <32> on the F(2x2,3x3) path of upsample2 -> conv5x5 (models.lua:217-218), forward + data gradient
-    + weight gradient (the Winograd-domain weight gradient runs on the TN kernels: quad / glds there too), ragged tile count."""
-    how = {"b32": dict(CG_WINO_GLDS=0, CG_TN_GLDS=0), "quad": dict(CG_WINO_GLDS=0, CG_TN_GLDS=0, CG_WINO_QUAD=1, CG_TN_QUAD=2),
-           "glds": dict(CG_WINO_GLDS=1, CG_TN_GLDS=1)}[stage]
+@pytest.mark.parametrize("bk,stage", [(16, "b32"), (32, "b32"), (16, "glds"), (32, "glds")])
+def test_forced_winograd_variants(cg, bk, stage):
+    """wino_gemm_kernel<8,16>, <8,32> (register staging, the fallback) and the LDS-direct-load kernels wino_gemm_g_kernel<16>, <32> on
+    the F(2x2,3x3) path of upsample2 -> conv5x5 (models.lua:217-218), forward + data gradient + weight gradient (the Winograd-domain
+    weight gradient runs on the TN kernels: glds there too), ragged tile count."""
+    how = {"b32": dict(CG_WINO_GLDS=0, CG_TN_GLDS=0), "glds": dict(CG_WINO_GLDS=1, CG_TN_GLDS=1)}[stage]
     cg.nn.SpatialConvolution.winograd_min_tiles = 0
     try:
-        with options(cg, CG_WINO_WAVES=waves, CG_WINO_BK=bk, **how):
-            m = run_conv(cg, 3, 128, 6, 4, 128, 5, 1, seed=waves + bk)
+        with options(cg, CG_WINO_BK=bk, **how):
+            m = run_conv(cg, 3, 128, 6, 4, 128, 5, 1, seed=8 + bk)
             assert getattr(m, "_wino", False)
-            m = run_conv(cg, 2, 256, 8, 8, 128, 5, 1, seed=waves * bk)
+            m = run_conv(cg, 2, 256, 8, 8, 128, 5, 1, seed=8 * bk)
             assert getattr(m, "_wino", False)
     finally:
         cg.nn.SpatialConvolution.winograd_min_tiles = 2048
