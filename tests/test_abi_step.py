@@ -147,7 +147,7 @@ def test_replayer_dispatch_covers_every_compute_entry_point():
     protos = cg._abi.parse_header()
     inc = open(os.path.join(ROOT, "tools", "abi_dispatch.inc")).read()
     host_only = {"cg_comm_available", "cg_comm_init", "cg_comm_size", "cg_comm_version", "cg_device_count", "cg_get_option", "cg_malloc", "cg_set_option",
-                 "cg_stream_create", "cg_abi_version", "cg_pack_conv_weight_batch", "cg_concat_channels",
+                 "cg_stream_create", "cg_stream_on_queue", "cg_abi_version", "cg_pack_conv_weight_batch", "cg_concat_channels",
                  "cg_split_channels", "cg_concat_channels_dropout", "cg_split_channels_masked",   # the last five: host int arrays (fused hosts only)
                  "cg_conv2d_wgrad_pending", "cg_host_alloc", "cg_event_create",
                  # the planned executor's host-only services: callbacks, tracing, introspection
