@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA = 157.3e12               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM = 8.0e12                       # HBM3E spec (6.29 TB/s measured with a float4 copy)
 # counter passes of the roofline launches (scripts/pmc_kernels.sh), newest first
-PMC_FILE = next((f for f in ("r04_pmc_kernels.json", "r03_pmc_kernels.json", "r03a_pmc_kernels.json", "r02b_pmc_kernels.json")
+PMC_FILE = next((f for f in ("r05_pmc_kernels.json", "r04_pmc_kernels.json", "r03_pmc_kernels.json", "r03a_pmc_kernels.json", "r02b_pmc_kernels.json")
                  if os.path.exists(os.path.join(ROOT, "profiles", f))), "r02b_pmc_kernels.json")
 
 CONFIGS = {   # BASELINE.json configs (index + 1)

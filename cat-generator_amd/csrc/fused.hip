@@ -440,10 +440,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stats_k(const float* __restric
             const long re = min(r1, rb + 64L * RL);
             float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
             float sg = 0.f;
-#pragma unroll 4
-            for (long r = rb; r < re; r += RL) {
-                const long i = r * cq + q;
-                const float4 v = ldv(x, i), d = ldv(dy, i);
 #define ST1(f)                                                          \
                 {                                                       \
                     const float xh = (v.f - mu.f) * is.f;               \
@@ -452,9 +448,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stats_k(const float* __restric
                     s1.f += dd; s2.f += dd * xh;                        \
                     if (alpha && u <= 0.f) sg += u * d.f;               \
                 }
-                ST1(x) ST1(y) ST1(z) ST1(w)
-#undef ST1
+            // Batches of UB rows: all 2 UB loads of a batch are issued before the first value is used.  Beside another queue's GEMM this
+            // kernel gets ONE workgroup per CU at best, so the bytes in flight per wave decide its rate (round 5; same summation order)
+            constexpr int UB = 8;
+            long r = rb;
+            for (; r + (UB - 1) * RL < re; r += UB * RL) {
+                float4 vv[UB], dv[UB];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) { const long i = (r + (long)k * RL) * cq + q; vv[k] = ldv(x, i); dv[k] = ldv(dy, i); }
+#pragma unroll
+                for (int k = 0; k < UB; ++k) { const float4 v = vv[k], d = dv[k]; ST1(x) ST1(y) ST1(z) ST1(w) }
             }
+            for (; r < re; r += RL) {
+                const long i = r * cq + q;
+                const float4 v = ldv(x, i), d = ldv(dy, i);
+                ST1(x) ST1(y) ST1(z) ST1(w)
+            }
+#undef ST1
             a1[0] += s1.x; a1[1] += s1.y; a1[2] += s1.z; a1[3] += s1.w;
             a2[0] += s2.x; a2[1] += s2.y; a2[2] += s2.z; a2[3] += s2.w;
             ga += sg;

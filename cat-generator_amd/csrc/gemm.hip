@@ -1290,6 +1290,24 @@ __global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int flat) {
     if (do_bias && tid < BN && n0 + tid < g.Cout)
         a.bias_part[(long)(split * (a.ngroups * g.nphase) + zz) * g.Cout + n0 + tid] = bsum;
     float* pout = a.part + (long)(split * (a.ngroups * g.nphase) + zz) * g.Ktot * g.Cout;
+    // lean path (round 5, as nn_store_lean): a FULL tile stores through a buffer descriptor at (per-lane byte offset) + (row offset in an
+    // SGPR) - no bounds test, no 64-bit address per value (the generic loop below is ~2000 instructions per wave, 1 VALU per MFMA of the
+    // whole launch; the partial sums of one (split, phase) plane always fit the 2 GB a descriptor spans)
+    if (m0 + BM <= g.Ktot && n0 + BN <= g.Cout && (long)g.Ktot * g.Cout * 4L < 0x7fffffffL) {
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)pout, 0, 0x7fffffff, 0x00020000);
+        const unsigned vo = ((unsigned)(m0 + wm0 + 4 * h) * (unsigned)g.Cout + (unsigned)(n0 + wn0 + l31)) * 4u;
+        const int c4 = g.Cout * 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int soff = (i * 32 + (r & 3) + 8 * (r >> 2)) * c4;   // wave-uniform
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rp, (int)(vo + j * 128), soff, 0);
+            }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn0 + j * 32 + l31;
@@ -1914,6 +1932,8 @@ static bool tng_flat(const Geom& g) { return g.ntaps == 1 && g.td.r0y0 == 0 && g
 
 template <int BM, int BN, int WM, int WN>
 static void launch_tng(const TNArgs& a, dim3 grid, hipStream_t st) {
+    // (round 5: capping the workgroups per CU with unused dynamic LDS - 3, 2, 1 instead of 4 - to leave slots for the other queues'
+    // memory-bound kernels measured 6.05 / 5.95 / 6.10 ms per step against 5.93: profiles/r05_sweeps.txt)
     hipLaunchKernelGGL((igemm_tng_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, a, tng_flat(a.g) ? 1 : 0);
 }
 
