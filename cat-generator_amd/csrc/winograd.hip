@@ -295,6 +295,7 @@ struct WinoArgs {
     int xcd;             // XCD-aware placement of the workgroups that share a V block (CG_XCD_SWIZZLE)
     int vpp;             // 1: V holds NPOS planes PER PHASE ([P][NPOS][T][K], F(2x2,2x2)); 0: one set shared by the phases ([NPOS][T][K])
     int kz;              // > 0 (wino_gemm_g_kernel, so == 1): blockIdx.z is a K slice of kz rows, its partial result goes to y + z * T*4*Nc
+    int lg_tw, lg_th;    // log2(tW), log2(tH) when both are powers of two and the output is below 2 GB (wino_gemm_g_kernel's lean epilogue), else -1
 };
 
 // The register-staged form (8 waves, wave tile 32 x 32; BK = K step): the fallback of wino_gemm_g_kernel below for tensors whose
@@ -578,19 +579,57 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
         const float cx0 = NPOS == 16 ? (xx < 3 ? 1.f : 0.f) : (xx < 2 ? 1.f : 0.f);
         const float cx1 = NPOS == 16 ? (xx == 0 ? 0.f : (xx == 1 ? 1.f : -1.f)) : (xx > 0 ? 1.f : 0.f);
         const float c00 = cy0 * cx0, c01 = cy0 * cx1, c10 = cy1 * cx0, c11 = cy1 * cx1;
+        // the coefficients are 0 / +-1 and wave-uniform (xi is): a zero term is skipped by a scalar branch - 36 of the 64 products of
+        // F(2x2,3x3) (16 of 36 for F(2x2,2x2)) are non-zero, and fp32 MFMA time is VALU time (round 5)
+        if (c00 != 0.f) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float m = accM[r];
-            accY[0][r] += c00 * m; accY[1][r] += c01 * m;
-            accY[2][r] += c10 * m; accY[3][r] += c11 * m;
-            accM[r] = 0.f;
+            for (int r = 0; r < 16; ++r) accY[0][r] += c00 * accM[r];
         }
+        if (c01 != 0.f) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accY[1][r] += c01 * accM[r];
+        }
+        if (c10 != 0.f) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accY[2][r] += c10 * accM[r];
+        }
+        if (c11 != 0.f) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accY[3][r] += c11 * accM[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accM[r] = 0.f;
     }
 
     // ---- epilogue (as wino_gemm_kernel, NI = 1): D[i][j], i = (r&3) + 8*(r>>2) + 4*h (tile), j = l31 (column)
     const int pa = a.so == 2 ? (phase >> 1) : 0, pb = a.so == 2 ? (phase & 1) : 0;
     float st1 = 0.f, st2 = 0.f;
     const float bcol = a.bias ? a.bias[n0 + wn0 + l31] : 0.f;
+    if (a.lg_tw >= 0) {
+        // lean path (round 5): power-of-two tile grids and an output below 2 GB - the tile decode is shifts and masks, the pixel's byte
+        // offset one 32-bit value per accumulator row, the four outputs of a tile sit at wave-uniform distances (an SGPR offset of the
+        // buffer store), and a row past the last tile stores to the out-of-range offset.  The generic loop below (two integer divisions
+        // per row, a 64-bit address per value) was ~1.5 VALU per MFMA of the whole launch.
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)yout, 0, 0x7fffffff, 0x00020000);
+        const int colb = (n0 + wn0 + l31) * 4;
+        const int rowp = a.Wo * a.Nc * 4;                      // bytes per output row of pixels
+        int soffs[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) soffs[o] = ((o >> 1) * a.so) * rowp + ((o & 1) * a.so) * a.Nc * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int tj = m & (a.tW - 1), ti = (m >> a.lg_tw) & (a.tH - 1), n = m >> (a.lg_tw + a.lg_th);
+            const int oy = 2 * ti * a.so + pa, ox = 2 * tj * a.so + pb;
+            const unsigned vo = m < a.T ? (unsigned)(((n * a.Ho + oy) * a.Wo + ox) * a.Nc * 4 + colb) : 0x80000000u;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const float v = accY[o][r] + bcol;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)vo, soffs[o], 0);
+                if (a.stats && m < a.T) { st1 += v; st2 += v * v; }
+            }
+        }
+    } else
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -880,12 +919,18 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
     a.xcd = (int)cg::opt(cg::OPT_XCD_SWIZZLE);
     a.vpp = npos == 9 && !dgrad ? 1 : 0;
     a.kz = 0;
+    a.lg_tw = a.lg_th = -1;
     CG_REQUIRE(!stats || !dgrad, "wino_gemm: statistics only on the forward launch");
     if (dgrad) { a.K = 4 * Cout; a.Nc = Cin; a.so = 1; a.Ho = Hp; a.Wo = Wp; }
     else { a.K = Cin; a.Nc = Cout; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp; }
     const int bk = (int)cg::opt(cg::OPT_WINO_BK);
     CG_REQUIRE(kslices <= 1 || (dgrad && a.K % kslices == 0 && (a.K / kslices) % 64 == 0), "wino_gemm: K slices only on the data gradient, in multiples of 64 rows");
     if (kslices > 1) a.kz = a.K / kslices;
+    {
+        auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+        const long ybytes = (long)N * a.Ho * a.Wo * a.Nc * 4L;
+        if (lg(a.tW) >= 0 && lg(a.tH) >= 0 && ybytes < 0x7fffffffL) { a.lg_tw = lg(a.tW); a.lg_th = lg(a.tH); }
+    }
     const dim3 grid(cg::cdiv(T, 64) * (a.Nc / 128), 1, dgrad ? (kslices > 1 ? kslices : 1) : 4);
     // K step 32 (half the barriers per MFMA) pays when the launch is at most ~one workgroup per CU - the data-gradient
     // geometry at batch 128 (0.53 -> 0.41 ms) - and costs 6 % when two workgroups per CU already hide each other's barriers
