@@ -770,6 +770,44 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
             CG_STAMP(3);
             return;
         }
+        // lean STRIDED path (round 5): the phase-folded forward of a layer behind an upsampling (output pixel (2 oy + a, 2 ox + b), so == 2)
+        // with or without the batch-norm statistics of the layer behind it - power-of-two grids, full tiles, no fused activation, an
+        // output below 2 GB: the pixel decode is shifts and masks, the byte offset of an accumulator row one 32-bit value, a row past
+        // the end stores to the out-of-range offset.  (The generic loop below decodes, bounds-checks and builds a 64-bit address per
+        // VALUE.)  Same values, same order of the statistics' sums.
+        if (!partial && !act && g.lgW >= 0 && m0 + BM <= g.M && n0 + BN <= g.Cout && !lin &&
+            (long)(g.M >> g.lgHW) * g.Hout * g.Wout * g.Cout * 4L < 0x7fffffffL) {
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)yout, 0, 0x7fffffff, 0x00020000);
+            const int colb = (n0 + wn0 + l31) * 4;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int n = m >> g.lgHW, oy = (m >> g.lgW) & (g.Hg - 1), ox = m & (g.Wg - 1);
+                    const int vo = ((n * g.Hout + oy * g.so + pa) * g.Wout + ox * g.so + pb) * g.Cout * 4 + colb;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const float v = acc[i][j][r] + bj[j];
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, vo, j * 128, 0);
+                        if (stats) { s1[j] += v; s2[j] += v * v; }
+                    }
+                }
+            }
+            if (stats) {
+                const int srow = (zz * (int)((g.M + BM - 1) / BM) + tm) * WM + wave / WN;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64), t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+                    if (h == 0) {
+                        a.stats[((long)srow * 2 + 0) * g.Cout + n0 + wn0 + j * 32 + l31] = t1;
+                        a.stats[((long)srow * 2 + 1) * g.Cout + n0 + wn0 + j * 32 + l31] = t2;
+                    }
+                }
+            }
+            CG_STAMP(3);
+            return;
+        }
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
