@@ -15,6 +15,7 @@ import torch
 PTR_TYPES = {"void*", "const void*", "float*", "const float*", "double*", "const double*", "int32_t*", "const int32_t*",
              "uint64_t*", "const uint64_t*"}
 PARR_TYPES = {"const float* const*", "float* const*"}
+HOST_ONLY = {"cg_stream_on_queue"}   # a side stream on a chosen hardware queue (adversarial._side_stream): scheduling, not data
 NET_OUT = {"id", "draws", "y", "ynd", "ydims", "yfmt", "gx", "gnd", "gdims", "gfmt", "nbuckets"}   # scripts/gen_abi_dispatch.py
 
 
@@ -122,6 +123,8 @@ class Recorder:
                 ncall += 1
         self.prologue_calls = ncall
         for name, args in calls:
+            if name in HOST_ONLY:        # services with host out-parameters that move no data: the replayer has its one stream
+                continue
             if name.startswith(("cg_net_", "cg_graph_")):
                 lines.append("|".join(["call", name] + self._net_args(name, args, ncall)))
                 ncall += 1
