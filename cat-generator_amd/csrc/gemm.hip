@@ -1191,6 +1191,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int flat) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
+    // (Round 5 tried INTERLEAVING a wave's 32-row blocks with the other waves' - 64 floats apart, so that a fragment pair is one
+    // ds_read2st64_b32 with immediate offsets and the K loop has no address VALU at all (the ds_read2_b32 pairs below need one v_add_u32
+    // per pair: their 8-bit offsets reach 1 KB).  Alone the weight gradients measured the same; in the step it cost 0.12 ms
+    // (6.00 against 5.88 ms, profiles/r05_sweeps.txt) - the two reads of a pair then hit the same LDS banks.  Not kept.)
     const int wm0 = (wave / WN) * (BM / WM);
     const int wn0 = (wave % WN) * (BN / WN);
 

@@ -1,8 +1,12 @@
 #!/bin/bash
-# round 5, call k: lean strided (+ statistics) epilogue of igemm_nng_kernel: parity, G's forward layers alone, the step - against _base on the same box
+# round 5, call k: is the hardware-queue probe stable?  classes printed by five processes, step time of each, _base in between
 mkdir -p gpurun_out/r05k
-python -m pytest tests/test_gpu_parity_full.py tests/test_gpu_parity.py -x -q -m gpu -k "forced_nn or lean or full_conv or generator or statistics or epilogue" 2>&1 | tail -2
-for d in _base . _base .; do echo "== $d"; (cd $d && python scripts/kbench.py 128 --quick --pass fwd 2>/dev/null | grep -v "^layer" | cut -c1-62); done | tee gpurun_out/r05k/kbench_fwd.txt
-for rep in 1 2 3; do for d in _base .; do (cd $d && python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-kernel-roofline 2>/dev/null | python -c "
+for rep in 1 2 3; do
+  python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-kernel-roofline 2> gpurun_out/r05k/err.txt | python -c "
 import json,sys
-j=json.loads(sys.stdin.read()); print('$d', round(j['ms_per_step'],4))"); done; done | tee gpurun_out/r05k/ab3.txt
+j=json.loads(sys.stdin.read()); print('.', round(j['ms_per_step'],4))"
+  grep "cg: hardware" gpurun_out/r05k/err.txt
+  (cd _base && python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-kernel-roofline 2>/dev/null | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); print('_base', round(j['ms_per_step'],4))")
+done | tee gpurun_out/r05k/probe_stability.txt
