@@ -169,6 +169,7 @@ struct MS {
     bool use_wino = false, use_wino22 = false;
     bool fused = false; int fG = 0; Val fX, fmask; long fN = 0, fC = 0, fH = 0, fW = 0;   // act_pool segment state (on the activation)
     bool bn_fused = false; long bnM = 0, bnC = 0;            // gemm_bn_act segment state (on the batch-norm)
+    Val bstats_part; long bstats_rows = 0;                   // backward sums left by the next layer's data-gradient epilogue (round 5)
     double count = 0;            // BN: samples behind the statistics (x world under sync-BN)
     vector<long> sizes;          // nn.Concat: channels per branch
     vector<Seg> ran;             // nn.Sequential: the plan its forward ran
@@ -230,6 +231,9 @@ struct Net {
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
         cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_lag = 0,
+        bn_epilogue = 0,       // 1: backward sums of a [batch-norm, PReLU] pair in the epilogue of the Winograd data-gradient GEMM that produces its
+                               // gradOutput (round 5; parity-clean, but that launch has ONE workgroup per CU, so its epilogue - 64 loads of the
+                               // batch-norm input per lane - is exposed: 5.89 -> 5.94 ms per step, config #3 +-0; profiles/r05_sweeps.txt.  Off)
         wino_dsplit = 1;       // the F(2x2,3x3) data gradient in K slices when its unsplit launch is <= one workgroup per CU (cg_conv2d_ups2_wino_dgrad_split)
     long wino_min_tiles = 2048;
     int wino22 = 3;                            // F(2x2,2x2) for upsample2 -> conv3x3 above wino_min_tiles: bit 0 forward, 1 data gradient, 2 weight gradient
@@ -317,6 +321,7 @@ struct Compiler {
     bool wg_used[4] = {false, false, false, false};   // the weight-gradient stream beside stream s has work to join
     vector<std::function<void()>> wg_pending[4];      // option wgrad_lag: weight gradients held back until the next data-gradient GEMM of stream s
     bool acc_pass = false;        // compiling Module:backward (weight gradients deferred) rather than updateGradInput
+    Mod *epi_bn = nullptr, *epi_act = nullptr;   // the [batch-norm, PReLU] whose backward sums the data gradient being emitted may compute in its epilogue
 
     Compiler(Net* n, Prog* p) : net(n), pr(p) {}
     const KTable* K() const { return net->K; }
@@ -1799,9 +1804,18 @@ struct Compiler {
             if (s.use_wino) {
                 Val vdy = buf(m, "wino_vdy", {(long)cg_conv2d_ups2_wino_v_floats((int)N, (int)Hp, (int)Wp, (int)(4 * Co))});
                 const long np = net->wino_dsplit ? (long)cg_conv2d_ups2_wino_dgrad_part_floats((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co) : 0;
+                const long brows = (!np && epi_bn && S(*epi_bn).bnC == Ci && S(*epi_bn).bnM == N * Hp * Wp)
+                                       ? (long)cg_conv2d_ups2_wino_dgrad_bn_rows((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co) : 0;
                 if (np) {
                     Val part = buf(m, "wino_dpart", {np});
                     emit([=](Run& c) { return k->conv2d_ups2_wino_dgrad_split(c.CS(), c.P(dy), mp->u_bwd, c.P(lo), c.P(vdy), c.P(part), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
+                } else if (brows) {
+                    Mod *bp = epi_bn, *ap = epi_act;
+                    MS& sb = S(*bp);
+                    Val bpart = buf(*bp, "bstats_part", {brows, 3, Ci}), bx = sb.x, sm = buf(*bp, "save_mean", {Ci}), sv = buf(*bp, "save_std", {Ci});
+                    emit([=](Run& c) { return k->conv2d_ups2_wino_dgrad_bn(c.CS(), c.P(dy), mp->u_bwd, c.P(lo), c.P(vdy), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co,
+                                                                           c.P(bx), c.P(sm), c.P(sv), bp->w, bp->b, ap->w, c.P(bpart)); });
+                    sb.bstats_part = bpart; sb.bstats_rows = brows;
                 } else
                     emit([=](Run& c) { return k->conv2d_ups2_wino_dgrad(c.CS(), c.P(dy), mp->u_bwd, c.P(lo), c.P(vdy), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
             } else if (s.use_wino22 && (net->wino22 & 2) && mp->u22b && cg_conv2d_ups2_wino22_dgrad_supported((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co)) {
@@ -2019,7 +2033,16 @@ struct Compiler {
             if (sg.kind == S_ACT_POOL && S(kid(sg.i)).fused && S(kid(sg.i)).fG == 1) {
                 cur = bwd_act_pool({&kid(sg.i)}, {&kid(sg.i + 1)}, sg.j - sg.i == 3 ? vector<Mod*>{&kid(sg.i + 2)} : vector<Mod*>{}, {cur}, acc)[0];
             } else if (sg.kind == S_GEMM_BN_ACT && S(kid(sg.i + 1)).bn_fused) {
+                // [conv, BN, PReLU] -> nn.SpatialUpSamplingNearest(2) (folded) -> this layer: this layer's data gradient IS the gradOutput of
+                // the pair in front, whose backward sums can ride in its epilogue instead of a pass of their own (models.lua:212-218)
+                epi_bn = epi_act = nullptr;
+                if (net->bn_epilogue && net->fusion && si >= 2 && pl[si - 1].kind == S_ONE && pl[si - 1].j - pl[si - 1].i == 1 &&
+                    kid(pl[si - 1].i).kind == K_UPS && pl[si - 2].kind == S_GEMM_BN_ACT && S(kid(pl[si - 2].i + 1)).bn_fused) {
+                    epi_bn = &kid(pl[si - 2].i + 1); epi_act = &kid(pl[si - 2].i + 2);
+                    S(*epi_bn).bstats_rows = 0;
+                }
                 cur = bwd_gemm_bn_act(kid(sg.i), kid(sg.i + 1), kid(sg.i + 2), inp, cur, acc);
+                epi_bn = epi_act = nullptr;
             } else if (sg.kind == S_CAT_DROP) {
                 cur = bwd_concat(kid(sg.i), inp, cur, acc, &kid(sg.i + 1));
             } else if (sg.kind == S_HEAD && S(kid(sg.i)).head_fused) {
@@ -2310,7 +2333,27 @@ struct Compiler {
         const Val x = sb.x;
         Val dy = as_nhwc(go);
         Mod *bp = &bn, *ap = &act;
-        Val b3 = buf(bn, "bsums3", {2 * C + 1}, PLAIN, 8), sm = buf(bn, "save_mean", {C}), sv = buf(bn, "save_std", {C});
+        Val sm = buf(bn, "save_mean", {C}), sv = buf(bn, "save_std", {C});
+        if (sb.bstats_rows > 0) {
+            // the sums arrived with the gradOutput: per-workgroup rows from the producing data gradient's epilogue -> one small finalize
+            const long rows = sb.bstats_rows; Val bpart = sb.bstats_part;
+            sb.bstats_rows = 0;
+            Val b3c = buf(bn, "bsums3c", {3 * C}, PLAIN, 8);
+            emit([=](Run& c) { return k->bn_act_backward_stats_finalize(c.CS(), c.P(bpart), rows, (int)C, (double*)c.P(b3c)); });
+            Val gsc = b3c;
+            if (net->world > 1 && net->sync_bn) {
+                gsc = buf(bn, "bsums3c_g", {3 * C}, PLAIN, 8);
+                emit([=](Run& c) { return k->memcpy_d2d(c.CS(), c.P(gsc), c.P(b3c), (size_t)(3 * C) * 8); });
+                emit_allreduce_sum(gsc, 2 * C, 1);
+            }
+            Val dxc = buf_like(bn, "gin", x, NHWC);
+            const double cntc = sb.count;
+            emit([=](Run& c) { return k->bn_act_backward_cols(c.CS(), c.P(x), c.P(dy), bp->w, bp->b, c.P(sm), c.P(sv), ap->w, (const double*)c.P(gsc), cntc, (const double*)c.P(b3c),
+                                                              Mr, (int)C, c.P(dxc), acc ? bp->gw : nullptr, acc ? bp->gb : nullptr, acc ? ap->gw : nullptr, c.scale); });
+            S(act).gin = Val(); sb.gin = dxc;
+            return bwd(conv, in, dxc, acc);
+        }
+        Val b3 = buf(bn, "bsums3", {2 * C + 1}, PLAIN, 8);
         emit([=](Run& c) { return k->bn_act_backward_stats(c.CS(), c.P(x), c.P(dy), c.P(sm), c.P(sv), bp->w, bp->b, ap->w, Mr, (int)C, (double*)c.P(b3)); });
         Val gs = b3;
         if (net->world > 1 && net->sync_bn) {
@@ -2557,7 +2600,7 @@ std::string prog_key(Net* n, int nd, const long* dims, int fmt) {
     k += "|o" + std::to_string(n->overlap_groups) + std::to_string(n->defer_wgrad) + std::to_string(n->winograd) + std::to_string(n->fusion) +
          std::to_string(n->stacking) + std::to_string(n->grouped) + std::to_string(n->share_pool) + std::to_string(n->sampler_shared) +
          std::to_string(n->view_fuse) + std::to_string(n->cat_fuse) + std::to_string(n->fuse_locnet) + std::to_string(n->head_fuse) +
-         std::to_string(n->wgrad_stream) + std::to_string(n->wgrad_lag) + std::to_string(n->wino22) + std::to_string(n->wino_dsplit) + "m" +
+         std::to_string(n->wgrad_stream) + std::to_string(n->wgrad_lag) + std::to_string(n->wino22) + std::to_string(n->wino_dsplit) + std::to_string(n->bn_epilogue) + "m" +
          std::to_string(n->wino_min_tiles);
     return k;
 }
@@ -2583,6 +2626,7 @@ int cg_net_create(void** net) {
     if ((e = getenv("CG_HEAD_FUSE"))) n->head_fuse = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_STREAM"))) n->wgrad_stream = atoi(e) != 0;
     if ((e = getenv("CG_WINO_DSPLIT"))) n->wino_dsplit = atoi(e) != 0;
+    if ((e = getenv("CG_BN_EPILOGUE"))) n->bn_epilogue = atoi(e) != 0;
     if ((e = getenv("CG_WGRAD_LAG"))) n->wgrad_lag = atoi(e);
     if ((e = getenv("CG_WINOGRAD22"))) n->wino22 = atoi(e);
     *net = n;
@@ -2609,7 +2653,8 @@ int cg_net_set_option(void* net, const char* name, long value) {
         {"overlap_groups", &n->overlap_groups}, {"defer_wgrad", &n->defer_wgrad}, {"winograd", &n->winograd}, {"share_pool", &n->share_pool},
         {"sampler_shared", &n->sampler_shared}, {"view_fuse", &n->view_fuse}, {"cat_fuse", &n->cat_fuse}, {"stacking", &n->stacking},
         {"grouped", &n->grouped}, {"fusion", &n->fusion}, {"fuse_locnet", &n->fuse_locnet}, {"pack_overlap", &n->pack_overlap},
-        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wgrad_lag", &n->wgrad_lag}, {"wino_dsplit", &n->wino_dsplit}};
+        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wgrad_lag", &n->wgrad_lag}, {"wino_dsplit", &n->wino_dsplit},
+        {"bn_epilogue", &n->bn_epilogue}};
     if (!strcmp(name, "trace")) {
         CG_REQUIRE(n->progs.empty(), "cg_net_set_option: trace must be chosen before the first pass");
         n->trace = value != 0; n->K = n->trace ? &kTraceTable : &kRealTable;

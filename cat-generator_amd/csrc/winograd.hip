@@ -296,6 +296,12 @@ struct WinoArgs {
     int vpp;             // 1: V holds NPOS planes PER PHASE ([P][NPOS][T][K], F(2x2,2x2)); 0: one set shared by the phases ([NPOS][T][K])
     int kz;              // > 0 (wino_gemm_g_kernel, so == 1): blockIdx.z is a K slice of kz rows, its partial result goes to y + z * T*4*Nc
     int lg_tw, lg_th;    // log2(tW), log2(tH) when both are powers of two and the output is below 2 GB (wino_gemm_g_kernel's lean epilogue), else -1
+    // bstats != null (lean epilogue of the unsplit data-gradient launch): y is the gradient w.r.t. the OUTPUT of y' = prelu(bn(bnx)) - the
+    // [conv, SpatialBatchNormalization, PReLU] in front of this layer (models.lua:212-214 in front of :217-218) - and the launch leaves the
+    // column sums that layer's backward needs, per (tile block, wave row): bstats[rows][3][Nc] = sum d, sum d xhat, sum_{u <= 0} u dy
+    // with xhat = (bnx - mean) invstd, u = xhat gamma + beta, d = prelu'(u) dy: what bn_act_bwd_stats_k computes in a pass of its own
+    const float* bnx; const float* bn_mean; const float* bn_is; const float* bn_g; const float* bn_b; const float* bn_alpha;
+    float* bstats;
 };
 
 // The register-staged form (8 waves, wave tile 32 x 32; BK = K step): the fallback of wino_gemm_g_kernel below for tensors whose
@@ -616,6 +622,16 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
         int soffs[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) soffs[o] = ((o >> 1) * a.so) * rowp + ((o & 1) * a.so) * a.Nc * 4;
+        const bool bs = a.bstats != nullptr;
+        float bmu = 0.f, bis = 0.f, bga = 0.f, bbe = 0.f, bal = 1.f, b1 = 0.f, b2 = 0.f, bg = 0.f;
+        const bool balpha = bs && a.bn_alpha != nullptr;
+        __amdgpu_buffer_rsrc_t rx = ry;
+        if (bs) {
+            const int col = n0 + wn0 + l31;
+            bmu = a.bn_mean[col]; bis = a.bn_is[col]; bga = a.bn_g[col]; bbe = a.bn_b[col];
+            if (balpha) bal = *a.bn_alpha;
+            rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.bnx, 0, 0x7fffffff, 0x00020000);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -627,6 +643,25 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
                 const float v = accY[o][r] + bcol;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)vo, soffs[o], 0);
                 if (a.stats && m < a.T) { st1 += v; st2 += v * v; }
+                if (bs) {   // the same arithmetic per element as bn_act_bwd_stats_k (fused.hip); an out-of-range row loads 0 and is masked
+                    const float xv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)vo, soffs[o], 0));
+                    if (m < a.T) {
+                        const float xh = (xv - bmu) * bis;
+                        const float u = xh * bga + bbe;
+                        const float dd = (!balpha || u > 0.f) ? v : bal * v;
+                        b1 += dd; b2 += dd * xh;
+                        if (balpha && u <= 0.f) bg += u * v;
+                    }
+                }
+            }
+        }
+        if (bs) {
+            const int srow = tm * 2 + (wave & 1);
+            const float t1 = b1 + __shfl_xor(b1, 32, 64), t2 = b2 + __shfl_xor(b2, 32, 64), t3 = bg + __shfl_xor(bg, 32, 64);
+            if (h == 0) {
+                a.bstats[((long)srow * 3 + 0) * a.Nc + n0 + wn0 + l31] = t1;
+                a.bstats[((long)srow * 3 + 1) * a.Nc + n0 + wn0 + l31] = t2;
+                a.bstats[((long)srow * 3 + 2) * a.Nc + n0 + wn0 + l31] = t3;
             }
         }
     } else
@@ -895,8 +930,9 @@ int cg_conv2d_ups2_wino_pack(void* stream, const float* wf_ph, const float* wb_p
 // The 16 GEMMs + output transform alone, on an already transformed input (what the two entry points below launch after
 // their input transform; exported so that it can be timed / profiled in isolation).
 // dgrad == 0: v [16][T][Cin], u = u_fwd, y [N][2Hp][2Wp][Cout];  dgrad == 1: v [16][T][4*Cout], u = u_bwd, y [N][Hp][Wp][Cin].
+struct WinoBn { const float *x, *mean, *is, *g, *b, *alpha; float* part; };
 static int wino_gemm_launch(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
-                            int Cin, int Cout, int dgrad, float* stats, int npos = 16, int kslices = 1);
+                            int Cin, int Cout, int dgrad, float* stats, int npos = 16, int kslices = 1, const WinoBn* bn = nullptr);
 
 int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
                              int Cin, int Cout, int dgrad) {
@@ -910,7 +946,7 @@ size_t cg_conv2d_ups2_wino_stats_rows(int N, int Hp, int Wp, int Cin, int Cout) 
 }
 
 static int wino_gemm_launch(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
-                            int Cin, int Cout, int dgrad, float* stats, int npos, int kslices) {
+                            int Cin, int Cout, int dgrad, float* stats, int npos, int kslices, const WinoBn* bn) {
     CG_REQUIRE(v && u && y, "cg_conv2d_ups2_wino_gemm: null pointer");
     CG_REQUIRE(wino_dims_ok(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino_gemm: unsupported dimensions");
     const int T = N * (Hp / 2) * (Wp / 2);
@@ -920,6 +956,7 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
     a.vpp = npos == 9 && !dgrad ? 1 : 0;
     a.kz = 0;
     a.lg_tw = a.lg_th = -1;
+    a.bnx = a.bn_mean = a.bn_is = a.bn_g = a.bn_b = a.bn_alpha = nullptr; a.bstats = nullptr;
     CG_REQUIRE(!stats || !dgrad, "wino_gemm: statistics only on the forward launch");
     if (dgrad) { a.K = 4 * Cout; a.Nc = Cin; a.so = 1; a.Ho = Hp; a.Wo = Wp; }
     else { a.K = Cin; a.Nc = Cout; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp; }
@@ -931,6 +968,11 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
         const long ybytes = (long)N * a.Ho * a.Wo * a.Nc * 4L;
         if (lg(a.tW) >= 0 && lg(a.tH) >= 0 && ybytes < 0x7fffffffL) { a.lg_tw = lg(a.tW); a.lg_th = lg(a.tH); }
     }
+    if (bn) {
+        CG_REQUIRE(dgrad && kslices <= 1 && a.lg_tw >= 0 && bn->x && bn->mean && bn->is && bn->g && bn->b && bn->part,
+                   "wino_gemm: batch-norm backward sums need the unsplit data-gradient launch with a power-of-two tile grid");
+        a.bnx = bn->x; a.bn_mean = bn->mean; a.bn_is = bn->is; a.bn_g = bn->g; a.bn_b = bn->b; a.bn_alpha = bn->alpha; a.bstats = bn->part;
+    }
     const dim3 grid(cg::cdiv(T, 64) * (a.Nc / 128), 1, dgrad ? (kslices > 1 ? kslices : 1) : 4);
     // K step 32 (half the barriers per MFMA) pays when the launch is at most ~one workgroup per CU - the data-gradient
     // geometry at batch 128 (0.53 -> 0.41 ms) - and costs 6 % when two workgroups per CU already hide each other's barriers
@@ -938,6 +980,7 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
     // LDS-direct loads (CG_WINO_GLDS): one xi plane of V must stay below the 2 GB a buffer offset reaches
     const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && (long)T * a.K * 4L < 0x7fffffffL &&
                       16L * a.K * a.Nc * 4L < 0x7fffffffL;
+    CG_REQUIRE(!bn || glds, "wino_gemm: batch-norm backward sums need the LDS-direct-load kernel (CG_WINO_GLDS)");
     if (npos == 9) {     // F(2x2,2x2): the LDS-direct-load kernel only (cg_conv2d_ups2_wino22_supported checks the same conditions)
         CG_REQUIRE(glds, "wino_gemm: the 9-position form needs the LDS-direct-load kernel (CG_WINO_GLDS)");
         if (k32 && (a.kz ? a.kz : a.K) % 64 == 0) hipLaunchKernelGGL((wino_gemm_g_kernel<32, 9>), grid, dim3(512), 0, cg::S(stream), a);
@@ -1078,6 +1121,33 @@ int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd,
                        4 * Cout, Cout);
     CG_LAUNCH_CHECK();
     return cg_conv2d_ups2_wino_gemm(stream, v_dy, u_bwd, nullptr, dx_lo, N, Hp, Wp, Cin, Cout, 1);
+}
+
+// cg_conv2d_ups2_wino_dgrad with the backward sums of the [SpatialBatchNormalization, PReLU] in front of the layer in its epilogue:
+// part[cg_conv2d_ups2_wino_dgrad_bn_rows()][3][Cin] (see WinoArgs::bstats); rows == 0: this geometry / option set cannot (sliced launch,
+// tile grid not a power of two, register-staged kernel) - use cg_bn_act_backward_stats on dx_lo.
+static int wino_dgrad_slices(int N, int Hp, int Wp, int Cin, int Cout);
+size_t cg_conv2d_ups2_wino_dgrad_bn_rows(int N, int Hp, int Wp, int Cin, int Cout) {
+    if (!wino_dims_ok(N, Hp, Wp, Cin, Cout) || cg::opt(cg::OPT_EPILOGUE_STATS) == 0) return 0;
+    const long T = (long)N * (Hp / 2) * (Wp / 2);
+    const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && T * 4L * Cout * 4L < 0x7fffffffL && 16L * 4L * Cout * Cin * 4L < 0x7fffffffL;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (!glds || !pow2(Hp / 2) || !pow2(Wp / 2) || (long)N * Hp * Wp * Cin * 4L >= 0x7fffffffL) return 0;
+    if (wino_dgrad_slices(N, Hp, Wp, Cin, Cout) > 1) return 0;
+    return (size_t)2 * cg::cdiv(T, 64);
+}
+int cg_conv2d_ups2_wino_dgrad_bn(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy, int N, int Hp, int Wp, int Cin,
+                                 int Cout, const float* bn_x, const float* save_mean, const float* save_invstd, const float* gamma,
+                                 const float* beta, const float* alpha, float* part) {
+    CG_REQUIRE(dy && u_bwd && dx_lo && v_dy && bn_x && save_mean && save_invstd && gamma && beta && part, "cg_conv2d_ups2_wino_dgrad_bn: null pointer");
+    CG_REQUIRE(cg_conv2d_ups2_wino_dgrad_bn_rows(N, Hp, Wp, Cin, Cout) > 0, "cg_conv2d_ups2_wino_dgrad_bn: unsupported dimensions / options");
+    hipStream_t st = cg::S(stream);
+    const int T = N * (Hp / 2) * (Wp / 2);
+    hipLaunchKernelGGL(wino_input_transform_kernel<1>, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, st, dy, v_dy, N, Hp, Wp,
+                       4 * Cout, Cout);
+    CG_LAUNCH_CHECK();
+    const WinoBn bn{bn_x, save_mean, save_invstd, gamma, beta, alpha, part};
+    return wino_gemm_launch(stream, v_dy, u_bwd, nullptr, dx_lo, N, Hp, Wp, Cin, Cout, 1, nullptr, 16, 1, &bn);
 }
 
 // The same data gradient with its K rows (the four phases' channels) in 2 or 4 slices over blockIdx.z and a fixed-order sum of the partial

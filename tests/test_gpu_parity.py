@@ -1093,6 +1093,32 @@ def test_plan_options_are_result_neutral(cg, which):
     bulk_close(res["head modules one by one"], res["default"], max_rel=2e-4, mean_rel=2e-6, what=f"{which} fused vs separate head")
 
 
+def test_bn_backward_sums_in_the_data_gradient_epilogue(cg):
+    """Round 5 (plan option bn_epilogue): the 5x5 layer's Winograd data gradient is the gradOutput of the [batch-norm, PReLU] pair in front
+    of it, and its epilogue leaves that pair's backward sums as per-workgroup rows (cg_conv2d_ups2_wino_dgrad_bn ->
+    cg_bn_act_backward_stats_finalize -> cg_bn_act_backward_cols) instead of a pass over (x, gradOutput) - at the benchmarked batch, where
+    the launch is unsplit.  Same sums in another order: the flat gradient of G32up-c with and without, and the plan really took the path."""
+    import ctypes
+    N = 128
+    res = {}
+    for on in (1, 0):
+        P, _, _ = _pair(cg, 33, "G")
+        pP, gP = P.getParameters()
+        rs = np.random.RandomState(10)
+        x = (rs.rand(N, 100) * 2 - 1).astype(f32); dy = (rs.randn(N, 3, 32, 32) * 0.1).astype(f32)
+        xin, dyt = cg.Tensor.from_numpy(x), cg.Tensor.from_numpy(dy)
+        net = P._planned_net()
+        cg.lib().net_set_option(net.h, b"bn_epilogue", on)
+        P.forward(xin)
+        gP.zero()
+        gi = cg.nn.as_plain(P.backward(xin, dyt)).numpy()
+        res[on] = (gP.numpy().copy(), gi)
+        assert np.abs(res[on][0]).max() > 0
+    assert cg.lib().conv2d_ups2_wino_dgrad_bn_rows(N, 16, 16, 256, 128) == 2 * (N * 64 // 64)
+    bulk_close(res[1][0], res[0][0], max_rel=2e-4, mean_rel=2e-6, what="G32up-c flat gradient: BN backward sums from the epilogue vs their own pass")
+    bulk_close(res[1][1], res[0][1], max_rel=2e-4, mean_rel=2e-6, what="G32up-c gradInput")
+
+
 def test_collectives_through_the_c_abi_single_rank(cg):
     """csrc/comm.hip on the one GPU gpurun provides: RCCL bound at run time, a 1-rank communicator, all-reduce (sum, average,
     fp32 and fp64) and broadcast on the side stream with event fork/join against the compute stream.  With one rank every

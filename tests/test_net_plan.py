@@ -120,7 +120,23 @@ def test_generator_plan_uses_epilogue_statistics_and_winograd_at_the_benchmarked
     assert f.count("cg_conv2d_ups2_wino_forward_stats") == 1      # the 5x5 layer's phases in Winograd F(2x2,3x3)
     assert "cg_upsample2x_forward" not in f and "cg_prelu_forward" not in f
     b = [c[0] for c in T.calls(r["backward"])]
-    assert b.count("cg_conv2d_ups2_wino_dgrad") == 1 and b.count("cg_conv2d_ups2_wino_wgrad") == 1
+    # round 5: the 5x5 layer's data gradient IS the gradOutput of the [batch-norm, PReLU] in front of it (behind the folded upsampling), so
+    # that pair's backward sums ride in the GEMM's epilogue: partial rows -> one small finalize instead of a pass over (x, gradOutput)
+    assert b.count("cg_conv2d_ups2_wino_dgrad") == 1 and b.count("cg_conv2d_ups2_wino_wgrad") == 1 and b.count("cg_bn_act_backward_stats") == 3
+    # option bn_epilogue (round 5; off: no gain measured): the 5x5 layer's data gradient IS the gradOutput of the [batch-norm, PReLU] in
+    # front of it (behind the folded upsampling), so that pair's backward sums can ride in the GEMM's epilogue: partial rows -> one small
+    # finalize instead of a pass over (x, gradOutput)
+    r_on = T.trace("G32up-c", 128, options=[("bn_epilogue", 1)])
+    bo = [c[0] for c in T.calls(r_on["backward"])]
+    assert bo.count("cg_conv2d_ups2_wino_dgrad_bn") == 1 and "cg_conv2d_ups2_wino_dgrad" not in bo and bo.count("cg_conv2d_ups2_wino_wgrad") == 1
+    assert bo.count("cg_bn_act_backward_stats") == 2 and bo.count("cg_bn_act_backward_stats_finalize") == 1 and bo.count("cg_bn_act_backward_cols") == 1
+    i_d = bo.index("cg_conv2d_ups2_wino_dgrad_bn")
+    assert [x for x in bo[i_d + 1:] if not x.startswith("cg_conv2d_ups2_wino_wgrad")][:2] == ["cg_bn_act_backward_stats_finalize", "cg_bn_act_backward_cols"]
+    calls_b = T.calls(r_on["backward"])
+    a_d = [a for n_, a in calls_b if n_ == "cg_conv2d_ups2_wino_dgrad_bn"][0]
+    a_f = [a for n_, a in calls_b if n_ == "cg_bn_act_backward_stats_finalize"][0]
+    a_c = [a for n_, a in calls_b if n_ == "cg_bn_act_backward_cols"][0]
+    assert a_d["part"] == a_f["partials"] and a_f["sums3"] == a_c["local_sums"] and a_d["dx_lo"] == a_c["dy"] and a_d["bn_x"] == a_c["x"]
     # a Winograd data gradient whose unsplit launch is below one workgroup per CU runs in K slices over blockIdx.z + a fixed-order sum (option
     # wino_dsplit): G32up's 128 -> 256 layer at batch 256 (64 workgroups), not its 256 -> 128 layer (512) nor G32up-c's (256, above)
     b3 = [c[0] for c in T.calls(T.trace("G32up", 256)["backward"])]
