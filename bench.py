@@ -81,7 +81,7 @@ def time_kernel(fn, iters=20, warm=3):
     """Average duration (s) of one launch group: `iters` launches captured into ONE hipGraph on the launch stream and the replay
     bracketed by HIP events on that stream.  (Round 2 timed eager launches from Python: the host gap between two dependent launches
     - 20-25 us of interpreter + dispatch per call - sat inside the bracket, 8 % of a 0.29 ms kernel; the replay leaves the ~2 us
-    dependent-launch floor, so the figure follows the rocprofv3 duration of the same launch in profiles/r04_roofline_launch_durations.txt, a kernel trace of
+    dependent-launch floor, so the figure follows the rocprofv3 duration of the same launch in profiles/r05_roofline_launch_durations.txt, a kernel trace of
     `scripts/kbench.py --only <layer>` in which every row is one of these launches and nothing else.)"""
     for _ in range(warm):
         fn()
@@ -199,7 +199,7 @@ def kernel_rooflines(cg, cfg, N):
     px = N * h2 * h2
     entry("tn128x128", "igemm_tng_kernel<128,128,2,2> (gemm.hip; LDS-direct loads)",
           f"weight-gradient GEMM of upsample2 -> conv3x3 512->256 @{h2}->{2 * h2}, batch {N}: 4 phases x [2048 x {px}]^T.[{px} x 256], pixels split",
-          2.0 * px * 4 * 2048 * 256, t, direct, "16 % of the step's kernel time at config 2 (6 launches; profiles/r04_eager_breakdown.txt)",
+          2.0 * px * 4 * 2048 * 256, t, direct, "14 % of the step's kernel time at config 2 (6 launches; profiles/r05_eager_breakdown.txt)",
           {"launch_group_ms": 1e3 * t_group, "launch_group": "accGradParameters of the layer = this GEMM + wgrad_reduce_kernel<true> + bias_part_reduce_kernel"},
           alg_bytes=4.0 * (px * 512 + 4 * px * 256 + 9 * 512 * 256))
     # (2) igemm_nng_kernel<64,128,2,2,32> (LDS-direct loads): forward of G's first convolution behind the first upsampling
@@ -431,10 +431,12 @@ def main():
                 }
             if args.config == 2:
                 res["roofline"]["step"].update({
-                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.56, "D forward": 0.57, "D backward + Adam": 1.26,
-                                         "generator forward on N": 0.83, "D forward + data gradient (G step)": 1.19, "generator backward + Adam": 1.71},
-                    "phases_source": "profiles/r04_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
-                                     "launches, 6.12 ms under the tracer; committed numbers, not measured in this run)"})
+                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.87, "D forward": 0.87, "D backward + Adam": 1.28,
+                                         "D forward + data gradient (G step)": 1.18, "generator backward + Adam": 1.71},
+                    "phases_note": "the generator's forward on N for the G step runs BESIDE the first three phases on its own hardware queue since round 5 "
+                                   "(adversarial.py: concurrent_g_both), so it has no interval of its own and the intervals it shares are longer than in round 4",
+                    "phases_source": "profiles/r05_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
+                                     "launches, 5.90 ms under the tracer; committed numbers, not measured in this run)"})
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baselines(cfg)

@@ -9,8 +9,8 @@ TAG=${TAG:-r05}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 if [ "${PART:-a}" = "a" ]; then
-  echo "== pytest -m gpu"; ( time timeout 1500 python -m pytest tests -m gpu -x -q -s -p no:cacheprovider ) > gpurun_out/${TAG}_pytest.log 2>&1; echo "rc=$?"
-  grep -h " passed\| failed\|^real" gpurun_out/${TAG}_pytest.log | tail -2; grep -h "^E " gpurun_out/${TAG}_pytest.log | head -5
+  echo "== pytest -m gpu"; ( time timeout 1500 python -m pytest tests -m gpu -x -q -s -p no:cacheprovider --durations=40 ) > gpurun_out/${TAG}_pytest.log 2>&1; echo "rc=$?"
+  grep -h " passed\| failed\|^real\|s call \|s setup " gpurun_out/${TAG}_pytest.log | tail -45; grep -h "^E " gpurun_out/${TAG}_pytest.log | head -5
   grep -h "^\[grad\]\|^\[adam\]\|^\[outliers\]" gpurun_out/${TAG}_pytest.log > gpurun_out/${TAG}_step_gradients_vs_oracle.txt 2>/dev/null
   python __graft_entry__.py smoke > gpurun_out/${TAG}_smoke.txt 2>&1; tail -3 gpurun_out/${TAG}_smoke.txt
   exit 0

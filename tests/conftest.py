@@ -22,3 +22,15 @@ def pkg():
 @pytest.fixture(scope="session")
 def catgan():
     return pkg()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    """The C oracle's OpenMP loops run over the samples of a batch (oracle/ops.c); on the GPU box's 128+ host threads a batch-128 step
+    takes ~17 s (one weight-gradient accumulator per thread: 1.2 GB cleared and summed for G's 512->512 layer), at 32 threads ~4 s -
+    bench.py's cpu_baseline found the same optimum.  The thread count changes only the order in which the per-thread weight-gradient
+    partial sums are added (fp32 rounding of a 32- instead of a 128-term sum), which every bound of the parity tests already allows."""
+    from oracle import oracle as O
+
+    O.set_num_threads(min(O.num_threads(), 32))
+    yield

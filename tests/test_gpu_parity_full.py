@@ -29,7 +29,6 @@ def cg():
     mod = importlib.import_module("cat-generator_amd")
     assert torch.cuda.is_available(), "these tests need the MI355X"
     mod.lib()
-    O.set_num_threads(O.num_threads())
     return mod
 
 
