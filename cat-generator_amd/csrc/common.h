@@ -43,7 +43,7 @@ constexpr int kNumCU = 256;  // MI355X: 8 XCDs x 32 CUs
 enum Opt {
     OPT_SPLIT_TARGET, OPT_SPLIT_MINK, OPT_TN_SMAX, OPT_TN_TARGET, OPT_SKINNY, OPT_GEMM_BK32,
     OPT_COLREDUCE_WGS_PER_CU, OPT_WINO_BK, OPT_NN_TILE, OPT_TN_TILE, OPT_NN_SPLITS, OPT_TN_SPLITS,
-    OPT_EPILOGUE_STATS, OPT_XCD_SWIZZLE, OPT_NN_GLDS, OPT_TN_GLDS, OPT_WINO_GLDS, OPT_EW_WGS_PER_CU, OPT_COUNT
+    OPT_EPILOGUE_STATS, OPT_XCD_SWIZZLE, OPT_NN_GLDS, OPT_TN_GLDS, OPT_WINO_GLDS, OPT_EW_WGS_PER_CU, OPT_PAD_SKIP, OPT_COUNT
 };
 long opt(Opt o);
 

@@ -84,6 +84,11 @@ struct Geom {
     int ntaps, Ktot;       // per phase; Ktot = ntaps*Cin
     TapDesc td;
     int minoff0, minoff1, minoff2, minoff3;   // per phase: min(0, smallest tap element offset) - host-computed (finish_geom), the kernels' descriptor base
+    // POSITION-MAJOR rows (round 5; igemm_nng_kernel<..., PM>): pmn = N (a power of two, a multiple of the row tile) puts grid pixel
+    // (n, oy, ox) at row m = (oy * Wg + ox) * N + n, so that a row tile holds ONE pixel position of 64 images and all its rows share
+    // their zero-padding taps, which the K loop then skips (D32_st3's 7x7 layer at 8x8: 38 % of the MACs multiply padding).  0 = the
+    // image-major order everywhere else.  Split partials are in row order either way; out_row() maps a row to its output pixel.
+    int pmn, pm_lg;
 };
 
 constexpr int MAXG = 4;  // groups per launch: same geometry, separate tensors (D32_st3's identical branches)
@@ -180,10 +185,23 @@ __device__ __forceinline__ void pix_decode(const Geom& g, int m, int& n, int& oy
 
 // element offset of grid pixel m (phase bits pa,pb) in the [N,Hout,Wout,Cout] tensor
 __device__ __forceinline__ long out_row(const Geom& g, int m, int pa, int pb) {
+    if (g.pmn) return ((long)(m & (g.pmn - 1)) * (g.Hg * g.Wg) + (m >> g.pm_lg)) * g.Cout;   // so == 1, nphase == 1 (host)
     if (g.so == 1 && g.nphase == 1) return (long)m * g.Cout;
     int n, oy, ox;
     pix_decode(g, m, n, oy, ox);
     return ((long)(n * g.Hout + oy * g.so + pa) * g.Wout + ox * g.so + pb) * g.Cout;
+}
+
+// position-major launches (Geom::pmn): the number of taps of a plain convolution that fall inside the image at pixel position pos.
+// A tile at that position walks them in cdiv(taps * Cin, kchunk) equal K units (igemm_nng_kernel<..., PM>); the reduce adds as many.
+__device__ __forceinline__ int pm_valid_taps(const Geom& g, int pos) {
+    const TapDesc& d = g.td;
+    const int kh = d.kk / d.kw;
+    const int oy = g.lgW >= 0 ? pos >> g.lgW : pos / g.Wg, ox = pos - oy * g.Wg;
+    const int ylo = d.sgn > 0 ? d.r0y0 : -(d.r0y0 + kh - 1), xlo = d.sgn > 0 ? d.r0x0 : -(d.r0x0 + d.kw - 1);
+    const int vy = min(g.Hv - 1 - oy, ylo + kh - 1) - max(-oy, ylo) + 1;
+    const int vx = min(g.Wv - 1 - ox, xlo + d.kw - 1) - max(-ox, xlo) + 1;
+    return max(vy, 0) * max(vx, 0);
 }
 
 // Column XOR of the K-major A tile, as a function of the k quad kv = k / 4: a half-wave of the transposed store holds
@@ -550,7 +568,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
 // MFMA step (g, s) multiplies A[m][8g + 4h + s] with B[8g + 4h + s][n] (h = lane / 32).
 // FAST && VECB geometries only (Cin % BK == 0, 16-byte aligned operands, Cout % 4 == 0); prologue and epilogue as above.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN, int BK, bool PM = false>
 __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int MI = BM / WM / 32;
@@ -583,7 +601,9 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
 
     const int ntn = (g.Cout + BN - 1) / BN;
     int bid = blockIdx.x;
-    if ((a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    // (PM: the natural order - consecutive tiles on consecutive XCDs - spreads the short border positions and the long centre ones
+    // evenly over the XCDs; contiguous ranges would give one XCD the top row of the image and another the middle)
+    if (!PM && (a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int tn = ntn == 1 ? 0 : bid % ntn, tm = ntn == 1 ? bid : bid / ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
@@ -593,9 +613,10 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
     const float* gx = sel4(group, a.x0, a.x1, a.x2, a.x3);
     const float* gbias = sel4(group, a.b0, a.b1, a.b2, a.b3);
     float* gy = sel4(group, a.y0, a.y1, a.y2, a.y3);
-    const int ks = split * a.kchunk;
+    int ks = split * a.kchunk;
     const int kend = min(g.Ktot, ks + a.kchunk);
-    const int T = (kend - ks + BK - 1) / BK;
+    int T = (kend - ks + BK - 1) / BK;
+    const int pos_u = PM ? (m0 >> g.pm_lg) : 0;      // PM: the tile's pixel position (wave-uniform; N is a multiple of BM)
     const float* wph = sel4(group, a.w0, a.w1, a.w2, a.w3) + (long)phase * g.Ktot * g.Cout;
 
     // ---- A: lane -> (row a_r + ARPP p, LDS quad position a_kv); the quad it loads is a_kv ^ swz(row)
@@ -608,13 +629,18 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
         const int m = m0 + a_r + ARPP * p;
         r_ok[p] = m < g.M;
         int n, oy, ox;
-        pix_decode(g, r_ok[p] ? m : 0, n, oy, ox);
+        if (PM) {
+            n = m & (g.pmn - 1);
+            oy = g.lgW >= 0 ? pos_u >> g.lgW : pos_u / g.Wg;
+            ox = pos_u - oy * g.Wg;
+        } else pix_decode(g, r_ok[p] ? m : 0, n, oy, ox);
         r_oy[p] = oy; r_ox[p] = ox;
         rowb[p] = ((n * g.Hs + oy * g.td.ss) * g.Ws + ox * g.td.ss) * g.Cin;
     }
     const int b_nv = tid % NVEC, b_kr = tid / NVEC;
 
     unsigned long long cur[AROWS];     // tap-validity mask of each row, shifted so bit 0 = next tile's tap
+    unsigned long long um = 0ull;      // PM: the tile's tap-validity mask (unshifted, wave-uniform)
     unsigned rowbytes[AROWS];
     unsigned bvoff[BPASS];
     int tapi = 0, ci0 = 0, toff = 0, minoff = 0;
@@ -644,8 +670,26 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
             }
         }
         minoff = sel4(phase, g.minoff0, g.minoff1, g.minoff2, g.minoff3);   // host-computed (finish_geom)
+        if (PM) {
+            // every row of the tile has the mask of row 0; the tile's VALID taps (16 .. 49 of the 7x7 kernel at 8x8) are walked in tap
+            // order, in as many equal K units as their length asks for (a.kchunk = the unit the host aims at), one workgroup each
+            um = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cur[0] >> 32)) << 32) |
+                 (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur[0]);   // (the builtin returns int: no sign extension)
+            const int kv = __builtin_popcountll(um) * g.Cin;
+            const int nunits = (kv + a.kchunk - 1) / a.kchunk;        // <= gridDim.y; a workgroup past them has nothing to do:
+            if (split >= nunits) return;                              // the reduce adds this tile's nunits partials only
+            const int kch = ((kv / BK + nunits - 1) / nunits) * BK;
+            const int ksv = split * kch, kev = min(kv, ksv + kch);
+            T = kev > ksv ? (kev - ksv) / BK : 0;
+            const int vi = ksv / g.Cin;
+            ci0 = ksv - vi * g.Cin;
+            unsigned long long r = um;
+            for (int c = 0; c < vi; ++c) r &= r - 1;
+            tapi = r ? __builtin_ctzll(r) : g.ntaps;
+        } else {
         tapi = ks == 0 ? 0 : ks / g.Cin;
         ci0 = ks - tapi * g.Cin;
+        }
         { int ty, tx; tap_decode(g, tapi, pa, pb, ty, tx, toff); }
 #pragma unroll
         for (int p = 0; p < AROWS; ++p) {
@@ -669,9 +713,10 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
         float* A = buf ? As1 : As0;
         float* B = buf ? Bs1 : Bs0;
         const int soff = (toff - minoff + ci0) * 4;
+        if (PM) k0 = tapi * g.Cin + ci0;       // the weight rows of the tap the walk is at
 #pragma unroll
         for (int p = 0; p < AROWS; ++p) {
-            const unsigned voff = ((unsigned)cur[p] & 1u) ? rowbytes[p] : OOB;
+            const unsigned voff = (PM || ((unsigned)cur[p] & 1u)) ? rowbytes[p] : OOB;   // PM: only valid taps are visited
             glds16(rsx, A + (ARPP * p + wave * RPW) * BK, voff, soff);
         }
         const int sb = k0 * g.Cout * 4;
@@ -684,9 +729,14 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
         ci0 += BK;
         if (ci0 >= g.Cin) {
             ci0 = 0;
+            if (PM) {
+                const unsigned long long rest = um >> (tapi + 1);      // tapi + 1 <= 64 taps - 1 (finish_geom caps a launch at 64 taps ...)
+                tapi = rest ? tapi + 1 + __builtin_ctzll(rest) : g.ntaps;
+            } else {
             ++tapi;
 #pragma unroll
             for (int p = 0; p < AROWS; ++p) cur[p] >>= 1;
+            }
             if (tapi < g.ntaps) { int ty, tx; tap_decode(g, tapi, pa, pb, ty, tx, toff); }
         }
     };
@@ -760,6 +810,15 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
     }
     {
         // lean path: full tile, consecutive output rows, byte offsets inside the 2 GB a buffer descriptor spans
+        if (PM && !partial) {
+            // position-major tile: 64 images at one pixel - the accumulator rows are an image apart (host: full tiles, < 2 GB)
+            const int hwc = g.Hg * g.Wg * g.Cout;
+            const unsigned vo = ((unsigned)((m0 & (g.pmn - 1)) + wm0 + 4 * h) * (unsigned)hwc + (unsigned)(pos_u * g.Cout + n0 + wn0 + l31)) * 4u;
+            if (act) nn_store_lean<MI, NI, true>(acc, bj, yout, zout, vo, hwc * 4, act, aslope);
+            else nn_store_lean<MI, NI, false>(acc, bj, yout, nullptr, vo, hwc * 4, 0, 0.f);
+            CG_STAMP(3);
+            return;
+        }
         const bool lin = partial || (g.so == 1 && g.nphase == 1);
         const long rows_total = partial ? (long)a.nsplit * a.ngroups * g.nphase * g.M : (long)g.M;
         if (lin && !stats && m0 + BM <= g.M && n0 + BN <= g.Cout && rows_total * g.Cout < 0x1fffffffL) {
@@ -856,8 +915,11 @@ __global__ __launch_bounds__(256) void nn_splitk_reduce_kernel(NNArgs a, int S) 
     for (long i0 = blockIdx.x * (long)OUTS; i0 < PMN; i0 += (long)gridDim.x * OUTS) {
         const long i = i0 + ol;
         float s = 0.f;
-        if (i < PMN)
-            for (int k = ln; k < S; k += LANES) s += a.part[(long)k * PMN + i];
+        if (i < PMN) {
+            int Se = S;
+            if (g.pmn) Se = (pm_valid_taps(g, (int)((i / g.Cout) % g.M) >> g.pm_lg) * g.Cin + a.kchunk - 1) / a.kchunk;   // this pixel's K units
+            for (int k = ln; k < Se; k += LANES) s += a.part[(long)k * PMN + i];
+        }
         if (LANES > 1) {
             __syncthreads();
             sh[ln][ol] = s;
@@ -1928,8 +1990,15 @@ static int pick_splits(long tiles, long kiters) {
     return s;
 }
 
+// position-major rows + skipped padding taps (Geom::pmn): the 64-row LDS-direct tiles at K step 32 only
+template <int BM, int BN, int WM, int WN>
+static void launch_nn_pm(const NNArgs& a, dim3 grid, hipStream_t st) {
+    if constexpr (BM == 64 && (BN == 128 || BN == 64)) hipLaunchKernelGGL((igemm_nng_kernel<BM, BN, WM, WN, 32, true>), grid, dim3(256), 0, st, a);
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_nn(const NNArgs& a, dim3 grid, hipStream_t st, bool fast, bool vecb, bool bk32) {
+    if (a.g.pmn) { launch_nn_pm<BM, BN, WM, WN>(a, grid, st); return; }
     if (fast && vecb) {
         // LDS-direct loads (igemm_nng_kernel).  CG_NN_GLDS = 1: the 64-row tiles at K step 32 (a pixel's 128 consecutive
         // bytes per 8 lanes; measured inside the replayed step 2.43 -> 1.91 ms for the 64x128 tile), 2: K step 32 for every
@@ -2062,11 +2131,31 @@ static int geom_phase_dgrad(Geom& g, int N, int Hp, int Wp, int CinF, int CoutF,
     return finish_geom(g, N);
 }
 
-struct NNPlan { TileCfg tc; int splits; int kchunk; };
-static NNPlan plan_nn(const Geom& g, int ngroups) {
+struct NNPlan { TileCfg tc; int splits; int kchunk; bool pm; };
+static long pad_skip_valid(const Geom& g, const TileCfg& tc);
+static NNPlan plan_nn(const Geom& g, int ngroups, bool allow_pm = true) {
     NNPlan p;
     const int zdim = g.nphase * ngroups;
     p.tc = pick_tile(g.M, g.Cout, zdim);
+    p.pm = false;
+    const long valid = (allow_pm && ngroups == 1 && g.Cin % 32 == 0) ? pad_skip_valid(g, p.tc) : 0;
+    if (valid > 0) {
+        // position-major tiles (Geom::pmn): K units of equal length cut out of every tile's VALID taps, about one workgroup per CU in
+        // total, a unit not shorter than 8 K tiles; gridDim.y = the units of an interior tile.  (Units per CU, D's 7x7 layer at batch
+        // 128, alone: 1 -> 0.136 ms as image-major, 2 -> 0.113, 3 -> 0.130; in the step the short units cost more in partial sums
+        // than the launch gains - config #2 5.92 / 5.95 ms at 1.5 / 2 against 5.93 image-major, config #3 9.13 / 9.16 at 1 / 2
+        // against 9.19: profiles/r05_sweeps.txt)
+        const long tiles_per_pos = (long)(g.M / (g.Hg * g.Wg) / 64) * (g.Cout / p.tc.bn);
+        const long ksteps = valid * g.Cin / 32 * tiles_per_pos;                       // K tiles of the whole launch
+        long unit = cg::cdiv(ksteps, cg::kNumCU);
+        unit = std::max<long>(unit, 8);
+        const int forced = (int)cg::opt(cg::OPT_NN_SPLITS);
+        if (forced > 0) unit = cg::cdiv(g.Ktot / 32, forced);
+        p.kchunk = (int)std::min<long>(unit * 32, g.Ktot);
+        p.splits = cg::cdiv(g.Ktot, p.kchunk);
+        p.pm = true;
+        return p;
+    }
     const long tiles = (long)cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn) * zdim;
     const long kiters = cg::cdiv(g.Ktot, BK);
     p.splits = pick_splits(tiles, kiters);
@@ -2075,7 +2164,9 @@ static NNPlan plan_nn(const Geom& g, int ngroups) {
     return p;
 }
 static size_t nn_ws_bytes(const Geom& g, const NNPlan& p, int ngroups) {
-    return p.splits > 1 ? (size_t)p.splits * ngroups * g.nphase * g.M * g.Cout * sizeof(float) : 0;
+    size_t b = p.splits > 1 ? (size_t)p.splits * ngroups * g.nphase * g.M * g.Cout * sizeof(float) : 0;
+    if (p.pm) b = std::max(b, nn_ws_bytes(g, plan_nn(g, ngroups, false), ngroups));   // run_nn may fall back (unaligned operands, statistics)
+    return b;
 }
 
 struct TNPlan { TileCfg tc; int splits; int pchunk; };
@@ -2134,11 +2225,36 @@ static void skinny_wgrad_launch(hipStream_t st, const float* x, const float* dy,
 
 struct Epi { int act; float slope; const float* const* alpha; float* const* y_act; float* stats; };
 
+// Position-major rows with the zero-padding taps skipped (Geom::pmn): a plain stride-1 convolution whose padding is a real share of
+// its MACs (CG_PAD_SKIP = the least share in per cent, 0 = off), batch a power of two and a multiple of the 64-row tile.  Returns the
+// number of (pixel position, tap) pairs inside the image, 0 = not this launch.
+static long pad_skip_valid(const Geom& g, const TileCfg& tc) {
+    const long thr = cg::opt(cg::OPT_PAD_SKIP);
+    if (thr <= 0 || !cg::opt(cg::OPT_NN_GLDS) || !cg::opt(cg::OPT_GEMM_BK32)) return 0;
+    if (g.nphase != 1 || g.so != 1 || g.td.ngroups != 1 || g.td.ss != 1 || g.ntaps < 9 || tc.bm != 64 || !(tc.bn == 128 || tc.bn == 64)) return 0;
+    const int hw = g.Hg * g.Wg, N = g.M / hw;
+    if (N * hw != g.M || N % 64 || ilog2_exact(N) < 0 || g.Cout % tc.bn || (long)g.M * g.Cout * 4L >= 0x7fffffffL) return 0;
+    long valid = 0;
+    for (int oy = 0; oy < g.Hg; ++oy)
+        for (int ox = 0; ox < g.Wg; ++ox)
+            for (int t = 0; t < g.ntaps; ++t) {
+                int ty, tx, off;
+                tap_decode(g, t, 0, 0, ty, tx, off);
+                valid += (unsigned)(oy + ty) < (unsigned)g.Hv && (unsigned)(ox + tx) < (unsigned)g.Wv;
+            }
+    return (long)hw * g.ntaps * (100 - thr) >= valid * 100 ? valid : 0;
+}
+
 static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const* x, const float* const* w,
                   const float* const* bias, float* const* y, void* ws, size_t ws_bytes, const char* who,
                   const Epi* ep = nullptr) {
     CG_REQUIRE(ngroups >= 1 && ngroups <= MAXG, "%s: 1..%d groups per launch", who, MAXG);
     NNPlan p = plan_nn(g, ngroups);
+    {
+        bool al16 = true;
+        for (int i = 0; i < ngroups; ++i) al16 = al16 && x[i] && w[i] && (uintptr_t)x[i] % 16 == 0 && (uintptr_t)w[i] % 16 == 0;
+        if (p.pm && (!al16 || g.Cout % 4 || (ep && ep->stats))) p = plan_nn(g, ngroups, false);   // the LDS-direct kernel cannot: image-major plan
+    }
     const size_t need = nn_ws_bytes(g, p, ngroups);
     CG_REQUIRE(need == 0 || (ws && ws_bytes >= need), "%s: workspace too small (%zu < %zu)", who, ws_bytes, need);
     NNArgs a;
@@ -2185,6 +2301,10 @@ static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const
     const bool fast = (g.Cin % BK == 0) && al;
     const bool vecb = (g.Cout % 4 == 0) && alw;
     const bool bk32 = cg::opt(cg::OPT_GEMM_BK32) != 0 && (g.Cin % 32 == 0) && (p.kchunk % 32 == 0);
+    if (p.pm) {
+        a.g.pmn = g.M / (g.Hg * g.Wg);
+        a.g.pm_lg = ilog2_exact(a.g.pmn);
+    }
     dim3 grid(cg::cdiv(g.M, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, g.nphase * ngroups);
     if (p.tc.bm == 128 && p.tc.bn == 128) launch_nn<128, 128, 2, 2>(a, grid, st, fast, vecb, bk32);
     else if (p.tc.bm == 64 && p.tc.bn == 128) launch_nn<64, 128, 2, 2>(a, grid, st, fast, vecb, bk32);

@@ -77,6 +77,7 @@ def main():
                   lambda: lin_case("D.linear 20480->256", N, 20480, 256)]
     named = {"conv3": lambda: conv_case("G.conv3 5x5 256->128 @16^2 ups", N, 256, 16, 128, 5, 1),
              "b4": lambda: conv_case("D.b4 7x7 128->128 @8^2", N, 128, 8, 128, 7, 0),
+             "b45": lambda: conv_case("D.b4 5x5 64->128 @16^2", N, 64, 16, 128, 5, 0),
              "conv1": lambda: conv_case("G.conv1 3x3 512->512 @4^2 ups", N, 512, 4, 512, 3, 1),
              "conv2": lambda: conv_case("G.conv2 3x3 512->256 @8^2 ups", N, 512, 8, 256, 3, 1),
              "dconv2": lambda: conv_case("D.conv2 3x3 64->64 @32^2", N, 64, 32, 64, 3, 0),

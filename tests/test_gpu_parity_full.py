@@ -275,6 +275,34 @@ def test_lean_epilogue_on_full_tiles(cg, tile, splits, glds):
         close(outs[0][2], outs[1][2], K=1024, tol=4e-5, what="flat gradient planned vs per-module")
 
 
+@pytest.mark.parametrize("splits", [0, 1, 3, 8])
+@pytest.mark.parametrize("shape", [(64, 128, 8, 128, 7), (128, 64, 16, 128, 5), (64, 64, 8, 64, 3), (64, 32, 4, 64, 5)])
+def test_position_major_tiles_skip_the_padding_taps(cg, shape, splits):
+    """igemm_nng_kernel<64, BN, ..., PM> (gemm.hip, Geom::pmn; round 5): a plain stride-1 convolution whose zero padding is a real share
+    of its MACs runs with POSITION-major row tiles - 64 images at one pixel position - whose rows share their padding taps, and the K
+    loop walks the valid taps only (D32_st3's 7x7 layer at 8x8, models.lua:685: 38 % of the MACs; the 5x5 layer at 16x16: 14 %).
+    Forward and data gradient (= the same kernel on dy with the flipped kernel) against the oracle, unsplit and with the valid K range
+    of every tile cut into 3 / 8 splits (more splits than a corner tile has K tiles included); then against the image-major form
+    (CG_PAD_SKIP = 0): equal up to the re-association of the K splits, and BIT-equal unsplit - a skipped product is an exact zero."""
+    N, Cin, H, Cout, k = shape
+    with options(cg, CG_PAD_SKIP=1, CG_NN_TILE=64000 + (128 if Cout >= 128 else 64), CG_NN_SPLITS=splits, CG_SKINNY=0):
+        run_conv(cg, N, Cin, H, H, Cout, k, 0, seed=5 + k, wino=False)
+    if splits > 1:
+        return
+    outs = []
+    for thr in (1, 0):
+        with options(cg, CG_PAD_SKIP=thr, CG_NN_TILE=64000 + (128 if Cout >= 128 else 64), CG_NN_SPLITS=1, CG_SKINNY=0):
+            rs = np.random.RandomState(3)
+            m = cg.nn.SpatialConvolution(Cin, Cout, k, k, 1, 1, (k - 1) // 2)
+            m.weight.copy((rs.randn(Cout, Cin, k, k) / np.sqrt(Cin * k * k)).astype(f32)); m.bias.copy(rs.randn(Cout).astype(f32))
+            x = cg.Tensor.from_numpy(rs.randn(N, Cin, H, H).astype(f32))
+            y = m.forward(x).numpy().copy()
+            gi = m.updateGradInput(x, cg.Tensor.from_numpy(rs.randn(*y.shape).astype(f32))).numpy().copy()
+            outs.append((y, gi))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
 def run_linear(cg, N, i, o, seed=0):
     rs = np.random.RandomState(seed)
     m = cg.nn.Linear(i, o)
