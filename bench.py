@@ -168,7 +168,7 @@ def kernel_rooflines(cg, cfg, N):
         v = m3._get("wino_v", (lib.conv2d_ups2_wino_v_floats(N, h, h, ci),))
         t = time_kernel(lambda: lib.conv2d_ups2_wino_gemm(cg.tensor.stream(), v.ptr, m3._u_fwd.data_ptr(), m3.bias.ptr, y.ptr, N, h, h, ci, co, 0))
         d3 = 2.0 * N * (2 * h) ** 2 * co * ci * 25
-        tiles = N * h * h // 4 * 4          # 2x2-output tiles per phase x 4 phases
+        tiles = N * h * h // 4              # 2x2-output tiles of the low-res grid: ONE V block serves the four phases
         entry("wino_g16" if first else None, "wino_gemm_g_kernel<*,16> (winograd.hip; LDS-direct loads)",
               f"forward GEMMs of upsample2 -> conv5x5 {ci}->{co} @{h}->{2 * h}, batch {N}: 4 phases x 16 GEMMs [tiles x {ci}].[{ci} x {co}] + output transform",
               d3 * 36 / 100 * 16 / 36, t, d3, None,
@@ -431,12 +431,12 @@ def main():
                 }
             if args.config == 2:
                 res["roofline"]["step"].update({
-                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.87, "D forward": 0.87, "D backward + Adam": 1.28,
-                                         "D forward + data gradient (G step)": 1.18, "generator backward + Adam": 1.71},
+                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.85, "D forward": 0.87, "D backward + Adam": 1.23,
+                                         "D forward + data gradient (G step)": 1.20, "generator backward + Adam": 1.84},
                     "phases_note": "the generator's forward on N for the G step runs BESIDE the first three phases on its own hardware queue since round 5 "
                                    "(adversarial.py: concurrent_g_both), so it has no interval of its own and the intervals it shares are longer than in round 4",
                     "phases_source": "profiles/r05_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
-                                     "launches, 5.90 ms under the tracer; committed numbers, not measured in this run)"})
+                                     "launches, 5.99 ms under the tracer; committed numbers, not measured in this run)"})
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baselines(cfg)

@@ -603,8 +603,20 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
     int bid = blockIdx.x;
     // (PM: the natural order - consecutive tiles on consecutive XCDs - spreads the short border positions and the long centre ones
     // evenly over the XCDs; contiguous ranges would give one XCD the top row of the image and another the middle)
-    if (!PM && (a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-    const int tn = ntn == 1 ? 0 : bid % ntn, tm = ntn == 1 ? bid : bid / ntn;
+    int tn, tm;
+    const int tiles_m = (int)gridDim.x / ntn, xg = ntn <= 8 ? 8 / ntn : 0;       // xg: XCDs per column tile
+    if (!PM && (a.xcd_swizzle & 4) && (ntn == 2 || ntn == 4 || ntn == 8) && (gridDim.x & 7) == 0 && tiles_m % xg == 0) {
+        // WEIGHTS-stationary XCDs (round 5): XCD k = bid % 8 owns column tile k % ntn and one of 8 / ntn row ranges, so its
+        // L2 holds ONE [Ktot x BN] slice of the (phase) kernel - 1 MB for conv1's forward, where the row-range order below made all eight
+        // XCDs fetch all four column slices: 8 x 16.8 MB of kernels per launch against 4 x 4.2 MB of input now (r x c XCD grid over
+        // rows x columns: traffic = c * |x| + r * |w|)
+        const int k = bid & 7, j = bid >> 3;
+        tn = k % ntn;
+        tm = (k / ntn) * (tiles_m / xg) + j;
+    } else {
+        if (!PM && (a.xcd_swizzle & 1) && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+        tn = ntn == 1 ? 0 : bid % ntn; tm = ntn == 1 ? bid : bid / ntn;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
     const int zz = blockIdx.z;
@@ -2301,6 +2313,14 @@ static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const
     const bool fast = (g.Cin % BK == 0) && al;
     const bool vecb = (g.Cout % 4 == 0) && alw;
     const bool bk32 = cg::opt(cg::OPT_GEMM_BK32) != 0 && (g.Cin % 32 == 0) && (p.kchunk % 32 == 0);
+    if (a.xcd_swizzle & 4) {
+        // weights-stationary XCDs only where they move fewer bytes: an r x c XCD grid over (row tiles) x (column tiles) fetches
+        // c |x| + r |w| per phase - row ranges (r = 8, c = 1) against (8 / ntn, ntn).  conv1's forward: |x| = |w| = 4.2 MB -> stationary
+        // (161 -> 68 MB measured); conv2's direct data gradient: |x| = 33.5, |w| = 8.4 MB -> row ranges (118 MB; 258 MB stationary)
+        const int ntn = cg::cdiv(g.Cout, p.tc.bn);
+        const double xb = (double)(g.M / (g.Hg * g.Wg)) * g.Hs * g.Ws * g.Cin * 4.0, wb = (double)g.Ktot * g.Cout * 4.0;
+        if (!(ntn == 2 || ntn == 4 || ntn == 8) || ntn * xb + (8 / ntn) * wb >= xb + 8 * wb) a.xcd_swizzle &= ~4;
+    }
     if (p.pm) {
         a.g.pmn = g.M / (g.Hg * g.Wg);
         a.g.pm_lg = ilog2_exact(a.g.pmn);

@@ -2612,24 +2612,22 @@ extern "C" {
 int cg_net_create(void** net) {
     CG_REQUIRE(net, "cg_net_create: null pointer");
     Net* n = new Net();
-    const char* e;
-    if ((e = getenv("CG_WINOGRAD"))) n->winograd = atoi(e) != 0;
-    if ((e = getenv("CG_CONCAT_OVERLAP"))) n->overlap_groups = atoi(e) != 0;
-    if ((e = getenv("CG_WGRAD_DEFER"))) n->defer_wgrad = atoi(e) != 0;
-    if ((e = getenv("CG_SHARE_POOL"))) n->share_pool = atoi(e) != 0;
-    if ((e = getenv("CG_SAMPLER_SHARED"))) n->sampler_shared = atoi(e) != 0;
-    if ((e = getenv("CG_VIEW_FUSE"))) n->view_fuse = atoi(e) != 0;
-    if ((e = getenv("CG_CAT_FUSE"))) n->cat_fuse = atoi(e) != 0;
-    if ((e = getenv("CG_FUSION"))) n->fusion = atoi(e) != 0;
-    if ((e = getenv("CG_FUSE_LOCNET"))) n->fuse_locnet = atoi(e);
-    if ((e = getenv("CG_PACK_OVERLAP"))) n->pack_overlap = atoi(e) != 0;
-    if ((e = getenv("CG_HEAD_FUSE"))) n->head_fuse = atoi(e) != 0;
-    if ((e = getenv("CG_WGRAD_STREAM"))) n->wgrad_stream = atoi(e) != 0;
-    if ((e = getenv("CG_WINO_DSPLIT"))) n->wino_dsplit = atoi(e) != 0;
-    if ((e = getenv("CG_BN_EPILOGUE"))) n->bn_epilogue = atoi(e) != 0;
-    if ((e = getenv("CG_WGRAD_LAG"))) n->wgrad_lag = atoi(e);
-    if ((e = getenv("CG_WINOGRAD22"))) n->wino22 = atoi(e);
     *net = n;
+    // CG_NET_OPTIONS="name=value,name=value": plan options of EVERY net of the process, through cg_net_set_option below (same-box A/B runs
+    // of bench.py; round 5 folded the eighteen per-option variables - CG_WINOGRAD22, CG_WGRAD_STREAM, CG_FUSION ... - into this one)
+    if (const char* e = getenv("CG_NET_OPTIONS")) {
+        std::string all(e);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string kv = all.substr(pos, end - pos);
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos || eq == 0) { delete n; *net = nullptr; return cg::fail("CG_NET_OPTIONS: expected name=value, got '%s'", kv.c_str()); }
+            if (cg_net_set_option(n, kv.substr(0, eq).c_str(), atol(kv.c_str() + eq + 1))) { delete n; *net = nullptr; return 1; }
+            pos = end + 1;
+        }
+    }
     return 0;
 }
 

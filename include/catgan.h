@@ -46,7 +46,8 @@ int         cg_abi_version(void);
 const char* cg_last_error(void);
 /* Tunables of the kernel dispatch, named like the environment variables that set their defaults - 19 (18 after the round-5 pruning + CG_PAD_SKIP):
  * block tiles CG_NN_TILE / CG_TN_TILE (bm*1000+bn) and splits CG_NN_SPLITS / CG_TN_SPLITS / CG_SPLIT_TARGET / CG_SPLIT_MINK / CG_TN_SMAX /
- * CG_TN_TARGET; K step CG_GEMM_BK32 / CG_WINO_BK; CG_SKINNY; CG_EPILOGUE_STATS; CG_XCD_SWIZZLE; grid caps CG_COLREDUCE_WGS_PER_CU /
+ * CG_TN_TARGET; K step CG_GEMM_BK32 / CG_WINO_BK; CG_SKINNY; CG_EPILOGUE_STATS; CG_XCD_SWIZZLE (bits: 1 row ranges per XCD, 2 pixel chunks per XCD in the weight gradients, 4 weights-stationary
+ * XCDs in the LDS-direct forward kernel; default 7); grid caps CG_COLREDUCE_WGS_PER_CU /
  * CG_EW_WGS_PER_CU; and how a K tile reaches the MFMAs: CG_NN_GLDS (0..3) / CG_TN_GLDS / CG_WINO_GLDS = LDS-direct loads (default)
  * or the register-staged kernels (0); CG_PAD_SKIP = least share (per cent) of zero-padding MACs from which a plain convolution runs with
  * position-major row tiles and skips them (0 = never; default 8: D32_st3's 7x7 and 5x5 layers, models.lua:680-686).  Removed after losing every A/B of rounds 2-4: the k-quad LDS layouts, loads two tiles ahead,

@@ -13,8 +13,8 @@ bash scripts/pmc.sh k_conv1f python $ROOTD/scripts/kbench.py 128 --only conv1 --
 python3 - "$ROOTD" "$SRC" <<'PY'
 import json, subprocess, sys
 root, src = sys.argv[1], sys.argv[2]
-want = {"nn64x128": ("k_conv1f", "igemm_nng_kernel<64, 128, 2, 2, 32>"),
-        "nn64x128_dgrad_conv2": ("k_conv2", "igemm_nng_kernel<64, 128, 2, 2, 32>"),
+want = {"nn64x128": ("k_conv1f", "igemm_nng_kernel<64, 128, 2, 2, 32"),
+        "nn64x128_dgrad_conv2": ("k_conv2", "igemm_nng_kernel<64, 128, 2, 2, 32"),
         "tn128x128": ("k_conv2", "igemm_tng_kernel<128, 128, 2, 2>"),
         "nn128x64": ("k_dconv2", "igemm_nn_kernel<128, 64, 2, 2, true, true, 16"),
         "wino_g16": ("k_conv3", "wino_gemm_g_kernel<16, 16>"),

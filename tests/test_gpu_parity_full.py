@@ -303,6 +303,17 @@ def test_position_major_tiles_skip_the_padding_taps(cg, shape, splits):
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("swizzle", [0, 1, 3, 7])
+def test_xcd_tile_orders(cg, swizzle):
+    """CG_XCD_SWIZZLE: which tile a workgroup takes is a pure relabelling - natural order (0), contiguous row ranges per XCD (bit 0; bit 1
+    = pixel chunks per XCD in the weight-gradient kernels), weights-stationary XCDs in igemm_nng_kernel (bit 2, default since round 5:
+    conv1's forward 161 -> 68 MB of fabric traffic, profiles/r05_pmc_kernels.json).  Shapes with 2 and 4 column tiles whose tile counts are
+    multiples of 8, phase-folded and plain, with the batch-norm statistics rows of the epilogue in the plan's order."""
+    with options(cg, CG_XCD_SWIZZLE=swizzle, CG_NN_TILE=64128, CG_SKINNY=0):
+        run_conv(cg, 32, 64, 4, 4, 256, 3, 1, seed=21, wino=False)     # 4 phases x (8 row tiles x 2 column tiles)
+        run_conv(cg, 16, 32, 8, 8, 512, 3, 0, seed=22)                 # 16 row tiles x 4 column tiles
+
+
 def run_linear(cg, N, i, o, seed=0):
     rs = np.random.RandomState(seed)
     m = cg.nn.Linear(i, o)
