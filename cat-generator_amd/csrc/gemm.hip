@@ -917,12 +917,54 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
 // split-K reduce for NN: y_group[out_row(m)][n] = bias_group[n] + sum_s part[s][group*nphase+phase][m][n]
 // LANES > 1: 256/LANES outputs per workgroup, the S partials of one output shared by LANES threads (small outputs
 // with many splits would otherwise be one long serial load chain per thread).
-template <int LANES>
+template <int LANES, bool V4 = false>
 __global__ __launch_bounds__(256) void nn_splitk_reduce_kernel(NNArgs a, int S) {
     constexpr int OUTS = 256 / LANES;
     __shared__ float sh[LANES > 1 ? LANES : 1][OUTS + 1];
     const Geom& g = a.g;
     const long PMN = (long)a.ngroups * g.nphase * g.M * g.Cout;
+    if (LANES == 1 && V4) {
+        // four consecutive channels of one output row per thread (host: Cout % 4 == 0, 16-byte aligned tensors): 16-byte loads, four
+        // partial planes in flight, each element's splits still added in order 0 .. S-1 - the same bits as the scalar form below,
+        // which moved 12 MB in 41 us beside the other queue's GEMMs (round 5)
+        const long PMN4 = PMN >> 2;
+        const int C4 = g.Cout >> 2;
+        const float4* part4 = reinterpret_cast<const float4*>(a.part);
+        for (long i4 = blockIdx.x * 256L + threadIdx.x; i4 < PMN4; i4 += (long)gridDim.x * 256) {
+            const int n = (int)(i4 % C4) * 4;
+            const long pm = i4 / C4;
+            const int m = (int)(pm % g.M);
+            const int zz = (int)(pm / g.M);
+            int Se = S;
+            if (g.pmn) Se = (pm_valid_taps(g, m >> g.pm_lg) * g.Cin + a.kchunk - 1) / a.kchunk;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            int k = 0;
+            for (; k + 4 <= Se; k += 4) {
+                const float4 p0 = part4[(long)k * PMN4 + i4], p1 = part4[(long)(k + 1) * PMN4 + i4];
+                const float4 p2 = part4[(long)(k + 2) * PMN4 + i4], p3 = part4[(long)(k + 3) * PMN4 + i4];
+                s.x += p0.x; s.y += p0.y; s.z += p0.z; s.w += p0.w;
+                s.x += p1.x; s.y += p1.y; s.z += p1.z; s.w += p1.w;
+                s.x += p2.x; s.y += p2.y; s.z += p2.z; s.w += p2.w;
+                s.x += p3.x; s.y += p3.y; s.z += p3.z; s.w += p3.w;
+            }
+            for (; k < Se; ++k) {
+                const float4 p0 = part4[(long)k * PMN4 + i4];
+                s.x += p0.x; s.y += p0.y; s.z += p0.z; s.w += p0.w;
+            }
+            const int group = zz / g.nphase, phase = zz - group * g.nphase;
+            const float* gbias = sel4(group, a.b0, a.b1, a.b2, a.b3);
+            float* gy = sel4(group, a.y0, a.y1, a.y2, a.y3);
+            if (gbias) { const float4 b = ld4(gbias + n); s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w; }
+            const long o = out_row(g, m, phase >> 1, phase & 1) + n;
+            *reinterpret_cast<float4*>(gy + o) = s;
+            if (a.act) {
+                const float al = a.act == 1 ? *sel4(group, a.al0, a.al1, a.al2, a.al3) : a.slope;
+                *reinterpret_cast<float4*>(sel4(group, a.z0, a.z1, a.z2, a.z3) + o) =
+                    make_float4(apply_act(a.act, s.x, al), apply_act(a.act, s.y, al), apply_act(a.act, s.z, al), apply_act(a.act, s.w, al));
+            }
+        }
+        return;
+    }
     const int ol = threadIdx.x % OUTS, ln = threadIdx.x / OUTS;
     for (long i0 = blockIdx.x * (long)OUTS; i0 < PMN; i0 += (long)gridDim.x * OUTS) {
         const long i = i0 + ol;
@@ -1454,6 +1496,40 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
     const int ci0 = blockIdx.x * CI_T, co0 = blockIdx.y * 32;
     const long plane = (long)(UPS ? kp * kp : KK) * Cin * Cout;
     const int n1 = KK * CI_T * 32;
+    if (UPS && k == 3 && kp == 2 && pad == 1 && co0 + 32 <= Cout && ci0 + CI_T <= Cin && (CI_T & 31) == 0 && (Cout & 3) == 0 && ((uintptr_t)part & 15) == 0 &&
+        (sstride & 3) == 0) {
+        // 3x3 behind an upsampling, full block, 16-byte loads (round 5): a thread owns four output channels of one input channel and
+        // reads each of the 16 (phase, low-res tap) partial elements of a split ONCE (the scalar form below re-reads them per canonical
+        // tap: 36 loads for 16 values), adding them to the nine canonical taps in the same order - split by split, phase by phase.
+        const int c4 = threadIdx.x & 7;
+        for (int ci_l = threadIdx.x >> 3; ci_l < CI_T; ci_l += 32) {
+            float4 acc[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* base = part + (long)(ci0 + ci_l) * Cout + co0 + 4 * c4;
+            for (int sp = 0; sp < S; ++sp) {
+                float4 v[4][4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) v[p][tp] = ld4(base + (long)sp * sstride + (long)p * plane + (long)tp * Cin * Cout);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = t / 3, dx = t - 3 * (t / 3);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const float4 q = v[p][phase_map(p >> 1, dy, 1) * 2 + phase_map(p & 1, dx, 1)];
+                        acc[t].x += q.x; acc[t].y += q.y; acc[t].z += q.z; acc[t].w += q.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float* d = sh + (ci_l * KK + t) * 33 + 4 * c4;
+                d[0] = acc[t].x; d[1] = acc[t].y; d[2] = acc[t].z; d[3] = acc[t].w;
+            }
+        }
+    } else
     for (int idx = threadIdx.x; idx < n1; idx += 256) {
         const int co_l = idx & 31;
         const int r = idx >> 5;
@@ -1552,16 +1628,61 @@ __device__ __forceinline__ void wgrad_reduce_small_body(float (*sh)[33], int bx,
     }
 }
 
+// The plain (not phase-folded) weight blocks with 16-byte loads (round 5): a workgroup owns 128 consecutive partial elements - lane ol
+// the float4 at bx * 128 + 4 ol, the S partial planes split over the 8 lane groups as above, four planes in flight per thread - and
+// 128 threads add the eight lane sums in the same order and scatter them to the canonical layout.  Same bits as the 32-element form
+// (per element: lane group ln adds planes ln, ln + 8, ..., then groups 0..7 in order); a quarter of the workgroups and load instructions.
+__device__ __forceinline__ void wgrad_reduce_small_body_v4(float* shf, int bx, int group, const float* part, const RedPtrs& rp, int Cin,
+                                                           int Cout, int KK, int S, float scale, long sstride, long gstride) {
+    float4* sh4 = reinterpret_cast<float4*>(shf);     // [8][32]
+    const int ol = threadIdx.x & 31, ln = threadIdx.x >> 5;
+    const long total = (long)KK * Cin * Cout;
+    const long i = bx * 128L + 4 * ol;
+    const float* pg = part + (long)group * gstride + i;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total) {
+        int sp = ln;
+        for (; sp + 24 < S; sp += 32) {
+            const float4 p0 = ld4(pg + (long)sp * sstride), p1 = ld4(pg + (long)(sp + 8) * sstride);
+            const float4 p2 = ld4(pg + (long)(sp + 16) * sstride), p3 = ld4(pg + (long)(sp + 24) * sstride);
+            s.x += p0.x; s.y += p0.y; s.z += p0.z; s.w += p0.w;
+            s.x += p1.x; s.y += p1.y; s.z += p1.z; s.w += p1.w;
+            s.x += p2.x; s.y += p2.y; s.z += p2.z; s.w += p2.w;
+            s.x += p3.x; s.y += p3.y; s.z += p3.z; s.w += p3.w;
+        }
+        for (; sp < S; sp += 8) {
+            const float4 p0 = ld4(pg + (long)sp * sstride);
+            s.x += p0.x; s.y += p0.y; s.z += p0.z; s.w += p0.w;
+        }
+    }
+    sh4[ln * 32 + ol] = s;
+    __syncthreads();
+    if (ln < 4 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += f4c(sh4[r * 32 + ol], ln);
+        const long e = i + ln;                      // element (tap, ci, co) of the partial plane
+        const int co = (int)(e % Cout);
+        const long rr = e / Cout;
+        const int ci = (int)(rr % Cin), tap = (int)(rr / Cin);
+        float* gw = rp.gws ? rp.gw0 + (long)group * rp.gws : sel4(group, rp.gw0, rp.gw1, rp.gw2, rp.gw3);
+        gw[((long)co * Cin + ci) * KK + tap] += scale * t;
+    }
+}
+
 template <bool UPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* part, const float* bias_part, RedPtrs rp, int Cin,
                                                                  int Cout, int k, int KK, int pad, int kp, int S, int P,
                                                                  float scale, long sstride, long gstride, long bsstride,
-                                                                 int wblocks, int nblocks) {
-    __shared__ float sh[8][33];
+                                                                 int wblocks, int nblocks, int v4) {
+    __shared__ __attribute__((aligned(16))) float sh[32][33];
     // blockIdx.x walks the group's wblocks + bblocks blocks with stride gridDim.x (= all of them for short launches)
     for (int bx = (int)blockIdx.x; bx < nblocks; bx += (int)gridDim.x) {
-        wgrad_reduce_small_body<UPS>(sh, bx, (int)blockIdx.y, part, bias_part, rp, Cin, Cout, k, KK, pad, kp, S, P, scale,
-                                     sstride, gstride, bsstride, wblocks);
+        if (!UPS && v4 && bx < wblocks)
+            wgrad_reduce_small_body_v4(&sh[0][0], bx, (int)blockIdx.y, part, rp, Cin, Cout, KK, S, scale, sstride, gstride);
+        else
+            wgrad_reduce_small_body<UPS>(sh, bx, (int)blockIdx.y, part, bias_part, rp, Cin, Cout, k, KK, pad, kp, S, P, scale,
+                                         sstride, gstride, bsstride, wblocks);
         __syncthreads();
     }
 }
@@ -1601,6 +1722,7 @@ struct RedJob {
     int Cin, Cout, k, KK, pad, kp, S, P, ups, wblocks, bblocks, block0;
     float scale;
     int tr;      // KK == 1, planes multiples of 32: the weight blocks are 32 x 32 transpose tiles (wgrad_reduce_t_tile), not 32-element runs
+    int v4;      // plain layout, Cout % 4 == 0, 16-byte aligned planes: the weight blocks are 128-element runs (wgrad_reduce_small_body_v4)
 };
 constexpr int kRedJobs = 20;
 struct RedJobTable { RedJob j[kRedJobs]; int n; };
@@ -1608,7 +1730,7 @@ struct RedJobTable { RedJob j[kRedJobs]; int n; };
 // A workgroup walks blocks b, b + gridDim.x, ... of the `total` 32-element blocks (round 4: the launch used to have one workgroup per
 // block - 31 000 of them for D's flush, each waiting for a slot of its own beside the GEMMs of the other queues; see ew_grid)
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedJobTable t, int total) {
-    __shared__ float sh[32][33];
+    __shared__ __attribute__((aligned(16))) float sh[32][33];
     for (int b = (int)blockIdx.x; b < total; b += (int)gridDim.x) {
         int ji = 0;
         for (int q = 1; q < t.n; ++q)
@@ -1620,7 +1742,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedJobTable t, 
             const int nci = J.Cin / 32;
             float* gw = J.rp.gws ? J.rp.gw0 + (long)group * J.rp.gws : sel4(group, J.rp.gw0, J.rp.gw1, J.rp.gw2, J.rp.gw3);
             wgrad_reduce_t_tile(sh, J.part + (long)group * J.gstride, gw, (bx % nci) * 32, (bx / nci) * 32, J.Cin, J.Cout, J.S, J.sstride, J.scale);
-        } else if (J.ups)
+        } else if (J.v4 && bx < J.wblocks)
+            wgrad_reduce_small_body_v4(&sh[0][0], bx, group, J.part, J.rp, J.Cin, J.Cout, J.KK, J.S, J.scale, J.sstride, J.gstride);
+        else if (J.ups)
             wgrad_reduce_small_body<true>(sh, bx, group, J.part, J.bias_part, J.rp, J.Cin, J.Cout, J.k, J.KK, J.pad, J.kp, J.S, J.P, J.scale,
                                           J.sstride, J.gstride, J.bsstride, J.wblocks);
         else
@@ -2334,7 +2458,12 @@ static int run_nn(hipStream_t st, const Geom& g, int ngroups, const float* const
     CG_LAUNCH_CHECK();
     if (p.splits > 1) {
         const long PMN = (long)ngroups * g.nphase * g.M * g.Cout;
-        if (PMN >= 256L * 1024 || p.splits < 8)
+        bool v4 = g.Cout % 4 == 0 && (uintptr_t)ws % 16 == 0;
+        for (int i = 0; i < ngroups; ++i)
+            v4 = v4 && (uintptr_t)ys[i] % 16 == 0 && (!bs[i] || (uintptr_t)bs[i] % 16 == 0) && (!a.act || (uintptr_t)ep->y_act[i] % 16 == 0);
+        if ((PMN >= 256L * 1024 || p.splits < 8) && v4)
+            hipLaunchKernelGGL((nn_splitk_reduce_kernel<1, true>), dim3(cg::ew_grid(PMN / 4)), dim3(256), 0, st, a, p.splits);
+        else if (PMN >= 256L * 1024 || p.splits < 8)
             hipLaunchKernelGGL(nn_splitk_reduce_kernel<1>, dim3(cg::ew_grid(PMN)), dim3(256), 0, st, a, p.splits);
         else
             hipLaunchKernelGGL(nn_splitk_reduce_kernel<8>, dim3((unsigned)cg::cdiv(PMN, 32)), dim3(256), 0, st, a, p.splits);
@@ -2479,10 +2608,10 @@ int small_reduce(hipStream_t st, bool defer, const RedJob& job, int ngroups) {
     dim3 sgrid((unsigned)std::min<long>(nblocks, cap), ngroups);
     if (job.ups)
         hipLaunchKernelGGL(wgrad_reduce_small_kernel<true>, sgrid, dim3(256), 0, st, job.part, job.bias_part, job.rp, job.Cin, job.Cout,
-                           job.k, job.KK, job.pad, job.kp, job.S, job.P, job.scale, job.sstride, job.gstride, job.bsstride, job.wblocks, nblocks);
+                           job.k, job.KK, job.pad, job.kp, job.S, job.P, job.scale, job.sstride, job.gstride, job.bsstride, job.wblocks, nblocks, 0);
     else
         hipLaunchKernelGGL(wgrad_reduce_small_kernel<false>, sgrid, dim3(256), 0, st, job.part, job.bias_part, job.rp, job.Cin, job.Cout,
-                           job.k, job.KK, job.pad, job.kp, job.S, job.P, job.scale, job.sstride, job.gstride, job.bsstride, job.wblocks, nblocks);
+                           job.k, job.KK, job.pad, job.kp, job.S, job.P, job.scale, job.sstride, job.gstride, job.bsstride, job.wblocks, nblocks, job.v4);
     CG_LAUNCH_CHECK();
     return 0;
 }
@@ -2665,6 +2794,8 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
         // a queued KK == 1 job (nn.Linear; D's 20480 -> 256 head is 5.2 M elements = 164 000 32-element blocks) reduces as transpose tiles
         if (defer && KK == 1 && !ups && Cin % 32 == 0 && Cout % 32 == 0 && g.nphase == 1) {
             job.tr = 1; job.wblocks = (Cin / 32) * (Cout / 32);
+        } else if (!ups && Cout % 4 == 0 && (uintptr_t)ws % 16 == 0 && sstride % 4 == 0 && job.gstride % 4 == 0) {
+            job.v4 = 1; job.wblocks = cg::cdiv(relems, 128);
         }
         return small_reduce(st, defer, job, ngroups);
     }
