@@ -1694,6 +1694,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* pa
 __device__ __forceinline__ void wgrad_reduce_t_tile(float (*t)[33], const float* __restrict__ pg, float* __restrict__ gw, int ci0, int co0,
                                                     int Cin, int Cout, int S, long sstride, float scale) {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if ((Cout & 3) == 0 && (sstride & 3) == 0 && ((uintptr_t)pg & 15) == 0) {
+        // 16-byte loads (round 5): thread = (row r = tid / 8, four columns), the S planes in order, four in flight
+        const int r = threadIdx.x >> 3, c4 = threadIdx.x & 7;
+        const float* src = pg + (long)(ci0 + r) * Cout + co0 + 4 * c4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sp = 0;
+        for (; sp + 4 <= S; sp += 4) {
+            const float4 p0 = ld4(src + (long)sp * sstride), p1 = ld4(src + (long)(sp + 1) * sstride);
+            const float4 p2 = ld4(src + (long)(sp + 2) * sstride), p3 = ld4(src + (long)(sp + 3) * sstride);
+            s.x += p0.x; s.y += p0.y; s.z += p0.z; s.w += p0.w;
+            s.x += p1.x; s.y += p1.y; s.z += p1.z; s.w += p1.w;
+            s.x += p2.x; s.y += p2.y; s.z += p2.z; s.w += p2.w;
+            s.x += p3.x; s.y += p3.y; s.z += p3.z; s.w += p3.w;
+        }
+        for (; sp < S; ++sp) {
+            const float4 p0 = ld4(src + (long)sp * sstride);
+            s.x += p0.x; s.y += p0.y; s.z += p0.z; s.w += p0.w;
+        }
+        t[r][4 * c4] = s.x; t[r][4 * c4 + 1] = s.y; t[r][4 * c4 + 2] = s.z; t[r][4 * c4 + 3] = s.w;
+    } else
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
         const long off = (long)(ci0 + r) * Cout + co0 + tx;
