@@ -431,12 +431,12 @@ def main():
                 }
             if args.config == 2:
                 res["roofline"]["step"].update({
-                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.85, "D forward": 0.87, "D backward + Adam": 1.23,
-                                         "D forward + data gradient (G step)": 1.20, "generator backward + Adam": 1.84},
+                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.88, "D forward": 0.95, "D backward + Adam": 1.25,
+                                         "D forward + data gradient (G step)": 1.20, "generator backward + Adam": 1.75},
                     "phases_note": "the generator's forward on N for the G step runs BESIDE the first three phases on its own hardware queue since round 5 "
                                    "(adversarial.py: concurrent_g_both), so it has no interval of its own and the intervals it shares are longer than in round 4",
                     "phases_source": "profiles/r05_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
-                                     "launches, 5.99 ms under the tracer; committed numbers, not measured in this run)"})
+                                     "launches, 6.03 ms under the tracer; committed numbers, not measured in this run)"})
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baselines(cfg)
