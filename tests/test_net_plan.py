@@ -368,3 +368,21 @@ def test_weight_packing_runs_beside_the_head_of_the_pass():
     assert not any(l.startswith("event|") and "packs" in l for l in r0["first_forward"])
     strip = lambda ls: [l for l in ls if not (l.startswith("event|") and "packs" in l)]
     assert [l.replace("|s1|", "|s0|") for l in strip(first)] == r0["first_forward"]
+
+
+def test_net_options_from_the_environment(monkeypatch):
+    """CG_NET_OPTIONS="name=value,..." (round 5: ONE variable instead of eighteen): every net created while it is set takes the pairs
+    through cg_net_set_option - the plan equals the one built with the same options through the ABI; an unknown name or a pair
+    without '=' fails cg_net_create with a message, it is not ignored."""
+    cg = T.cg_pkg()
+    want = T.trace("G32up-c", 128, options=[("winograd", 0), ("wgrad_stream", 0)])
+    monkeypatch.setenv("CG_NET_OPTIONS", "winograd=0,wgrad_stream=0")
+    got = T.trace("G32up-c", 128)
+    assert T.canon(got["forward"]) == T.canon(want["forward"]) and T.canon(got["backward"]) == T.canon(want["backward"])
+    assert not any("wino" in l for l in got["forward"])
+    monkeypatch.delenv("CG_NET_OPTIONS")
+    assert any("wino" in l for l in T.trace("G32up-c", 128)["forward"])
+    for bad in ("no_such_option=1", "winograd"):
+        monkeypatch.setenv("CG_NET_OPTIONS", bad)
+        with pytest.raises(cg._abi.CatganError, match="no_such_option|name=value"):
+            T.trace("G32up-c", 128)
