@@ -125,3 +125,22 @@ def test_generated_tables_are_fresh(tmp_path):
         out = tmp_path / os.path.basename(rel)
         gen.main(str(out))
         assert open(have).read() == out.read_text(), f"{rel} is stale against include/catgan.h: rebuild"
+
+
+def test_workspace_query_covers_the_position_major_plan_and_its_fallback(cg):
+    """cg_conv2d_workspace_bytes is what a host sizes its buffer with BEFORE the launch decides between position-major tiles (round 5,
+    CG_PAD_SKIP: K units of the valid taps, partial sums per unit) and the image-major plan it falls back to for unaligned operands or an
+    epilogue with statistics: the query returns the larger of the two.  Host code only - no device needed."""
+    L = cg.lib()
+    d77 = (128, 8, 8, 128, 128, 7, 7, 3, 3, 0)        # D32_st3's last convolution (models.lua:685) at batch 128: 38 % padding
+    d55 = (128, 16, 16, 64, 128, 5, 5, 2, 2, 0)       # models.lua:680: 14 % padding, below the default threshold of 20 %
+    try:
+        L.set_option(b"CG_PAD_SKIP", 0)
+        image_major = L.conv2d_workspace_bytes(*d77)
+        assert image_major == 2 * 128 * 64 * 128 * 4                          # two K splits of [8192 x 128] partial sums
+        L.set_option(b"CG_PAD_SKIP", 20)
+        assert L.conv2d_workspace_bytes(*d77) == 4 * 128 * 64 * 128 * 4       # an interior tile's 49 taps in four units
+        assert L.conv2d_workspace_bytes(*d77) >= image_major
+        assert L.conv2d_workspace_bytes(*d55) == 0                            # stays image-major, unsplit: direct output
+    finally:
+        L.set_option(b"CG_PAD_SKIP", -1)
