@@ -328,6 +328,7 @@ def _both_forwards_ok(S, N):
     return bool(OPT.get("concurrent_g_both", False) and not OPT.get("concurrent_g_forward", False) and has_gpu() and nn.planned
                 and parallel.world_size() == 1 and OPT["D_iterations"] == 1 and OPT["G_iterations"] == 1 and N in S._d_draws
                 and type(G) is nn.Sequential and getattr(G, "_pnet", None) and G._pnet[1] is not None and getattr(G, "_planned_last", False)
+                and getattr(G._pnet[1], "last_draws", 0) == 0     # a G that draws (Dropout) would move the counter stream under the side pass
                 and OPT["batchSize"] >= N)
 
 
@@ -358,7 +359,10 @@ class GraphedIteration:
         self.stream = torch.cuda.Stream()     # warm-up AND capture run here: per-stream scratch (column reductions, split-K
         self.stream.wait_stream(torch.cuda.current_stream())   # workspaces) must exist before the capture starts
         with torch.cuda.stream(self.stream):
-            for _ in range(max(1, warmup)):  # eager passes: allocate every buffer, pack weights, learn the stride
+            # eager passes: allocate every buffer, pack weights, learn the stride.  With concurrent_g_both the FIRST iteration runs the two
+            # generator forwards one after the other (D's draw count is not known yet) and the second creates the side stream and the
+            # noise buffer: at least two, so that nothing is allocated inside the capture
+            for _ in range(max(2 if S.OPT.get("concurrent_g_both") else 1, warmup)):
                 self._eager()
         torch.cuda.synchronize()
         ts = {k: S.OPTSTATE["adam"][k]["t"] for k in ("D", "G")}

@@ -71,6 +71,14 @@ int queue_class(hipStream_t ref, hipStream_t s);                // class of a po
 // leave partial sums behind for the next flush to add to a gradient.
 void wgrad_discard_all();
 
+// 3x3 convolutions with <= 3 output planes as a scatter-form GEMM on the MFMA, input read once (csrc/skinny.hip, round 6): widths that
+// are a multiple of 32 up to 128, 64 or 128 input planes.  CG_SKINNY: 1 = these where they apply (else round 1's VALU kernels of
+// gemm.hip), 2 = the VALU kernels always, 0 = the generic implicit GEMM.
+bool skinny_mfma_ok(int Cin, int Cout, int H, int W);
+int skinny_mfma_forward(hipStream_t st, const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Cout);
+int skinny_mfma_wgrad(hipStream_t st, const float* x, const float* dy, float* part, float* bias_part, int N, int H, int W, int Cin, int Cout,
+                      int max_blocks);   // returns the number of partial planes written, -1 on error
+
 // grid for memory-bound grid-stride kernels: enough blocks to fill 256 CUs x 8
 static inline int ew_grid(long n, int per_block = 256) {
     long b = (n + per_block - 1) / per_block;

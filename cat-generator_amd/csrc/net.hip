@@ -29,6 +29,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -2467,6 +2468,8 @@ int ensure_streams(Net* n, int nstreams, void* ref) {
     if ((int)n->side.size() < nstreams - 1) {
         static int netno = 0;
         static int slots[4] = {0, 0, 0, 0};
+        static std::mutex mu;                 // nets of several host threads share the pool's slot counters
+        std::lock_guard<std::mutex> lk(mu);
         if (n->qmap[0] < 0) {
             for (int t = 0; t < 8; ++t) n->qmap[t] = kQueueOf[t];
             const char* e = getenv("CG_QMAP");
@@ -2585,6 +2588,11 @@ int sync_packs(Net* n, Prog* pr, Run& c, int* join_before) {
     if (forked) {
         if (n->trace) trace_note(n, "event|record|packs|s1");
         else if (hipEventRecord(n->pack_ev, c.st[1]) != hipSuccess) return cg::fail("cg_net: hipEventRecord failed");
+        n->pack_inflight = true;
+    } else if ((!w.empty() || !ups.empty()) && !n->trace) {
+        // everything was re-packed on the caller's stream (pack_overlap off, fewer than two layers behind an upsampling, no side stream):
+        // a LATER pass of this net on ANOTHER stream - the side-by-side generator forward - still has to wait for it
+        if (hipEventRecord(n->pack_ev, c.st[0]) != hipSuccess) return cg::fail("cg_net: hipEventRecord failed");
         n->pack_inflight = true;
     }
     g_cur_net = nullptr;

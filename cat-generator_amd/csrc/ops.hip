@@ -155,7 +155,13 @@ hipStream_t queue_stream(hipStream_t ref, int cls, int slot) {
     const std::vector<int>& c = p.cls[ref];
     int nclass = 0;
     for (int v : c) nclass = std::max(nclass, v + 1);
-    if (nclass < 2) { cg::fail("queue_stream: the probe found one hardware queue only"); return nullptr; }
+    if (nclass < 2) {
+        // GPU_MAX_HW_QUEUES=1, a serialising profiler / HIP_LAUNCH_BLOCKING, or a busy shared GPU that skewed the probe: results never
+        // depend on the queue class (only the overlap does), so hand out distinct pool streams and say so once
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "cg: the hardware-queue probe found one queue only - side streams are plain pool streams (overlap not guaranteed)\n"); }
+        return p.s[(size_t)((cls & 3) * (kQueuePool / 4) + slot % (kQueuePool / 4)) % p.s.size()];
+    }
     cls = cls % nclass;                     // fewer than four queues (GPU_MAX_HW_QUEUES < 4): wrap
     int seen = 0;
     hipStream_t last = nullptr;

@@ -50,7 +50,7 @@ const char* cg_last_error(void);
  * XCDs in the LDS-direct forward kernel; default 7); grid caps CG_COLREDUCE_WGS_PER_CU /
  * CG_EW_WGS_PER_CU; and how a K tile reaches the MFMAs: CG_NN_GLDS (0..3) / CG_TN_GLDS / CG_WINO_GLDS = LDS-direct loads (default)
  * or the register-staged kernels (0); CG_PAD_SKIP = least share (per cent) of zero-padding MACs from which a plain convolution runs with
- * position-major row tiles and skips them (0 = never; default 8: D32_st3's 7x7 and 5x5 layers, models.lua:680-686).  Removed after losing every A/B of rounds 2-4: the k-quad LDS layouts, loads two tiles ahead,
+ * position-major row tiles and skips them (0 = never; default 20: D32_st3's 7x7 layer at 8x8 - 38 % padding, models.lua:685 - but not its 5x5 layer at 16x16 with 14 %).  Removed after losing every A/B of rounds 2-4: the k-quad LDS layouts, loads two tiles ahead,
  * the 4-wave Winograd GEMM, the sampler's atomic backward as an option, CG_GEMM_SLOW.
  * value == -1 restores the default.  Results never depend on them beyond
  * fp32 re-association; the parity tests use them to run every compiled kernel variant against the oracle. */

@@ -81,6 +81,12 @@ def main():
              "conv1": lambda: conv_case("G.conv1 3x3 512->512 @4^2 ups", N, 512, 4, 512, 3, 1),
              "conv2": lambda: conv_case("G.conv2 3x3 512->256 @8^2 ups", N, 512, 8, 256, 3, 1),
              "dconv2": lambda: conv_case("D.conv2 3x3 64->64 @32^2", N, 64, 32, 64, 3, 0),
+             "gconv4": lambda: conv_case("G.conv4 3x3 128->3 @32^2", N, 128, 32, 3, 3, 0),
+             "gconv4y": lambda: conv_case("G32up conv 3x3 128->1 @32^2", N, 128, 32, 1, 3, 0),
+             "dconv1": lambda: conv_case("D.conv1 3x3 3->64 @32^2", N, 3, 32, 64, 3, 0),
+             "dbr16": lambda: conv_case("D.br conv 3x3 64->64 @16^2", N, 64, 16, 64, 3, 0),
+             "dbr8": lambda: conv_case("D.br conv 3x3 64->64 @8^2", N, 64, 8, 64, 3, 0),
+             "dlin": lambda: lin_case("D.linear 20480->256", N, 20480, 256),
              "loc": lambda: conv_case("D.loc 3x3 64->16 @8^2 (3 branches stacked)", 3 * N, 64, 8, 16, 3, 0)}
     if only:
         cases = [named[o] for o in only.split(",")]

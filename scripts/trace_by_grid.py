@@ -19,5 +19,5 @@ for r in rows:
     agg[(n, grid)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print(f"{'kernel':62s} {'grid (threads)':>18s} {'launches':>8s} {'avg us':>9s} {'min us':>9s}")
 for (n, grid), d in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-    if len(d) >= 8:
+    if len(d) >= int(__import__("os").environ.get("MINL", "8")):
         print(f"{n[:62]:62s} {grid:>18s} {len(d):8d} {sum(d) / len(d):9.1f} {min(d):9.1f}")

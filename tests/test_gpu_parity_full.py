@@ -152,6 +152,21 @@ def test_conv_layer_at_benchmarked_batch(cg, name, N, Cin, H, W, Cout, k, ups):
         assert getattr(m, "_wino", False), "the benchmarked dispatch runs this layer on the Winograd kernels"
 
 
+# (N, Cin, H, W, Cout): 3x3 layers with <= 3 planes on ONE side.  Cout <= 3: forward + weight gradient run the skinny kernels
+# (csrc/skinny.hip on the MFMA for widths % 32 == 0, gemm.hip's VALU kernels otherwise / with CG_SKINNY=2); Cin <= 3: the DATA gradient
+# does (D's first layer seen from its output, models.lua:646).  Batches that are not a multiple of 8 (block -> image map), heights that
+# are not a multiple of the strip, every compiled (planes, width) combination, a width the MFMA path refuses (8, 40).
+SKINNY_CASES = [(3, 128, 32, 32, 3), (9, 64, 40, 32, 3), (2, 128, 64, 64, 3), (16, 128, 32, 32, 1), (2, 64, 24, 96, 1), (5, 128, 6, 128, 3),
+                (2, 64, 8, 8, 1), (3, 128, 5, 40, 3), (3, 3, 32, 32, 64), (2, 1, 64, 64, 64), (24, 3, 20, 32, 64)]
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["mfma", "valu"])
+@pytest.mark.parametrize("N,Cin,H,W,Cout", SKINNY_CASES)
+def test_skinny_3x3_layers_on_both_kernel_families(cg, mode, N, Cin, H, W, Cout):
+    with options(cg, CG_SKINNY=mode):
+        run_conv(cg, N, Cin, H, W, Cout, 3, 0, seed=N + Cin + H + W + Cout)
+
+
 FULL_LINEARS = [
     ("G32up-c Linear 100->8192 (models.lua:199)", 128, 100, 8192),
     ("G32up-c Linear 100->8192, half batch", 64, 100, 8192),
