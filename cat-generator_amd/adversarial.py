@@ -359,11 +359,14 @@ class GraphedIteration:
         self.stream = torch.cuda.Stream()     # warm-up AND capture run here: per-stream scratch (column reductions, split-K
         self.stream.wait_stream(torch.cuda.current_stream())   # workspaces) must exist before the capture starts
         with torch.cuda.stream(self.stream):
-            # eager passes: allocate every buffer, pack weights, learn the stride.  With concurrent_g_both the FIRST iteration runs the two
-            # generator forwards one after the other (D's draw count is not known yet) and the second creates the side stream and the
-            # noise buffer: at least two, so that nothing is allocated inside the capture
-            for _ in range(max(2 if S.OPT.get("concurrent_g_both") else 1, warmup)):
+            for _ in range(max(1, warmup)):  # eager passes: allocate every buffer, pack weights, learn the stride
                 self._eager()
+            # the capture may be the first iteration that runs both generator forwards side by side (the first eager one goes one after
+            # the other: D's draw count is not known yet): its side stream and events exist before the capture starts (the
+            # N-row noise buffer is the one the first iteration's G-step already allocated)
+            if S.OPT.get("concurrent_g_both") and S._side is None:
+                S._side = (_side_stream(), torch.cuda.Event(), torch.cuda.Event())
+                S._side_a = torch.cuda.Event()
         torch.cuda.synchronize()
         ts = {k: S.OPTSTATE["adam"][k]["t"] for k in ("D", "G")}
         self.exec = ctypes.c_void_p()

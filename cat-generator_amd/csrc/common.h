@@ -43,7 +43,7 @@ constexpr int kNumCU = 256;  // MI355X: 8 XCDs x 32 CUs
 enum Opt {
     OPT_SPLIT_TARGET, OPT_SPLIT_MINK, OPT_TN_SMAX, OPT_TN_TARGET, OPT_SKINNY, OPT_GEMM_BK32,
     OPT_COLREDUCE_WGS_PER_CU, OPT_WINO_BK, OPT_NN_TILE, OPT_TN_TILE, OPT_NN_SPLITS, OPT_TN_SPLITS,
-    OPT_EPILOGUE_STATS, OPT_XCD_SWIZZLE, OPT_NN_GLDS, OPT_TN_GLDS, OPT_WINO_GLDS, OPT_EW_WGS_PER_CU, OPT_PAD_SKIP, OPT_COUNT
+    OPT_EPILOGUE_STATS, OPT_XCD_SWIZZLE, OPT_NN_GLDS, OPT_TN_GLDS, OPT_WINO_GLDS, OPT_EW_WGS_PER_CU, OPT_PAD_SKIP, OPT_WINO3, OPT_COUNT
 };
 long opt(Opt o);
 
@@ -78,6 +78,14 @@ bool skinny_mfma_ok(int Cin, int Cout, int H, int W);
 int skinny_mfma_forward(hipStream_t st, const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Cout);
 int skinny_mfma_wgrad(hipStream_t st, const float* x, const float* dy, float* part, float* bias_part, int N, int H, int W, int Cin, int Cout,
                       int max_blocks);   // returns the number of partial planes written, -1 on error
+
+// Fused-transform Winograd F(2x2,3x3) for plain 64 -> 64 plane 3x3 convolutions (csrc/wino3.hip, round 6).  CG_WINO3: 1 = where the
+// geometry fits and the launch has >= 2 workgroups per CU, 2 = wherever the geometry fits (tests), 0 = never (the direct implicit GEMM).
+bool wino3_geom_ok(int ngroups, int N, int H, int W, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups);
+int wino3_note_pack(hipStream_t st, int n, const float* const* w, float* const* wf, float* const* wb, const int* Cout, const int* Cin,
+                    const int* kH, const int* kW, const int* wb_map);
+int wino3_forward(hipStream_t st, int ngroups, const float* const* x, const float* const* wpk, const float* const* bias, float* const* y,
+                  int N, int H, int W);   // 1 launched, 0 not this path, -1 error
 
 // grid for memory-bound grid-stride kernels: enough blocks to fill 256 CUs x 8
 static inline int ew_grid(long n, int per_block = 256) {

@@ -2563,6 +2563,10 @@ int cg_conv2d_forward_grouped(void* stream, int ngroups, const float* const* x, 
         CG_LAUNCH_CHECK();
         return 0;
     }
+    if (cg::wino3_geom_ok(ngroups, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) {   // fused F(2x2,3x3): csrc/wino3.hip
+        const int rc = cg::wino3_forward(cg::S(stream), ngroups, x, wpk, bias, y, N, Hp, Wp);
+        if (rc) return rc < 0 ? 1 : 0;
+    }
     return run_nn(cg::S(stream), g, ngroups, x, wpk, bias, y, ws, ws_bytes, "cg_conv2d_forward_grouped");
 }
 
@@ -2870,7 +2874,7 @@ int cg_pack_conv_weight(void* stream, const float* w, float* wf, float* wb, int 
     hipLaunchKernelGGL(pack_weight_kernel, dim3(cg::cdiv(Cin, 32), cg::cdiv(Cout, 32), KK), dim3(256), 0, cg::S(stream), w,
                        wf, wb, Cout, Cin, KK, 0);
     CG_LAUNCH_CHECK();
-    return 0;
+    return cg::wino3_note_pack(cg::S(stream), 1, &w, &wf, &wb, &Cout, &Cin, &kH, &kW, nullptr);
 }
 
 // nn.View(C*H*W) -> nn.Linear(C*H*W -> Cout) on an NHWC map (models.lua:696-697, 849-850) without materialising the NCHW
@@ -2910,7 +2914,7 @@ int cg_pack_conv_weight_batch(void* stream, int n, const float* const* w_canonic
         hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(blocks), dim3(256), 0, cg::S(stream), b);
         CG_LAUNCH_CHECK();
     }
-    return 0;
+    return cg::wino3_note_pack(cg::S(stream), n, w_canonical, wf, wb, Cout, Cin, kH, kW, wb_map);
 }
 
 size_t cg_pack_conv_weight_ups2_floats(int Cout, int Cin, int k, int pad) {

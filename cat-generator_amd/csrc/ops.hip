@@ -27,7 +27,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"CG_SPLIT_TARGET", 1}, {"CG_SPLIT_MINK", 8}, {"CG_TN_SMAX", 256}, {"CG_TN_TARGET", 3}, {"CG_SKINNY", 1}, {"CG_GEMM_BK32", 1},
     {"CG_COLREDUCE_WGS_PER_CU", 1}, {"CG_WINO_BK", 0}, {"CG_NN_TILE", 0}, {"CG_TN_TILE", 0}, {"CG_NN_SPLITS", 0}, {"CG_TN_SPLITS", 0},
     {"CG_EPILOGUE_STATS", 1}, {"CG_XCD_SWIZZLE", 7}, {"CG_NN_GLDS", 1}, {"CG_TN_GLDS", 1}, {"CG_WINO_GLDS", 1}, {"CG_EW_WGS_PER_CU", 4},
-    {"CG_PAD_SKIP", 20},
+    {"CG_PAD_SKIP", 20}, {"CG_WINO3", 1},
 };
 long g_opt_val[OPT_COUNT];
 int g_opt_state[OPT_COUNT];   // 0 = not read yet, 1 = default / environment, 2 = set through the ABI

@@ -44,7 +44,7 @@ extern "C" {
  * utils/nn_utils.lua:638-643). */
 int         cg_abi_version(void);
 const char* cg_last_error(void);
-/* Tunables of the kernel dispatch, named like the environment variables that set their defaults - 19 (18 after the round-5 pruning + CG_PAD_SKIP):
+/* Tunables of the kernel dispatch, named like the environment variables that set their defaults (round 6 adds CG_WINO3: 1 = fused-transform Winograd F(2x2,3x3) for plain 64 -> 64 plane 3x3 layers with >= 2 workgroups per CU, 2 = wherever the geometry fits, 0 = never; CG_SKINNY: 1 = the MFMA scatter-form kernels of csrc/skinny.hip, 2 = round 1's VALU kernels, 0 = the generic GEMM):
  * block tiles CG_NN_TILE / CG_TN_TILE (bm*1000+bn) and splits CG_NN_SPLITS / CG_TN_SPLITS / CG_SPLIT_TARGET / CG_SPLIT_MINK / CG_TN_SMAX /
  * CG_TN_TARGET; K step CG_GEMM_BK32 / CG_WINO_BK; CG_SKINNY; CG_EPILOGUE_STATS; CG_XCD_SWIZZLE (bits: 1 row ranges per XCD, 2 pixel chunks per XCD in the weight gradients, 4 weights-stationary
  * XCDs in the LDS-direct forward kernel; default 7); grid caps CG_COLREDUCE_WGS_PER_CU /

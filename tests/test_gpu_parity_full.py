@@ -167,6 +167,25 @@ def test_skinny_3x3_layers_on_both_kernel_families(cg, mode, N, Cin, H, W, Cout)
         run_conv(cg, N, Cin, H, W, Cout, 3, 0, seed=N + Cin + H + W + Cout)
 
 
+# (N, H, W): plain 64 -> 64 plane 3x3 layers (models.lua:648,655,664,673) on the fused-transform Winograd kernel (csrc/wino3.hip; CG_WINO3 = 2
+# takes it wherever the geometry fits, 0 never) and on the direct implicit GEMM: forward and data gradient (flipped filters) run the
+# fused kernel, the weight gradient stays direct.  One block per image, several block rows / columns, image borders on every side of a
+# block, a batch that is not a multiple of anything, the benchmarked layer itself on the DIRECT kernel (the default takes the fused one).
+WINO3_CASES = [(2, 8, 16), (3, 16, 16), (2, 24, 32), (5, 32, 48), (1, 64, 64)]
+
+
+@pytest.mark.parametrize("mode", [2, 0], ids=["fused", "direct"])
+@pytest.mark.parametrize("N,H,W", WINO3_CASES)
+def test_fused_winograd_for_the_64_plane_3x3_layers(cg, mode, N, H, W):
+    with options(cg, CG_WINO3=mode):
+        run_conv(cg, N, 64, H, W, 64, 3, 0, seed=N + H + W)
+
+
+def test_direct_kernel_still_covers_the_benchmarked_64_plane_layer(cg):
+    with options(cg, CG_WINO3=0):
+        run_conv(cg, 128, 64, 32, 32, 64, 3, 0, seed=7)
+
+
 FULL_LINEARS = [
     ("G32up-c Linear 100->8192 (models.lua:199)", 128, 100, 8192),
     ("G32up-c Linear 100->8192, half batch", 64, 100, 8192),
