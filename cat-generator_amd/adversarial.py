@@ -29,16 +29,12 @@ DEFAULT_OPT = dict(  # train.lua:15-49
     batchSize=32, N_epoch=1000, G_L1=0.0, G_L2=0.0, D_L1=0.0, D_L2=1e-4, D_iterations=1, G_iterations=1,
     D_maxAcc=1.01, D_clamp=1.0, G_clamp=5.0, D_optmethod="adam", G_optmethod="adam", noiseDim=100, scale=32,
     seed=1, colorSpace="rgb", fused_update=True, exact_reference_backward=False, overlap_comm=True,
-    # the G-step's generator forward on a side stream beside the D update (single rank).  Round 2: 7.52 -> 7.45 ms/step.  Round 4: OFF -
-    # beside the generator's GEMMs the launch-bound kernels of D's chain queue for slots, and what the overlap wins
-    # they lose: same box 6.32 / 6.33 with, 6.29 / 6.29 ms without (config #3: 9.64 / 9.54); CG_CONCURRENT_G=1 switches it back on
-    concurrent_g_forward=os.environ.get("CG_CONCURRENT_G", "0") != "0",
-    # Round 5: BOTH generator forwards of an iteration - the D-step's fake images on N/2 noise rows (adversarial.lua:232-233)
-    # and the G-step's pass on N rows (:185) - read the same G parameters (G moves at :262 only), so the second one starts at the head of
-    # the iteration on a side stream, beside the first, instead of after D's update: two serial chains of GEMM -> statistics ->
-    # normalise -> transform fill each other's launch gaps.  Result-neutral: the G-step's noise is drawn from the position it has in
-    # the reference's order (behind the D-step's dropout masks), the side pass leaves the batch-norm running statistics alone and
-    # they are moved after the join, in the reference's order (cg_net_apply_running).  CG_CONCURRENT_G_BOTH=0 switches it off.
+    # BOTH generator forwards of an iteration - the D-step's fake images on N/2 noise rows (adversarial.lua:232-233) and the G-step's pass
+    # on N rows (:185) - read the same G parameters (G moves at :262 only), so the second one starts at the head of the iteration beside
+    # the first instead of after D's update (round 5: 6.15 -> 5.95 ms; since round 6 ONE call below the ABI, cg_net_forward_pair, so a
+    # LuaJIT host gets the same schedule from MODEL_G:forwardPair).  Result-neutral: the G-step's noise is drawn from the position it has
+    # in the reference's order (behind the D-step's dropout masks), the second pass leaves the batch-norm running statistics alone and
+    # the library moves them behind the first pass's update.  CG_CONCURRENT_G_BOTH=0 = the reference's order of calls.
     concurrent_g_both=os.environ.get("CG_CONCURRENT_G_BOTH", "1") != "0",
 )
 
@@ -78,7 +74,6 @@ class State:
         self._cache = {}
         self.keep_outputs = False  # tests: snapshot D's output before the G-step reuses the buffer
         self.device_rng = False    # draw the real-batch indices on the device (required under hipGraph replay)
-        self._side = None          # side HIP stream + fork/join events for the concurrent G-step forward
         self._d_draws = {}         # batch -> counter-stream draws of MODEL_D:forward (learned in the first iteration)
 
 
@@ -169,9 +164,8 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         S.GRAD_PARAMETERS_G.zero()
         targets = buf["targets_G"]
         samples = st.pop("samples_pre", None)
-        if "join" in st:  # the forward ran on the side stream: join before anything consumes it
-            torch.cuda.current_stream().wait_event(st.pop("join"))
         if st.pop("both", False):
+            samples = S.MODEL_G.pairJoin()       # cg_net_pair_join: the step's stream waits for the second pass, which hands out its images
             off = st.pop("noise_off", None)
             if off is not None:
                 r = rng()
@@ -222,58 +216,20 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         noise = nn.to_device(noise_D) if noise_D is not None else nn_utils.stepNoiseInputs(S, half)
         both = _both_forwards_ok(S, N)
         if both:
-            if S._side is None:
-                S._side = (_side_stream(), torch.cuda.Event(), torch.cuda.Event())
-            side, ev_fork, ev_join = S._side
-            ev_fork.record()
-            side.wait_event(ev_fork)
-        samples = nn.as_nhwc(nn_utils.createImagesFromNoise(S, noise, False))
-        if both:
-            ev_a = S._side_a = getattr(S, "_side_a", None) or torch.cuda.Event()
-            ev_a.record()      # the fake-image pass (and with it its running-statistics update) is complete on the step's stream
-            # the G-step's forward, issued behind the fake-image pass on the side stream: its plan (the N-row one) becomes the net's last
-            # forward, which is what MODEL_G:backward continues
-            pn = S.MODEL_G._pnet[1]
-            r = rng()
-            with torch.cuda.stream(side):
-                if noise_G is not None:
-                    st["noiseInputs"] = nn.to_device(noise_G)
-                else:
-                    st["noise_off"] = r.offset + S._d_draws[N]       # behind the D-step's dropout masks (drawn by MODEL_D:forward below)
-                    st["noiseInputs"] = nn_utils.stepNoiseInputsAt(S, N, st["noise_off"])
-                pn.set_defer_running(True)
-                try:
-                    st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
-                finally:
-                    pn.set_defer_running(False)
-                # the side pass left the running statistics alone: move them here, off the step's chain, but behind the fake-image pass's
-                # update (the reference's order, adversarial.lua:232 then :185)
-                side.wait_event(ev_a)
-                pn.apply_running()
-                ev_join.record()
-            st["join"] = ev_join
+            # ONE call below the ABI (cg_net_forward_pair, round 6): the fake-image pass on the step's stream, the G-step's pass on a library
+            # stream of another hardware queue, its running statistics applied behind the first pass's.  The G-step's noise is drawn HERE at
+            # the position it has in the reference's order: behind the D-step's dropout masks (drawn by MODEL_D:forward below)
+            if noise_G is not None:
+                st["noiseInputs"] = nn.to_device(noise_G)
+            else:
+                st["noise_off"] = rng().offset + S._d_draws[N]
+                st["noiseInputs"] = nn_utils.stepNoiseInputsAt(S, N, st["noise_off"])
+            samples = nn.as_nhwc(S.MODEL_G.forwardPair(noise, st["noiseInputs"]))
             st["both"] = True
+        else:
+            samples = nn.as_nhwc(nn_utils.createImagesFromNoise(S, noise, False))
         lib().memcpy_d2d(stream(), inputs.ptr + half * rowlen * 4, samples.ptr, half * rowlen * 4)
         S._last_fake = samples.clone() if S.keep_outputs else samples
-        # Fork: the G-step's generator forward (fresh noise) depends only on G's parameters, not on anything the
-        # D update does, and D's many small kernels leave CUs idle -> run it on a side HIP stream concurrently
-        # with fevalD / D's Adam.  It must follow the fake-generation forward (shared BN statistics buffers).
-        if (OPT.get("concurrent_g_forward", False) and has_gpu() and parallel.world_size() == 1 and OPT["D_iterations"] == 1
-                and OPT["G_iterations"] == 1):
-            if S._side is None:
-                S._side = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
-            side, ev_fork, ev_join = S._side
-
-            def fork():
-                ev_fork.record()
-                side.wait_event(ev_fork)
-                with torch.cuda.stream(side):
-                    st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.stepNoiseInputs(S, N)
-                    st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
-                    ev_join.record()
-                st["join"] = ev_join
-
-            fork()
         fused = dict(l1=OPT["D_L1"], l2=OPT["D_L2"], clamp=OPT["D_clamp"]) if OPT["fused_update"] else None
         m = OPT["D_optmethod"]  # adversarial.lua:240-248
         assert m in ("sgd", "adagrad", "adam"), "[Warning] Unknown optimizer method chosen for D."
@@ -283,7 +239,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
                          and OPT["D_iterations"] == 1 and OPT["G_iterations"] == 1)
         if st["overlap"]:
             fD, gD = fevalD(S.PARAMETERS_D)
-            if "samples_pre" not in st:
+            if "samples_pre" not in st and not st.get("both"):
                 st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.stepNoiseInputs(S, N)
                 st["samples_pre"] = nn_utils.createImagesFromNoise(S, st["noiseInputs"], False, True)
             st.pop("pendingD").finish()
@@ -295,7 +251,7 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
 
     # ----------------------------------------------------------------- (2) update G (:253-266)
     for _ in range(OPT["G_iterations"]):
-        if "samples_pre" not in st:
+        if "samples_pre" not in st and not st.get("both"):
             st["noiseInputs"] = nn.to_device(noise_G) if noise_G is not None else nn_utils.stepNoiseInputs(S, N)
         # upstream multiplies the L1 sign term by G_L2 (:206): keep that in the fused form too
         fused = dict(l1=OPT["G_L2"] if OPT["G_L1"] != 0 or OPT["G_L2"] != 0 else 0.0, l2=OPT["G_L2"],
@@ -308,24 +264,16 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
     return st["doTrainD"]
 
 
-def _side_stream():
-    """The host's side stream for the G-step's generator forward, on a hardware queue of its own choice (cg_stream_on_queue: the runtime
-    serves all streams from four hardware queues, and a torch.cuda.Stream() lands on whichever is next in creation order - possibly the
-    step's own, where nothing overlaps: +0.2 ms per step).  Any class but 0 measures the same (profiles/r05_queue_classes.txt); CG_QMAP_T
-    overrides."""
-    import ctypes
-    h = ctypes.c_void_p()
-    lib().stream_on_queue(stream(), int(os.environ.get("CG_QMAP_T", "2")), 7, ctypes.byref(h))
-    return torch.cuda.ExternalStream(h.value)
-
-
 def _both_forwards_ok(S, N):
     """Both generator forwards of the iteration side by side (OPT.concurrent_g_both)?  Single rank (a second pass would put its sync-BN
     collectives on the communicator of the first), one D and one G iteration, planned generator, and D's draw count at this batch known
     from an earlier iteration (the first iteration of a run goes one after the other)."""
     OPT = S.OPT
     G = S.MODEL_G
-    return bool(OPT.get("concurrent_g_both", False) and not OPT.get("concurrent_g_forward", False) and has_gpu() and nn.planned
+    last = G.modules[-1] if getattr(G, "modules", None) else None
+    if isinstance(last, nn.Copy) and "Cuda" not in last.outtype:
+        return False          # a net that hands host tensors back (models.lua:704 style wrapping) takes the plain path
+    return bool(OPT.get("concurrent_g_both", False) and has_gpu() and nn.planned
                 and parallel.world_size() == 1 and OPT["D_iterations"] == 1 and OPT["G_iterations"] == 1 and N in S._d_draws
                 and type(G) is nn.Sequential and getattr(G, "_pnet", None) and G._pnet[1] is not None and getattr(G, "_planned_last", False)
                 and getattr(G._pnet[1], "last_draws", 0) == 0     # a G that draws (Dropout) would move the counter stream under the side pass
@@ -361,12 +309,6 @@ class GraphedIteration:
         with torch.cuda.stream(self.stream):
             for _ in range(max(1, warmup)):  # eager passes: allocate every buffer, pack weights, learn the stride
                 self._eager()
-            # the capture may be the first iteration that runs both generator forwards side by side (the first eager one goes one after
-            # the other: D's draw count is not known yet): its side stream and events exist before the capture starts (the
-            # N-row noise buffer is the one the first iteration's G-step already allocated)
-            if S.OPT.get("concurrent_g_both") and S._side is None:
-                S._side = (_side_stream(), torch.cuda.Event(), torch.cuda.Event())
-                S._side_a = torch.cuda.Event()
         torch.cuda.synchronize()
         ts = {k: S.OPTSTATE["adam"][k]["t"] for k in ("D", "G")}
         self.exec = ctypes.c_void_p()

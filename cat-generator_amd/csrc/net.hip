@@ -228,6 +228,9 @@ struct Net {
     int qmap[8] = {-1, 0, 0, 0, 0, 0, 0, 0};  // hardware-queue class of stream index t (ensure_streams)
     bool pack_inflight = false;               // sync_packs forked a re-packing that a LATER pass on another stream may still have to wait for
     int defer_running = 0;                     // run-time switch: batch-norm forwards leave the running statistics to cg_net_apply_running
+    // cg_net_forward_pair: the second pass's stream (another hardware queue than the caller's), fork / "first pass complete" / join events
+    hipStream_t pair_stream = nullptr; hipEvent_t pair_fork_ev = nullptr, pair_a_ev = nullptr, pair_join_ev = nullptr;
+    bool pair_pending = false; float* pair_y = nullptr; int pair_ynd = 0, pair_yfmt = 0; long pair_ydims[4] = {0, 0, 0, 0};
     bool fresh_allocs = false;                 // library-owned buffers were allocated + zeroed since the last device synchronise
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
@@ -2647,6 +2650,7 @@ int cg_net_destroy(void* net) {
     for (auto e : n->side_ev) (void)hipEventDestroy(e);
     if (n->fork_ev) (void)hipEventDestroy(n->fork_ev);
     if (n->pack_ev) { (void)hipEventDestroy(n->pack_fork_ev); (void)hipEventDestroy(n->pack_ev); }
+    if (n->pair_fork_ev) { (void)hipEventDestroy(n->pair_fork_ev); (void)hipEventDestroy(n->pair_a_ev); (void)hipEventDestroy(n->pair_join_ev); }
     for (int t = 0; t < 4; ++t) if (n->wg_fork_ev[t]) { (void)hipEventDestroy(n->wg_fork_ev[t]); (void)hipEventDestroy(n->wg_join_ev[t]); }
     delete n;
     return 0;
@@ -2873,6 +2877,67 @@ int cg_net_apply_running(void* net, void* stream) {
         if (n->K->bn_running_update(stream, (const double*)b.sums.p, b.cnt, (int)b.C, b.mom, b.bn->rmean, b.bn->rvar)) { g_cur_net = nullptr; return 1; }
     }
     g_cur_net = nullptr;
+    return 0;
+}
+
+// Two forward passes of ONE net side by side (SURVEY.md 8b "optional coarse entry"): adversarial.lua:232-233 runs MODEL_G on
+// the D-step's N/2 noise rows and :185 on the G-step's N rows, and MODEL_G moves only at :262 - both passes read the same parameters.  Pass
+// 1 runs on the caller's stream exactly as cg_net_forward would; pass 2 (its input must already be enqueued on `stream`) runs on a
+// library stream of ANOTHER hardware queue, leaves the batch-norm running statistics alone and applies its update behind pass 1's, so
+// that results, running statistics and the plan cg_net_backward continues (pass 2's) are those of forward(x) followed by forward(x2).
+// The caller's stream does not wait for pass 2 until cg_net_pair_join, which also hands out pass 2's output.  draws = both passes'.
+int cg_net_forward_pair(void* net, void* stream, const float* x, int nd, const long* dims, int fmt, const float* x2, int nd2, const long* dims2,
+                        int fmt2, uint64_t rng_seed, uint64_t rng_offset, const uint64_t* rng_base, uint64_t* draws, float** y, int* ynd,
+                        long* ydims, int* yfmt) {
+    Net* n = NET(net);
+    CG_REQUIRE(n && x && x2 && dims && dims2, "cg_net_forward_pair: null pointer");
+    CG_REQUIRE(!n->pair_pending, "cg_net_forward_pair: the previous pair was never joined (cg_net_pair_join)");
+    if (n->trace) {      // a trace records the launches of both passes one after the other
+        uint64_t d1 = 0, d2 = 0;
+        if (cg_net_forward(net, stream, x, nd, dims, fmt, rng_seed, rng_offset, rng_base, &d1, y, ynd, ydims, yfmt)) return 1;
+        trace_note(n, "pair|second pass on the pair stream");
+        if (cg_net_forward(net, stream, x2, nd2, dims2, fmt2, rng_seed, rng_offset + d1, rng_base, &d2, &n->pair_y, &n->pair_ynd, n->pair_ydims, &n->pair_yfmt)) return 1;
+        if (draws) *draws = d1 + d2;
+        n->pair_pending = true;
+        return 0;
+    }
+    if (!n->pair_fork_ev) {
+        n->pair_stream = cg::queue_stream(cg::S(stream), 2, 7);     // any class but the caller's own measures the same (profiles/r05_queue_classes.txt)
+        if (!n->pair_stream) return 1;
+        CG_HIP(hipEventCreateWithFlags(&n->pair_fork_ev, hipEventDisableTiming));
+        CG_HIP(hipEventCreateWithFlags(&n->pair_a_ev, hipEventDisableTiming));
+        CG_HIP(hipEventCreateWithFlags(&n->pair_join_ev, hipEventDisableTiming));
+    }
+    hipStream_t st = cg::S(stream), side = n->pair_stream;
+    CG_HIP(hipEventRecord(n->pair_fork_ev, st));
+    CG_HIP(hipStreamWaitEvent(side, n->pair_fork_ev, 0));
+    uint64_t d1 = 0, d2 = 0;
+    if (cg_net_forward(net, stream, x, nd, dims, fmt, rng_seed, rng_offset, rng_base, &d1, y, ynd, ydims, yfmt)) return 1;
+    CG_HIP(hipEventRecord(n->pair_a_ev, st));      // pass 1, its running-statistics update included, is complete on the caller's stream
+    const int defer = n->defer_running;
+    n->defer_running = 1;
+    const int rc = cg_net_forward(net, (void*)side, x2, nd2, dims2, fmt2, rng_seed, rng_offset + d1, rng_base, &d2, &n->pair_y, &n->pair_ynd,
+                                  n->pair_ydims, &n->pair_yfmt);
+    n->defer_running = defer;
+    if (rc) return 1;
+    CG_HIP(hipStreamWaitEvent(side, n->pair_a_ev, 0));
+    if (cg_net_apply_running(net, (void*)side)) return 1;      // off the caller's chain, but behind pass 1's update: the reference's order
+    CG_HIP(hipEventRecord(n->pair_join_ev, side));
+    n->pair_pending = true;
+    if (draws) *draws = d1 + d2;
+    return 0;
+}
+
+int cg_net_pair_join(void* net, void* stream, float** y, int* ynd, long* ydims, int* yfmt) {
+    Net* n = NET(net);
+    CG_REQUIRE(n, "cg_net_pair_join: null net");
+    CG_REQUIRE(n->pair_pending, "cg_net_pair_join: no pair in flight");
+    if (!n->trace) CG_HIP(hipStreamWaitEvent(cg::S(stream), n->pair_join_ev, 0));
+    n->pair_pending = false;
+    if (y) *y = n->pair_y;
+    if (ynd) *ynd = n->pair_ynd;
+    if (ydims) for (int i = 0; i < 4; ++i) ydims[i] = n->pair_ydims[i];
+    if (yfmt) *yfmt = n->pair_yfmt;
     return 0;
 }
 

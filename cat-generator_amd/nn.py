@@ -259,6 +259,20 @@ class Sequential(Module):
         self.output = out
         return out
 
+    def forwardPair(self, input, input2):
+        """MODEL:forward(input) now and MODEL:forward(input2) beside it (cg_net_forward_pair; planned nets on a GPU only): returns
+        the first output; pairJoin() returns the second, which becomes .output and what :backward continues."""
+        net = self._planned_net()
+        assert net is not None and planned and has_gpu() and type(self) is Sequential, "forwardPair needs the planned executor"
+        x, x2 = materialise(to_device(input)), materialise(to_device(input2))
+        out = net.forward_pair(x, x2)
+        self._planned_last, self._planned_x = True, x2
+        return out
+
+    def pairJoin(self):
+        self.output = self._pnet[1].pair_join()
+        return self.output
+
     def _planned_backward(self, gradOutput, scale, acc):
         net = self._pnet[1]
         g = materialise(to_device(gradOutput))

@@ -257,6 +257,29 @@ class PlannedNet:
             return Tensor(torch.empty(0), tuple(int(ydims[i]) for i in range(ynd.value)), "nhwc" if yfmt.value & 1 else "plain")
         return self._wrap(y.value, ynd.value, ydims, yfmt.value)
 
+    def forward_pair(self, x, x2):
+        """cg_net_forward_pair: forward(x) on the current stream, forward(x2) beside it on a library stream; returns pass 1's output.
+        pair_join() returns pass 2's, which is also what backward() continues."""
+        self._sync()
+        r = rng()
+        d1 = (ctypes.c_long * 4)(*(list(x.shape) + [0] * (4 - len(x.shape))))
+        d2 = (ctypes.c_long * 4)(*(list(x2.shape) + [0] * (4 - len(x2.shape))))
+        y, ynd, yfmt, draws = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int(), ctypes.c_uint64()
+        ydims = (ctypes.c_long * 4)()
+        self.L.net_forward_pair(self.h, stream(), x.ptr, len(x.shape), d1, 1 if x.fmt == "nhwc" else 0, x2.ptr, len(x2.shape), d2,
+                                1 if x2.fmt == "nhwc" else 0, r.seed, r.offset, r.base_ptr(), ctypes.addressof(draws), ctypes.byref(y),
+                                ctypes.byref(ynd), ydims, ctypes.byref(yfmt))
+        r.offset += draws.value
+        self.last_draws = int(draws.value)
+        self._x = x2
+        return self._wrap(y.value, ynd.value, ydims, yfmt.value)
+
+    def pair_join(self):
+        y, ynd, yfmt = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+        ydims = (ctypes.c_long * 4)()
+        self.L.net_pair_join(self.h, stream(), ctypes.byref(y), ctypes.byref(ynd), ydims, ctypes.byref(yfmt))
+        return self._wrap(y.value, ynd.value, ydims, yfmt.value)
+
     def backward(self, x, gy, acc, scale=1.0):
         gx, gnd, gfmt = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
         gdims = (ctypes.c_long * 4)()

@@ -613,7 +613,13 @@ int cg_comm_sync(void* comm);
  *   such pass (cg_bn_running_update per layer, bit-identical to the in-line update).  For a host that runs two forward passes of one
  *   net side by side on two streams - the generator's fake-image pass and the G-step's pass, adversarial.lua:232-233 and :185, which
  *   read the same parameters - and still wants the running statistics moved in the reference's order.  A pass that did not re-pack
- *   the weights itself waits (device-side) for a re-packing another pass of the net has in flight. */
+ *   the weights itself waits (device-side) for a re-packing another pass of the net has in flight.
+ * cg_net_forward_pair / cg_net_pair_join (round 6): that schedule as ONE call, below the ABI.  Pass 1 (x) runs on `stream` exactly as
+ *   cg_net_forward would and its output is returned; pass 2 (x2: already enqueued on `stream` when the call is made) runs on a library
+ *   stream of another hardware queue, leaves the running statistics to a deferred update the library applies behind pass 1's, and
+ *   becomes the plan cg_net_backward continues.  Results, running statistics and counter-stream draws (*draws = both passes') are those
+ *   of cg_net_forward(x) followed by cg_net_forward(x2) - adversarial.lua:232-233 then :185; MODEL_G moves only at :262.
+ *   cg_net_pair_join makes `stream` wait for pass 2 and returns ITS output; exactly one join per pair, before the net's next pass. */
 int cg_net_create(void** net);
 int cg_net_destroy(void* net);
 int cg_net_set_option(void* net, const char* name, long value);
@@ -631,6 +637,10 @@ int cg_net_forward(void* net, void* stream, const float* x, int nd, const long* 
 int cg_net_backward(void* net, void* stream, const float* x, const float* gy, int gy_fmt, int acc, float scale, float** gx, int* gnd,
                     long* gdims, int* gfmt);
 int cg_net_apply_running(void* net, void* stream);
+int cg_net_forward_pair(void* net, void* stream, const float* x, int nd, const long* dims, int fmt, const float* x2, int nd2, const long* dims2,
+                        int fmt2, uint64_t rng_seed, uint64_t rng_offset, const uint64_t* rng_base, uint64_t* draws, float** y, int* ynd,
+                        long* ydims, int* yfmt);
+int cg_net_pair_join(void* net, void* stream, float** y, int* ynd, long* ydims, int* yfmt);
 int cg_net_buckets(void* net, int* nbuckets);
 int cg_net_module_state(void* net, int id, int which, float** ptr, int* nd, long* dims, int* fmt);
 int cg_net_stats(void* net, long* nprograms, long* nlaunch_fwd, long* nlaunch_bwd, size_t* bytes);

@@ -139,6 +139,26 @@ function Net:forward(x, rng, rng_base)
    return wrap(y[0], ynd[0], ydims, yfmt[0])
 end
 
+-- MODEL:forwardPair(input, input2) / MODEL:pairJoin() (cg_net_forward_pair / cg_net_pair_join, round 6): forward(input) on the step's stream
+-- and forward(input2) beside it on a library stream of another hardware queue - adversarial.lua:232-233 (fake images, N/2 rows) and :185
+-- (the G-step's pass, N rows) read the same parameters.  Returns the first output; pair_join returns the second, which backward continues.
+function Net:forward_pair(x, x2, rng, rng_base)
+   self:sync()
+   local d1 = ffi.new('long[4]'); for i, v in ipairs(x.shape) do d1[i - 1] = v end
+   local d2 = ffi.new('long[4]'); for i, v in ipairs(x2.shape) do d2[i - 1] = v end
+   local y, ynd, ydims, yfmt, draws = ffi.new('float*[1]'), ffi.new('int[1]'), ffi.new('long[4]'), ffi.new('int[1]'), ffi.new('uint64_t[1]')
+   check(C.cg_net_forward_pair(self.h, T.stream, x.ptr, #x.shape, d1, (x.fmt == 'nhwc') and 1 or 0, x2.ptr, #x2.shape, d2,
+                               (x2.fmt == 'nhwc') and 1 or 0, rng.seed, rng.offset, rng_base, draws, y, ynd, ydims, yfmt))
+   rng.offset = rng.offset + tonumber(draws[0])
+   self._x = x2
+   return wrap(y[0], ynd[0], ydims, yfmt[0])
+end
+function Net:pair_join()
+   local y, ynd, ydims, yfmt = ffi.new('float*[1]'), ffi.new('int[1]'), ffi.new('long[4]'), ffi.new('int[1]')
+   check(C.cg_net_pair_join(self.h, T.stream, y, ynd, ydims, yfmt))
+   return wrap(y[0], ynd[0], ydims, yfmt[0])
+end
+
 -- MODEL:backward(input, gradOutput, scale) (acc = true) / MODEL:updateGradInput(input, gradOutput) (acc = false: what
 -- fevalG_on_D needs of D, adversarial.lua:192-193 - the reference accumulates D's weight gradients there and never reads them)
 function Net:backward(gy, acc, scale)

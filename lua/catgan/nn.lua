@@ -204,6 +204,17 @@ function Sequential:forward(input)
    self.output = out
    return out
 end
+-- Both generator forwards of an iteration side by side (a six-line change to adversarial.lua, INTEGRATION.md section 1): planned nets only
+function Sequential:forwardPair(input, input2)
+   local net = assert(planned_net(self), 'forwardPair needs the planned executor')
+   local out = net:forward_pair(to_device(input):materialise(), to_device(input2):materialise(), rng, nil)
+   self._planned_last = true
+   return out
+end
+function Sequential:pairJoin()
+   self.output = self._pnet:pair_join()
+   return self.output
+end
 local function planned_backward(self, gradOutput, scale, acc)
    local gi = self._pnet:backward(to_device(gradOutput):materialise(), acc, scale)
    local first = self.modules[1]

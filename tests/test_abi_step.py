@@ -5,8 +5,8 @@ no PyTorch in that process.
 
 Two recordings:
   * the PLANNED step at the benchmarked batch (128): the description of G32up-c and D32_st3 (cg_net_create / _add / _bind), then one
-    cg_net_forward / cg_net_backward per pass with the batch assembly, criterion and optimiser calls between them - the path
-    bench.py times, as a LuaJIT host issues it (lua/catgan/net.lua);
+    cg_net_forward / cg_net_backward per pass - the two generator forwards as one cg_net_forward_pair - with the batch assembly,
+    criterion and optimiser calls between them: the path AND the schedule bench.py times, as a LuaJIT host issues it (lua/catgan/net.lua);
   * the per-module walk at a small batch: one C call per nn.Module method, the sequence the per-module classes of
     lua/catgan/nn.lua issue (the LuaJIT layer cannot run in this image; scripts/check_lua_binding.py checks its C calls against
     the header statically).
@@ -77,8 +77,11 @@ def _record_and_replay(tmp_path, planned, N):
 def test_planned_step_at_the_benchmarked_batch_replayed_without_python(tmp_path):
     names, out = _record_and_replay(tmp_path, True, 128)
     assert names.count("cg_net_create") == 2 and names.count("cg_net_add") > 120            # G32up-c (17 modules) + D32_st3
-    # 3 forwards of G?  no: fake generation (N/2) + the G-step's forward (N); D: the D-step's and the G-step's forward
-    assert names.count("cg_net_forward") == 4 and names.count("cg_net_backward") == 3        # D backward, D updateGradInput, G backward
+    # G: fake generation (N/2) + the G-step's forward (N) as ONE cg_net_forward_pair + its join - the BENCHMARKED schedule, issued below the ABI
+    # (round 6; round 5's host-side streams and events were invisible to this recording); D: the D-step's and the G-step's forward
+    assert names.count("cg_net_forward_pair") == 1 and names.count("cg_net_pair_join") == 1 and names.count("cg_net_forward") == 2
+    assert names.index("cg_net_forward_pair") < names.index("cg_net_forward") < names.index("cg_net_pair_join")
+    assert names.count("cg_net_backward") == 3        # D backward, D updateGradInput, G backward
     per_module = [n for n in names if n.startswith(("cg_conv2d", "cg_prelu", "cg_bn_", "cg_act_pool", "cg_bilinear", "cg_affine", "cg_avgpool",
                                                     "cg_maxpool", "cg_mask_mul", "cg_sigmoid", "cg_leakyrelu", "cg_pack_"))]
     assert not per_module, f"the planned step issues no per-module launch through the host: {per_module[:5]}"

@@ -583,35 +583,11 @@ def test_full_batch_step_runs_and_stays_finite(cg):
     assert S.CONFUSION.counts.sum().item() == 256
 
 
-def test_generator_forward_beside_the_discriminator_update_is_result_neutral(cg):
-    """OPT.concurrent_g_forward (the G step's generator forward on a side stream beside fevalD / D's Adam; off by default since round 4,
-    CG_CONCURRENT_G=1) is a schedule, not arithmetic.  It does move the G step's noise draw in front of D's dropout draws in the counter
-    stream, so the comparison injects the indices and both noise batches: the only draws left are D's masks, in the same order either
-    way - and three steps give the same bits."""
-    rs = np.random.RandomState(8)
-    N = 16
-    steps = [(rs.randint(0, 64, size=N // 2), (rs.rand(N // 2, 100) * 2 - 1).astype(f32), (rs.rand(N, 100) * 2 - 1).astype(f32)) for _ in range(3)]
-
-    def run(concurrent):
-        cg.manual_seed(43)
-        G, D = cg.models.create_G((3, 32, 32), 100), cg.models.create_D((3, 32, 32))
-        S = cg.adversarial.State(dict(batchSize=N, concurrent_g_forward=concurrent), G, D)
-        data = cg.adversarial.TrainData(np.random.RandomState(6).rand(64, 3, 32, 32).astype(f32))
-        for idx, nd, ng in steps:
-            cg.adversarial.iteration(S, data, N, real_idx=idx, noise_D=nd, noise_G=ng)
-        torch.cuda.synchronize()
-        return S.PARAMETERS_G.numpy(), S.PARAMETERS_D.numpy()
-    g0, d0 = run(False)
-    g1, d1 = run(True)
-    np.testing.assert_array_equal(g0, g1)
-    np.testing.assert_array_equal(d0, d1)
-
-
 def test_both_generator_forwards_side_by_side_are_result_neutral(cg):
-    """OPT.concurrent_g_both (round 5; both generator forwards of an iteration side by side from its head, adversarial.lua:232-233 and :185
-    read the same G parameters) is a schedule, not arithmetic - WITHOUT injecting anything: the G-step's noise is drawn ahead of time at
-    the position it has in the reference's order (behind the D-step's dropout masks), the side pass defers its batch-norm running
-    statistics and they are moved after the join (cg_net_apply_running), behind the fake-image pass's.  Four iterations (the first one
+    """OPT.concurrent_g_both (both generator forwards of an iteration side by side from its head - adversarial.lua:232-233 and :185 read the
+    same G parameters; since round 6 ONE call below the ABI, cg_net_forward_pair / cg_net_pair_join) is a schedule, not arithmetic - WITHOUT
+    injecting anything: the G-step's noise is drawn ahead of time at the position it has in the reference's order (behind the D-step's
+    dropout masks), the second pass defers its batch-norm running statistics and the library moves them behind the fake-image pass's.  Four iterations (the first one
     runs one after the other either way: D's draw count is learned there) give the same bits in the parameters of G and D, in the
     running statistics and in the position of the counter stream."""
     N = 16

@@ -90,8 +90,9 @@ class Recorder:
                 out.append(f"u:{int(v)}")
             else:
                 out.append(f"i:{int(v)}")
-        if name in ("cg_net_forward", "cg_net_backward"):   # the tensor this call returned
-            yi, ni, di = (10, 11, 12) if name == "cg_net_forward" else (7, 8, 9)
+        RET = {"cg_net_forward": (10, 11, 12), "cg_net_backward": (7, 8, 9), "cg_net_forward_pair": (14, 15, 16), "cg_net_pair_join": (2, 3, 4)}
+        if name in RET:   # the tensor this call returned
+            yi, ni, di = RET[name]
             ptr, nd, dims = args[yi]._obj.value, args[ni]._obj.value, args[di]
             n = 1
             for k in range(nd):

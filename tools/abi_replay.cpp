@@ -134,8 +134,9 @@ int main(int argc, char** argv) {
                 }
             }
             ck(dispatch(f[1], A), f[1]);
-            if (f[1] == "cg_net_forward" || f[1] == "cg_net_backward") {   // keep the returned tensor's address under this call's index
-                const size_t yi = f[1] == "cg_net_forward" ? 10 : 7;
+            if (f[1] == "cg_net_forward" || f[1] == "cg_net_backward" || f[1] == "cg_net_forward_pair" || f[1] == "cg_net_pair_join") {
+                // keep the returned tensor's address under this call's index (cg_net_forward_pair: the first pass's, cg_net_pair_join: the second's)
+                const size_t yi = f[1] == "cg_net_forward" ? 10 : (f[1] == "cg_net_backward" ? 7 : (f[1] == "cg_net_forward_pair" ? 14 : 2));
                 if ((size_t)ncalls >= g_vals.size()) g_vals.resize(ncalls + 1, nullptr);
                 g_vals[ncalls] = *(char**)A[yi].out();
             }
