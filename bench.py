@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA = 157.3e12               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM = 8.0e12                       # HBM3E spec (6.29 TB/s measured with a float4 copy)
 # counter passes of the roofline launches (scripts/pmc_kernels.sh), newest first
-PMC_FILE = next((f for f in ("r05_pmc_kernels.json", "r04_pmc_kernels.json", "r03_pmc_kernels.json", "r03a_pmc_kernels.json", "r02b_pmc_kernels.json")
+PMC_FILE = next((f for f in ("r06_pmc_kernels.json", "r05_pmc_kernels.json", "r04_pmc_kernels.json", "r03_pmc_kernels.json", "r03a_pmc_kernels.json", "r02b_pmc_kernels.json")
                  if os.path.exists(os.path.join(ROOT, "profiles", f))), "r02b_pmc_kernels.json")
 
 CONFIGS = {   # BASELINE.json configs (index + 1)
@@ -74,7 +74,24 @@ def step_work(cfg, N):
     fd = (loc(C, s, 1) + conv(C, 64, 3, s) + conv(64, 64, 3, s)
           + 3 * (loc(64, s // 2, 4) + conv(64, 64, 3, s // 2) + conv(64, 64, 3, s // 4))
           + conv(64, 128, 5, s // 2) + conv(128, 128, 7, s // 4) + lin(320 * (s // 4) ** 2, 256) + lin(256, 1))
-    return dict(F_G=fg, F_D=fd, W=3.5 * fg + 5.0 * fd, W_executed=3.5 * fg_x + 5.0 * fd)
+    # What D's forward and data-gradient passes no longer issue (the executed count was overstated):
+    #   * the zero-padding taps of the 7x7 layer (position-major tiles, CG_PAD_SKIP = 20 %: taken when the padding share is above it and the
+    #     batch is a power of two and a multiple of the 64-row tile) - forward and data gradient; the weight gradient multiplies them still;
+    #   * 20 / 36 of the 64 -> 64 plane 3x3 layers that run the fused F(2x2,3x3) kernel (csrc/wino3.hip: >= 2 workgroups per CU of 8 x 16
+    #     pixel blocks; the full-resolution layer and the three 16 x 16 branch layers as one grouped launch) - forward and data gradient.
+    def pad_share(k, w):
+        v = sum(min(w - 1, x + k // 2) - max(0, x - k // 2) + 1 for x in range(w))
+        return 1.0 - (v / (w * k)) ** 2
+    skip = 0.0
+    if pad_share(7, s // 4) > 0.20 and N & (N - 1) == 0 and N % 64 == 0:
+        skip += pad_share(7, s // 4) * conv(128, 128, 7, s // 4)
+    blocks = lambda g, sz: g * N * (sz // 8) * (sz // 16) if sz % 16 == 0 else 0
+    if blocks(1, s) >= 512:
+        skip += 20 / 36 * conv(64, 64, 3, s)
+    if blocks(3, s // 2) >= 512:
+        skip += 20 / 36 * 3 * conv(64, 64, 3, s // 2)
+    fd_x = 4.0 * (fd - skip) + fd          # two forward + two data-gradient passes without them, one weight-gradient pass in full
+    return dict(F_G=fg, F_D=fd, W=3.5 * fg + 5.0 * fd, W_executed=3.5 * fg_x + fd_x, D_skipped_per_pass=skip)
 
 
 def time_kernel(fn, iters=20, warm=3):
@@ -151,13 +168,41 @@ def kernel_rooflines(cg, cfg, N):
     s = cfg["size"]
 
     def d_conv2():
-        # igemm_nn_kernel<128,64,...,16>: D's 64->64 3x3 convolution at full resolution (models.lua:648)
+        # D's 64->64 3x3 convolution at full resolution (models.lua:648): wino3_fused_k (csrc/wino3.hip, fused-transform F(2x2,3x3): 16/36
+        # of the direct MACs) where the launch has >= 2 workgroups per CU, igemm_nn_kernel<128,64,...,16> otherwise / with CG_WINO3=0
         m2, x2, dy2, _ = conv(64, 64, 3, s, N, 0)
-        t = time_kernel(lambda: m2.updateOutput(x2))
         f2 = 2.0 * N * s * s * 64 * 64 * 9
-        entry("nn128x64", "igemm_nn_kernel<128,64,2,2,true,true,16> (gemm.hip)",
-              f"updateOutput of conv3x3 64->64 @{s}x{s}, batch {N}: M={N * s * s} K=576 N=64", f2, t, f2, None,
-              alg_bytes=4.0 * (2 * N * s * s * 64 + 576 * 64))
+        strict = 4.0 * (2 * N * s * s * 64 + 576 * 64)
+        import ctypes
+        w3 = ctypes.c_long(0)
+        lib.get_option(b"CG_WINO3", ctypes.byref(w3))
+        fused = N * (s // 8) * (s // 16) >= 512 and s % 16 == 0 and w3.value != 0
+        t = time_kernel(lambda: m2.updateOutput(x2))
+        if fused:
+            lib.set_option(b"CG_WINO3", 0)
+            try:
+                t_direct = time_kernel(lambda: m2.updateOutput(x2))
+            finally:
+                lib.set_option(b"CG_WINO3", -1)
+            entry("wino3", "wino3_fused_k (wino3.hip; fused-transform Winograd F(2x2,3x3), patch in LDS, U from L2)",
+                  f"updateOutput of conv3x3 64->64 @{s}x{s}, batch {N}: {N * s * s // 4} tiles x 16 positions x [64].[64 x 64]", f2 * 16 / 36, t, f2, None,
+                  {"direct_kernel_ms": 1e3 * t_direct, "direct_kernel": "igemm_nn_kernel<128,64,2,2,true,true,16>",
+                   "direct_kernel_frac": f2 / t_direct / PEAK_FP32_MFMA}, alg_bytes=strict + 4.0 * 16 * 64 * 64)
+        else:
+            entry("nn128x64", "igemm_nn_kernel<128,64,2,2,true,true,16> (gemm.hip)",
+                  f"updateOutput of conv3x3 64->64 @{s}x{s}, batch {N}: M={N * s * s} K=576 N=64", f2, t, f2, None, alg_bytes=strict)
+
+    def skinny():
+        # G's last layer 128 -> C planes (models.lua:222 / :154): HBM-bound (512 bytes per pixel read once); csrc/skinny.hip
+        c = cfg["ch"]
+        m4, x4, dy4, _ = conv(128, c, 3, s, N, 0)
+        t = time_kernel(lambda: m4.updateOutput(x4))
+        tw = time_kernel(lambda: m4.accGradParameters(x4, dy4))
+        by = 4.0 * N * s * s * (128 + c)
+        out.append({"bound": "hbm", "kernel": "skinny_mfma_fwd_k (skinny.hip; scatter-form GEMM on the MFMA, input read once)",
+                    "launch": f"updateOutput of conv3x3 128->{c} @{s}x{s}, batch {N}", "launch_ms": 1e3 * t, "achieved": by / t / 1e9,
+                    "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": by / t / PEAK_HBM, "traffic": None, "algorithmic_bytes_strict": by,
+                    "wgrad_group_ms": 1e3 * tw, "wgrad_group": "skinny_mfma_wgrad_k + wgrad_reduce_small_kernel (accGradParameters)"})
 
     def wino5(ci, co, h, first):
         # wino_gemm_g_kernel<*,16>: the 16 Winograd-domain GEMMs + in-register output transform of an upsample2 -> conv5x5 layer
@@ -173,8 +218,11 @@ def kernel_rooflines(cg, cfg, N):
               f"forward GEMMs of upsample2 -> conv5x5 {ci}->{co} @{h}->{2 * h}, batch {N}: 4 phases x 16 GEMMs [tiles x {ci}].[{ci} x {co}] + output transform",
               d3 * 36 / 100 * 16 / 36, t, d3, None,
               {"layer_ms": {"fwd": 1e3 * time_kernel(lambda: m3.updateOutput(x3)), "dgrad": 1e3 * time_kernel(lambda: m3.updateGradInput(x3, dy3)),
-                            "wgrad": 1e3 * time_kernel(lambda: m3.accGradParameters(x3, dy3))}},
-              alg_bytes=4.0 * (16 * tiles * ci + 4 * 16 * ci * co + N * (2 * h) ** 2 * co))
+                            "wgrad": 1e3 * time_kernel(lambda: m3.accGradParameters(x3, dy3))},
+               "launch_input_bytes_incl_V": 4.0 * (16 * tiles * ci + 4 * 16 * ci * co + N * (2 * h) ** 2 * co),
+               "note": "algorithmic_bytes_strict is the LAYER's (x + y + U): V, the transformed input this launch reads (16 x tiles x planes floats, written "
+                       "by wino_input_transform_kernel = layer_ms.fwd - launch_ms), is not algorithmic; it makes one round trip through HBM / MALL"},
+              alg_bytes=4.0 * (N * h * h * ci + 4 * 16 * ci * co + N * (2 * h) ** 2 * co))
 
     if cfg["gen"] != "G32up-c":
         # G32up (configs[2]): two upsample2 -> conv5x5 layers (models.lua:145,150), both in F(2x2,3x3); the 256->128 layer at 16->32 carries
@@ -182,6 +230,7 @@ def kernel_rooflines(cg, cfg, N):
         wino5(256, 128, 16, True)
         wino5(128, 256, 8, False)
         d_conv2()
+        skinny()
         return out
 
     b = s // 8            # G32up-c: 4x4 at 32x32, 8x8 at 64x64 (models.lua:196-228 scaled)
@@ -231,6 +280,7 @@ def kernel_rooflines(cg, cfg, N):
               {"timed": "launch group (transform + GEMMs)", "direct_kernel_ms": 1e3 * time_kernel(lambda: m.updateOutput(xin)),
                "dgrad_group_ms": 1e3 * tb, "dgrad_direct_kernel_ms": 1e3 * time_kernel(lambda: m.updateGradInput(xin, dy))},
               alg_bytes=4.0 * (px * 512 + 36 * 512 * 256 + 4 * px * 256))
+    skinny()
     return out
 
 
@@ -295,6 +345,47 @@ def cpu_baselines(cfg):
     return best
 
 
+def time_steps(cg, S, data, N, steps, warmup):
+    """HIP-event time per step (ms) of `steps` eager iterations after `warmup`, on the current stream."""
+    for _ in range(warmup):
+        cg.adversarial.iteration(S, data, N)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        cg.adversarial.iteration(S, data, N)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def other_config_line(cg, num, steps, warmup):
+    """One of the other single-GPU configurations of BASELINE.json, timed in THIS run (VERDICT r05 #6c: the driver's command times configs[1]
+    only; builder-run lines of the others are claims): ms per step, images/s, the step's executed MFMA fraction and the configuration's
+    dominant kernel timed live."""
+    cfg = CONFIGS[num]
+    N = cfg["batch"]
+    dims = (cfg["ch"], cfg["size"], cfg["size"])
+    cg.manual_seed(1)
+    G = cg.models.create_G(dims, 100) if cfg["gen"] == "G32up-c" else cg.models.create_G_decoder_upsampling32(dims, 100)
+    D = cg.models.create_D(dims)
+    S = cg.adversarial.State(dict(batchSize=N, seed=1), G, D)
+    data = cg.adversarial.TrainData(np.random.RandomState(100).rand(512, *dims).astype(np.float32))
+    ms = time_steps(cg, S, data, N, steps, warmup)
+    w = step_work(cfg, N)
+    line = {"config": num, "workload": cfg["name"], "batch": N, "steps": steps, "warmup": warmup, "ms_per_step": ms, "value": 1e3 * N / ms, "unit": "images/sec",
+            "executed_frac": 1e3 * N / ms * w["W_executed"] / PEAK_FP32_MFMA, "gflop_per_image_executed": w["W_executed"] / 1e9,
+            "finite": bool(np.isfinite(S.PARAMETERS_G.numpy()).all() and np.isfinite(S.PARAMETERS_D.numpy()).all())}
+    del S, G, D, data
+    try:
+        top = kernel_rooflines(cg, cfg, N)[0]
+        line["roofline"] = {k: top[k] for k in ("bound", "kernel", "launch", "launch_ms", "achieved", "peak", "unit", "frac") if k in top}
+    except Exception as e:                # noqa: BLE001
+        line["roofline"] = {"error": str(e)[:160]}
+    torch.cuda.empty_cache()
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,6 +397,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default) launch eagerly: with the planned executor a step costs the host ~1.1 ms")
     ap.add_argument("--graph", action="store_true", help="capture the iteration once (cg_graph_*) and replay the hipGraph")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the same-run lines of configs 3 and 5 (default run of config 2 on one GPU)")
     ap.add_argument("--strict-comm", action="store_true",
                     help="N > 1: the engine's transport (cg_comm_*: RCCL through the C ABI) or failure - never the torch.distributed fallback "
                          "(CG_COMM_STRICT=1).  config.collectives.transport names the transport of a run either way.")
@@ -437,6 +529,27 @@ def main():
                                    "(adversarial.py: concurrent_g_both), so it has no interval of its own and the intervals it shares are longer than in round 4",
                     "phases_source": "profiles/r05_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
                                      "launches, 6.03 ms under the tracer; committed numbers, not measured in this run)"})
+        # the reference's ORDER of calls (adversarial.lua:232-233 ... :185: the G-step's generator forward after D's update) in the same run:
+        # what an unchanged adversarial.lua gets from the drop-in host; the headline issues the two generator forwards as one
+        # cg_net_forward_pair (MODEL_G:forwardPair - six lines of adversarial.lua)
+        if world == 1 and launch == "eager" and S.OPT.get("concurrent_g_both"):
+            try:
+                S.OPT["concurrent_g_both"] = False
+                res["config"]["reference_order_ms"] = time_steps(cg, S, data, N, min(args.steps, 30), 3)
+                res["config"]["reference_order_note"] = ("the same step with the two generator forwards issued where the reference has them "
+                                                         "(CG_CONCURRENT_G_BOTH=0), same process, HIP events")
+            except Exception as e:                # noqa: BLE001
+                res["config"]["reference_order_ms"] = None
+                res["config"]["reference_order_note"] = "failed: " + str(e)[:160]
+            finally:
+                S.OPT["concurrent_g_both"] = True
+        if world == 1 and args.config == 2 and not args.no_other_configs and not args.batch_per_gpu:
+            res["other_configs"] = []
+            for num in (3, 5):
+                try:
+                    res["other_configs"].append(other_config_line(cg, num, 20, 5))
+                except Exception as e:            # noqa: BLE001
+                    res["other_configs"].append({"config": num, "error": str(e)[:200]})
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baselines(cfg)
