@@ -397,6 +397,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default) launch eagerly: with the planned executor a step costs the host ~1.1 ms")
     ap.add_argument("--graph", action="store_true", help="capture the iteration once (cg_graph_*) and replay the hipGraph")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--no-dp-dry-run", action="store_true", help="skip the data-parallel dry run of the default one-GPU line")
+    ap.add_argument("--dp-dry-run", type=int, nargs="?", const=8, default=None, metavar="R",
+                    help="one GPU: also time the per-rank step of an R-rank data-parallel job (sync-BN, gradient buckets, D's all-reduce under the "
+                         "generator forward) on single-rank RCCL communicators through cg_comm_* -> config.collectives.dry_run_ms_per_step")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the same-run lines of configs 3 and 5 (default run of config 2 on one GPU)")
     ap.add_argument("--strict-comm", action="store_true",
                     help="N > 1: the engine's transport (cg_comm_*: RCCL through the C ABI) or failure - never the torch.distributed fallback "
@@ -543,6 +547,28 @@ def main():
                 res["config"]["reference_order_note"] = "failed: " + str(e)[:160]
             finally:
                 S.OPT["concurrent_g_both"] = True
+        if args.dp_dry_run is None:     # default: on for the plain one-GPU line of configs[1] (8 ranks = configs[3]'s plan), off otherwise
+            args.dp_dry_run = 8 if (world == 1 and args.config == 2 and not args.no_dp_dry_run and not args.batch_per_gpu and launch == "eager") else 0
+        if world == 1 and args.dp_dry_run > 1:
+            try:
+                cg.parallel.dry_run(args.dp_dry_run)
+                cg.manual_seed(1)
+                G2 = cg.models.create_G(dims, 100) if cfg["gen"] == "G32up-c" else cg.models.create_G_decoder_upsampling32(dims, 100)
+                S2 = cg.adversarial.State(dict(batchSize=N, seed=1), G2, cg.models.create_D(dims))
+                dms = time_steps(cg, S2, data, N, min(args.steps, 30), 5)
+                res["config"]["collectives"] = dict(cg.parallel.comm_info(), dry_run_world=args.dp_dry_run, dry_run_ms_per_step=dms,
+                                                    dry_run_over_headline=dms / ms,
+                                                    note="per-rank step of the data-parallel plan on ONE GPU: sync-BN all-reduces, G's gradient buckets and "
+                                                         "D's overlapped all-reduce run through cg_comm_* on single-rank RCCL communicators (device copies on the "
+                                                         "communicators' streams): schedule and fork / join cost are real, xGMI traffic is absent")
+                del S2, G2
+            except Exception as e:                # noqa: BLE001
+                res["config"]["collectives"] = {"dry_run_error": str(e)[:200]}
+            finally:
+                try:
+                    cg.parallel.shutdown()
+                except Exception:                 # noqa: BLE001
+                    pass
         if world == 1 and args.config == 2 and not args.no_other_configs and not args.batch_per_gpu:
             res["other_configs"] = []
             for num in (3, 5):

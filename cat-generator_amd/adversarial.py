@@ -265,16 +265,18 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
 
 
 def _both_forwards_ok(S, N):
-    """Both generator forwards of the iteration side by side (OPT.concurrent_g_both)?  Single rank (a second pass would put its sync-BN
-    collectives on the communicator of the first), one D and one G iteration, planned generator, and D's draw count at this batch known
-    from an earlier iteration (the first iteration of a run goes one after the other)."""
+    """Both generator forwards of the iteration side by side (OPT.concurrent_g_both)?  One D and one G iteration, planned generator, and D's
+    draw count at this batch known from an earlier iteration (the first iteration of a run goes one after the other).  Data parallel
+    (round 6): allowed - the second pass's sync-BN all-reduces are ENQUEUED behind the first pass's on the same communicator, in the
+    same order on every rank (host call order), so they cannot cross; the second pass then runs under D's forward / backward instead of
+    beside the fake-image pass, which is still off the step's chain."""
     OPT = S.OPT
     G = S.MODEL_G
     last = G.modules[-1] if getattr(G, "modules", None) else None
     if isinstance(last, nn.Copy) and "Cuda" not in last.outtype:
         return False          # a net that hands host tensors back (models.lua:704 style wrapping) takes the plain path
     return bool(OPT.get("concurrent_g_both", False) and has_gpu() and nn.planned
-                and parallel.world_size() == 1 and OPT["D_iterations"] == 1 and OPT["G_iterations"] == 1 and N in S._d_draws
+                and OPT["D_iterations"] == 1 and OPT["G_iterations"] == 1 and N in S._d_draws
                 and type(G) is nn.Sequential and getattr(G, "_pnet", None) and G._pnet[1] is not None and getattr(G, "_planned_last", False)
                 and getattr(G._pnet[1], "last_draws", 0) == 0     # a G that draws (Dropout) would move the counter stream under the side pass
                 and OPT["batchSize"] >= N)

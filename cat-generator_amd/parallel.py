@@ -14,7 +14,7 @@ import warnings
 import torch
 import torch.distributed as dist
 
-_S = {"world": 1, "rank": 0, "init": False, "sync_bn": True, "comm_grad": None, "comm_bn": None, "hybrid": False, "selftest": None}
+_S = {"world": 1, "rank": 0, "init": False, "sync_bn": True, "comm_grad": None, "comm_bn": None, "hybrid": False, "selftest": None, "dry": False}
 
 
 def init_from_env(backend=None):
@@ -213,6 +213,20 @@ def _init_single_rank_comms():
     _S["selftest"] = "ok (single-rank communicators)"
 
 
+def dry_run(world=8):
+    """bench.py --dp-dry-run (VERDICT r05 #5b): ONE process plans and runs the per-rank step of a `world`-rank data-parallel job - sync-BN
+    exchanges between statistics and normalisation, G's gradient buckets started inside the backward, D's all-reduce under the G-step's
+    generator forward, both communicators through cg_comm_* - on SINGLE-rank RCCL communicators: a collective is then a device copy on
+    the communicator's stream, so the schedule and its fork / join cost are real and the cross-rank traffic is absent.  Timing only:
+    gradients are averaged as if the other ranks had contributed zeros."""
+    assert not _S["init"] and _S["world"] == 1, "dry_run() is for a single process"
+    _S["world"], _S["rank"] = int(world), 0
+    _init_single_rank_comms()
+    _S["hybrid"] = False      # no torch.distributed leg: there is no process group
+    _S["dry"] = True
+    _S["selftest"] = "ok (single-rank communicators, dry run)"
+
+
 def attach(world, rank):
     """Use an already initialised process group (tests)."""
     _S["world"], _S["rank"] = world, rank
@@ -229,7 +243,7 @@ def shutdown():
     if _S["init"]:
         dist.destroy_process_group()
         _S["init"] = False
-    _S["world"], _S["rank"] = 1, 0
+    _S["world"], _S["rank"], _S["dry"], _S["hybrid"] = 1, 0, False, False
 
 
 def world_size():
@@ -343,7 +357,7 @@ def allreduce_mean_async_torch(t):
 
 def allreduce_sum_host(values):
     """SUM over ranks of a few host scalars (accuracy gate, confusion counts): returns a list of floats."""
-    if _S["world"] <= 1:
+    if _S["world"] <= 1 or _S.get("dry"):
         return [float(v) for v in values]
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)   # "cpu:gloo,cuda:nccl": host tensor, gloo
@@ -357,6 +371,8 @@ def barrier():
             from .tensor import lib
             lib().comm_sync(_S["comm_grad"])
             lib().comm_sync(_S["comm_bn"])
+        if _S.get("dry"):
+            return
         if torch.cuda.is_available() and dist.get_backend() == "nccl":
             dist.barrier(device_ids=[torch.cuda.current_device()])   # explicit device: no guessing from the rank
         else:
