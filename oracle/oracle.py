@@ -10,9 +10,26 @@ semantics of adversarial.lua:72-167 / :171-215 / :221-266 and Torch7's
 optim.adam.  Heavy operators (conv / linear / bilinear sampler) are in
 oracle/ops.c; everything elementwise is numpy fp32.
 
-Every [upstream] semantic choice is listed in SURVEY.md Appendix B; the ones
-that differ from PyTorch are: Adam's epsilon placement, BCE eps=1e-12,
-SpatialDropout without 1/(1-p) rescale, BN gamma ~ U(0,1), stn (y,x) order.
+ASSUMPTIONS.  Everything the reference takes from an un-vendored rock is RECALLED, not read; where the
+rock changed over time the oracle has to pick an era (the reference's README dates it to late 2015 / early 2016, "cudnn3").
+"in-tree" = the reference's own file says so; "recalled" = upstream Torch7 behaviour of that era as we remember it.  The
+last column names the test that pins the choice INSIDE this repo (engine == oracle) and would have to change with it; no
+test can pin it against Torch7 itself - that is what "parity unpinned" means.
+
+| # | choice made here | source | the other era / reading | what would change | pinned by |
+|---|---|---|---|---|---|
+| 1 | nn.LeakyReLU(): slope 0.333, x == 0 takes the positive branch | in-tree, LeakyReLU.lua:8,13-31 | LeakyReLU.lua:2-4 RETURNS EARLY when upstream nn already defines nn.LeakyReLU (torch/nn gained one around Dec 2015, default negval 1/100, x == 0 on the negative branch): models.lua:845-853 call nn.LeakyReLU() without an argument, so on such an install the localisation nets would run with slope 0.01 | the 12 LeakyReLUs of the four localisation nets (models.lua:845-853): the transformers' theta and D's gradient; nothing in G | LeakyReLU.forward/backward below; tests/test_gpu_parity.py::test_activations_and_bce, test_spatial_transformer_module |
+| 2 | nn.SpatialDropout(p): train y = x * mask, mask ~ Bernoulli(1 - p) per (sample, plane), NO 1/(1-p) rescale; evaluate y = (1 - p) x; default p = 0.5 (models.lua:695 passes none) | recalled (nn/SpatialDropout.lua of that era) | later nn versions added a `stochasticInference` flag but never the rescale; a PyTorch-style dropout2d rescales by 1/(1-p) in training | D's activations behind the six SpatialDropouts by 1/(1-p) = 1.25 / 2; D's gradient likewise | SpatialDropout below; tests/test_oracle_vs_torch.py::test_whole_step_gradients_match_torch_autograd (explicit masks), test_gpu_parity.py::test_dropout_masks_share_the_counter_stream |
+| 3 | nn.Dropout(): p = 0.5, "v2": train y = x * mask / (1 - p), evaluate identity | recalled (nn/Dropout.lua, v1 = false default) | v1 (nn.Dropout(p, true)): no rescale in training, y = (1 - p) x in evaluate | the head's Linear(256,1) input by a factor 2 (models.lua:699) | Dropout below; tests/test_gpu_parity.py::test_concat_dropout_and_head_launches |
+| 4 | nn.SpatialBatchNormalization(n): eps 1e-5, momentum 0.1, affine, gamma ~ U(0,1), beta 0, normalise with the BIASED batch variance, running_var updated with the unbiased one | recalled (nn/BatchNormalization.lua: weight:uniform()) | later nn initialises gamma = 1 (as PyTorch does); cudnn.SpatialBatchNormalization has a different eps floor | G's initial parameters (the three BN gammas) and with them every synthetic benchmark's numerics, not the kernels | SpatialBatchNormalization below; tests/test_abi_and_host.py::test_models_match_oracle_structure_bit_for_bit, test_oracle_vs_torch.py::test_bn_train_matches_torch |
+| 5 | optim.adam: m, v updates, then x -= lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps): eps added to sqrt(v) WITHOUT bias-correcting v; t starts at 0 and is incremented before use; defaults 1e-3, 0.9, 0.999, 1e-8 | recalled (optim/adam.lua) | PyTorch: eps added after dividing sqrt(v) by sqrt(1 - b2^t) | every update with |g| near eps; first steps visibly (closed forms for both in the test) | adam() below; tests/test_oracle_vs_torch.py::test_torch7_adam_five_steps_against_a_scalar_double_loop, test_bce_and_adam_known_answers, test_gpu_parity.py::test_adam_and_fused_penalty_clamp |
+| 6 | nn.BCECriterion: eps = 1e-12 inside both logs, mean over the batch (sizeAverage) | recalled (nn/BCECriterion.lua) | PyTorch clamps log at -100 instead; an older nn had no eps | only saturated D outputs (|logit| > ~27) | BCECriterion below; tests/test_gpu_parity.py::test_activations_and_bce |
+| 7 | image.scale (dataset.lua:129-131): separable, on the float image; down-scaling = box average with fractional ends, up-scaling = linear with the last sample copied | recalled (image/generic/image.c scaleLinear_rowcol) | 'simple' / 'bicubic' modes exist upstream but are not the default the reference uses | the real half of every D batch (input pipeline, row f2), nothing in the timed step (the pool is resident) | tests/test_dataset_cli.py::test_image_scale_follows_the_oracle_rule, test_oracle_vs_torch.py::test_image_scale_rule_against_torch_interpolate |
+| 8 | stn: AffineTransformMatrixGenerator consumes [theta][scale][tx, ty] in that order, AffineGridGeneratorBHWD puts y first, BilinearSamplerBHWD samples corner-aligned with zeros outside; theta = +pi/2 turns the picture clockwise | recalled (qassemoquab/stnbhwd) + the in-tree initial bias {0, 1, 0, 0} (models.lua:859-860) which fixes the order rot, scale, trans | the rotation sign and the (y, x) order are conventions of the rock | the learned transformer parameters' meaning; at the identity initialisation nothing | tests/test_oracle_vs_torch.py::test_transformer_conventions_as_geometry, test_transformer_trio_second_restatement_with_explicit_axis_swap; test_gpu_parity.py::test_spatial_transformer_module |
+| 9 | weight-init 'heuristic' is NOT recursive (weight-init.lua:52 iterates net.modules): nn.Concat's children keep the default reset(); cudnn.SpatialConvolution does not match the typename test but gets its bias zeroed (:70-72) | in-tree, weight-init.lua:14-16,52-72 | - | - | tests/test_abi_and_host.py::test_models_match_oracle_structure_bit_for_bit (Concat children keep their default bias) |
+| 10 | adversarial.lua:206 multiplies the L1 sign term by G_L2 (an upstream slip, inert at the defaults) and is kept | in-tree | - | - | Trainer.step below |
+
+Every [upstream] semantic choice is also listed in SURVEY.md Appendix B.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 import this module.  The product package never does.
