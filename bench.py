@@ -499,6 +499,10 @@ def main():
                           "direct_count_tflops": per_gpu * w["W"] / 1e12, "peak_tflops": PEAK_FP32_MFMA / 1e12},
             "event_ms_per_step": e0.elapsed_time(e1) / args.steps, "finite": finite,
         }
+        if getattr(cg.lib(), "timing_probe", False):
+            res["TIMING_PROBE_BUILD"] = ("the library was built with -DCG_TIMING_PROBE (halved K loops, csrc/common.h): every number of this line is a "
+                                         "sensitivity probe, results are wrong by construction - NOT a measurement of the engine")
+            res["value"] = None
         pts = [(0, e0)] + marks + [(args.steps, e1)]
         blocks = [pa[1].elapsed_time(pb[1]) / (pb[0] - pa[0]) for pa, pb in zip(pts[:-1], pts[1:])]
         res["spread"] = {"ms_per_step_blocks": [round(v, 4) for v in blocks], "min": min(blocks), "max": max(blocks),

@@ -20,6 +20,10 @@ SOURCES = ["gemm.hip", "winograd.hip", "skinny.hip", "wino3.hip", "ops.hip", "fu
 ARCH = "gfx950"
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"]   # no -munsafe-fp-atomics: nothing on the path adds floats atomically
+# extra -D switches of the instrumented builds: CG_BUILD_DEFINES="-DCG_TRACE" (per-workgroup timestamps, scripts/wg_trace.py) or
+# "-DCG_TIMING_PROBE=<mask>" (timing-only: halved K loops per GEMM family, csrc/common.h; such a library reports ABI version -1 and the
+# hosts refuse it unless CG_ALLOW_TIMING_PROBE=1 - bench.py then labels its line).  A change of the value forces a full rebuild.
+FLAGS += os.environ.get("CG_BUILD_DEFINES", "").split()
 
 
 def _headers():
@@ -33,9 +37,16 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _defines_changed():
+    """the -D switches the objects were built with (lib/obj/defines.txt) differ from this build's"""
+    tag = os.path.join(OBJ_DIR, "defines.txt")
+    cur = os.environ.get("CG_BUILD_DEFINES", "")
+    return (open(tag).read() if os.path.exists(tag) else "") != cur
+
+
 def _stale():
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    return _newer(LIB_PATH, srcs + _headers())
+    return _newer(LIB_PATH, srcs + _headers()) or _defines_changed()
 
 
 def build(force=False, verbose=False):
@@ -43,6 +54,9 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or os.path.join(ROCM, "bin", "hipcc")
     os.makedirs(OBJ_DIR, exist_ok=True)
+    if _defines_changed():
+        force = True
+        open(os.path.join(OBJ_DIR, "defines.txt"), "w").write(os.environ.get("CG_BUILD_DEFINES", ""))
     _generate("gen_net_ktable.py", os.path.join(CSRC, "net_ktable.inc"))   # the launch table net.hip dispatches through
     hdrs = _headers()
     jobs = []
@@ -94,7 +108,7 @@ def build_tools(hipcc, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    # stand-alone micro-benchmarks (tools/*.hip, run by scripts/gpu_peak.sh): MFMA ceiling, LDS -> MFMA loop, LDS-direct-load semantics
+    # stand-alone micro-benchmarks (tools/*.hip): MFMA ceiling, LDS -> MFMA loop, LDS-direct-load semantics
     tools = os.path.join(root, "tools")
     jobs = [("mfma_peak.hip", "mfma_peak", []), ("lds_mfma.hip", "lds_mfma", []), ("lds_mfma.hip", "lds_mfma_agpr", ["-DACC_AGPR"]),
             ("glds_test.hip", "glds_test", [])]

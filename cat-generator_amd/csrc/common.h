@@ -38,12 +38,27 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 constexpr int kNumCU = 256;  // MI355X: 8 XCDs x 32 CUs
 
+// Timing-only builds (VERDICT r05 #6e: the sensitivity numbers that steer the work must be reproducible from the repo).
+//   CG_BUILD_DEFINES="-DCG_TIMING_PROBE=<mask>" python -c "import __graft_entry__ as g; g.build()"
+// makes every K loop of the masked GEMM families run HALF its tiles - the same launches, the same memory-bound kernels around them,
+// wrong results by construction - so that `python bench.py` shows how much of a family's duration the step's time follows:
+//   1 direct implicit GEMMs (igemm_nn / igemm_nng)   2 weight gradients (igemm_tn / igemm_tng)   4 Winograd GEMMs (wino_gemm / wino_gemm_g)
+//   8 the fused Winograd kernel's position loops (wino3_fused_k)
+// Never set in a build whose results are used; cg_abi_version() of such a build returns -1 so that every host refuses it.
+#ifndef CG_TIMING_PROBE
+#define CG_TIMING_PROBE 0
+#endif
+#define CG_PROBE_HALF(fam, T) (((CG_TIMING_PROBE) & (fam)) ? ((T) + 1) / 2 : (T))
+// grid caps of the memory-bound kernels, swept in round 4 and constants since round 6 (profiles/r04_sweeps.txt): 4 workgroups per CU for the
+// grid-stride kernels (8 until round 4: beside another queue's GEMM fewer, longer-lived workgroups get through sooner), 1 per CU for the
+// column reductions
+constexpr int kEwWgsPerCU = 4, kColReduceWgsPerCU = 1;
+
 // Tunables (cg_set_option / cg_get_option, catgan.h).  Default = the environment variable of the same name if set,
 // else the built-in value; cg_set_option overrides both at run time (tests force every kernel variant this way).
 enum Opt {
-    OPT_SPLIT_TARGET, OPT_SPLIT_MINK, OPT_TN_SMAX, OPT_TN_TARGET, OPT_SKINNY, OPT_GEMM_BK32,
-    OPT_COLREDUCE_WGS_PER_CU, OPT_WINO_BK, OPT_NN_TILE, OPT_TN_TILE, OPT_NN_SPLITS, OPT_TN_SPLITS,
-    OPT_EPILOGUE_STATS, OPT_XCD_SWIZZLE, OPT_NN_GLDS, OPT_TN_GLDS, OPT_WINO_GLDS, OPT_EW_WGS_PER_CU, OPT_PAD_SKIP, OPT_WINO3, OPT_COUNT
+    OPT_SKINNY, OPT_GEMM_BK32, OPT_WINO_BK, OPT_NN_TILE, OPT_TN_TILE, OPT_NN_SPLITS, OPT_TN_SPLITS,
+    OPT_XCD_SWIZZLE, OPT_NN_GLDS, OPT_TN_GLDS, OPT_WINO_GLDS, OPT_PAD_SKIP, OPT_WINO3, OPT_COUNT
 };
 long opt(Opt o);
 
@@ -91,9 +106,9 @@ int wino3_forward(hipStream_t st, int ngroups, const float* const* x, const floa
 static inline int ew_grid(long n, int per_block = 256) {
     long b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;
-    // CG_EW_WGS_PER_CU, default 4 (8 until round 4): beside a GEMM from another queue a memory-bound kernel waits for a slot per workgroup,
+    // kEwWgsPerCU = 4 (8 until round 4): beside a GEMM from another queue a memory-bound kernel waits for a slot per workgroup,
     // so fewer, longer-lived workgroups get through sooner - same-box step 6.36 -> 6.27 ms, alone no difference (profiles/r04_sweeps.txt)
-    const long cap = (long)kNumCU * opt(OPT_EW_WGS_PER_CU);
+    const long cap = (long)kNumCU * kEwWgsPerCU;
     if (b > cap) b = cap;
     return (int)b;
 }

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_v4k(const float* __restrict__ 
                                                       const float* alpha, const double* __restrict__ sums, double count,
                                                       const double* __restrict__ local_sums, long n4, int C4,
                                                       float* __restrict__ dx, float* ggamma, float* gbeta, float* galpha,
-                                                      float scale, int alpha_cols) {
+                                                      float scale) {
     const int C = C4 * 4;
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += 256) {
@@ -510,18 +510,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_v4k(const float* __restrict__ 
             if (ggamma) ggamma[c] += scale * (float)local_sums[C + c];
         }
         if (galpha && alpha) {
-            if (alpha_cols) {     // the slope's sum arrives per channel (epilogue form): added here in channel order
-                __shared__ double sh_a[256];
-                double t = 0.0;
-                for (int c = threadIdx.x; c < C; c += 256) t += local_sums[2 * C + c];
-                sh_a[threadIdx.x] = t;
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    double a_ = 0.0;
-                    for (int i = 0; i < 256; ++i) a_ += sh_a[i];
-                    *galpha += scale * (float)a_;
-                }
-            } else if (threadIdx.x == 0) *galpha += scale * (float)local_sums[2 * C];
+            if (threadIdx.x == 0) *galpha += scale * (float)local_sums[2 * C];
         }
     }
     const long i0 = blockIdx.x * 256L + threadIdx.x;
@@ -558,7 +547,7 @@ static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // grid whose stride (grid * 256 float4s) is a multiple of C4, so that a thread's channel quad is loop invariant
 static int fixed_channel_grid(long n4, int C4) {
     long b = (n4 + 255) / 256;
-    const long cap = (long)cg::kNumCU * cg::opt(cg::OPT_EW_WGS_PER_CU);   // as cg::ew_grid
+    const long cap = (long)cg::kNumCU * cg::kEwWgsPerCU;   // as cg::ew_grid
     if (b > cap) b = cap;
     if (256 % C4 != 0) {
         // stride multiple of C4 needs grid % (C4 / gcd(C4, 256)) == 0
@@ -828,7 +817,7 @@ int cg_bn_act_backward_stats(void* stream, const float* x, const float* dy, cons
     CG_REQUIRE(C % 4 == 0 && al16(x) && al16(dy), "cg_bn_act_backward_stats: needs C %% 4 == 0 and 16-byte aligned tensors");
     const int qb = C >= 128 ? 32 : 16;
     const int cblocks = cg::cdiv(C / 4, qb);
-    const int cmul = (int)cg::opt(cg::OPT_COLREDUCE_WGS_PER_CU);
+    const int cmul = cg::kColReduceWgsPerCU;
     long chunks = std::max(1L, std::min((M + 63) / 64, (long)cg::kNumCU * cmul / cblocks));
     const long rows_per_block = ((M + chunks - 1) / chunks + 3) / 4 * 4;
     chunks = (M + rows_per_block - 1) / rows_per_block;
@@ -856,31 +845,7 @@ int cg_bn_act_backward(void* stream, const float* x, const float* dy, const floa
     CG_REQUIRE(C % 4 == 0 && al16(x) && al16(dy) && al16(dx), "cg_bn_act_backward: needs C %% 4 == 0 and 16-byte aligned tensors");
     const long n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_act_bwd_v4k, dim3(fixed_channel_grid(n4, C / 4)), dim3(256), 0, cg::S(stream), x, dy, gamma, beta, save_mean,
-                       save_invstd, alpha, sums, count, local_sums, n4, C / 4, dx, ggamma, gbeta, galpha, scale, 0);
-    CG_LAUNCH_CHECK();
-    return 0;
-}
-
-// The sums of cg_bn_act_backward_stats from the per-workgroup partial rows a data-gradient GEMM's epilogue left behind
-// (cg_conv2d_ups2_wino_dgrad_bn): sums3[0..C) = sum d, [C..2C) = sum d xhat, [2C..3C) = the PReLU slope's sum PER CHANNEL (fp64, fixed order).
-int cg_bn_act_backward_stats_finalize(void* stream, const float* partials, long rows, int C, double* sums3) {
-    CG_REQUIRE(partials && sums3 && rows > 0 && rows < (1L << 30) && C > 0 && C % 2 == 0, "cg_bn_act_backward_stats_finalize: bad args");
-    // bn_stats_finalize_k walks a [rows][2 C'] matrix: C' = 3 C / 2 covers the three statistics
-    hipLaunchKernelGGL(bn_stats_finalize_k, dim3(cg::cdiv(3L * C, 16)), dim3(256), 0, cg::S(stream), partials, (int)rows, 3 * C / 2, sums3);
-    CG_LAUNCH_CHECK();
-    return 0;
-}
-// cg_bn_act_backward with `local_sums` / `sums` in that layout (3 C doubles; a data-parallel host all-reduces the first 2 C of `sums`)
-int cg_bn_act_backward_cols(void* stream, const float* x, const float* dy, const float* gamma, const float* beta,
-                            const float* save_mean, const float* save_invstd, const float* alpha, const double* sums, double count,
-                            const double* local_sums, long M, int C, float* dx, float* ggamma, float* gbeta, float* galpha,
-                            float scale) {
-    CG_REQUIRE(x && dy && gamma && beta && save_mean && save_invstd && sums && local_sums && dx && C > 0 && count > 0 && M > 0,
-               "cg_bn_act_backward_cols: bad args");
-    CG_REQUIRE(C % 4 == 0 && al16(x) && al16(dy) && al16(dx), "cg_bn_act_backward_cols: needs C %% 4 == 0 and 16-byte aligned tensors");
-    const long n4 = M * (C / 4);
-    hipLaunchKernelGGL(bn_act_bwd_v4k, dim3(fixed_channel_grid(n4, C / 4)), dim3(256), 0, cg::S(stream), x, dy, gamma, beta, save_mean,
-                       save_invstd, alpha, sums, count, local_sums, n4, C / 4, dx, ggamma, gbeta, galpha, scale, 1);
+                       save_invstd, alpha, sums, count, local_sums, n4, C / 4, dx, ggamma, gbeta, galpha, scale);
     CG_LAUNCH_CHECK();
     return 0;
 }

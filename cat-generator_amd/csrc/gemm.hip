@@ -44,7 +44,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;
 constexpr unsigned OOB = 0x80000000u;
-// -DCG_TRACE (scripts/build_exp.sh trace): every igemm_nn_kernel workgroup records 100 MHz timestamps at its start, behind
+// -DCG_TRACE (CG_BUILD_DEFINES=-DCG_TRACE, build.py): every igemm_nn_kernel workgroup records 100 MHz timestamps at its start, behind
 // the prologue (first tile in LDS), behind the K loop and at its end, plus the hardware id of the CU it ran on, into the
 // buffer handed to cg_debug_set_trace - scripts/wg_trace.py turns that into the dispatch balance and the phase times.
 #ifdef CG_TRACE
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void igemm_nn_kernel(NNArgs 
     float* gy = sel4(group, a.y0, a.y1, a.y2, a.y3);
     const int ks = split * a.kchunk;
     const int kend = min(g.Ktot, ks + a.kchunk);
-    const int T = (kend - ks + BK - 1) / BK;
+    const int T = CG_PROBE_HALF(1, (kend - ks + BK - 1) / BK);
     const float* wph = sel4(group, a.w0, a.w1, a.w2, a.w3) + (long)phase * g.Ktot * g.Cout;
 
     // ---- A staging: thread owns k-vector a_kv (4 consecutive k) of rows a_r + 64p
@@ -761,6 +761,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nng_kernel(NNArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    T = CG_PROBE_HALF(1, T);
     if (T > 0) dma_tile(ks, std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1047,7 +1048,7 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
     const float* gdy = a.dgs ? a.d0 + (long)group * a.dgs : sel4(group, a.d0, a.d1, a.d2, a.d3);
     const int ps = split * a.pchunk;
     const int pend = min(g.M, ps + a.pchunk);
-    const int T = (pend - ps + BK - 1) / BK;
+    const int T = CG_PROBE_HALF(2, (pend - ps + BK - 1) / BK);
 
     // A staging: fixed (tap,ci) columns per thread, pixel rows vary per tile
     const int a_mv = tid % AVEC, a_kr = tid / AVEC;
@@ -1332,7 +1333,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int flat) {
     const float* gdy = a.dgs ? a.d0 + (long)group * a.dgs : sel4(group, a.d0, a.d1, a.d2, a.d3);
     const int ps = split * a.pchunk;
     const int pend = min(g.M, ps + a.pchunk);
-    const int T = (pend - ps) / BK;
+    const int T = CG_PROBE_HALF(2, (pend - ps) / BK);
 
     const int a_mv = tid % AVEC, a_kr = tid / AVEC;
     const int b_nv = tid % BVEC, b_kr = tid / BVEC;
@@ -2108,6 +2109,9 @@ __global__ __launch_bounds__(256) void skinny_wgrad3x3_kernel(const float* __res
 
 // ---- host-side dispatch -----------------------------------------------------
 struct TileCfg { int bm, bn; };
+// swept in rounds 2-5 (profiles/r0N_sweeps.txt: flat or worse around these), constants since round 6
+constexpr int kSplitTarget = 1, kSplitMinK = 8;      // forward / data gradient: split K until one workgroup per CU, >= 8 K iterations per split
+constexpr int kTnSplitMax = 256, kTnTarget = 3;      // weight gradients: pixel splits up to 256, three workgroups per CU
 
 // pick the block tile: BN covers Cout with least padding, BM chosen so the grid
 // fills the 256 CUs at >= ~2 workgroups each when the problem allows it.
@@ -2135,11 +2139,10 @@ static TileCfg pick_tile(long M, int Cout, int nphase) {
 
 static int pick_splits(long tiles, long kiters) {
     // Small grids are latency-bound (one global-load round trip per K tile, nothing to overlap it with), so
-    // split K until there are CG_SPLIT_TARGET workgroups per CU, keeping >= CG_SPLIT_MINK K-iterations per split.
-    const int target = (int)cg::opt(cg::OPT_SPLIT_TARGET), mink = (int)cg::opt(cg::OPT_SPLIT_MINK);
+    // split K until there are kSplitTarget workgroups per CU, keeping >= kSplitMinK K-iterations per split.
+    const int target = kSplitTarget, mink = kSplitMinK;   // swept in rounds 2-5 (profiles/r0N_sweeps.txt): constants since round 6
     const int forced = (int)cg::opt(cg::OPT_NN_SPLITS);
     if (forced > 0) return (int)std::min<long>(forced, std::max<long>(1, kiters / 2));
-    // CG_SPLIT_TARGET < 16: workgroups per CU; larger values: the workgroup count itself
     const long want = target < 16 ? (long)target * cg::kNumCU : (long)target;
     int s = 1;
     while (tiles * s < want && kiters / (s * 2) >= mink && s < 64) s *= 2;
@@ -2336,7 +2339,7 @@ static TNPlan plan_tn(const Geom& g, int ngroups) {
     bm = p.tc.bm; bn = p.tc.bn;
     const long tiles = (long)cg::cdiv(g.Ktot, bm) * cg::cdiv(g.Cout, bn) * g.nphase * ngroups;
     const long piters = cg::cdiv(g.M, BK);
-    const int smax = (int)cg::opt(cg::OPT_TN_SMAX), tgt = (int)cg::opt(cg::OPT_TN_TARGET);
+    const int smax = kTnSplitMax, tgt = kTnTarget;
     const int forced = (int)cg::opt(cg::OPT_TN_SPLITS);
     int s = 1;
     if (forced > 0) s = (int)std::min<long>(forced, std::max<long>(1, piters));
@@ -2523,7 +2526,7 @@ size_t cg_conv2d_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout, int k
 size_t cg_conv2d_stats_rows(int N, int Hp, int Wp, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups) {
     Geom g;
     if (conv_geom(g, N, Hp, Wp, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
-    if (skinny_ok(1, Cin, Cout, kH, kW, padH, padW, ups) || cg::opt(cg::OPT_EPILOGUE_STATS) == 0) return 0;
+    if (skinny_ok(1, Cin, Cout, kH, kW, padH, padW, ups)) return 0;
     const NNPlan p = plan_nn(g, 1, false);   // run_nn launches the image-major plan whenever statistics are asked for: query THAT plan
     if (p.splits != 1) return 0;
     const int wm = p.tc.bn == 32 ? 4 : 2;

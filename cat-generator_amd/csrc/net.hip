@@ -170,7 +170,6 @@ struct MS {
     bool use_wino = false, use_wino22 = false;
     bool fused = false; int fG = 0; Val fX, fmask; long fN = 0, fC = 0, fH = 0, fW = 0;   // act_pool segment state (on the activation)
     bool bn_fused = false; long bnM = 0, bnC = 0;            // gemm_bn_act segment state (on the batch-norm)
-    Val bstats_part; long bstats_rows = 0;                   // backward sums left by the next layer's data-gradient epilogue (round 5)
     double count = 0;            // BN: samples behind the statistics (x world under sync-BN)
     vector<long> sizes;          // nn.Concat: channels per branch
     vector<Seg> ran;             // nn.Sequential: the plan its forward ran
@@ -234,13 +233,10 @@ struct Net {
     bool fresh_allocs = false;                 // library-owned buffers were allocated + zeroed since the last device synchronise
     // options
     int trace = 0, overlap_groups = 1, defer_wgrad = 1, winograd = 1, share_pool = 1, sampler_shared = 1, view_fuse = 1,
-        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1, wgrad_lag = 0,
-        bn_epilogue = 0,       // 1: backward sums of a [batch-norm, PReLU] pair in the epilogue of the Winograd data-gradient GEMM that produces its
-                               // gradOutput (round 5; parity-clean, but that launch has ONE workgroup per CU, so its epilogue - 64 loads of the
-                               // batch-norm input per lane - is exposed: 5.89 -> 5.94 ms per step, config #3 +-0; profiles/r05_sweeps.txt.  Off)
+        cat_fuse = 1, stacking = 1, grouped = 1, fusion = 1, fuse_locnet = 1, pack_overlap = 1, head_fuse = 1, wgrad_stream = 1,
         wino_dsplit = 1;       // the F(2x2,3x3) data gradient in K slices when its unsplit launch is <= one workgroup per CU (cg_conv2d_ups2_wino_dgrad_split)
     long wino_min_tiles = 2048;
-    int wino22 = 3;                            // F(2x2,2x2) for upsample2 -> conv3x3 above wino_min_tiles: bit 0 forward, 1 data gradient, 2 weight gradient
+    int wino22 = 3;                            // F(2x2,2x2) for upsample2 -> conv3x3 above wino_min_tiles: bit 0 forward, 1 data gradient
                                                // (option "winograd22"; the weight gradient is 292 -> 257 us alone but no gain in the step: off)
     std::string trace_log;
     const KTable* K = &kRealTable;
@@ -323,9 +319,7 @@ struct Compiler {
     bool failed = false;
     int pend[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // deferred weight-gradient reductions queued per stream index
     bool wg_used[4] = {false, false, false, false};   // the weight-gradient stream beside stream s has work to join
-    vector<std::function<void()>> wg_pending[4];      // option wgrad_lag: weight gradients held back until the next data-gradient GEMM of stream s
     bool acc_pass = false;        // compiling Module:backward (weight gradients deferred) rather than updateGradInput
-    Mod *epi_bn = nullptr, *epi_act = nullptr;   // the [batch-norm, PReLU] whose backward sums the data gradient being emitted may compute in its epilogue
 
     Compiler(Net* n, Prog* p) : net(n), pr(p) {}
     const KTable* K() const { return net->K; }
@@ -1364,8 +1358,8 @@ struct Compiler {
         });
         if (acc) {
             // weight gradients of the four layers on the GEMM path (grouped over the sibling branches), reductions deferred; their
-            // gradOutputs come out of the launch above, so (without wgrad_lag) the fork sits behind it
-            if (!wg_lag()) wg_fork();
+            // gradOutputs come out of the launch above, so the fork sits behind it
+            wg_fork();
             const long P_ = d.P;
             MS* s0p = &s0;
             wg_after_dgrad([this, k, G, N, S_, Cin, K3, P_, pooled, ga1, h1, ga2, h2, g3, h3, g4, n_, qv, s0p]() {
@@ -1442,7 +1436,6 @@ struct Compiler {
             emit([=](Run& c) { return c.net->trace ? (trace_note(c.net, "event|wait|fork|s" + std::to_string(sidx)), 0)
                                                     : (hipStreamWaitEvent((hipStream_t)c.S(sidx), c.net->fork_ev, 0) == hipSuccess ? 0 : 1); });
             thunks[t]();
-            wg_release();     // wgrad_lag: what the group still holds back starts here, in front of the group's join
             flush_wgrad();
             emit([=](Run& c) { return c.net->trace ? (trace_note(c.net, "event|record|join" + std::to_string(sidx) + "|s" + std::to_string(sidx)), 0)
                                                     : (hipEventRecord(c.net->side_ev[sidx - 1], (hipStream_t)c.S(sidx)) == hipSuccess ? 0 : 1); });
@@ -1487,37 +1480,13 @@ struct Compiler {
         return s;
     }
     void wg_leave(int s) { cs = s; }
-    // Option wgrad_lag: a layer's weight-gradient launches are not issued where its gradOutput is complete but right in front of the
-    // NEXT data-gradient GEMM of the same stream (the layer in front of it), and at the end of the pass.  Forked at gradOutput, the
-    // weight-gradient GEMM of layer L outlives the data-gradient GEMM of L it runs beside, and the launch-bound kernels that follow on
-    // the chain (BN backward sums 35 -> 156 us, BN backward, split-K reductions) queue for the slots its workgroups hold; one layer
-    // later it starts together with the data gradient of L-1 and those kernels have the chip to themselves.  OFF by default: it also
-    // shifts the whole weight-gradient stream one layer back, and where that stream is as long as the chain (G32up-c: 0.92 ms beside
-    // 0.97 ms) its tail then sticks out behind the pass - same box 6.20 -> 6.46-6.61 ms per step for config #2, but 9.56 -> 9.25 ms for
-    // config #3 (G32up, two Winograd layers whose transforms sit on the chain); profiles/r04_sweeps.txt.
-    bool net_has_sampler() const { for (auto& m : net->mods) if (m && m->kind == K_SAMPLER) return true; return false; }
-    bool wg_lag() const {   // option value 2 / 3 (experiment): only nets with / without a spatial transformer (D / G)
-        if (!(wg_on() && net->wgrad_lag && net->world <= 1)) return false;
-        return net->wgrad_lag == 1 || (net->wgrad_lag == 2) == net_has_sampler();
-    }
-    void wg_before_dgrad() { if (wg_lag()) wg_release(); else wg_fork(); }   // call in front of a layer's data-gradient launch ...
+    void wg_before_dgrad() { wg_fork(); }                                      // call in front of a layer's data-gradient launch ...
     void wg_after_dgrad(std::function<void()> f) {                             // ... and behind it, with the layer's weight-gradient launches
-        if (wg_lag()) { wg_pending[cs].push_back(std::move(f)); return; }
         const int s_ = wg_enter(); f(); wg_leave(s_);
-    }
-    void wg_release() {   // on stream cs: fork here, issue what was held back
-        if (dry || cs >= 4 || wg_pending[cs].empty()) return;
-        vector<std::function<void()>> fs;
-        fs.swap(wg_pending[cs]);
-        wg_fork();
-        const int s_ = wg_enter();
-        for (auto& f : fs) f();
-        wg_leave(s_);
     }
     void wg_join_all() {   // end of the pass: reductions still queued on the weight-gradient streams, then stream 0 waits for them
         if (dry) return;
         const int back = cs;
-        for (int s = 0; s < 4; ++s) { cs = s; wg_release(); }
         for (int s = 0; s < 4; ++s) {
             if (!wg_used[s]) continue;
             cs = 4 + s;
@@ -1767,17 +1736,6 @@ struct Compiler {
             emit([=](Run& c) { return k->conv2d_ups2_wino_wgrad(c.CS(), c.P(v), c.P(dy), mp->gw, mp->gb, (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co, c.scale, c.W(), c.WB()); });
             return;
         }
-        if (m.kind == K_CONV && s.x.ups && s.use_wino22 && (net->wino22 & 4) &&
-            cg_conv2d_ups2_wino22_wgrad_supported((int)s.x.d[0], (int)(s.x.d[2] >> 1), (int)(s.x.d[3] >> 1), (int)m.ia[0], (int)m.ia[1])) {
-            // F(2x2,2x2)-domain weight gradient from the transformed input the forward of this batch left in wino22_v
-            Val dy = as_nhwc(go);
-            const Val& x = s.x;
-            const long N = x.d[0], Hp = x.d[2] >> 1, Wp = x.d[3] >> 1, Ci = m.ia[0], Co = m.ia[1];
-            Val v = buf(m, "wino22_v", {(long)cg_conv2d_ups2_wino22_v_floats((int)N, (int)Hp, (int)Wp, (int)Ci)});
-            ws_need(cg_conv2d_ups2_wino22_wgrad_workspace_bytes((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co));
-            emit([=](Run& c) { return k->conv2d_ups2_wino22_wgrad(c.CS(), c.P(v), c.P(dy), mp->gw, mp->gb, (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co, c.scale, c.W(), c.WB()); });
-            return;
-        }
         PrepAcc p = prep_acc(m, go);
         if (net->defer_wgrad && net->fusion) {
             const size_t need = std::max<size_t>(cg_conv2d_wgrad_workspace_bytes(GEO(p.g)), 4096);
@@ -1808,18 +1766,9 @@ struct Compiler {
             if (s.use_wino) {
                 Val vdy = buf(m, "wino_vdy", {(long)cg_conv2d_ups2_wino_v_floats((int)N, (int)Hp, (int)Wp, (int)(4 * Co))});
                 const long np = net->wino_dsplit ? (long)cg_conv2d_ups2_wino_dgrad_part_floats((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co) : 0;
-                const long brows = (!np && epi_bn && S(*epi_bn).bnC == Ci && S(*epi_bn).bnM == N * Hp * Wp)
-                                       ? (long)cg_conv2d_ups2_wino_dgrad_bn_rows((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co) : 0;
                 if (np) {
                     Val part = buf(m, "wino_dpart", {np});
                     emit([=](Run& c) { return k->conv2d_ups2_wino_dgrad_split(c.CS(), c.P(dy), mp->u_bwd, c.P(lo), c.P(vdy), c.P(part), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
-                } else if (brows) {
-                    Mod *bp = epi_bn, *ap = epi_act;
-                    MS& sb = S(*bp);
-                    Val bpart = buf(*bp, "bstats_part", {brows, 3, Ci}), bx = sb.x, sm = buf(*bp, "save_mean", {Ci}), sv = buf(*bp, "save_std", {Ci});
-                    emit([=](Run& c) { return k->conv2d_ups2_wino_dgrad_bn(c.CS(), c.P(dy), mp->u_bwd, c.P(lo), c.P(vdy), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co,
-                                                                           c.P(bx), c.P(sm), c.P(sv), bp->w, bp->b, ap->w, c.P(bpart)); });
-                    sb.bstats_part = bpart; sb.bstats_rows = brows;
                 } else
                     emit([=](Run& c) { return k->conv2d_ups2_wino_dgrad(c.CS(), c.P(dy), mp->u_bwd, c.P(lo), c.P(vdy), (int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co); });
             } else if (s.use_wino22 && (net->wino22 & 2) && mp->u22b && cg_conv2d_ups2_wino22_dgrad_supported((int)N, (int)Hp, (int)Wp, (int)Ci, (int)Co)) {
@@ -1854,7 +1803,7 @@ struct Compiler {
             return table_sum(m, gs);
         }
         case K_LINEAR: case K_CONV: {
-            if (acc) wg_before_dgrad();   // wgrad_lag: the layer behind this one starts its weight gradient beside THIS data gradient
+            if (acc) wg_before_dgrad();
             Val gi = dgrad(m, go);
             if (acc) { Mod* mp_ = &m; const Val go_ = go; wg_after_dgrad([this, mp_, go_]() { wgrad(*mp_, go_); }); }
             return gi;
@@ -2037,16 +1986,7 @@ struct Compiler {
             if (sg.kind == S_ACT_POOL && S(kid(sg.i)).fused && S(kid(sg.i)).fG == 1) {
                 cur = bwd_act_pool({&kid(sg.i)}, {&kid(sg.i + 1)}, sg.j - sg.i == 3 ? vector<Mod*>{&kid(sg.i + 2)} : vector<Mod*>{}, {cur}, acc)[0];
             } else if (sg.kind == S_GEMM_BN_ACT && S(kid(sg.i + 1)).bn_fused) {
-                // [conv, BN, PReLU] -> nn.SpatialUpSamplingNearest(2) (folded) -> this layer: this layer's data gradient IS the gradOutput of
-                // the pair in front, whose backward sums can ride in its epilogue instead of a pass of their own (models.lua:212-218)
-                epi_bn = epi_act = nullptr;
-                if (net->bn_epilogue && net->fusion && si >= 2 && pl[si - 1].kind == S_ONE && pl[si - 1].j - pl[si - 1].i == 1 &&
-                    kid(pl[si - 1].i).kind == K_UPS && pl[si - 2].kind == S_GEMM_BN_ACT && S(kid(pl[si - 2].i + 1)).bn_fused) {
-                    epi_bn = &kid(pl[si - 2].i + 1); epi_act = &kid(pl[si - 2].i + 2);
-                    S(*epi_bn).bstats_rows = 0;
-                }
                 cur = bwd_gemm_bn_act(kid(sg.i), kid(sg.i + 1), kid(sg.i + 2), inp, cur, acc);
-                epi_bn = epi_act = nullptr;
             } else if (sg.kind == S_CAT_DROP) {
                 cur = bwd_concat(kid(sg.i), inp, cur, acc, &kid(sg.i + 1));
             } else if (sg.kind == S_HEAD && S(kid(sg.i)).head_fused) {
@@ -2338,25 +2278,6 @@ struct Compiler {
         Val dy = as_nhwc(go);
         Mod *bp = &bn, *ap = &act;
         Val sm = buf(bn, "save_mean", {C}), sv = buf(bn, "save_std", {C});
-        if (sb.bstats_rows > 0) {
-            // the sums arrived with the gradOutput: per-workgroup rows from the producing data gradient's epilogue -> one small finalize
-            const long rows = sb.bstats_rows; Val bpart = sb.bstats_part;
-            sb.bstats_rows = 0;
-            Val b3c = buf(bn, "bsums3c", {3 * C}, PLAIN, 8);
-            emit([=](Run& c) { return k->bn_act_backward_stats_finalize(c.CS(), c.P(bpart), rows, (int)C, (double*)c.P(b3c)); });
-            Val gsc = b3c;
-            if (net->world > 1 && net->sync_bn) {
-                gsc = buf(bn, "bsums3c_g", {3 * C}, PLAIN, 8);
-                emit([=](Run& c) { return k->memcpy_d2d(c.CS(), c.P(gsc), c.P(b3c), (size_t)(3 * C) * 8); });
-                emit_allreduce_sum(gsc, 2 * C, 1);
-            }
-            Val dxc = buf_like(bn, "gin", x, NHWC);
-            const double cntc = sb.count;
-            emit([=](Run& c) { return k->bn_act_backward_cols(c.CS(), c.P(x), c.P(dy), bp->w, bp->b, c.P(sm), c.P(sv), ap->w, (const double*)c.P(gsc), cntc, (const double*)c.P(b3c),
-                                                              Mr, (int)C, c.P(dxc), acc ? bp->gw : nullptr, acc ? bp->gb : nullptr, acc ? ap->gw : nullptr, c.scale); });
-            S(act).gin = Val(); sb.gin = dxc;
-            return bwd(conv, in, dxc, acc);
-        }
         Val b3 = buf(bn, "bsums3", {2 * C + 1}, PLAIN, 8);
         emit([=](Run& c) { return k->bn_act_backward_stats(c.CS(), c.P(x), c.P(dy), c.P(sm), c.P(sv), bp->w, bp->b, ap->w, Mr, (int)C, (double*)c.P(b3)); });
         Val gs = b3;
@@ -2405,7 +2326,6 @@ void Compiler::bucket_done(int first_module) {
             if (pr->bucket_first[bi] != t) continue;
             // the bucket's weight gradients are on the weight-gradient stream (behind everything this stream has issued: fork here), maybe
             // still queued as deferred reductions; its collective starts from there
-            wg_release();
             wg_fork();
             const int s_ = wg_enter();
             flush_wgrad();
@@ -2464,28 +2384,17 @@ int settle_allocs(Net* n) {
 // stream beside stream s.  Measured on the batch-128 step (profiles/r05_queue_classes.txt; one box, ms per step): what must overlap has to
 // sit on DIFFERENT queues - a weight-gradient stream or the host's side stream on the step's own queue costs 0.2-0.4 ms - and beyond that
 // the choice is flat within 0.03 ms; D's best was its chain's weight gradients on the branch stream's queue and the branch's on a third
-// (5.91 against 5.95-6.2 for the other fifteen).  CG_QMAP="c1,..,c7[;next net's list]" overrides the table per net in creation order.
+// (5.91 against 5.95-6.2 for the other fifteen).  (The CG_QMAP override of round 5 went with round 6's pruning: the
+// assignments were swept there and the choice is flat beyond "what must overlap sits on different queues".)
 static const int kQueueOf[8] = {0, 1, 2, 3, 1, 3, 2, 1};
 int ensure_streams(Net* n, int nstreams, void* ref) {
     if (n->trace) return 0;
     if ((int)n->side.size() < nstreams - 1) {
-        static int netno = 0;
         static int slots[4] = {0, 0, 0, 0};
         static std::mutex mu;                 // nets of several host threads share the pool's slot counters
         std::lock_guard<std::mutex> lk(mu);
         if (n->qmap[0] < 0) {
             for (int t = 0; t < 8; ++t) n->qmap[t] = kQueueOf[t];
-            const char* e = getenv("CG_QMAP");
-            if (e) {
-                const char* q = e;
-                for (int i = 0; i < netno && q; ++i) { q = strchr(q, ';'); if (q) ++q; }
-                for (int t = 1; t < 8 && q && *q && *q != ';'; ++t) {
-                    n->qmap[t] = atoi(q) & 3;
-                    while (*q && *q != ',' && *q != ';') ++q;
-                    if (*q == ',') ++q;
-                }
-            }
-            ++netno;
         }
         while ((int)n->side.size() < nstreams - 1) {
             const int t = (int)n->side.size() + 1;
@@ -2611,7 +2520,7 @@ std::string prog_key(Net* n, int nd, const long* dims, int fmt) {
     k += "|o" + std::to_string(n->overlap_groups) + std::to_string(n->defer_wgrad) + std::to_string(n->winograd) + std::to_string(n->fusion) +
          std::to_string(n->stacking) + std::to_string(n->grouped) + std::to_string(n->share_pool) + std::to_string(n->sampler_shared) +
          std::to_string(n->view_fuse) + std::to_string(n->cat_fuse) + std::to_string(n->fuse_locnet) + std::to_string(n->head_fuse) +
-         std::to_string(n->wgrad_stream) + std::to_string(n->wgrad_lag) + std::to_string(n->wino22) + std::to_string(n->wino_dsplit) + std::to_string(n->bn_epilogue) + "m" +
+         std::to_string(n->wgrad_stream) + std::to_string(n->wino22) + std::to_string(n->wino_dsplit) + "m" +
          std::to_string(n->wino_min_tiles);
     return k;
 }
@@ -2663,8 +2572,7 @@ int cg_net_set_option(void* net, const char* name, long value) {
         {"overlap_groups", &n->overlap_groups}, {"defer_wgrad", &n->defer_wgrad}, {"winograd", &n->winograd}, {"share_pool", &n->share_pool},
         {"sampler_shared", &n->sampler_shared}, {"view_fuse", &n->view_fuse}, {"cat_fuse", &n->cat_fuse}, {"stacking", &n->stacking},
         {"grouped", &n->grouped}, {"fusion", &n->fusion}, {"fuse_locnet", &n->fuse_locnet}, {"pack_overlap", &n->pack_overlap},
-        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wgrad_lag", &n->wgrad_lag}, {"wino_dsplit", &n->wino_dsplit},
-        {"bn_epilogue", &n->bn_epilogue}};
+        {"head_fuse", &n->head_fuse}, {"wgrad_stream", &n->wgrad_stream}, {"wino_dsplit", &n->wino_dsplit}};
     if (!strcmp(name, "trace")) {
         CG_REQUIRE(n->progs.empty(), "cg_net_set_option: trace must be chosen before the first pass");
         n->trace = value != 0; n->K = n->trace ? &kTraceTable : &kRealTable;
@@ -2672,7 +2580,7 @@ int cg_net_set_option(void* net, const char* name, long value) {
     }
     if (!strcmp(name, "defer_running")) { n->defer_running = value != 0; return 0; }   // run-time switch, plans unchanged
     if (!strcmp(name, "winograd_min_tiles")) { n->wino_min_tiles = value; return 0; }
-    if (!strcmp(name, "winograd22")) { n->wino22 = (int)value; return 0; }     // bit mask: 1 forward, 2 data gradient, 4 weight gradient
+    if (!strcmp(name, "winograd22")) { n->wino22 = (int)value & 3; return 0; }     // bit mask: 1 forward, 2 data gradient
     if (!strcmp(name, "fuse_locnet")) { n->fuse_locnet = (int)value; return 0; }   // 0 off, 1 every localisation branch, 2 ungrouped ones only
     for (auto& t : tab) if (!strcmp(name, t.nm)) { *t.p = value != 0; return 0; }
     return cg::fail("cg_net_set_option: unknown option %s", name);

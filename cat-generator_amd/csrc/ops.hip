@@ -24,10 +24,8 @@ namespace {
 struct OptDef { const char* name; long dflt; };
 // order = enum Opt (common.h)
 const OptDef kOptDefs[OPT_COUNT] = {
-    {"CG_SPLIT_TARGET", 1}, {"CG_SPLIT_MINK", 8}, {"CG_TN_SMAX", 256}, {"CG_TN_TARGET", 3}, {"CG_SKINNY", 1}, {"CG_GEMM_BK32", 1},
-    {"CG_COLREDUCE_WGS_PER_CU", 1}, {"CG_WINO_BK", 0}, {"CG_NN_TILE", 0}, {"CG_TN_TILE", 0}, {"CG_NN_SPLITS", 0}, {"CG_TN_SPLITS", 0},
-    {"CG_EPILOGUE_STATS", 1}, {"CG_XCD_SWIZZLE", 7}, {"CG_NN_GLDS", 1}, {"CG_TN_GLDS", 1}, {"CG_WINO_GLDS", 1}, {"CG_EW_WGS_PER_CU", 4},
-    {"CG_PAD_SKIP", 20}, {"CG_WINO3", 1},
+    {"CG_SKINNY", 1}, {"CG_GEMM_BK32", 1}, {"CG_WINO_BK", 0}, {"CG_NN_TILE", 0}, {"CG_TN_TILE", 0}, {"CG_NN_SPLITS", 0}, {"CG_TN_SPLITS", 0},
+    {"CG_XCD_SWIZZLE", 7}, {"CG_NN_GLDS", 1}, {"CG_TN_GLDS", 1}, {"CG_WINO_GLDS", 1}, {"CG_PAD_SKIP", 20}, {"CG_WINO3", 1},
 };
 long g_opt_val[OPT_COUNT];
 int g_opt_state[OPT_COUNT];   // 0 = not read yet, 1 = default / environment, 2 = set through the ABI
@@ -1289,7 +1287,7 @@ static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" {
 
-int cg_abi_version(void) { return CG_ABI_VERSION; }
+int cg_abi_version(void) { return CG_TIMING_PROBE ? -1 : CG_ABI_VERSION; }   // a timing-only build (common.h) is refused by every host
 int cg_set_option(const char* name, long value) {
     CG_REQUIRE(name, "cg_set_option: null name");
     for (int i = 0; i < cg::OPT_COUNT; ++i)
@@ -1450,7 +1448,7 @@ static int colreduce_launch(void* stream, int mode, const float* x, const float*
     const int cblocks = v4 ? cg::cdiv(C / 4, qb) : cg::cdiv(C, 64);
     // row chunks: every chunk ends in one double atomic per channel, and same-address atomics serialise (~10 ns each),
     // so aim at one workgroup per CU in total (CG_COLREDUCE_WGS_PER_CU) rather than at maximum occupancy
-    const int cmul = (int)cg::opt(cg::OPT_COLREDUCE_WGS_PER_CU);
+    const int cmul = cg::kColReduceWgsPerCU;
     long chunks = std::max(1L, std::min((M + 63) / 64, (long)cg::kNumCU * cmul / cblocks));
     const long rows_per_block = ((M + chunks - 1) / chunks + 3) / 4 * 4;
     chunks = (M + rows_per_block - 1) / rows_per_block;

@@ -84,7 +84,7 @@ __device__ __forceinline__ void wino_row(const float* P, int tyl, int txl, int h
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 #pragma unroll 2
-    for (int s = 0; s < 8; ++s) {                      // MFMA (s, comp) contracts input planes 8 s + {comp, 4 + comp} (lane half h: the second)
+    for (int s = 0; s < CG_PROBE_HALF(8, 8); ++s) {    // MFMA (s, comp) contracts input planes 8 s + {comp, 4 + comp} (lane half h: the second)
         float4 e[4];                                   // the row transform, shared by the four positions
 #pragma unroll
         for (int c = 0; c < 4; ++c) {

@@ -296,12 +296,6 @@ struct WinoArgs {
     int vpp;             // 1: V holds NPOS planes PER PHASE ([P][NPOS][T][K], F(2x2,2x2)); 0: one set shared by the phases ([NPOS][T][K])
     int kz;              // > 0 (wino_gemm_g_kernel, so == 1): blockIdx.z is a K slice of kz rows, its partial result goes to y + z * T*4*Nc
     int lg_tw, lg_th;    // log2(tW), log2(tH) when both are powers of two and the output is below 2 GB (wino_gemm_g_kernel's lean epilogue), else -1
-    // bstats != null (lean epilogue of the unsplit data-gradient launch): y is the gradient w.r.t. the OUTPUT of y' = prelu(bn(bnx)) - the
-    // [conv, SpatialBatchNormalization, PReLU] in front of this layer (models.lua:212-214 in front of :217-218) - and the launch leaves the
-    // column sums that layer's backward needs, per (tile block, wave row): bstats[rows][3][Nc] = sum d, sum d xhat, sum_{u <= 0} u dy
-    // with xhat = (bnx - mean) invstd, u = xhat gamma + beta, d = prelu'(u) dy: what bn_act_bwd_stats_k computes in a pass of its own
-    const float* bnx; const float* bn_mean; const float* bn_is; const float* bn_g; const float* bn_b; const float* bn_alpha;
-    float* bstats;
 };
 
 // The register-staged form (8 waves, wave tile 32 x 32; BK = K step): the fallback of wino_gemm_g_kernel below for tensors whose
@@ -336,7 +330,7 @@ __global__ __launch_bounds__(64 * NW, 4) void wino_gemm_kernel(WinoArgs a) {
         tn = member - phase * ntn;
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int KT = a.K / BK;
+    const int KT = CG_PROBE_HALF(4, a.K / BK);
 
     // staging: A one float4 per thread (row a_r, k quad a_kv); B two float4 per thread
     const int a_kv = tid % KV, a_r = (tid / KV) % BM;
@@ -508,7 +502,7 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
     const int koff = a.kz ? phase * a.kz : 0;
     float* const yout = a.y + (a.kz ? (long)phase * a.T * 4 * a.Nc : 0L);
     if (a.kz) phase = 0;
-    const int KT = Kext / BK;
+    const int KT = CG_PROBE_HALF(4, Kext / BK);
 
     // ---- staging: lane -> (row, LDS quad position) of A, (k row, column quad) of B
     const int a_row_l = (wave % AW) * RPW + lane / KV;            // row of the tile block this lane brings (waves >= AW: unused)
@@ -622,16 +616,6 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
         int soffs[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) soffs[o] = ((o >> 1) * a.so) * rowp + ((o & 1) * a.so) * a.Nc * 4;
-        const bool bs = a.bstats != nullptr;
-        float bmu = 0.f, bis = 0.f, bga = 0.f, bbe = 0.f, bal = 1.f, b1 = 0.f, b2 = 0.f, bg = 0.f;
-        const bool balpha = bs && a.bn_alpha != nullptr;
-        __amdgpu_buffer_rsrc_t rx = ry;
-        if (bs) {
-            const int col = n0 + wn0 + l31;
-            bmu = a.bn_mean[col]; bis = a.bn_is[col]; bga = a.bn_g[col]; bbe = a.bn_b[col];
-            if (balpha) bal = *a.bn_alpha;
-            rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.bnx, 0, 0x7fffffff, 0x00020000);
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -643,25 +627,6 @@ __global__ __launch_bounds__(512, 4) void wino_gemm_g_kernel(WinoArgs a) {
                 const float v = accY[o][r] + bcol;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)vo, soffs[o], 0);
                 if (a.stats && m < a.T) { st1 += v; st2 += v * v; }
-                if (bs) {   // the same arithmetic per element as bn_act_bwd_stats_k (fused.hip); an out-of-range row loads 0 and is masked
-                    const float xv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)vo, soffs[o], 0));
-                    if (m < a.T) {
-                        const float xh = (xv - bmu) * bis;
-                        const float u = xh * bga + bbe;
-                        const float dd = (!balpha || u > 0.f) ? v : bal * v;
-                        b1 += dd; b2 += dd * xh;
-                        if (balpha && u <= 0.f) bg += u * v;
-                    }
-                }
-            }
-        }
-        if (bs) {
-            const int srow = tm * 2 + (wave & 1);
-            const float t1 = b1 + __shfl_xor(b1, 32, 64), t2 = b2 + __shfl_xor(b2, 32, 64), t3 = bg + __shfl_xor(bg, 32, 64);
-            if (h == 0) {
-                a.bstats[((long)srow * 3 + 0) * a.Nc + n0 + wn0 + l31] = t1;
-                a.bstats[((long)srow * 3 + 1) * a.Nc + n0 + wn0 + l31] = t2;
-                a.bstats[((long)srow * 3 + 2) * a.Nc + n0 + wn0 + l31] = t3;
             }
         }
     } else
@@ -818,77 +783,9 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
     }
 }
 
-// ---------------------------------------------------------------------------
-// Weight gradient of upsample2 -> conv3x3 in the F(2x2,2x2) domain, from the V the forward left behind ([p][xi][T][Cin]):
-//   dM = A dY_p A^T per tile and phase (A = [1 0; 1 1; 0 1]) -> Mdy[p][xi][tile][Cout];  dU_{p,xi}^T [Cout][Cin] = Mdy^T V: 36 equally
-//   spaced TN GEMMs with K = T in ONE launch (9/16 of the direct kernel's multiplies);  G^T dU_p G (G^T = [1 1 0; 0 1 1]) is the 2x2 phase
-//   kernel's gradient, its taps scattered onto the canonical 3x3 taps like the direct path's reduce.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wino22_dy_transform_kernel(const float* __restrict__ dy, float* __restrict__ Mdy, int N, int Hl, int Wl,
-                                                                  int Cout) {
-    const int cq_n = Cout;   // 4 phases x Cout / 4 quads
-    const int tH = Hl >> 1, tW = Wl >> 1;
-    const long T = (long)N * tH * tW;
-    const long total = T * cq_n;
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
-        const int cq = (int)(idx % cq_n);
-        const long tile = idx / cq_n;
-        const int tj = (int)(tile % tW);
-        const int ti = (int)((tile / tW) % tH);
-        const long n = tile / ((long)tW * tH);
-        const int p = (cq * 4) / Cout, co = cq * 4 - p * Cout;
-        const int pa = p >> 1, pb = p & 1;
-        float4 e[2][2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int v = 0; v < 2; ++v)
-                e[u][v] = ld4(dy + ((n * 2 * Hl + 2 * (2 * ti + u) + pa) * (long)(2 * Wl) + 2 * (2 * tj + v) + pb) * Cout + co);
-        float4 r[3][2];
-#pragma unroll
-        for (int v = 0; v < 2; ++v) { r[0][v] = e[0][v]; r[1][v] = f4add(e[0][v], e[1][v]); r[2][v] = e[1][v]; }
-        float* out = Mdy + ((long)p * 9 * T + tile) * Cout + co;
-        const long xs = T * Cout;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            *reinterpret_cast<float4*>(out + (i * 3 + 0) * xs) = r[i][0];
-            *reinterpret_cast<float4*>(out + (i * 3 + 1) * xs) = f4add(r[i][0], r[i][1]);
-            *reinterpret_cast<float4*>(out + (i * 3 + 2) * xs) = r[i][1];
-        }
-    }
-}
 
 __device__ __host__ __forceinline__ int wino22_phase_map(int a, int d) { return ((a + d - 1) >> 1) - ((a - 1) >> 1); }
 
-// gw[co][ci][3][3] += scale * sum_p (G^T dU_p G)[map_p(dy,dx)];  dUt layout [p*9 + xi][co][ci].  One thread per (co, ci).
-__global__ __launch_bounds__(256) void wino22_wgrad_finish_kernel(const float* __restrict__ dUt, float* __restrict__ gw, int Cout, int Cin,
-                                                                  float scale) {
-    const long total = (long)Cout * Cin;
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
-        float acc[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float u[3][3];
-#pragma unroll
-            for (int xi = 0; xi < 9; ++xi) u[xi / 3][xi % 3] = dUt[((long)p * 9 + xi) * total + idx];
-            float t[2][3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { t[0][c] = u[0][c] + u[1][c]; t[1][c] = u[1][c] + u[2][c]; }
-            float g[2][2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) { g[r][0] = t[r][0] + t[r][1]; g[r][1] = t[r][1] + t[r][2]; }
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] += g[wino22_phase_map(p >> 1, dy)][wino22_phase_map(p & 1, dx)];
-        }
-        float* dst = gw + idx * 9;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) dst[t] += scale * acc[t];
-    }
-}
 
 static bool wino_dims_ok(int N, int Hp, int Wp, int Cin, int Cout) {
     return N > 0 && Hp > 0 && Wp > 0 && (Hp & 1) == 0 && (Wp & 1) == 0 && Cin > 0 && Cout > 0 && Cin % 128 == 0 &&
@@ -930,9 +827,8 @@ int cg_conv2d_ups2_wino_pack(void* stream, const float* wf_ph, const float* wb_p
 // The 16 GEMMs + output transform alone, on an already transformed input (what the two entry points below launch after
 // their input transform; exported so that it can be timed / profiled in isolation).
 // dgrad == 0: v [16][T][Cin], u = u_fwd, y [N][2Hp][2Wp][Cout];  dgrad == 1: v [16][T][4*Cout], u = u_bwd, y [N][Hp][Wp][Cin].
-struct WinoBn { const float *x, *mean, *is, *g, *b, *alpha; float* part; };
 static int wino_gemm_launch(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
-                            int Cin, int Cout, int dgrad, float* stats, int npos = 16, int kslices = 1, const WinoBn* bn = nullptr);
+                            int Cin, int Cout, int dgrad, float* stats, int npos = 16, int kslices = 1);
 
 int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
                              int Cin, int Cout, int dgrad) {
@@ -941,12 +837,12 @@ int cg_conv2d_ups2_wino_gemm(void* stream, const float* v, const float* u, const
 
 // rows of the [rows][2][Cout] statistics buffer cg_conv2d_ups2_wino_forward_stats fills
 size_t cg_conv2d_ups2_wino_stats_rows(int N, int Hp, int Wp, int Cin, int Cout) {
-    if (!wino_dims_ok(N, Hp, Wp, Cin, Cout) || cg::opt(cg::OPT_EPILOGUE_STATS) == 0) return 0;
+    if (!wino_dims_ok(N, Hp, Wp, Cin, Cout)) return 0;
     return (size_t)4 * cg::cdiv((long)N * (Hp / 2) * (Wp / 2), 64) * 2;
 }
 
 static int wino_gemm_launch(void* stream, const float* v, const float* u, const float* bias, float* y, int N, int Hp, int Wp,
-                            int Cin, int Cout, int dgrad, float* stats, int npos, int kslices, const WinoBn* bn) {
+                            int Cin, int Cout, int dgrad, float* stats, int npos, int kslices) {
     CG_REQUIRE(v && u && y, "cg_conv2d_ups2_wino_gemm: null pointer");
     CG_REQUIRE(wino_dims_ok(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino_gemm: unsupported dimensions");
     const int T = N * (Hp / 2) * (Wp / 2);
@@ -956,7 +852,6 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
     a.vpp = npos == 9 && !dgrad ? 1 : 0;
     a.kz = 0;
     a.lg_tw = a.lg_th = -1;
-    a.bnx = a.bn_mean = a.bn_is = a.bn_g = a.bn_b = a.bn_alpha = nullptr; a.bstats = nullptr;
     CG_REQUIRE(!stats || !dgrad, "wino_gemm: statistics only on the forward launch");
     if (dgrad) { a.K = 4 * Cout; a.Nc = Cin; a.so = 1; a.Ho = Hp; a.Wo = Wp; }
     else { a.K = Cin; a.Nc = Cout; a.so = 2; a.Ho = 2 * Hp; a.Wo = 2 * Wp; }
@@ -968,11 +863,6 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
         const long ybytes = (long)N * a.Ho * a.Wo * a.Nc * 4L;
         if (lg(a.tW) >= 0 && lg(a.tH) >= 0 && ybytes < 0x7fffffffL) { a.lg_tw = lg(a.tW); a.lg_th = lg(a.tH); }
     }
-    if (bn) {
-        CG_REQUIRE(dgrad && kslices <= 1 && a.lg_tw >= 0 && bn->x && bn->mean && bn->is && bn->g && bn->b && bn->part,
-                   "wino_gemm: batch-norm backward sums need the unsplit data-gradient launch with a power-of-two tile grid");
-        a.bnx = bn->x; a.bn_mean = bn->mean; a.bn_is = bn->is; a.bn_g = bn->g; a.bn_b = bn->b; a.bn_alpha = bn->alpha; a.bstats = bn->part;
-    }
     const dim3 grid(cg::cdiv(T, 64) * (a.Nc / 128), 1, dgrad ? (kslices > 1 ? kslices : 1) : 4);
     // K step 32 (half the barriers per MFMA) pays when the launch is at most ~one workgroup per CU - the data-gradient
     // geometry at batch 128 (0.53 -> 0.41 ms) - and costs 6 % when two workgroups per CU already hide each other's barriers
@@ -980,7 +870,6 @@ static int wino_gemm_launch(void* stream, const float* v, const float* u, const 
     // LDS-direct loads (CG_WINO_GLDS): one xi plane of V must stay below the 2 GB a buffer offset reaches
     const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && (long)T * a.K * 4L < 0x7fffffffL &&
                       16L * a.K * a.Nc * 4L < 0x7fffffffL;
-    CG_REQUIRE(!bn || glds, "wino_gemm: batch-norm backward sums need the LDS-direct-load kernel (CG_WINO_GLDS)");
     if (npos == 9) {     // F(2x2,2x2): the LDS-direct-load kernel only (cg_conv2d_ups2_wino22_supported checks the same conditions)
         CG_REQUIRE(glds, "wino_gemm: the 9-position form needs the LDS-direct-load kernel (CG_WINO_GLDS)");
         if (k32 && (a.kz ? a.kz : a.K) % 64 == 0) hipLaunchKernelGGL((wino_gemm_g_kernel<32, 9>), grid, dim3(512), 0, cg::S(stream), a);
@@ -1028,11 +917,6 @@ size_t cg_conv2d_ups2_wino22_supported(int N, int Hp, int Wp, int Cin, int Cout)
 // question would compile the forward and fail in Module:backward for a large batch x Cout)
 size_t cg_conv2d_ups2_wino22_dgrad_supported(int N, int Hp, int Wp, int Cin, int Cout) {
     return cg_conv2d_ups2_wino22_supported(N, Hp, Wp, Cin, Cout) && (long)N * (Hp / 2) * (Wp / 2) * Cout * 16L < 0x7fffffffL ? 1 : 0;
-}
-size_t cg_conv2d_ups2_wino22_wgrad_supported(int N, int Hp, int Wp, int Cin, int Cout) {
-    if (!cg_conv2d_ups2_wino22_supported(N, Hp, Wp, Cin, Cout)) return 0;
-    const long T = (long)N * (Hp / 2) * (Wp / 2);
-    return T * Cout * 4L < 0x7fffffffL && T * Cin * 4L < 0x7fffffffL && 36L * Cin * Cout * 4L < 0x7fffffffL ? 1 : 0;
 }
 size_t cg_conv2d_ups2_wino22_v_floats(int N, int Hp, int Wp, int Cin) { return (size_t)36 * ((size_t)N * (Hp / 2) * (Wp / 2)) * Cin; }
 size_t cg_conv2d_ups2_wino22_u_floats(int Cin, int Cout) { return (size_t)4 * 9 * Cin * Cout; }
@@ -1121,33 +1005,6 @@ int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd,
                        4 * Cout, Cout);
     CG_LAUNCH_CHECK();
     return cg_conv2d_ups2_wino_gemm(stream, v_dy, u_bwd, nullptr, dx_lo, N, Hp, Wp, Cin, Cout, 1);
-}
-
-// cg_conv2d_ups2_wino_dgrad with the backward sums of the [SpatialBatchNormalization, PReLU] in front of the layer in its epilogue:
-// part[cg_conv2d_ups2_wino_dgrad_bn_rows()][3][Cin] (see WinoArgs::bstats); rows == 0: this geometry / option set cannot (sliced launch,
-// tile grid not a power of two, register-staged kernel) - use cg_bn_act_backward_stats on dx_lo.
-static int wino_dgrad_slices(int N, int Hp, int Wp, int Cin, int Cout);
-size_t cg_conv2d_ups2_wino_dgrad_bn_rows(int N, int Hp, int Wp, int Cin, int Cout) {
-    if (!wino_dims_ok(N, Hp, Wp, Cin, Cout) || cg::opt(cg::OPT_EPILOGUE_STATS) == 0) return 0;
-    const long T = (long)N * (Hp / 2) * (Wp / 2);
-    const bool glds = cg::opt(cg::OPT_WINO_GLDS) != 0 && T * 4L * Cout * 4L < 0x7fffffffL && 16L * 4L * Cout * Cin * 4L < 0x7fffffffL;
-    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (!glds || !pow2(Hp / 2) || !pow2(Wp / 2) || (long)N * Hp * Wp * Cin * 4L >= 0x7fffffffL) return 0;
-    if (wino_dgrad_slices(N, Hp, Wp, Cin, Cout) > 1) return 0;
-    return (size_t)2 * cg::cdiv(T, 64);
-}
-int cg_conv2d_ups2_wino_dgrad_bn(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy, int N, int Hp, int Wp, int Cin,
-                                 int Cout, const float* bn_x, const float* save_mean, const float* save_invstd, const float* gamma,
-                                 const float* beta, const float* alpha, float* part) {
-    CG_REQUIRE(dy && u_bwd && dx_lo && v_dy && bn_x && save_mean && save_invstd && gamma && beta && part, "cg_conv2d_ups2_wino_dgrad_bn: null pointer");
-    CG_REQUIRE(cg_conv2d_ups2_wino_dgrad_bn_rows(N, Hp, Wp, Cin, Cout) > 0, "cg_conv2d_ups2_wino_dgrad_bn: unsupported dimensions / options");
-    hipStream_t st = cg::S(stream);
-    const int T = N * (Hp / 2) * (Wp / 2);
-    hipLaunchKernelGGL(wino_input_transform_kernel<1>, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, st, dy, v_dy, N, Hp, Wp,
-                       4 * Cout, Cout);
-    CG_LAUNCH_CHECK();
-    const WinoBn bn{bn_x, save_mean, save_invstd, gamma, beta, alpha, part};
-    return wino_gemm_launch(stream, v_dy, u_bwd, nullptr, dx_lo, N, Hp, Wp, Cin, Cout, 1, nullptr, 16, 1, &bn);
 }
 
 // The same data gradient with its K rows (the four phases' channels) in 2 or 4 slices over blockIdx.z and a fixed-order sum of the partial
@@ -1240,38 +1097,6 @@ int cg_conv2d_ups2_wino_wgrad(void* stream, const float* v, const float* dy, flo
     return 0;
 }
 
-size_t cg_conv2d_ups2_wino22_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout) {
-    if (!wino_dims_ok(N, Hp, Wp, Cin, Cout)) return 0;
-    const size_t T = (size_t)N * (Hp / 2) * (Wp / 2);
-    return wino_align(36 * T * Cout * sizeof(float)) + wino_align((size_t)36 * Cout * Cin * sizeof(float)) + wino_align(sizeof(double) * Cout) +
-           cg_conv2d_wgrad_workspace_bytes_strided(36, (int)T, 1, 1, Cin, Cout, 1, 1, 0, 0, 0);
-}
 
-// gw_canonical[Cout][Cin][3][3] += scale * dW, gb += scale * sum dy, from the transformed input v ([4][9][T][Cin]) the F(2x2,2x2) forward of
-// this batch left behind.
-int cg_conv2d_ups2_wino22_wgrad(void* stream, const float* v, const float* dy, float* gw_canonical, float* gb, int N, int Hp, int Wp, int Cin,
-                                int Cout, float scale, void* ws, size_t ws_bytes) {
-    CG_REQUIRE(v && dy && gw_canonical, "cg_conv2d_ups2_wino22_wgrad: null pointer");
-    CG_REQUIRE(cg_conv2d_ups2_wino22_wgrad_supported(N, Hp, Wp, Cin, Cout), "cg_conv2d_ups2_wino22_wgrad: unsupported dimensions / options");
-    const size_t need = cg_conv2d_ups2_wino22_wgrad_workspace_bytes(N, Hp, Wp, Cin, Cout);
-    CG_REQUIRE(ws && ws_bytes >= need && (uintptr_t)ws % 16 == 0, "cg_conv2d_ups2_wino22_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
-    hipStream_t st = cg::S(stream);
-    const int T = N * (Hp / 2) * (Wp / 2);
-    char* base = (char*)ws;
-    float* mdy = (float*)base;                    base += wino_align((size_t)36 * T * Cout * sizeof(float));
-    float* dut = (float*)base;                    base += wino_align((size_t)36 * Cout * Cin * sizeof(float));
-    void* bws = base;                             base += wino_align(sizeof(double) * Cout);
-    void* tws = base;
-    const size_t tws_bytes = ws_bytes - (size_t)(base - (char*)ws);
-    hipLaunchKernelGGL(wino22_dy_transform_kernel, dim3(cg::ew_grid((long)T * Cout)), dim3(256), 0, st, dy, mdy, N, Hp, Wp, Cout);
-    CG_LAUNCH_CHECK();
-    if (cg_memset_zero(stream, dut, (size_t)36 * Cout * Cin * sizeof(float))) return 1;
-    if (cg_conv2d_wgrad_strided(stream, 36, v, (long)T * Cin, mdy, (long)T * Cout, dut, (long)Cout * Cin, T, 1, 1, Cin, Cout, 1, 1, 0, 0, 0, 1.f,
-                                tws, tws_bytes)) return 1;
-    hipLaunchKernelGGL(wino22_wgrad_finish_kernel, dim3(cg::ew_grid((long)Cout * Cin)), dim3(256), 0, st, dut, gw_canonical, Cout, Cin, scale);
-    CG_LAUNCH_CHECK();
-    if (gb) return cg_bias_grad(stream, dy, gb, (long)N * 4 * Hp * Wp, Cout, scale, bws, wino_align(sizeof(double) * Cout));
-    return 0;
-}
 
 }  // extern "C"

@@ -242,13 +242,13 @@ int cg_conv2d_ups2_wino_forward_stats(void* stream, const float* x_lo, const flo
 /* F(2x2,2x2) for nn.SpatialUpSamplingNearest(2) -> 3x3 convolution (models.lua:211-212 at the full batch; round 4), FORWARD: the four
  * phases are 2x2-tap convolutions with windows one pixel apart - 9 multiplies per 2x2 low-res tile and phase instead of 16.  u22:
  * cg_conv2d_ups2_wino22_u_floats() floats from the phase-summed kernels (cg_pack_conv_weight_ups2's wf_ph); v: scratch of
- * cg_conv2d_ups2_wino22_v_floats() floats (4 phases x 9 planes; what cg_conv2d_ups2_wino22_wgrad consumes later); stats as
+ * cg_conv2d_ups2_wino22_v_floats() floats (4 phases x 9 planes); stats as
  * cg_conv2d_ups2_wino_forward_stats. */
 size_t cg_conv2d_ups2_wino22_supported(int N, int Hp, int Wp, int Cin, int Cout);
-/* ... and whether the data-gradient / weight-gradient launches below take the same geometry (their scratch adds limits of its own):
- * ask before choosing the path, fall back to cg_conv2d_dgrad_ups2 / cg_conv2d_wgrad otherwise. */
+/* ... and whether the data-gradient launch below takes the same geometry (its scratch adds limits of its own): ask before choosing
+ * the path, fall back to cg_conv2d_dgrad_ups2 otherwise.  (The weight gradient of these layers stays phase-folded: its F(2x2,2x2)-domain
+ * form of round 4 measured 6.04 against 6.06 ms per step for 430 MB of workspace and was removed in round 6.) */
 size_t cg_conv2d_ups2_wino22_dgrad_supported(int N, int Hp, int Wp, int Cin, int Cout);
-size_t cg_conv2d_ups2_wino22_wgrad_supported(int N, int Hp, int Wp, int Cin, int Cout);
 size_t cg_conv2d_ups2_wino22_v_floats(int N, int Hp, int Wp, int Cin);
 size_t cg_conv2d_ups2_wino22_u_floats(int Cin, int Cout);
 int cg_conv2d_ups2_wino22_pack(void* stream, const float* wf_ph, const float* wb_ph, float* u_fwd, float* u_bwd, int Cout, int Cin);
@@ -259,22 +259,9 @@ int cg_conv2d_ups2_wino22_forward_stats(void* stream, const float* x_lo, const f
 size_t cg_conv2d_ups2_wino22_dgrad_v_floats(int N, int Hp, int Wp, int Cin, int Cout);
 int cg_conv2d_ups2_wino22_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy,
                                 int N, int Hp, int Wp, int Cin, int Cout);
-/* accGradParameters of the same layers in the F(2x2,2x2) domain, from the v the forward of this batch wrote: gw_canonical[Cout][Cin][3][3] +=
- * scale*dW, gb (may be NULL) += scale * sum dy.  36 equally spaced weight-gradient GEMMs in one launch (cg_conv2d_wgrad_strided) + G^T . G. */
-size_t cg_conv2d_ups2_wino22_wgrad_workspace_bytes(int N, int Hp, int Wp, int Cin, int Cout);
-int cg_conv2d_ups2_wino22_wgrad(void* stream, const float* v, const float* dy, float* gw_canonical, float* gb,
-                                int N, int Hp, int Wp, int Cin, int Cout, float scale, void* ws, size_t ws_bytes);
+/* updateGradInput of the 5x5 layers in F(2x2,3x3) (cg_conv2d_ups2_wino_forward's layers). */
 int cg_conv2d_ups2_wino_dgrad(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy,
                               int N, int Hp, int Wp, int Cin, int Cout);
-/* The same launch with the backward sums of the nn.SpatialBatchNormalization -> nn.PReLU in front of the layer (models.lua:213-214 in front
- * of :217-218) in its epilogue (round 5): dx_lo IS that pair's gradOutput, bn_x its input (the convolution output the forward normalised),
- * and the launch leaves part[rows][3][Cin] - per-workgroup column sums of d, d xhat and the slope's term - from which
- * cg_bn_act_backward_stats_finalize builds what cg_bn_act_backward_stats would have computed in a pass of its own over (bn_x, dx_lo).
- * rows == 0: not for this geometry / option set (sliced launch, tile grid not a power of two). */
-size_t cg_conv2d_ups2_wino_dgrad_bn_rows(int N, int Hp, int Wp, int Cin, int Cout);
-int cg_conv2d_ups2_wino_dgrad_bn(void* stream, const float* dy, const float* u_bwd, float* dx_lo, float* v_dy, int N, int Hp, int Wp,
-                                 int Cin, int Cout, const float* bn_x, const float* save_mean, const float* save_invstd,
-                                 const float* gamma, const float* beta, const float* alpha, float* part);
 /* The same data gradient with its K rows (the four phases' channels) in 2 or 4 slices over the launch's z dimension and a fixed-order sum
  * of the partial results (round 4: the unsplit launch of G's 5x5 layer is one workgroup per CU).  part: scratch of
  * cg_conv2d_ups2_wino_dgrad_part_floats() floats; 0 floats / part == NULL = the unsplit launch above. */
@@ -362,12 +349,6 @@ int cg_bn_act_forward(void* stream, const float* x, float* y, const float* gamma
  *   cg_bn_act_backward:       dx = gamma*invstd*(d - s1/count - xhat*s2/count) from the (all-reduced) `sums`;
  *                             ggamma += scale*local s2, gbeta += scale*local s1, galpha += scale*local sums[2C]. */
 size_t cg_bn_act_backward_sums(int C);
-/* ... the same sums from a data-gradient epilogue's partial rows: sums3 = 3 C doubles, [2C..3C) the PReLU slope's sum per channel;
- * cg_bn_act_backward_cols is cg_bn_act_backward reading that layout. */
-int cg_bn_act_backward_stats_finalize(void* stream, const float* partials, long rows, int C, double* sums3);
-int cg_bn_act_backward_cols(void* stream, const float* x, const float* dy, const float* gamma, const float* beta,
-                            const float* save_mean, const float* save_invstd, const float* alpha, const double* sums, double count,
-                            const double* local_sums, long M, int C, float* dx, float* ggamma, float* gbeta, float* galpha, float scale);
 int cg_bn_act_backward_stats(void* stream, const float* x, const float* dy, const float* save_mean,
                              const float* save_invstd, const float* gamma, const float* beta, const float* alpha,
                              long M, int C, double* sums);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-workgroup timeline of igemm_nn_kernel launches (library built by `scripts/build_exp.sh trace`): dispatch balance over
+"""Per-workgroup timeline of igemm_nn_kernel launches (library built with CG_BUILD_DEFINES=-DCG_TRACE, cat-generator_amd/build.py): dispatch balance over
 the CUs and the time every workgroup spends in its prologue, K loop and epilogue.
 Usage: CATGAN_LIB=$PWD/cat-generator_amd/lib/libcatgan_hip_exptrace.so python scripts/wg_trace.py"""
 import collections

@@ -85,15 +85,6 @@ def test_segments_and_lockstep_branches_of_the_discriminator():
         if "cg_locnet_backward" in l:
             assert b[i + 1].startswith("event|record|wgfork") and b[i + 2].startswith("event|wait|wgfork")
             assert all("cg_conv2d_wgrad_grouped_deferred" in x for x in b[i + 3:i + 7])
-    # option wgrad_lag (off by default) holds a layer's weight gradients back until the next data-gradient GEMM of its stream - or the end
-    # of the pass - so they are found behind a LATER fork
-    r_lag = T.trace("D32_st3", 128, options=[("wgrad_lag", 1)])["backward"]
-    wl = [i for i, l in enumerate(r_lag) if "cg_conv2d_wgrad_grouped_deferred" in l]
-    for i, l in enumerate(r_lag):
-        if "cg_locnet_backward" in l:
-            assert not r_lag[i + 1].startswith("event|record|wgfork")
-            G_ = l.split("|")[3]
-            assert len([j for j in wl if j > i and r_lag[j].split("|")[3] == G_]) >= 4
     # updateGradInput only (fevalG_on_D's pass through D, adversarial.lua:192-193): no weight gradient of any kind
     u = r["updateGradInput"]
     assert not [c for c in T.calls(u) if "wgrad" in c[0]]
@@ -120,39 +111,19 @@ def test_generator_plan_uses_epilogue_statistics_and_winograd_at_the_benchmarked
     assert f.count("cg_conv2d_ups2_wino_forward_stats") == 1      # the 5x5 layer's phases in Winograd F(2x2,3x3)
     assert "cg_upsample2x_forward" not in f and "cg_prelu_forward" not in f
     b = [c[0] for c in T.calls(r["backward"])]
-    # round 5: the 5x5 layer's data gradient IS the gradOutput of the [batch-norm, PReLU] in front of it (behind the folded upsampling), so
-    # that pair's backward sums ride in the GEMM's epilogue: partial rows -> one small finalize instead of a pass over (x, gradOutput)
     assert b.count("cg_conv2d_ups2_wino_dgrad") == 1 and b.count("cg_conv2d_ups2_wino_wgrad") == 1 and b.count("cg_bn_act_backward_stats") == 3
-    # option bn_epilogue (round 5; off: no gain measured): the 5x5 layer's data gradient IS the gradOutput of the [batch-norm, PReLU] in
-    # front of it (behind the folded upsampling), so that pair's backward sums can ride in the GEMM's epilogue: partial rows -> one small
-    # finalize instead of a pass over (x, gradOutput)
-    r_on = T.trace("G32up-c", 128, options=[("bn_epilogue", 1)])
-    bo = [c[0] for c in T.calls(r_on["backward"])]
-    assert bo.count("cg_conv2d_ups2_wino_dgrad_bn") == 1 and "cg_conv2d_ups2_wino_dgrad" not in bo and bo.count("cg_conv2d_ups2_wino_wgrad") == 1
-    assert bo.count("cg_bn_act_backward_stats") == 2 and bo.count("cg_bn_act_backward_stats_finalize") == 1 and bo.count("cg_bn_act_backward_cols") == 1
-    i_d = bo.index("cg_conv2d_ups2_wino_dgrad_bn")
-    assert [x for x in bo[i_d + 1:] if not x.startswith("cg_conv2d_ups2_wino_wgrad")][:2] == ["cg_bn_act_backward_stats_finalize", "cg_bn_act_backward_cols"]
-    calls_b = T.calls(r_on["backward"])
-    a_d = [a for n_, a in calls_b if n_ == "cg_conv2d_ups2_wino_dgrad_bn"][0]
-    a_f = [a for n_, a in calls_b if n_ == "cg_bn_act_backward_stats_finalize"][0]
-    a_c = [a for n_, a in calls_b if n_ == "cg_bn_act_backward_cols"][0]
-    assert a_d["part"] == a_f["partials"] and a_f["sums3"] == a_c["local_sums"] and a_d["dx_lo"] == a_c["dy"] and a_d["bn_x"] == a_c["x"]
     # a Winograd data gradient whose unsplit launch is below one workgroup per CU runs in K slices over blockIdx.z + a fixed-order sum (option
     # wino_dsplit): G32up's 128 -> 256 layer at batch 256 (64 workgroups), not its 256 -> 128 layer (512) nor G32up-c's (256, above)
     b3 = [c[0] for c in T.calls(T.trace("G32up", 256)["backward"])]
     assert b3.count("cg_conv2d_ups2_wino_dgrad_split") == 1 and b3.count("cg_conv2d_ups2_wino_dgrad") == 1
     b3u = [c[0] for c in T.calls(T.trace("G32up", 256, options=[("wino_dsplit", 0)])["backward"])]
     assert b3u.count("cg_conv2d_ups2_wino_dgrad") == 2 and "cg_conv2d_ups2_wino_dgrad_split" not in b3u
-    # the 512 -> 256 3x3 layer behind the 8x8 -> 16x16 upsampling: forward and data gradient in F(2x2,2x2); the weight gradient in that
-    # domain (from the V the forward left behind) is option bit 2, off by default (no gain in the step)
-    assert f.count("cg_conv2d_ups2_wino22_forward_stats") == 1 and b.count("cg_conv2d_ups2_wino22_dgrad") == 1 and "cg_conv2d_ups2_wino22_wgrad" not in b
-    r7 = T.trace("G32up-c", 128, options=[("winograd22", 7)])
-    v_fwd = [a for n_, a in T.calls(r7["forward"]) if n_ == "cg_conv2d_ups2_wino22_forward_stats"][0]["v"]
-    assert [a for n_, a in T.calls(r7["backward"]) if n_ == "cg_conv2d_ups2_wino22_wgrad"][0]["v"] == v_fwd
+    # the 512 -> 256 3x3 layer behind the 8x8 -> 16x16 upsampling: forward and data gradient in F(2x2,2x2), the weight gradient phase-folded
+    assert f.count("cg_conv2d_ups2_wino22_forward_stats") == 1 and b.count("cg_conv2d_ups2_wino22_dgrad") == 1
     assert b.count("cg_conv2d_dgrad_ups2") == 1 and b.count("cg_bn_act_backward") == 3 and b[-1] == "cg_conv2d_wgrad_flush"
     r22 = T.trace("G32up-c", 128, options=[("winograd22", 1)])     # bit 0 only: the forward alone
     b22 = [c[0] for c in T.calls(r22["backward"])]
-    assert b22.count("cg_conv2d_dgrad_ups2") == 2 and "cg_conv2d_ups2_wino22_wgrad" not in b22
+    assert b22.count("cg_conv2d_dgrad_ups2") == 2
     r20 = T.trace("G32up-c", 128, options=[("winograd22", 0)])
     assert "cg_conv2d_ups2_wino22_forward_stats" not in [c[0] for c in T.calls(r20["forward"])]
     assert r["backward"][-2:] == ["event|record|wgjoin0|s4", "event|wait|wgjoin0|s0"]
@@ -282,23 +253,23 @@ def test_data_parallel_exchanges_sit_inside_the_plan():
         # complete gradients: the deferred reductions flushed, or the layer's own immediate (Winograd-domain) weight gradient
         # (on the weight-gradient stream s4, which first takes up everything s0 has issued: BN / PReLU gradients of the bucket)
         prev = [l for l in b[:i] if not l.startswith("event|")][-1]
-        assert "cg_conv2d_wgrad_flush|s4" in prev or "cg_conv2d_ups2_wino_wgrad|s4" in prev or "cg_conv2d_ups2_wino22_wgrad|s4" in prev or prev.startswith("hook|")
+        assert "cg_conv2d_wgrad_flush|s4" in prev or "cg_conv2d_ups2_wino_wgrad|s4" in prev or prev.startswith("hook|")
         assert b[i - 1] == "event|wait|wgfork0|s4" or "cg_conv2d_wgrad_flush|s4" in b[i - 1]
     for (i0, _), (i1, _) in zip(buckets, buckets[1:]):                                   # the next layer's backward runs under the bucket
         assert sum(1 for l in b[i0:i1] if l.startswith("call|")) >= 3
 
 
-@pytest.mark.parametrize("which,N,lag", [("D32_st3", 128, 0), ("G32up-c", 128, 0), ("G32up", 256, 0), ("D32_st3@64", 64, 0), ("D32_st3", 128, 1), ("G32up", 256, 1)])
-def test_weight_gradients_run_beside_the_data_gradient_chain(which, N, lag):
+@pytest.mark.parametrize("which,N", [("D32_st3", 128), ("G32up-c", 128), ("G32up", 256), ("D32_st3@64", 64)])
+def test_weight_gradients_run_beside_the_data_gradient_chain(which, N):
     """Option wgrad_stream (default on): Module:backward issues every accGradParameters launch - GEMM, Winograd-domain, the
     localisation nets' four, the deferred reductions - on stream 4 + s, forked from stream s where the layer's gradOutput is complete
     and joined into s0 once, at the end of the pass.  Nothing else changes: with the stream column and the fork / join events removed
     the plan IS the in-line plan (wgrad_stream 0, the configuration the golden sequences hold) up to the position of the launches
     that moved, and no data-gradient launch waits for a weight gradient."""
-    r1 = T.trace(which, N, options=[("wgrad_lag", lag)])
+    r1 = T.trace(which, N)
     r0 = T.trace(which, N, options=[("wgrad_stream", 0)])
     b1, b0 = r1["backward"], r0["backward"]
-    is_w = lambda l: l.startswith("call|cg_conv2d_wgrad") or l.startswith("call|cg_conv2d_ups2_wino_wgrad") or l.startswith("call|cg_conv2d_ups2_wino22_wgrad")
+    is_w = lambda l: l.startswith("call|cg_conv2d_wgrad") or l.startswith("call|cg_conv2d_ups2_wino_wgrad")
     # same launches, same arguments (workspace of the stream aside), same relative order within the weight gradients and within the rest
     def strip(l):      # entry point + every scalar argument; streams and buffer names dropped (holding a launch back moves the allocation
         f = l.split("|")   # order of its workspace, and with it the numbering of the regions)
@@ -308,8 +279,7 @@ def test_weight_gradients_run_beside_the_data_gradient_chain(which, N, lag):
     nonflush = lambda ls: [strip(l) for l in ls if "wgrad_flush" not in l]
     assert sorted(nonflush(calls1)) == sorted(nonflush(calls0))
     assert [strip(l) for l in calls1 if not is_w(l)] == [strip(l) for l in calls0 if not is_w(l)]
-    # the weight gradients keep their order PER STREAM (s4 + k carries what stream k carried in line); across streams the issue order
-    # moves, since a launch held back by wgrad_lag is issued in front of the next data-gradient GEMM of its own stream
+    # the weight gradients keep their order PER STREAM (s4 + k carries what stream k carried in line)
     on = lambda ls, st: nonflush([l for l in ls if is_w(l) and l.split("|")[2] == st])
     for k_ in (0, 1):
         assert on(T.canon(b1), "s%d" % (4 + k_)) == on(T.canon(b0), "s%d" % k_)

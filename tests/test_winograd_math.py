@@ -130,7 +130,7 @@ def test_f22_data_gradient_and_weight_gradient_of_an_upsampled_3x3_convolution()
     """The backward forms csrc/winograd.hip runs for the same layer.  Data gradient (wino22_dy_input_transform_kernel + the 9-position GEMMs
     over K = 4 Cout): dx[u][v] = sum_p sum_r dy_p[u - a + ry][v - b + rx] . g_p[1-ry][1-rx] on the phase sub-lattices dy_p = dy[a::2, b::2] -
     per phase F(2x2,2x2) with the FLIPPED 2x2 kernel on the 3x3 window that starts at row 2ti - a, the four phases summed.  Weight gradient
-    (wino22_dy_transform_kernel, 36 products, wino22_wgrad_finish_kernel): dU_p = sum_tiles V_p . (A dY_p A^T), A = [1 0; 1 1; 0 1];
+    (the F(2x2,2x2)-domain form round 4 built and round 6 removed from the engine - no gain in the step; the identity stays): dU_p = sum_tiles V_p . (A dY_p A^T), A = [1 0; 1 1; 0 1];
     dg_p = G^T dU_p G; the phase taps scatter onto the canonical 3x3 taps through the same map that folded them."""
     rs = np.random.RandomState(4)
     Hl = 6
