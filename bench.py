@@ -397,6 +397,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default) launch eagerly: with the planned executor a step costs the host ~1.1 ms")
     ap.add_argument("--graph", action="store_true", help="capture the iteration once (cg_graph_*) and replay the hipGraph")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--no-reference-order", action="store_true", help="skip the same-run timing of the reference's order of calls (kernel traces: the "
+                    "trace tools analyse the LAST steps of the process)")
     ap.add_argument("--no-dp-dry-run", action="store_true", help="skip the data-parallel dry run of the default one-GPU line")
     ap.add_argument("--dp-dry-run", type=int, nargs="?", const=8, default=None, metavar="R",
                     help="one GPU: also time the per-rank step of an R-rank data-parallel job (sync-BN, gradient buckets, D's all-reduce under the "
@@ -540,7 +542,7 @@ def main():
         # the reference's ORDER of calls (adversarial.lua:232-233 ... :185: the G-step's generator forward after D's update) in the same run:
         # what an unchanged adversarial.lua gets from the drop-in host; the headline issues the two generator forwards as one
         # cg_net_forward_pair (MODEL_G:forwardPair - six lines of adversarial.lua)
-        if world == 1 and launch == "eager" and S.OPT.get("concurrent_g_both"):
+        if world == 1 and launch == "eager" and S.OPT.get("concurrent_g_both") and not args.no_reference_order:
             try:
                 S.OPT["concurrent_g_both"] = False
                 res["config"]["reference_order_ms"] = time_steps(cg, S, data, N, min(args.steps, 30), 3)

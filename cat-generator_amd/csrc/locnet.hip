@@ -478,6 +478,10 @@ __device__ __forceinline__ void load_b16(const float* __restrict__ w, int lane, 
 
 template <int S, int CIN>
 __global__ __launch_bounds__(NT2) void locnet_fwd2_k(LocFwd a) {
+    // Highest wave priority: this is a latency-bound kernel at the head of D's chain that in the D-step becomes ready beside the second
+    // generator pass's Winograd GEMM (which keeps every SIMD's MFMA pipe and LDS busy): 249 -> 190 us in the traced step, step 5.62 -> 5.59 ms
+    // same box (profiles/r06_sweeps.txt).  What remains is contention a priority cannot remove (19 us alone).
+    __builtin_amdgcn_s_setprio(3);
     using C = Cfg<S, CIN>;
     extern __shared__ float sm[];
     float *pP = sm + C::F_P, *h1P = sm + C::F_H1, *m2 = sm + C::F_M2, *red = sm + C::F_RED, *h2 = sm + C::F_H2, *h3 = sm + C::F_H3, *prm = sm + C::F_PRM;
@@ -664,6 +668,7 @@ __global__ __launch_bounds__(NT2) void locnet_fwd2_k(LocFwd a) {
 
 template <int S, int CIN>
 __global__ __launch_bounds__(NT2) void locnet_bwd2_k(LocBwd a) {
+    __builtin_amdgcn_s_setprio(3);   // as locnet_fwd2_k
     using C = Cfg<S, CIN>;
     extern __shared__ float sm[];
     __shared__ double shd[6][NW];

@@ -64,6 +64,10 @@ __global__ void wino3_pack_k(PackJobs jobs) {
 
 // row i of an MFMA tile (= lane & 31 of the A operand) -> output tile (ty, tx) of the 4 x 8 block: ty = result >> 3, tx = result & 7.
 // The 16-lane groups of ds_read_b128 are lanes {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32): the first takes tile rows 0, 1, the second 2, 3
+constexpr int tile_of_row_c(int l) {
+    return ((l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28)) ? 0 : 16) +
+           ((l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28)) ? (l < 4 ? l : (l < 16 ? l - 8 : l - 12)) : (l < 12 ? l - 4 : (l < 20 ? l - 8 : l - 16)));
+}
 __device__ __forceinline__ int tile_of_row(int l) {
     const bool ga = l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28);
     const int rank = ga ? (l < 4 ? l : (l < 16 ? l - 8 : l - 12)) : (l < 12 ? l - 4 : (l < 20 ? l - 8 : l - 16));
@@ -134,14 +138,23 @@ __global__ __launch_bounds__(512, 2) void wino3_fused_k(W3Args a) {
     const int n = b / byn;
     const int y0 = by * 8, x0 = bx * 16;
 
-    // ---- patch -> LDS, plane quads XORed with the parity of the patch row pair
-    for (int idx = tid; idx < PH * PW * (C / 4); idx += 512) {
-        const int q = idx & 15, pix = idx >> 4;
-        const int pr = pix / PW, pc = pix - pr * PW;
-        const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4(x + (((long)n * H + iy) * W + ix) * C + q * 4);
-        *reinterpret_cast<float4*>(P + pix * PLD + ((q ^ ((pr >> 1) & 1)) << 2)) = v;
+    // ---- patch -> LDS, plane quads XORed with the parity of the patch row pair.  Lean form (PMC r06: the first version spent 9.6 VALU per
+    // MFMA of the whole launch, most of them index arithmetic here and in the stores): a thread keeps its plane quad, its pixel advances by
+    // 32 per pass = (1 row, 14 columns) of the 18-wide patch, out-of-image pixels are buffer loads at an out-of-range offset (-> 0)
+    {
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)n * H * W * C), 0, (unsigned)(H * W * C * 4), 0x00020000);
+        const int q = tid & 15;
+        int pix = tid >> 4, pr = pix / PW, pc = pix - pr * PW;          // pix < 32
+#pragma unroll
+        for (int it = 0; it < (PH * PW + 31) / 32; ++it) {
+            const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+            const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const unsigned voff = in ? (unsigned)(((iy * W + ix) * C + q * 4) * 4) : 0x80000000u;
+            const float4 v = bufld4(rsx, voff, 0);
+            if (pix < PH * PW) *reinterpret_cast<float4*>(P + pix * PLD + ((q ^ ((pr >> 1) & 1)) << 2)) = v;
+            pix += 32; pr += 1; pc += 14;
+            if (pc >= PW) { pc -= PW; pr += 1; }
+        }
     }
     __syncthreads();
 
@@ -171,6 +184,11 @@ __global__ __launch_bounds__(512, 2) void wino3_fused_k(W3Args a) {
     const int oa = xi >> 1, ob = xi & 1;
     const float* bias = a.bias[grp];
     const float bco = bias ? bias[nt * 32 + j] : 0.f;
+    // accumulator row r of lane half h is MFMA row (r & 3) + 8 (r >> 2) + 4 h -> tile_of_row() -> pixel (2 ty + oa, 2 tx + ob): the tile of
+    // every (r, h) is a compile-time constant, so a store is one select + one buffer store at (lane base) + (select)
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (long)n * H * W * C), 0, (unsigned)(H * W * C * 4), 0x00020000);
+    const int lane_base = (((y0 + oa) * W + x0 + ob) * C + nt * 32 + j) * 4;
+    const int rowb = 2 * W * C * 4, colb = 2 * C * 4;           // bytes per tile row / tile column
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int k = r * 64 + lane;
@@ -179,9 +197,10 @@ __global__ __launch_bounds__(512, 2) void wino3_fused_k(W3Args a) {
         else if (xi == 1) v = (X[2 * 1024 + k] + T[1][r]) + X[3 * 1024 + k];
         else if (xi == 2) v = (X[0 * 1024 + k] - T[0][r]) - X[4 * 1024 + k];
         else v = (X[5 * 1024 + k] - X[3 * 1024 + k]) - T[1][r];
-        const int t = tile_of_row((r & 3) + 8 * (r >> 2) + 4 * h);
-        const int oy = y0 + 2 * (t >> 3) + oa, ox = x0 + 2 * (t & 7) + ob;
-        y[(((long)n * H + oy) * W + ox) * C + nt * 32 + j] = v + bco;
+        const int row0 = (r & 3) + 8 * (r >> 2);
+        const int t0 = tile_of_row_c(row0), t1 = tile_of_row_c(row0 + 4);               // constants after unrolling
+        const int off0 = (t0 >> 3) * rowb + (t0 & 7) * colb, off1 = (t1 >> 3) * rowb + (t1 & 7) * colb;   // wave-uniform
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v + bco), rsy, lane_base + (h ? off1 : off0), 0, 0);
     }
 }
 
