@@ -98,7 +98,7 @@ def time_kernel(fn, iters=20, warm=3):
     """Average duration (s) of one launch group: `iters` launches captured into ONE hipGraph on the launch stream and the replay
     bracketed by HIP events on that stream.  (Round 2 timed eager launches from Python: the host gap between two dependent launches
     - 20-25 us of interpreter + dispatch per call - sat inside the bracket, 8 % of a 0.29 ms kernel; the replay leaves the ~2 us
-    dependent-launch floor, so the figure follows the rocprofv3 duration of the same launch in profiles/r05_roofline_launch_durations.txt, a kernel trace of
+    dependent-launch floor, so the figure follows the rocprofv3 duration of the same launch in profiles/r06_roofline_launch_durations.txt, a kernel trace of
     `scripts/kbench.py --only <layer>` in which every row is one of these launches and nothing else.)"""
     for _ in range(warm):
         fn()
@@ -118,7 +118,7 @@ def time_kernel(fn, iters=20, warm=3):
 
 
 def kernel_rooflines(cg, cfg, N):
-    """The kernels that carry the step of configuration `cfg` (profiles/r05_breakdown_config*.txt), each timed in isolation with
+    """The kernels that carry the step of configuration `cfg` (profiles/r06_eager_breakdown.txt for configs[1]), each timed in isolation with
     HIP events on the launch stream at the benchmarked batch: EXECUTED MFMA FLOPs per launch / duration against the fp32 MFMA
     peak.  The FIRST entry is the configuration's dominant kernel.  `traffic` / MFMA-pipe utilisation come from the committed PMC
     pass of the same launches where one exists (profiles/*_pmc_kernels.json, scripts/pmc_kernels.sh: config 2 only; bench.py
@@ -127,11 +127,14 @@ def kernel_rooflines(cg, cfg, N):
     lib, stream = cg.tensor.lib(), cg.tensor.stream()
     out = []
     pmc = {}
-    if cfg is CONFIGS[2]:
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-        except Exception:
-            pass
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+    except Exception:
+        pass
+    if cfg is CONFIGS[3]:       # the counter passes of the other configurations' dominant launches carry their own keys (round 6)
+        pmc = {"wino_g16": pmc.get("config3_wino_g16_bs256")} if pmc.get("config3_wino_g16_bs256") else {}
+    elif cfg is CONFIGS[5]:
+        pmc = {"tn128x128": pmc.get("config5_tn128x128_bs64_16to32")} if pmc.get("config5_tn128x128_bs64_16to32") else {}
 
     def entry(key, kernel, what, flop, t, direct=None, share=None, extra=None, alg_bytes=None):
         e = {"bound": "mfma", "kernel": kernel, "launch": what, "flop_per_launch": flop, "launch_ms": 1e3 * t,
@@ -248,7 +251,7 @@ def kernel_rooflines(cg, cfg, N):
     px = N * h2 * h2
     entry("tn128x128", "igemm_tng_kernel<128,128,2,2> (gemm.hip; LDS-direct loads)",
           f"weight-gradient GEMM of upsample2 -> conv3x3 512->256 @{h2}->{2 * h2}, batch {N}: 4 phases x [2048 x {px}]^T.[{px} x 256], pixels split",
-          2.0 * px * 4 * 2048 * 256, t, direct, "14 % of the step's kernel time at config 2 (6 launches; profiles/r05_eager_breakdown.txt)",
+          2.0 * px * 4 * 2048 * 256, t, direct, "15 % of the step's kernel time at config 2 (6 launches; profiles/r06_eager_breakdown.txt)",
           {"launch_group_ms": 1e3 * t_group, "launch_group": "accGradParameters of the layer = this GEMM + wgrad_reduce_kernel<true> + bias_part_reduce_kernel"},
           alg_bytes=4.0 * (px * 512 + 4 * px * 256 + 9 * 512 * 256))
     # (2) igemm_nng_kernel<64,128,2,2,32> (LDS-direct loads): forward of G's first convolution behind the first upsampling
@@ -533,12 +536,12 @@ def main():
                 }
             if args.config == 2:
                 res["roofline"]["step"].update({
-                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.88, "D forward": 0.95, "D backward + Adam": 1.25,
-                                         "D forward + data gradient (G step)": 1.20, "generator backward + Adam": 1.75},
-                    "phases_note": "the generator's forward on N for the G step runs BESIDE the first three phases on its own hardware queue since round 5 "
-                                   "(adversarial.py: concurrent_g_both), so it has no interval of its own and the intervals it shares are longer than in round 4",
-                    "phases_source": "profiles/r05_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
-                                     "launches, 6.03 ms under the tracer; committed numbers, not measured in this run)"})
+                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.86, "D forward": 0.85, "D backward + Adam": 1.15,
+                                         "D forward + data gradient (G step)": 1.09, "generator backward + Adam": 1.69},
+                    "phases_note": "the generator's forward on N for the G step runs BESIDE the first two phases on its own hardware queue (cg_net_forward_pair), "
+                                   "so it has no interval of its own and the intervals it shares are longer than they would be alone (0.55 / 0.53 ms in the reference order)",
+                    "phases_source": "profiles/r06_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
+                                     "launches, 5.70 ms under the tracer; committed numbers, not measured in this run)"})
         # the reference's ORDER of calls (adversarial.lua:232-233 ... :185: the G-step's generator forward after D's update) in the same run:
         # what an unchanged adversarial.lua gets from the drop-in host; the headline issues the two generator forwards as one
         # cg_net_forward_pair (MODEL_G:forwardPair - six lines of adversarial.lua)

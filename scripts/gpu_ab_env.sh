@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 for rep in 1 2; do
 for kv in "$@"; do
-  env $kv timeout 300 python bench.py --steps ${STEPS:-60} --warmup 10 --no-cpu-baseline --no-kernel-roofline ${BENCH_ARGS:-} 2>/dev/null | python -c "
+  env $kv timeout 300 python bench.py --steps ${STEPS:-60} --warmup 10 --no-cpu-baseline --no-kernel-roofline --no-other-configs --no-dp-dry-run --no-reference-order ${BENCH_ARGS:-} 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read()); print('$kv', j['config']['launch'], round(j['ms_per_step'],4), round(j['value'],1))"
 done
