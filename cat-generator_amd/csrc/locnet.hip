@@ -480,7 +480,7 @@ template <int S, int CIN>
 __global__ __launch_bounds__(NT2) void locnet_fwd2_k(LocFwd a) {
     // Highest wave priority: this is a latency-bound kernel at the head of D's chain that in the D-step becomes ready beside the second
     // generator pass's Winograd GEMM (which keeps every SIMD's MFMA pipe and LDS busy): 249 -> 190 us in the traced step, step 5.62 -> 5.59 ms
-    // same box (profiles/r06_sweeps.txt).  What remains is contention a priority cannot remove (19 us alone).
+    // same box (profiles/r06_sweeps.txt, call r06o).  What remains is contention a priority cannot remove (19 us alone).
     __builtin_amdgcn_s_setprio(3);
     using C = Cfg<S, CIN>;
     extern __shared__ float sm[];
