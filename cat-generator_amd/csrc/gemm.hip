@@ -129,6 +129,7 @@ struct TNArgs {
     Geom g;
     int pchunk;         // pixels per split (multiple of BK)
     int xcd_swizzle;
+    int pm_n;           // igemm_tng_kernel mode 2 (position-major K tiles): images per launch, a multiple of BK
     long xgs, dgs;      // != 0: group g reads x0 + g * xgs / d0 + g * dgs (up to kMaxStridedGroups equally spaced groups: the
                         // Winograd-domain weight-gradient GEMMs of winograd.hip in one launch), x1.. / d1.. unused
 };
@@ -1287,10 +1288,19 @@ __global__ __launch_bounds__(256, 4) void igemm_tn_kernel(TNArgs a) {
 // rows of 4 BM bytes into place (no swizzle, ds_read_b32 fragments exactly as in igemm_tn_kernel).  Lean addressing only
 // (the host checks, tng_ok): 16-byte aligned channel quads, a source tensor with the grid's geometry, a reduction range of whole K
 // tiles, and either a power-of-two grid with HWg >= 16 (a K tile never straddles two images) or a 1 x 1 kernel without padding
-// (`flat`: every row is valid and rows are simply consecutive - the linear layers and the Winograd-domain GEMMs).
+// (`flat`, mode 1: every row is valid and rows are simply consecutive - the linear layers and the Winograd-domain GEMMs).
+//
+// Mode 2, POSITION-MAJOR K tiles (round 6; models.lua:681,685 - D32_st3's 5x5 and 7x7 layers - and :696-697, the View -> Linear head as
+// an H x W convolution): a K tile is ONE grid position (oy, ox) of 16 consecutive images, so all its rows share their zero-padding taps
+// and a workgroup - whose dW rows belong to one or two taps - runs its K loop only over the rectangle of positions at which one of its
+// taps reads inside the image: the 38 % / 14 % of the MACs that multiply padding are not issued.  The splits divide each workgroup's
+// OWN tile list evenly, rows of a tile are a whole image apart (a per-lane offset, as before), and the grid needs no power-of-two
+// geometry, nor 16 pixels per image.  gradBias rides on the row tile that holds the centre tap (its rectangle is the whole grid).
 // ---------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int flat) {
+__global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int mode) {
+    const int flat = mode == 1;
+    const bool pm = mode == 2;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int MI = BM / WM / 32;
     constexpr int NI = BN / WN / 32;
@@ -1333,7 +1343,29 @@ __global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int flat) {
     const float* gdy = a.dgs ? a.d0 + (long)group * a.dgs : sel4(group, a.d0, a.d1, a.d2, a.d3);
     const int ps = split * a.pchunk;
     const int pend = min(g.M, ps + a.pchunk);
-    const int T = CG_PROBE_HALF(2, (pend - ps) / BK);
+    int T = CG_PROBE_HALF(2, (pend - ps) / BK);
+    int q_c = 0, q_x = 0, q_y = 0, q_x0 = 0, q_x1 = 0, q_nc = 1;   // mode 2: image chunk / position of the next tile, the rectangle's columns
+    if (pm) {
+        const int t_lo = m0 / g.Cin, t_hi = min(g.Ktot - 1, m0 + BM - 1) / g.Cin;
+        int y0 = g.Hg, y1 = 0, x0 = g.Wg, x1 = 0;
+        for (int t = t_lo; t <= t_hi; ++t) {
+            int ty, tx, off;
+            tap_decode(g, t, pa, pb, ty, tx, off);
+            y0 = min(y0, max(0, -ty)); y1 = max(y1, min(g.Hg, g.Hv - ty));
+            x0 = min(x0, max(0, -tx)); x1 = max(x1, min(g.Wg, g.Wv - tx));
+        }
+        const int rw = max(0, x1 - x0), rh = max(0, y1 - y0);
+        q_nc = a.pm_n / BK;
+        const long L = (long)rw * rh * q_nc;
+        const int u0 = (int)(L * split / (int)gridDim.y), u1 = (int)(L * (split + 1) / (int)gridDim.y);
+        T = CG_PROBE_HALF(2, u1 - u0);
+        if (T > 0) {
+            const int pos = u0 / q_nc;
+            q_c = u0 - pos * q_nc;
+            q_y = y0 + pos / rw; q_x = x0 + pos % rw;
+        }
+        q_x0 = x0; q_x1 = x1;
+    }
 
     const int a_mv = tid % AVEC, a_kr = tid / AVEC;
     const int b_nv = tid % BVEC, b_kr = tid / BVEC;
@@ -1360,29 +1392,47 @@ __global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int flat) {
 #pragma unroll
     for (int q = 0; q < APASS; ++q) {
         const int kr = a_kr + q * ARPP;
-        const int kyo = wide ? 0 : (kr >> g.lgW), kxo = flat ? 0 : (wide ? kr : (kr & (g.Wg - 1)));
+        const int kyo = (wide || pm) ? 0 : (kr >> g.lgW), kxo = (flat || pm) ? 0 : (wide ? kr : (kr & (g.Wg - 1)));
         l_ay[q] = kyo + c_ty;
         l_ax[q] = kxo + c_tx;
-        l_avoff[q] = (c_ok && kr < BK) ? (unsigned)(kr * g.Cin + c_off - l_minoff) * 4u : OOB;
+        l_avoff[q] = (c_ok && kr < BK) ? (unsigned)(kr * (pm ? g.Hs * g.Ws : 1) * g.Cin + c_off - l_minoff) * 4u : OOB;
     }
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
         const int kr = b_kr + q * BRPP;
         const int byo = wide ? 0 : (kr >> g.lgW), bxo = wide ? kr : (kr & (g.Wg - 1));
-        const int rel = lin_out ? kr * g.Cout : (byo * g.so * g.Wout + bxo * g.so) * g.Cout;
+        const int rel = pm ? kr * g.Hout * g.Wout * g.Cout : (lin_out ? kr * g.Cout : (byo * g.so * g.Wout + bxo * g.so) * g.Cout);
         l_bvoff[q] = (b_nok && kr < BK) ? (unsigned)(rel + n0 + 4 * b_nv) * 4u : OOB;
     }
-    // gradBias rides along on the row-tile 0 workgroups: column sums of the dy rows, read back from the LDS tile
-    const bool do_bias = a.bias_part != nullptr && tm == 0;
+    // gradBias rides along on the row-tile 0 workgroups (mode 2: the tile of the tap at offset (0, 0), which visits every position):
+    // column sums of the dy rows, read back from the LDS tile
+    const int tm_bias = pm ? ((-g.td.r0y0) * g.td.kw + (-g.td.r0x0)) * g.Cin / BM : 0;
+    const bool do_bias = a.bias_part != nullptr && tm == tm_bias;
     float bsum = 0.f;
 
     auto dma_tile = [&](int p0, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         float* A = buf ? As1 : As0;
         float* B = buf ? Bs1 : Bs0;
-        const int r0 = flat ? 0 : (p0 & (HWg - 1));
-        const int oyb = flat ? 0 : (r0 >> g.lgW), oxb = flat ? 0 : (r0 & (g.Wg - 1));
-        const int soa = p0 * g.Cin * 4;
+        int oyb, oxb, soa, sob;
+        if (pm) {   // wave-uniform: the next tile of this workgroup's list
+            oyb = q_y; oxb = q_x;
+            soa = ((q_c * BK * g.Hs + q_y) * g.Ws + q_x) * g.Cin * 4;
+            sob = ((q_c * BK * g.Hout + q_y) * g.Wout + q_x) * g.Cout * 4;
+            if (++q_c == q_nc) {
+                q_c = 0;
+                if (++q_x == q_x1) { q_x = q_x0; ++q_y; }
+            }
+        } else {
+            const int r0 = flat ? 0 : (p0 & (HWg - 1));
+            oyb = flat ? 0 : (r0 >> g.lgW); oxb = flat ? 0 : (r0 & (g.Wg - 1));
+            soa = p0 * g.Cin * 4;
+            if (lin_out) sob = p0 * g.Cout * 4;
+            else {
+                const int nimg = p0 >> g.lgHW;
+                sob = (((nimg * g.Hout + oyb * g.so + pa) * g.Wout + oxb * g.so + pb) * g.Cout) * 4;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < APASS; ++q) {
             const int row0 = q * ARPP + wave * ARPW;   // wave-uniform
@@ -1390,12 +1440,6 @@ __global__ __launch_bounds__(256, 2) void igemm_tng_kernel(TNArgs a, int flat) {
                 const bool ok = (unsigned)(oyb + l_ay[q]) < (unsigned)g.Hv && (unsigned)(oxb + l_ax[q]) < (unsigned)g.Wv;
                 glds16(rsx, A + row0 * LDA, ok ? l_avoff[q] : OOB, soa);
             }
-        }
-        int sob;
-        if (lin_out) sob = p0 * g.Cout * 4;
-        else {
-            const int nimg = p0 >> g.lgHW;
-            sob = (((nimg * g.Hout + oyb * g.so + pa) * g.Wout + oxb * g.so + pb) * g.Cout) * 4;
         }
 #pragma unroll
         for (int q = 0; q < BPASS; ++q) {
@@ -2200,11 +2244,41 @@ static bool tng_ok(const Geom& g, int pchunk, bool veca, bool vecb) {
 }
 static bool tng_flat(const Geom& g) { return g.ntaps == 1 && g.td.r0y0 == 0 && g.td.r0x0 == 0 && g.so == 1 && g.nphase == 1; }
 
+// Position-major K tiles (igemm_tng_kernel mode 2): the share of the layer's MACs that multiply zero padding in per cent, -1 = not this
+// geometry (a plain stride-1 convolution with a tap at offset (0, 0) that is valid at every position, whole K tiles of images).
+static int tn_pm_share(const Geom& g) {
+    if (g.nphase != 1 || g.so != 1 || g.td.ss != 1 || g.td.ngroups != 1 || g.td.sgn != 1 || g.ntaps < 2) return -1;
+    if (g.Hout != g.Hg || g.Wout != g.Wg || g.Hg > g.Hv || g.Wg > g.Wv || g.Cin % 4 || g.Cout % 4) return -1;
+    const int hw = g.Hg * g.Wg, N = g.M / hw, kh = g.td.kk / g.td.kw;
+    if ((long)N * hw != g.M || N % BK) return -1;
+    if (g.td.r0y0 > 0 || g.td.r0x0 > 0 || -g.td.r0y0 >= kh || -g.td.r0x0 >= g.td.kw) return -1;
+    if ((long)N * g.Hs * g.Ws * g.Cin * 4L >= 0x7fffffffL || (long)g.M * g.Cout * 4L >= 0x7fffffffL) return -1;
+    long valid = 0;
+    for (int t = 0; t < g.ntaps; ++t) {
+        int ty, tx, off;
+        tap_decode(g, t, 0, 0, ty, tx, off);
+        const int rh = std::min(g.Hg, g.Hv - ty) - std::max(0, -ty), rw = std::min(g.Wg, g.Wv - tx) - std::max(0, -tx);
+        if (rh <= 0 || rw <= 0) return -1;
+        valid += (long)rh * rw;
+    }
+    return (int)(100 - 100 * valid / ((long)g.ntaps * hw));
+}
+// ... used when the padding is at least HALF of CG_PAD_SKIP's share (default 20 -> 10 %: D32_st3's 7x7 at 8x8 38 %, 3x3 at 8x8 16 %, 5x5 at
+// 16x16 14 %), or when the image-major tiles cannot run at all (fewer than 16 pixels per image: the View -> Linear head's 1 x 1 grid)
+static bool tn_pm_use(const Geom& g, bool image_major_ok) {
+    const long thr = cg::opt(cg::OPT_PAD_SKIP);
+    if (thr <= 0 || !cg::opt(cg::OPT_TN_GLDS)) return false;
+    const int sh = tn_pm_share(g);
+    static const char* e = getenv("CG_TN_PM_THR");
+    const long t2 = e ? atol(e) : thr;
+    return sh >= 0 && (2 * sh >= t2 || !image_major_ok);
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_tng(const TNArgs& a, dim3 grid, hipStream_t st) {
     // (round 5: capping the workgroups per CU with unused dynamic LDS - 3, 2, 1 instead of 4 - to leave slots for the other queues'
     // memory-bound kernels measured 6.05 / 5.95 / 6.10 ms per step against 5.93: profiles/r05_sweeps.txt)
-    hipLaunchKernelGGL((igemm_tng_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, a, tng_flat(a.g) ? 1 : 0);
+    hipLaunchKernelGGL((igemm_tng_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, a, a.pm_n ? 2 : (tng_flat(a.g) ? 1 : 0));
 }
 
 static int ilog2_exact(int v) {
@@ -2328,8 +2402,11 @@ static size_t nn_ws_bytes(const Geom& g, const NNPlan& p, int ngroups) {
     return b;
 }
 
-struct TNPlan { TileCfg tc; int splits; int pchunk; };
-static TNPlan plan_tn(const Geom& g, int ngroups) {
+struct TNPlan { TileCfg tc; int splits; int pchunk; bool pm; };
+static bool tn_pm_use(const Geom& g, bool image_major_ok);
+static bool tng_ok(const Geom& g, int pchunk, bool veca, bool vecb);
+static int tn_pm_share(const Geom& g);
+static TNPlan plan_tn(const Geom& g, int ngroups, bool allow_pm = true) {
     TNPlan p;
     int bn = g.Cout > 64 ? 128 : (g.Cout > 32 ? 64 : 32);
     int bm = g.Ktot > 64 ? 128 : 64;
@@ -2341,6 +2418,17 @@ static TNPlan plan_tn(const Geom& g, int ngroups) {
     const long piters = cg::cdiv(g.M, BK);
     const int smax = kTnSplitMax, tgt = kTnTarget;
     const int forced = (int)cg::opt(cg::OPT_TN_SPLITS);
+    p.pm = allow_pm && tn_pm_use(g, tng_ok(g, BK, true, true));
+    if (p.pm) {
+        // position-major tiles: a split is a share of every workgroup's OWN tile list, so any count works - the one that fills tgt
+        // workgroups per CU most exactly (D32_st3's 5x5 layer: 13 tiles x 59 = 767 workgroups 119 us, x 64 = 832 130 us), with >= 8 K
+        // tiles per workgroup on average (profiles/r06_sweeps.txt)
+        const long kt = std::max<long>(1, piters * (100 - tn_pm_share(g)) / 100);
+        long sp = forced > 0 ? forced : std::min<long>((long)tgt * cg::kNumCU / std::max<long>(1, tiles), kt / 8);
+        p.splits = (int)std::max<long>(1, std::min<long>(sp, smax));
+        p.pchunk = 0;
+        return p;
+    }
     int s = 1;
     if (forced > 0) s = (int)std::min<long>(forced, std::max<long>(1, piters));
     else
@@ -2350,7 +2438,9 @@ static TNPlan plan_tn(const Geom& g, int ngroups) {
     return p;
 }
 static size_t tn_ws_bytes(const Geom& g, const TNPlan& p, int ngroups) {
-    return (size_t)p.splits * ngroups * g.nphase * ((size_t)g.Ktot + 1) * g.Cout * sizeof(float);
+    // a position-major plan falls back to the image-major one for unaligned operands: room for either
+    const int splits = p.pm ? std::max(p.splits, plan_tn(g, ngroups, false).splits) : p.splits;
+    return (size_t)splits * ngroups * g.nphase * ((size_t)g.Ktot + 1) * g.Cout * sizeof(float);
 }
 
 // ---- skinny 3x3 path (see skinny_conv3x3_kernel) ----
@@ -2774,6 +2864,7 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
         any_gb = any_gb || (gb && gb[i]);
     }
     if (strided) { veca = veca && xgs % 4 == 0; vecb = vecb && dgs % 4 == 0; }
+    if (p.pm && !(veca && vecb)) p = plan_tn(g, ngroups, false);   // unaligned operands: the image-major plan (the workspace holds either)
     a.xgs = xgs; a.dgs = dgs;
     a.x0 = xs[0]; a.x1 = xs[1]; a.x2 = xs[2]; a.x3 = xs[3];
     a.d0 = ds[0]; a.d1 = ds[1]; a.d2 = ds[2]; a.d3 = ds[3];
@@ -2784,7 +2875,8 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
     a.bias_part = any_gb ? (float*)ws + (size_t)p.splits * ZP * wplane : nullptr;
     hipStream_t st = cg::S(stream);
     dim3 grid(cg::cdiv(g.Ktot, p.tc.bm) * cg::cdiv(g.Cout, p.tc.bn), p.splits, ZP);
-    if (tng_ok(g, p.pchunk, veca, vecb)) {
+    if (p.pm && veca && vecb) a.pm_n = g.M / (g.Hg * g.Wg);
+    if (a.pm_n || tng_ok(g, p.pchunk, veca, vecb)) {
         if (p.tc.bm == 128 && p.tc.bn == 128) launch_tng<128, 128, 2, 2>(a, grid, st);
         else if (p.tc.bm == 64 && p.tc.bn == 128) launch_tng<64, 128, 2, 2>(a, grid, st);
         else if (p.tc.bm == 128 && p.tc.bn == 64) launch_tng<128, 64, 2, 2>(a, grid, st);

@@ -53,6 +53,20 @@ def lin_case(name, N, i, o):
     return name, flop, r
 
 
+def head_case(name, N, C, H, o):
+    """View(C*H*H) -> Linear on the NHWC map through the planned executor (an H x H convolution with a 1 x 1 grid): forward, and
+    backward = data gradient + weight gradient in one call (the wgrad column)."""
+    net = cg.nn.Sequential()
+    net.add(cg.nn.View(C * H * H)); net.add(cg.nn.Linear(C * H * H, o))
+    net.getParameters()
+    x = cg.nn.as_nhwc(cg.Tensor(torch.rand(N * C * H * H, device="cuda") - 0.5, (N, C, H, H)))
+    dy = cg.Tensor(torch.rand(N * o, device="cuda") - 0.5, (N, o))
+    net.forward(x)
+    flop = 2.0 * N * C * H * H * o
+    r = {"fwd": tk(lambda: net.forward(x)), "dgrad": float("inf"), "wgrad": tk(lambda: net.backward(x, dy))}
+    return name, flop, r
+
+
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 128
     quick = "--quick" in sys.argv
@@ -87,6 +101,7 @@ def main():
              "dbr16": lambda: conv_case("D.br conv 3x3 64->64 @16^2", N, 64, 16, 64, 3, 0),
              "dbr8": lambda: conv_case("D.br conv 3x3 64->64 @8^2", N, 64, 8, 64, 3, 0),
              "dlin": lambda: lin_case("D.linear 20480->256", N, 20480, 256),
+             "dhead": lambda: head_case("D.head View->Linear 320x8x8->256", N, 320, 8, 256),
              "loc": lambda: conv_case("D.loc 3x3 64->16 @8^2 (3 branches stacked)", 3 * N, 64, 8, 16, 3, 0)}
     if only:
         cases = [named[o] for o in only.split(",")]
