@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libcatgan_hip.so")
-SOURCES = ["gemm.hip", "winograd.hip", "skinny.hip", "wino3.hip", "ops.hip", "fused.hip", "comm.hip", "locnet.hip", "net.hip"]
+SOURCES = ["gemm.hip", "winograd.hip", "skinny.hip", "wino3.hip", "headwg.hip", "ops.hip", "fused.hip", "comm.hip", "locnet.hip", "net.hip"]
 ARCH = "gfx950"
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"]   # no -munsafe-fp-atomics: nothing on the path adds floats atomically

@@ -96,6 +96,9 @@ int skinny_mfma_wgrad(hipStream_t st, const float* x, const float* dy, float* pa
 
 // Fused-transform Winograd F(2x2,3x3) for plain 64 -> 64 plane 3x3 convolutions (csrc/wino3.hip, round 6).  CG_WINO3: 1 = where the
 // geometry fits and the launch has >= 2 workgroups per CU, 2 = wherever the geometry fits (tests), 0 = never (the direct implicit GEMM).
+// headwg.hip: weight gradient of nn.View -> nn.Linear on an NHWC map (T = H*W taps of C planes) straight into the canonical gradWeight
+bool head_wgrad_ok(int N, int T, int C, int Co);
+int head_wgrad(hipStream_t st, const float* x, const float* dy, float* gw, float* gb, int N, int T, int C, int Co, float scale);
 bool wino3_geom_ok(int ngroups, int N, int H, int W, int Cin, int Cout, int kH, int kW, int padH, int padW, int ups);
 int wino3_note_pack(hipStream_t st, int n, const float* const* w, float* const* wf, float* const* wb, const int* Cout, const int* Cin,
                     const int* kH, const int* kW, const int* wb_map);

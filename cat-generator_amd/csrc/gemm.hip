@@ -2850,6 +2850,11 @@ int wgrad_impl(void* stream, int ngroups, const float* const* x, const float* co
         job.wblocks = cg::cdiv(9L * Cin * Cout, 32); job.bblocks = gb0 ? cg::cdiv(Cout, 32) : 0;
         return small_reduce(st, defer, job, 1);
     }
+    // nn.View -> nn.Linear (an H x W kernel on the H x W map, 1 x 1 grid): one kernel straight into gradWeight (headwg.hip)
+    if (!strided && !gemm_only && ngroups == 1 && !ups && kH == Hp && kW == Wp && padH == 0 && padW == 0 && cg::opt(cg::OPT_PAD_SKIP) > 0 &&
+        cg::opt(cg::OPT_TN_GLDS) && cg::head_wgrad_ok(N, kH * kW, Cin, Cout) && x[0] && dy[0] && gw[0] && (uintptr_t)x[0] % 16 == 0 &&
+        (uintptr_t)dy[0] % 16 == 0 && (uintptr_t)gw[0] % 4 == 0)
+        return cg::head_wgrad(cg::S(stream), x[0], dy[0], gw[0], gb ? gb[0] : nullptr, N, kH * kW, Cin, Cout, scale) != 0;
     TNPlan p = plan_tn(g, ngroups);
     const size_t need = tn_ws_bytes(g, p, ngroups);
     CG_REQUIRE(ws && ws_bytes >= need, "cg_conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);

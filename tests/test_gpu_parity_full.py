@@ -337,13 +337,13 @@ def test_position_major_tiles_skip_the_padding_taps(cg, shape, splits):
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("splits", [0, 1, 3, 16])
+@pytest.mark.parametrize("splits", [0, 3, 16])
 @pytest.mark.parametrize("shape", [(32, 128, 8, 128, 7), (16, 64, 16, 128, 5), (48, 64, 8, 64, 3), (16, 16, 16, 16, 3), (32, 64, 6, 64, 5)])
 def test_position_major_weight_gradient_skips_the_padding(cg, shape, splits):
     """igemm_tng_kernel mode 2 (gemm.hip; round 6): the weight gradient's K tiles are ONE grid position of 16 images, and a workgroup -
     whose dW rows belong to one or two taps (eight with 16 input planes) - visits only the rectangle of positions at which one of its
     taps reads inside the image (models.lua:681,685: 14 % / 38 % of the MACs multiply padding).  gradWeight and gradBias (which rides on
-    the centre tap's tile) against the oracle: the plan's splits, unsplit, and 3 / 16 splits of every workgroup's own tile list (more
+    the centre tap's tile) against the oracle: the plan's splits and 3 / 16 splits of every workgroup's own tile list (more
     splits than a corner tap has tiles included); a 6 x 6 map (no power-of-two geometry needed); then against the image-major tiles
     (CG_PAD_SKIP = 0) - equal up to the order of the pixel sum."""
     N, Cin, H, Cout, k = shape
@@ -356,12 +356,12 @@ def test_position_major_weight_gradient_skips_the_padding(cg, shape, splits):
     close(gws[0][1], gws[1][1], K=N * H * H, tol=4e-5, what="gradBias position-major vs image-major")
 
 
-@pytest.mark.parametrize("N", [16, 128])
-def test_view_linear_head_weight_gradient_on_position_major_tiles(cg, N):
+@pytest.mark.parametrize("N", [16, 64, 128])
+def test_view_linear_head_weight_gradient_straight_into_gradweight(cg, N):
     """models.lua:696-697: View(320*8*8) -> Linear(20480, 256) on the NHWC map runs as an 8 x 8 convolution with a 1 x 1 output grid
-    (cg_pack_conv_weight_map); its weight gradient has 16-image K tiles of that one position (mode 2 of igemm_tng_kernel; the
-    image-major LDS-direct tiles need 16 pixels per image).  Against the oracle's linear layer, and against CG_PAD_SKIP = 0 (the
-    register-staged igemm_tn_kernel)."""
+    (cg_pack_conv_weight_map); its weight gradient is ONE kernel that adds into the canonical gradWeight[co][c][tap] (headwg.hip: the
+    batch is the K dimension, an accumulator register holds 16 taps of one plane).  Against a float64 product, accumulate semantics
+    included, and against CG_PAD_SKIP = 0 (the register-staged igemm_tn_kernel + the transposing reduction it replaces)."""
     C, H, Co = 320, 8, 256
     rs = np.random.RandomState(21)
     w = (rs.randn(Co, C * H * H) / np.sqrt(C * H * H)).astype(f32)
@@ -384,6 +384,9 @@ def test_view_linear_head_weight_gradient_on_position_major_tiles(cg, N):
             gw = lin.gradWeight.numpy().copy()
             close(gw, gw_ref, K=N, tol=4e-5, what="gradWeight")
             close(lin.gradBias.numpy(), dy.sum(0), K=N, tol=4e-5, what="gradBias")
+            net.backward(xin, cg.Tensor.from_numpy(dy))          # accGradParameters accumulates
+            close(lin.gradWeight.numpy(), 2.0 * gw_ref, K=N, tol=4e-5, what="gradWeight accumulated twice")
+            close(lin.gradBias.numpy(), 2.0 * dy.sum(0), K=N, tol=4e-5, what="gradBias accumulated twice")
             got.append(gw)
     close(got[0], got[1], K=N, tol=4e-5, what="gradWeight position-major vs register-staged")
 
