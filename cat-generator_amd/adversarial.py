@@ -113,6 +113,10 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
     st = {"doTrainD": True}
     # data parallelism: G's gradient travels in per-layer buckets started from inside the planned backward
     S.MODEL_G._bucket_overlap = bool(parallel.world_size() > 1 and OPT.get("overlap_comm", True) and _bucketable(S.MODEL_G) and nn.planned)
+    # ... and so does D's (round 6): Linear(20480, 256) is 79 % of D's gradient and the FIRST bucket its backward completes, so it travels
+    # under the whole of D's backward instead of after it (with both generator forwards at the head of the iteration nothing else is left
+    # to hide it under).  Not with exact_reference_backward, whose G-step would start exchanges of a D gradient nobody reads.
+    S.MODEL_D._bucket_overlap = bool(S.MODEL_G._bucket_overlap and _bucketable(S.MODEL_D) and not OPT["exact_reference_backward"])
 
     # ------------------------------------------------------------------ fevalD (adversarial.lua:72-167)
     def fevalD(x):
@@ -127,7 +131,9 @@ def iteration(S, trainData, thisBatchSize=None, maxAccuracyD=1.01, accsInterval=
         f = S.CRITERION.forward(outputs, targets)
         df_do = S.CRITERION.backward(outputs, targets)
         S.MODEL_D.backward(inputs, df_do)   # planned: weight-gradient reductions deferred and flushed inside cg_net_backward
-        if st.get("overlap"):  # start the xGMI all-reduce now, finish it after the G-step's generator forward
+        if getattr(S.MODEL_D, "_bucket_overlap", False) and S.MODEL_D._planned_last and S.MODEL_D._pnet[1].finish_buckets():
+            st["pendingD"] = _Done()        # the buckets travelled under the backward and are joined
+        elif st.get("overlap"):  # start the xGMI all-reduce now, finish it after the G-step's generator forward
             st["pendingD"] = parallel.allreduce_mean_async(S.GRAD_PARAMETERS_D.t)
         else:
             parallel.allreduce_mean_(S.GRAD_PARAMETERS_D.t)
@@ -280,6 +286,11 @@ def _both_forwards_ok(S, N):
                 and type(G) is nn.Sequential and getattr(G, "_pnet", None) and G._pnet[1] is not None and getattr(G, "_planned_last", False)
                 and getattr(G._pnet[1], "last_draws", 0) == 0     # a G that draws (Dropout) would move the counter stream under the side pass
                 and OPT["batchSize"] >= N)
+
+
+class _Done:
+    def finish(self):
+        pass
 
 
 def _bucketable(G):

@@ -319,6 +319,7 @@ struct Compiler {
     bool failed = false;
     int pend[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // deferred weight-gradient reductions queued per stream index
     bool wg_used[4] = {false, false, false, false};   // the weight-gradient stream beside stream s has work to join
+    bool wg_unjoined[4] = {false, false, false, false};   // ... that no gradient bucket has waited for yet
     bool acc_pass = false;        // compiling Module:backward (weight gradients deferred) rather than updateGradInput
 
     Compiler(Net* n, Prog* p) : net(n), pr(p) {}
@@ -1476,7 +1477,7 @@ struct Compiler {
         cs = 4 + s;
         emit([=](Run& c) { return c.net->trace ? (trace_note(c.net, "event|wait|wgfork" + std::to_string(s) + "|s" + std::to_string(4 + s)), 0)
                                                 : (hipStreamWaitEvent((hipStream_t)c.S(4 + s), c.net->wg_fork_ev[s], 0) == hipSuccess ? 0 : 1); });
-        wg_used[s] = true;
+        wg_used[s] = true; wg_unjoined[s] = true;
         return s;
     }
     void wg_leave(int s) { cs = s; }
@@ -2296,7 +2297,8 @@ struct Compiler {
 
     // ---------------------------------------------------------------------------------------- data-parallel exchanges
     void bucket_done(int first_module);   // root Sequential, acc pass: every parameter gradient of modules[first_module:] is on the stream
-    int bucket_done_upto = 0;
+    void buckets_start();                 // start the all-reduce of every complete bucket that has not been started
+    int bucket_done_upto = 0, bucket_ready = -1;
 };
 
 enum { HOOK_ALLREDUCE_SUM = 0, HOOK_BUCKET_START = 1, HOOK_BUCKETS_FINISH = 2 };
@@ -2315,12 +2317,31 @@ void Compiler::emit_allreduce_sum(const Val& v, long count, int dtype) {
         if (n->hook) return n->hook(n->hook_user, HOOK_ALLREDUCE_SUM, p, (size_t)count, dtype, c.CS()) ? cg::fail("cg_net: the host hook failed (sync-BN all-reduce of %ld elements)", count) : 0;
         return cg::fail("cg_net: world > 1 with sync-BN but neither a communicator (cg_net_set_dp) nor a host hook is set");
     });
+    if (acc_pass && cs == 0) buckets_start();   // a bucket held back for this exchange (bucket_done) goes behind it
 }
 // Gradient buckets of the root nn.Sequential: each convolution / linear layer with the parameters of the modules
 // up to the next one is a contiguous range of the flat gradient vector; as soon as the backward walk has passed it, its all-reduce
 // starts on the gradient communicator's stream, under the backward of the layers in front of it.
+// Collectives of the two communicators are ordered on the device (comm.hip), and a bucket's all-reduce sits behind its layer's whole weight
+// gradient: started right away it would make the sync-BN exchange of the NEXT layer's backward - the first thing on the data-gradient
+// chain - wait for that weight gradient (157 us of stall per layer in the one-GPU dry run, profiles/r06_dp_dry_run.txt).  So while a
+// batch-norm layer in front still has its exchange to make, a complete bucket is held back and started right behind that exchange.
 void Compiler::bucket_done(int first_module) {
     if (dry || !net->bucket_overlap || net->world <= 1) return;
+    bucket_ready = first_module;
+    bool bn_ahead = false;
+    if (net->sync_bn) {
+        const Mod& root = *net->mods[0];
+        for (int t = 0; t < first_module && t < (int)root.kids.size(); ++t) {
+            const Mod& m = *net->mods[root.kids[t]];
+            bn_ahead = bn_ahead || (m.kind == K_BN && m.train);
+        }
+    }
+    if (!bn_ahead) buckets_start();
+}
+void Compiler::buckets_start() {
+    if (dry || !net->bucket_overlap || net->world <= 1 || bucket_ready < 0 || bucket_ready >= bucket_done_upto) return;
+    const int first_module = bucket_ready;
     for (int t = bucket_done_upto - 1; t >= first_module; --t) {
         for (size_t bi = 0; bi < pr->bucket_first.size(); ++bi) {
             if (pr->bucket_first[bi] != t) continue;
@@ -2329,6 +2350,21 @@ void Compiler::bucket_done(int first_module) {
             wg_fork();
             const int s_ = wg_enter();
             flush_wgrad();
+            // ... and on the weight-gradient streams of the branch groups behind it (D32_st3's nn.Concat: streams 5..7), which nothing
+            // joins before the end of the pass: the collective's stream waits for what they hold so far (stream 0 does not)
+            const int here = cs;
+            for (int s = 0; s < 4; ++s) {
+                if (!wg_unjoined[s] || 4 + s == here) continue;
+                cs = 4 + s;
+                flush_wgrad();
+                emit([=](Run& c) { return c.net->trace ? (trace_note(c.net, "event|record|wgjoin" + std::to_string(s) + "|s" + std::to_string(4 + s)), 0)
+                                                        : (hipEventRecord(c.net->wg_join_ev[s], (hipStream_t)c.S(4 + s)) == hipSuccess ? 0 : 1); });
+                cs = here;
+                emit([=](Run& c) { return c.net->trace ? (trace_note(c.net, "event|wait|wgjoin" + std::to_string(s) + "|s" + std::to_string(here)), 0)
+                                                        : (hipStreamWaitEvent((hipStream_t)c.S(here), c.net->wg_join_ev[s], 0) == hipSuccess ? 0 : 1); });
+                wg_unjoined[s] = false;
+            }
+            wg_unjoined[s_] = false;
             float* ptr = pr->buckets[bi].first; const long cnt = pr->buckets[bi].second;
             emit([=](Run& c) -> int {
                 Net* n = c.net;
@@ -2753,7 +2789,7 @@ int cg_net_backward(void* net, void* stream, const float* x, const float* gy, in
         Val go = pr->out; go.ext = EXT_GY; go.off = 0; go.p = nullptr; go.fmt = gy_fmt; go.blk = 0; go.gi = go.gc = 0;
         Val gi = root.kind == K_SEQ ? C.walk_back(root, pr->in, go, acc != 0, true) : C.bwd(root, pr->in, go, acc != 0);
         if (C.failed) return cg::fail("%s", n->err);
-        if (acc) { C.flush_wgrad(); C.wg_join_all(); }
+        if (acc) { C.buckets_start(); C.flush_wgrad(); C.wg_join_all(); }
         CG_REQUIRE(!gi.is_tab, "cg_net_backward: the root module's gradInput is a table");
         pr->gin[acc] = gi;
         pr->have_bwd[acc] = true;

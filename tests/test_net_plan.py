@@ -257,6 +257,43 @@ def test_data_parallel_exchanges_sit_inside_the_plan():
         assert b[i - 1] == "event|wait|wgfork0|s4" or "cg_conv2d_wgrad_flush|s4" in b[i - 1]
     for (i0, _), (i1, _) in zip(buckets, buckets[1:]):                                   # the next layer's backward runs under the bucket
         assert sum(1 for l in b[i0:i1] if l.startswith("call|")) >= 3
+    # round 6: while a batch-norm layer in front still has its exchange to make, a bucket is held back and started right BEHIND that
+    # exchange (collectives of the two communicators are ordered on the device: started at once, the bucket - which sits behind its
+    # layer's whole weight gradient - would stall the next layer's sync-BN sums, the head of the data-gradient chain)
+    syncs = [i for i, l in enumerate(b) if l.startswith("hook|allreduce_sum")]
+    for (ib, _), isync in zip(buckets[:3], syncs):
+        between = [l for l in b[isync + 1:ib] if not l.startswith("event|")]
+        assert isync < ib and all("cg_conv2d_wgrad_flush|s4" in l for l in between), (isync, ib, between)
+        assert "cg_bn_act_backward|s0" in [l for l in b[ib + 1:] if l.startswith("call|")][0]     # the normalisation's backward follows
+    assert all(ib > syncs[-1] for ib, _ in buckets[3:])          # no exchange left in front: these start where their layer ends
+
+
+def test_discriminator_gradient_travels_in_buckets_too():
+    """Round 6: D32_st3's flat gradient in buckets started from inside cg_net_backward (adversarial.py sets _bucket_overlap on D as well):
+    nn.Linear(20480, 256) - 79 % of the vector - is the first large bucket the backward completes and travels under everything behind it.
+    The buckets tile the whole vector in reverse order, and a bucket that holds the nn.Concat's branches starts on a stream that has
+    waited for the branch groups' weight-gradient streams (s5..s7), which nothing else joins before the end of the pass."""
+    r = T.trace("D32_st3", 128, dp=dict(world=2, buckets=True))
+    b = r["backward"]
+    buckets = [(i, l.split("|")) for i, l in enumerate(b) if l.startswith("hook|bucket_start")]
+    assert len(buckets) >= 4
+    counts = [int(t[3]) for _, t in buckets]
+    offs = [int(t[2].split("+")[1]) // 4 for _, t in buckets]
+    assert sum(counts) == 6664777 and offs[-1] == 0
+    for (o0, c0), o1 in zip(zip(offs[1:], counts[1:]), offs):
+        assert o0 + c0 == o1                                     # contiguous, last layer first
+    assert max(counts) >= 20480 * 256 and counts.index(max(counts)) <= 1          # the head's bucket is among the first two started
+    big = buckets[counts.index(max(counts))][0]
+    assert sum(1 for l in b[big:] if l.startswith("call|")) >= 30                 # ... with the rest of the backward behind it
+    # the bucket that covers the branches: every used branch weight-gradient stream is recorded and waited for before it starts
+    used = sorted({l.split("|")[2] for l in b if l.startswith("call|") and l.split("|")[2] in ("s5", "s6", "s7")})
+    assert used, "the branch groups' weight gradients run on their own streams"
+    last_branch_call = max(i for i, l in enumerate(b) if l.startswith("call|") and l.split("|")[2] in used)
+    nxt = min(i for i, _ in buckets if i > last_branch_call)
+    for s_ in used:
+        k = s_[1:]
+        rec = [i for i, l in enumerate(b[:nxt]) if l.startswith(f"event|record|wgjoin{int(k) - 4}|")]
+        assert rec and rec[-1] > last_branch_call and any(l.startswith(f"event|wait|wgjoin{int(k) - 4}|") for l in b[rec[-1]:nxt])
 
 
 @pytest.mark.parametrize("which,N", [("D32_st3", 128), ("G32up-c", 128), ("G32up", 256), ("D32_st3@64", 64)])
