@@ -2784,6 +2784,20 @@ int cg_net_backward(void* net, void* stream, const float* x, const float* gy, in
                 pr->buckets.back().second += cnt;
             }
             if (!contiguous) { pr->buckets.clear(); pr->bucket_first.clear(); }
+            // buckets below 256 KB ride with the one the backward completes next (a collective costs a launch and a latency whatever it
+            // carries): G's last convolution (3 459 values) with the 256 -> 128 layer, D's head with Linear(20480, 256), D's first layers
+            // in one exchange at the end
+            constexpr long kMinBucket = 65536;
+            vector<std::pair<float*, long>> mb; vector<int> mf;
+            long accn = 0;
+            for (int j = (int)pr->buckets.size() - 1; j >= 0; --j) {
+                accn += pr->buckets[j].second;
+                if (accn >= kMinBucket || j == 0) {
+                    mb.insert(mb.begin(), {pr->buckets[j].first, accn}); mf.insert(mf.begin(), pr->bucket_first[j]);
+                    accn = 0;
+                }
+            }
+            pr->buckets.swap(mb); pr->bucket_first.swap(mf);
         }
         C.bucket_done_upto = (int)root.kids.size();
         Val go = pr->out; go.ext = EXT_GY; go.off = 0; go.p = nullptr; go.fmt = gy_fmt; go.blk = 0; go.gi = go.gc = 0;
