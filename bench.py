@@ -90,8 +90,16 @@ def step_work(cfg, N):
         skip += 20 / 36 * conv(64, 64, 3, s)
     if blocks(3, s // 2) >= 512:
         skip += 20 / 36 * 3 * conv(64, 64, 3, s // 2)
-    fd_x = 4.0 * (fd - skip) + fd          # two forward + two data-gradient passes without them, one weight-gradient pass in full
-    return dict(F_G=fg, F_D=fd, W=3.5 * fg + 5.0 * fd, W_executed=3.5 * fg_x + fd_x, D_skipped_per_pass=skip)
+    #   * round 6, weight gradient: position-major K tiles (igemm_tng_kernel mode 2) leave out the padding taps of every plain layer whose
+    #     padding share is >= 10 % when the batch is a multiple of 16: the 7x7 layer, the 5x5 layer at 16 x 16, the branch 3x3 layers at 8 x 8.
+    skip_w = 0.0
+    if N % 16 == 0:
+        for k, w, macs in ((7, s // 4, conv(128, 128, 7, s // 4)), (5, s // 2, conv(64, 128, 5, s // 2)), (3, s // 4, 3 * conv(64, 64, 3, s // 4)),
+                           (3, s // 2, 3 * conv(64, 64, 3, s // 2)), (3, s, conv(64, 64, 3, s))):
+            if pad_share(k, w) >= 0.10:
+                skip_w += pad_share(k, w) * macs
+    fd_x = 4.0 * (fd - skip) + (fd - skip_w)          # two forward + two data-gradient passes and one weight-gradient pass without them
+    return dict(F_G=fg, F_D=fd, W=3.5 * fg + 5.0 * fd, W_executed=3.5 * fg_x + fd_x, D_skipped_per_pass=skip, D_skipped_weight_gradient=skip_w)
 
 
 def time_kernel(fn, iters=20, warm=3):

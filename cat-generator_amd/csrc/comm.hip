@@ -96,15 +96,12 @@ bool serial_comms() {
     if (v < 0) { const char* e = getenv("CG_COMM_SERIAL"); v = (e && atoi(e) == 0) ? 0 : 1; }
     return v != 0;
 }
-// Exchanges of at most this many bytes run ON the compute stream (CG_COMM_INLINE_BYTES, default 16 KB, 0 = never): the sync-BN sums are
-// 2C fp64 values that the caller joins at once, so the side stream only added two cross-queue event hops to a latency-bound chain
-// (~50 us of stall per exchange around a 5 us kernel in the one-GPU dry run: profiles/r06_dp_dry_run.txt).  Gradient buckets (MBs, joined
-// later) keep the side stream.  The order of a communicator's collectives is the host's program order either way.
-size_t inline_bytes() {
-    static long v = -1;
-    if (v < 0) { const char* e = getenv("CG_COMM_INLINE_BYTES"); v = e ? atol(e) : 16384; if (v < 0) v = 0; }
-    return (size_t)v;
-}
+// Exchanges of at most 16 KB run ON the compute stream: the sync-BN sums are 2C fp64 values that the caller joins at once, so the side
+// stream only added two cross-queue event hops to a latency-bound chain (~50 us of stall per exchange around a 5 us kernel in the one-GPU
+// dry run, 6.03 -> 5.93 ms per step: profiles/r06_dp_dry_run.txt).  Gradient buckets (>= 256 KB, joined later) keep the side stream.  The
+// order of a communicator's collectives is the host's program order either way.
+constexpr size_t kInlineBytes = 16384;
+size_t inline_bytes() { return kInlineBytes; }
 int order_after_other_comm(Comm* c) {
     if (serial_comms() && g_last_comm && g_last_comm != c) CG_HIP(hipStreamWaitEvent(c->side, g_last_comm->join, 0));
     return 0;
@@ -180,7 +177,7 @@ int cg_comm_size(void* comm, int* nranks, int* rank) {
 }
 
 // In-place all-reduce of buf[0..count) over the communicator's ranks, enqueued on the communicator's side stream behind
-// everything `compute_stream` holds so far (on `compute_stream` itself when it is at most CG_COMM_INLINE_BYTES long).  dtype: 0 fp32, 1 fp64.  op: 0 sum, 1 average.  Returns at once; the result
+// everything `compute_stream` holds so far (on `compute_stream` itself when it is at most 16 KB long).  dtype: 0 fp32, 1 fp64.  op: 0 sum, 1 average.  Returns at once; the result
 // may be consumed on `compute_stream` only after cg_comm_wait(comm, compute_stream).
 int cg_comm_allreduce(void* comm, void* compute_stream, void* buf, size_t count, int dtype, int op) {
     CG_REQUIRE(comm && buf, "cg_comm_allreduce: null pointer");

@@ -2269,9 +2269,7 @@ static bool tn_pm_use(const Geom& g, bool image_major_ok) {
     const long thr = cg::opt(cg::OPT_PAD_SKIP);
     if (thr <= 0 || !cg::opt(cg::OPT_TN_GLDS)) return false;
     const int sh = tn_pm_share(g);
-    static const char* e = getenv("CG_TN_PM_THR");
-    const long t2 = e ? atol(e) : thr;
-    return sh >= 0 && (2 * sh >= t2 || !image_major_ok);
+    return sh >= 0 && (2 * sh >= thr || !image_major_ok);
 }
 
 template <int BM, int BN, int WM, int WN>

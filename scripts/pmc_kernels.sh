@@ -10,6 +10,9 @@ run k_conv1f python $ROOTD/scripts/kbench.py 128 --only conv1 --pass fwd
 run k_conv3 python $ROOTD/scripts/kbench.py 128 --only conv3
 run k_dconv2 python $ROOTD/scripts/kbench.py 128 --only dconv2
 run k_dconv2w python $ROOTD/scripts/kbench.py 128 --only dconv2,dbr16,b45,b4 --pass wgrad
+run k_b4w python $ROOTD/scripts/kbench.py 128 --only b4 --pass wgrad
+run k_b45w python $ROOTD/scripts/kbench.py 128 --only b45 --pass wgrad
+run k_head python $ROOTD/scripts/kbench.py 128 --only dhead
 run k_skinny python $ROOTD/scripts/kbench.py 128 --only gconv4,dconv1
 run k_c3 python $ROOTD/scripts/kbench.py 256 --only conv3 --pass fwd
 run k_c5 python $ROOTD/scripts/c5_wgrad.py
@@ -24,6 +27,9 @@ want = {"tn128x128": ("k_conv2", "igemm_tng_kernel<128, 128, 2, 2>", "kbench.py 
         "tn128x64_d_conv2_wgrad": ("k_dconv2", "igemm_tng_kernel<128, 64, 2, 2>", "kbench.py 128 --only dconv2"),
         "tn_d_wgrads": ("k_dconv2w", "igemm_tng_kernel<128, 64, 2, 2>", "kbench.py 128 --only dconv2,dbr16,b45,b4 --pass wgrad"),
         "tn128x128_d_wgrads": ("k_dconv2w", "igemm_tng_kernel<128, 128, 2, 2>", "kbench.py 128 --only dconv2,dbr16,b45,b4 --pass wgrad"),
+        "tn128x128_d_7x7_wgrad_position_major": ("k_b4w", "igemm_tng_kernel<128, 128, 2, 2>", "kbench.py 128 --only b4 --pass wgrad"),
+        "tn128x128_d_5x5_wgrad_position_major": ("k_b45w", "igemm_tng_kernel<128, 128, 2, 2>", "kbench.py 128 --only b45 --pass wgrad"),
+        "head_wgrad": ("k_head", "head_wgrad_k", "kbench.py 128 --only dhead"),
         "skinny_fwd": ("k_skinny", "skinny_mfma_fwd_k<3, 128>", "kbench.py 128 --only gconv4,dconv1"),
         "skinny_wgrad": ("k_skinny", "skinny_mfma_wgrad_k<3, 128>", "kbench.py 128 --only gconv4,dconv1"),
         "config3_wino_g16_bs256": ("k_c3", "wino_gemm_g_kernel<16, 16>", "kbench.py 256 --only conv3 --pass fwd"),
