@@ -44,16 +44,24 @@ extern "C" {
  * utils/nn_utils.lua:638-643). */
 int         cg_abi_version(void);
 const char* cg_last_error(void);
-/* Tunables of the kernel dispatch, named like the environment variables that set their defaults (round 6 adds CG_WINO3: 1 = fused-transform Winograd F(2x2,3x3) for plain 64 -> 64 plane 3x3 layers with >= 2 workgroups per CU, 2 = wherever the geometry fits, 0 = never; CG_SKINNY: 1 = the MFMA scatter-form kernels of csrc/skinny.hip, 2 = round 1's VALU kernels, 0 = the generic GEMM):
- * block tiles CG_NN_TILE / CG_TN_TILE (bm*1000+bn) and splits CG_NN_SPLITS / CG_TN_SPLITS / CG_SPLIT_TARGET / CG_SPLIT_MINK / CG_TN_SMAX /
- * CG_TN_TARGET; K step CG_GEMM_BK32 / CG_WINO_BK; CG_SKINNY; CG_EPILOGUE_STATS; CG_XCD_SWIZZLE (bits: 1 row ranges per XCD, 2 pixel chunks per XCD in the weight gradients, 4 weights-stationary
- * XCDs in the LDS-direct forward kernel; default 7); grid caps CG_COLREDUCE_WGS_PER_CU /
- * CG_EW_WGS_PER_CU; and how a K tile reaches the MFMAs: CG_NN_GLDS (0..3) / CG_TN_GLDS / CG_WINO_GLDS = LDS-direct loads (default)
- * or the register-staged kernels (0); CG_PAD_SKIP = least share (per cent) of zero-padding MACs from which a plain convolution runs with
- * position-major row tiles and skips them (0 = never; default 20: D32_st3's 7x7 layer at 8x8 - 38 % padding, models.lua:685 - but not its 5x5 layer at 16x16 with 14 %).  Removed after losing every A/B of rounds 2-4: the k-quad LDS layouts, loads two tiles ahead,
- * the 4-wave Winograd GEMM, the sampler's atomic backward as an option, CG_GEMM_SLOW.
- * value == -1 restores the default.  Results never depend on them beyond
- * fp32 re-association; the parity tests use them to run every compiled kernel variant against the oracle. */
+/* Tunables of the kernel dispatch, named like the environment variables that set their defaults (13 names; value == -1 restores the
+ * default).  Results never depend on them beyond fp32 re-association; the parity tests use them to run every compiled kernel variant
+ * against the oracle.
+ *   CG_NN_TILE / CG_TN_TILE (bm*1000+bn), CG_NN_SPLITS / CG_TN_SPLITS : block tile and split count of the forward (data-gradient) /
+ *       weight-gradient GEMMs, 0 = the plan's choice;
+ *   CG_GEMM_BK32, CG_WINO_BK : K step of the LDS-direct kernels;
+ *   CG_NN_GLDS (0..3) / CG_TN_GLDS / CG_WINO_GLDS : how a K tile reaches the MFMAs - LDS-direct loads (default) or register-staged (0);
+ *   CG_XCD_SWIZZLE : bits 1 row ranges per XCD, 2 pixel chunks per XCD in the weight gradients, 4 weights-stationary XCDs (default 7);
+ *   CG_SKINNY : 1 = the MFMA scatter-form kernels of csrc/skinny.hip for 3x3 layers with <= 3 planes on one side, 2 = round 1's VALU
+ *       kernels, 0 = the generic GEMM;
+ *   CG_WINO3 : 1 = fused-transform Winograd F(2x2,3x3) for plain 64 -> 64 plane 3x3 layers with >= 2 workgroups per CU, 2 = wherever the
+ *       geometry fits, 0 = never;
+ *   CG_PAD_SKIP : least share (per cent) of zero-padding MACs from which a plain convolution's forward / data gradient runs on
+ *       POSITION-MAJOR row tiles and does not issue them (default 20: D32_st3's 7x7 layer at 8x8 with 38 %, models.lua:685, not its 5x5
+ *       layer at 16x16 with 14 %).  The weight gradient (round 6: position-major K tiles, igemm_tng_kernel mode 2) takes HALF that share
+ *       (7x7, 5x5, the 3x3 layers at 8x8), and with any value > 0 the weight gradient of View -> Linear (an H x W kernel on the H x W map)
+ *       is one kernel straight into the canonical gradWeight (csrc/headwg.hip).  0 = image-major tiles everywhere.
+ * (CG_SPLIT_TARGET / _MINK, CG_TN_SMAX / _TARGET, CG_EPILOGUE_STATS, CG_COLREDUCE_WGS_PER_CU, CG_EW_WGS_PER_CU became constants in round 6.) */
 int cg_set_option(const char* name, long value);
 int cg_get_option(const char* name, long* value);
 int cg_device_count(int* count);
@@ -519,7 +527,9 @@ int cg_locnet_backward(void* stream, int ngroups, int n_per_group, const float* 
  *     never queue behind a gradient bucket.
  * A communicator owns one side HIP stream and two events: cg_comm_allreduce forks from `compute_stream` (everything
  * enqueued there so far is visible to the collective), runs the collective on the side stream and returns at once;
- * cg_comm_wait makes `compute_stream` wait (device-side) for everything enqueued on the communicator.
+ * cg_comm_wait makes `compute_stream` wait (device-side) for everything enqueued on the communicator.  An exchange of at most
+ * 16 KB (the sync-BN sums) runs on `compute_stream` itself - it is joined at once, the side stream would only add two event hops -
+ * and cg_comm_wait then has nothing to do.  Collectives of different communicators are ordered on the device.
  * Bootstrapping: rank 0 calls cg_comm_unique_id and ships the CG_COMM_ID_BYTES bytes to the other ranks by any host
  * channel (file, socket, MPI ...); every rank then calls cg_comm_init with its own GPU current (cg_set_device).
  * dtype: 0 fp32, 1 fp64.  op: 0 sum, 1 average.  *available == 0: librccl.so.1 could not be loaded. */
@@ -575,7 +585,9 @@ int cg_comm_sync(void* comm);
  *   the host); default cg_malloc-style memory owned by the net.
  * cg_net_set_dp: data parallelism: world size, sync-BN on/off, the two cg_comm_* communicators (sync-BN sums /
  *   gradient buckets; NULL: the host hook carries the exchange), bucket_overlap != 0: cg_net_backward starts the all-reduce
- *   (average) of each gradient bucket of the root nn.Sequential as soon as its backward is complete (join: cg_comm_wait).
+ *   (average) of each gradient bucket of the root nn.Sequential (a convolution / linear layer with the parameters up to the next one;
+ *   buckets below 256 KB ride with the next) once its backward is complete and the next sync-BN exchange in front of it has been
+ *   issued (join: cg_comm_wait).
  *   bucket_overlap & 2: BOTH transports - the communicator's collective, then the host hook on the same buffer (functional tests
  *   with single-rank communicators on one GPU: the cg_comm_* fork / join path runs, the cross-rank sum travels over the hook).
  * cg_net_set_hook: host transport for those exchanges when no communicator is set: hook(user, what, buf, count, dtype, stream),

@@ -55,16 +55,21 @@ def lin_case(name, N, i, o):
 
 
 def head_case(name, N, C, H, o):
-    """View(C*H*H) -> Linear on the NHWC map through the planned executor (an H x H convolution with a 1 x 1 grid): forward, and
-    backward = data gradient + weight gradient in one call (the wgrad column)."""
+    """View(C*H*H) -> Linear on the NHWC map the way the planned executor runs it (an H x H convolution with a 1 x 1 grid; the data
+    gradient as a linear layer on the [Cout][H*W*C] operand): forward and updateGradInput through the planned net, the weight gradient
+    through the convolution entry point the plan calls (cg_conv2d_wgrad with kH = H: headwg.hip)."""
     net = cg.nn.Sequential()
     net.add(cg.nn.View(C * H * H)); net.add(cg.nn.Linear(C * H * H, o))
     net.getParameters()
     x = cg.nn.as_nhwc(cg.Tensor(torch.rand(N * C * H * H, device="cuda") - 0.5, (N, C, H, H)))
     dy = cg.Tensor(torch.rand(N * o, device="cuda") - 0.5, (N, o))
     net.forward(x)
+    m = cg.nn.SpatialConvolution(C, o, H, H, 1, 1, 0)
+    dyc = cg.Tensor(dy.t, (N, o, 1, 1), "nhwc")
+    m.forward(x)
     flop = 2.0 * N * C * H * H * o
-    r = {"fwd": tk(lambda: net.forward(x)), "dgrad": float("inf"), "wgrad": tk(lambda: net.backward(x, dy))}
+    fns = {"fwd": lambda: net.forward(x), "dgrad": lambda: net.updateGradInput(x, dy), "wgrad": lambda: m.accGradParameters(x, dyc)}
+    r = {p: (tk(fns[p]) if PASS in (None, p) else float("inf")) for p in ("fwd", "dgrad", "wgrad")}
     return name, flop, r
 
 
@@ -90,7 +95,7 @@ def main():
                   lambda: conv_case("D.loc 3x3 64->16 @8^2", N, 64, 8, 16, 3, 0),
                   lambda: conv_case("D.loc 3x3 16->16 @16^2", N, 16, 16, 16, 3, 0),
                   # View(320*8*8) -> Linear(20480, 256) the way the planned executor runs it: an 8 x 8 convolution on the NHWC map, 1 x 1 grid
-                  lambda: conv_case("D.head View->Linear 20480->256", N, 320, 8, 256, 8, 0, pad=0)]
+                  lambda: head_case("D.head View->Linear 20480->256", N, 320, 8, 256)]
     named = {"conv3": lambda: conv_case("G.conv3 5x5 256->128 @16^2 ups", N, 256, 16, 128, 5, 1),
              "b4": lambda: conv_case("D.b4 7x7 128->128 @8^2", N, 128, 8, 128, 7, 0),
              "b45": lambda: conv_case("D.b4 5x5 64->128 @16^2", N, 64, 16, 128, 5, 0),
