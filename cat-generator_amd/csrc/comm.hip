@@ -83,7 +83,15 @@ struct Comm {
     hipEvent_t join = nullptr;      // side stream -> compute stream (last collective enqueued)
     int nranks = 1, rank = 0;
     bool pending = false;
+    hipStream_t last = nullptr;     // the stream this communicator's latest collective went to (`join` was recorded there)
 };
+// One communicator, several streams (the sync-BN sums of the two generator passes of cg_net_forward_pair run on two compute streams): the
+// next collective waits for the previous one's `join` whenever the stream changes, so that the communicator's collectives execute in the
+// host's program order on every rank whatever the library does about stream changes internally.
+int order_on_comm(Comm* c, hipStream_t s) {
+    if (c->last && c->last != s) CG_HIP(hipStreamWaitEvent(s, c->join, 0));
+    return 0;
+}
 
 // Collectives of DIFFERENT communicators on one device are ordered on the device: the side stream of the communicator that
 // launches next waits for the join event of the one that launched last.  Two RCCL kernels of different communicators can
@@ -186,18 +194,22 @@ int cg_comm_allreduce(void* comm, void* compute_stream, void* buf, size_t count,
     if (count == 0) return 0;
     hipStream_t cs = cg::S(compute_stream);
     if (count * (dtype == 0 ? 4 : 8) <= inline_bytes()) {
-        if (c->pending) { CG_HIP(hipStreamWaitEvent(cs, c->join, 0)); c->pending = false; }   // behind this communicator's side-stream work
+        if (order_on_comm(c, cs)) return 1;
+        c->pending = false;                                                                    // (that wait was the join of any side-stream work)
         if (serial_comms() && g_last_comm && g_last_comm != c) CG_HIP(hipStreamWaitEvent(cs, g_last_comm->join, 0));
         CG_NCCL(g_rccl.AllReduce(buf, buf, count, dtype == 0 ? ncclFloat32 : ncclFloat64, op == 0 ? ncclSum : ncclAvg, c->nccl, cs));
         CG_HIP(hipEventRecord(c->join, cs));   // what another communicator's next collective orders behind; cg_comm_wait has nothing to do
         g_last_comm = c;
+        c->last = cs;
         return 0;
     }
     CG_HIP(hipEventRecord(c->fork, cs));
     CG_HIP(hipStreamWaitEvent(c->side, c->fork, 0));
+    if (order_on_comm(c, c->side)) return 1;
     if (order_after_other_comm(c)) return 1;
     CG_NCCL(g_rccl.AllReduce(buf, buf, count, dtype == 0 ? ncclFloat32 : ncclFloat64, op == 0 ? ncclSum : ncclAvg, c->nccl, c->side));
     CG_HIP(hipEventRecord(c->join, c->side));
+    c->last = c->side;
     c->pending = true;
     g_last_comm = c;
     return 0;
@@ -213,9 +225,11 @@ int cg_comm_broadcast(void* comm, void* compute_stream, void* buf, size_t count,
     hipStream_t cs = cg::S(compute_stream);
     CG_HIP(hipEventRecord(c->fork, cs));
     CG_HIP(hipStreamWaitEvent(c->side, c->fork, 0));
+    if (order_on_comm(c, c->side)) return 1;
     if (order_after_other_comm(c)) return 1;
     CG_NCCL(g_rccl.Broadcast(buf, buf, count, dtype == 0 ? ncclFloat32 : ncclFloat64, root, c->nccl, c->side));
     CG_HIP(hipEventRecord(c->join, c->side));
+    c->last = c->side;
     c->pending = true;
     g_last_comm = c;
     return 0;
