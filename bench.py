@@ -292,6 +292,33 @@ def kernel_rooflines(cg, cfg, N):
                "dgrad_group_ms": 1e3 * tb, "dgrad_direct_kernel_ms": 1e3 * time_kernel(lambda: m.updateGradInput(xin, dy))},
               alg_bytes=4.0 * (px * 512 + 36 * 512 * 256 + 4 * px * 256))
     skinny()
+    # (6) round 6: D's 7x7 layer's weight gradient on position-major K tiles (models.lua:685; igemm_tng_kernel mode 2: the 38 % of the MACs that
+    #     multiply padding are not issued) and the View -> Linear head's in one kernel straight into gradWeight (models.lua:696-697; headwg.hip)
+    q = s // 4
+    m7, x7, dy7, _ = conv(128, 128, 7, q, N, 0)
+    t7 = time_kernel(lambda: m7.accGradParameters(x7, dy7))
+    d7 = 2.0 * N * q * q * 128 * 128 * 49
+    valid = sum(min(q - 1, v + 3) - max(0, v - 3) + 1 for v in range(q)) ** 2 / float(q * q * 49)
+    pm = N % 16 == 0 and (1.0 - valid) >= 0.10
+    entry("tn128x128_d_7x7_wgrad_position_major" if pm and cfg is CONFIGS[2] else None,
+          "igemm_tng_kernel<128,128,2,2> mode 2 + wgrad_reduce_small_kernel (gemm.hip; position-major K tiles)" if pm else "igemm_tng_kernel<128,128,2,2> + wgrad_reduce_small_kernel (gemm.hip)",
+          f"accGradParameters of conv7x7 128->128 @{q}x{q}, batch {N}: [6272 x {N * q * q}]^T.[{N * q * q} x 128], the valid positions of every tap only",
+          d7 * (valid if pm else 1.0), t7, d7, None, {"timed": "launch group (GEMM + reduction of the split partials)", "direct_count_frac": d7 / t7 / PEAK_FP32_MFMA},
+          alg_bytes=4.0 * (N * q * q * 256 + 49 * 128 * 128))
+    mh = cg.nn.SpatialConvolution(320, 256, q, q, 1, 1, 0)
+    xh = cg.Tensor(torch.rand(N * q * q * 320, device="cuda") - 0.5, (N, 320, q, q), "nhwc")
+    dyh = cg.Tensor(torch.rand(N * 256, device="cuda") - 0.5, (N, 256, 1, 1), "nhwc")
+    mh.forward(xh)
+    th = time_kernel(lambda: mh.accGradParameters(xh, dyh))
+    byh = 4.0 * (N * q * q * 320 + 2 * 256 * 320 * q * q + N * 256)
+    e = {"bound": "hbm", "kernel": "head_wgrad_k (headwg.hip; gradWeight[co][c][tap] += dy^T x in one kernel)",
+         "launch": f"accGradParameters of View -> Linear({320 * q * q}, 256), batch {N}", "launch_ms": 1e3 * th, "achieved": byh / th / 1e9,
+         "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": byh / th / PEAK_HBM, "traffic": None, "algorithmic_bytes_strict": byh,
+         "mfma_frac": 2.0 * N * 320 * q * q * 256 / th / PEAK_FP32_MFMA}
+    if pmc.get("head_wgrad") and cfg is CONFIGS[2]:
+        e["traffic"] = pmc["head_wgrad"].get("hbm_bytes_per_launch_corrected")
+        e["pmc_source"] = pmc["head_wgrad"].get("source")
+    out.append(e)
     return out
 
 

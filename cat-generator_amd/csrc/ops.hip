@@ -138,11 +138,6 @@ int queue_classify(hipStream_t ref) {     // fills qpool().cls[ref]; caller hold
     }
     (void)hipGetLastError();
     p.cls[ref] = c;
-    if (getenv("CG_QUEUE_DEBUG")) {
-        fprintf(stderr, "cg: hardware-queue classes of the %zu pool streams relative to stream %p:", c.size(), (void*)ref);
-        for (int v : c) fprintf(stderr, " %d", v);
-        fprintf(stderr, "\n");
-    }
     return 0;
 }
 
