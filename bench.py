@@ -305,20 +305,21 @@ def kernel_rooflines(cg, cfg, N):
           f"accGradParameters of conv7x7 128->128 @{q}x{q}, batch {N}: [6272 x {N * q * q}]^T.[{N * q * q} x 128], the valid positions of every tap only",
           d7 * (valid if pm else 1.0), t7, d7, None, {"timed": "launch group (GEMM + reduction of the split partials)", "direct_count_frac": d7 / t7 / PEAK_FP32_MFMA},
           alg_bytes=4.0 * (N * q * q * 256 + 49 * 128 * 128))
-    mh = cg.nn.SpatialConvolution(320, 256, q, q, 1, 1, 0)
-    xh = cg.Tensor(torch.rand(N * q * q * 320, device="cuda") - 0.5, (N, 320, q, q), "nhwc")
-    dyh = cg.Tensor(torch.rand(N * 256, device="cuda") - 0.5, (N, 256, 1, 1), "nhwc")
-    mh.forward(xh)
-    th = time_kernel(lambda: mh.accGradParameters(xh, dyh))
-    byh = 4.0 * (N * q * q * 320 + 2 * 256 * 320 * q * q + N * 256)
-    e = {"bound": "hbm", "kernel": "head_wgrad_k (headwg.hip; gradWeight[co][c][tap] += dy^T x in one kernel)",
-         "launch": f"accGradParameters of View -> Linear({320 * q * q}, 256), batch {N}", "launch_ms": 1e3 * th, "achieved": byh / th / 1e9,
-         "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": byh / th / PEAK_HBM, "traffic": None, "algorithmic_bytes_strict": byh,
-         "mfma_frac": 2.0 * N * 320 * q * q * 256 / th / PEAK_FP32_MFMA}
-    if pmc.get("head_wgrad") and cfg is CONFIGS[2]:
-        e["traffic"] = pmc["head_wgrad"].get("hbm_bytes_per_launch_corrected")
-        e["pmc_source"] = pmc["head_wgrad"].get("source")
-    out.append(e)
+    if q * q <= 64:      # the planned executor runs View -> Linear as an H x W convolution up to 64 positions (csrc/net.hip, fwd_view_gemm)
+        mh = cg.nn.SpatialConvolution(320, 256, q, q, 1, 1, 0)
+        xh = cg.Tensor(torch.rand(N * q * q * 320, device="cuda") - 0.5, (N, 320, q, q), "nhwc")
+        dyh = cg.Tensor(torch.rand(N * 256, device="cuda") - 0.5, (N, 256, 1, 1), "nhwc")
+        mh.forward(xh)
+        th = time_kernel(lambda: mh.accGradParameters(xh, dyh))
+        byh = 4.0 * (N * q * q * 320 + 2 * 256 * 320 * q * q + N * 256)
+        e = {"bound": "hbm", "kernel": "head_wgrad_k (headwg.hip; gradWeight[co][c][tap] += dy^T x in one kernel)",
+             "launch": f"accGradParameters of View -> Linear({320 * q * q}, 256), batch {N}", "launch_ms": 1e3 * th, "achieved": byh / th / 1e9,
+             "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": byh / th / PEAK_HBM, "traffic": None, "algorithmic_bytes_strict": byh,
+             "mfma_frac": 2.0 * N * 320 * q * q * 256 / th / PEAK_FP32_MFMA}
+        if pmc.get("head_wgrad") and cfg is CONFIGS[2]:
+            e["traffic"] = pmc["head_wgrad"].get("hbm_bytes_per_launch_corrected")
+            e["pmc_source"] = pmc["head_wgrad"].get("source")
+        out.append(e)
     return out
 
 
