@@ -142,5 +142,17 @@ def test_workspace_query_covers_the_position_major_plan_and_its_fallback(cg):
         assert L.conv2d_workspace_bytes(*d77) == 4 * 128 * 64 * 128 * 4       # an interior tile's 49 taps in four units
         assert L.conv2d_workspace_bytes(*d77) >= image_major
         assert L.conv2d_workspace_bytes(*d55) == 0                            # stays image-major, unsplit: direct output
+        # round 6, the weight gradient (igemm_tng_kernel mode 2: position-major K tiles from HALF the share, any split count): 49 row tiles x
+        # 15 splits fill three workgroups per CU, 13 x 59 for the 5x5 layer; the image-major plans (16 / 64 power-of-two splits) are the
+        # fallback for unaligned operands, and the query covers both
+        plane = lambda taps, cin, cout: (taps * cin + 1) * cout * 4
+        assert L.conv2d_wgrad_workspace_bytes(*d77) == 16 * plane(49, 128, 128)
+        assert L.conv2d_wgrad_workspace_bytes(*d55) == 64 * plane(25, 64, 128)
+        L.set_option(b"CG_TN_SPLITS", 40)                                     # forced: position-major takes any count, image-major 8192 / 40 -> 39
+        assert L.conv2d_wgrad_workspace_bytes(*d77) == 40 * plane(49, 128, 128)
+        L.set_option(b"CG_TN_SPLITS", -1)
+        L.set_option(b"CG_PAD_SKIP", 0)
+        assert L.conv2d_wgrad_workspace_bytes(*d77) == 16 * plane(49, 128, 128)
     finally:
         L.set_option(b"CG_PAD_SKIP", -1)
+        L.set_option(b"CG_TN_SPLITS", -1)
