@@ -2371,15 +2371,13 @@ static NNPlan plan_nn(const Geom& g, int ngroups, bool allow_pm = true) {
     p.pm = false;
     const long valid = (allow_pm && ngroups == 1 && g.Cin % 32 == 0) ? pad_skip_valid(g, p.tc) : 0;
     if (valid > 0) {
-        // position-major tiles (Geom::pmn): K units of equal length cut out of every tile's VALID taps, about one workgroup per CU in
-        // total, a unit not shorter than 8 K tiles; gridDim.y = the units of an interior tile.  (Units per CU, D's 7x7 layer at batch
-        // 128, alone: 1 -> 0.136 ms as image-major, 2 -> 0.113, 3 -> 0.130; in the step the short units cost more in partial sums
-        // than the launch gains - config #2 5.92 / 5.95 ms at 1.5 / 2 against 5.93 image-major, config #3 9.13 / 9.16 at 1 / 2
-        // against 9.19: profiles/r05_sweeps.txt)
-        const long tiles_per_pos = (long)(g.M / (g.Hg * g.Wg) / 64) * (g.Cout / p.tc.bn);
-        const long ksteps = valid * g.Cin / 32 * tiles_per_pos;                       // K tiles of the whole launch
-        long unit = cg::cdiv(ksteps, cg::kNumCU);
-        unit = std::max<long>(unit, 8);
+        // position-major tiles (Geom::pmn): K units of equal length cut out of every tile's VALID taps; gridDim.y = the units of an interior
+        // tile.  Round 5 aimed at one unit per CU (61 K tiles for D's 7x7 layer at batch 128: 312 workgroups, 1.2 per CU, the short last
+        // units of every tile in the way); round 6 measured the unit length itself: 28 K tiles (592 workgroups) run the layer in 96 us
+        // alone against 122 (61), 109 (49 / 33 / 25 / 20), 123 (40), and the step at 5.635 / 11.27 / 8.33 ms (configs 2 / 5 / 3) against
+        // 5.678 / 11.36 / 8.42; 20 and 33 sit between (profiles/r06_sweeps.txt)
+        constexpr long kPmUnit = 28;
+        long unit = kPmUnit;
         const int forced = (int)cg::opt(cg::OPT_NN_SPLITS);
         if (forced > 0) unit = cg::cdiv(g.Ktot / 32, forced);
         p.kchunk = (int)std::min<long>(unit * 32, g.Ktot);

@@ -139,7 +139,7 @@ def test_workspace_query_covers_the_position_major_plan_and_its_fallback(cg):
         image_major = L.conv2d_workspace_bytes(*d77)
         assert image_major == 2 * 128 * 64 * 128 * 4                          # two K splits of [8192 x 128] partial sums
         L.set_option(b"CG_PAD_SKIP", 20)
-        assert L.conv2d_workspace_bytes(*d77) == 4 * 128 * 64 * 128 * 4       # an interior tile's 49 taps in four units
+        assert L.conv2d_workspace_bytes(*d77) == 7 * 128 * 64 * 128 * 4       # an interior tile's 49 taps in seven units of 28 K tiles
         assert L.conv2d_workspace_bytes(*d77) >= image_major
         assert L.conv2d_workspace_bytes(*d55) == 0                            # stays image-major, unsplit: direct output
         # round 6, the weight gradient (igemm_tng_kernel mode 2: position-major K tiles from HALF the share, any split count): 49 row tiles x
