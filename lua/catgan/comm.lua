@@ -8,6 +8,10 @@ HIP stream with event fork / join).  One LuaJIT process per GPU (SURVEY.md 8e); 
                                                     -- a file a previous run left behind is never read
    -- in fevalD / fevalG_on_D, right after MODEL_X:backward and BEFORE the penalty / clamp lines (adversarial.lua:89-112):
    comm.allreduce_mean(GRAD_PARAMETERS_D)           -- or comm.allreduce_mean_async(...) ... comm.wait()
+   -- or, with the planned executor, in buckets that travel under the backward itself (both nets since round 6: Linear(20480, 256), 79 % of
+   -- D's gradient, is the first bucket D's backward completes): set MODEL_X._bucket_overlap = true before the first pass, then
+   --    MODEL_X:backward(input, gradOutput)
+   --    if MODEL_X:finishBuckets(comm) == 0 then comm.allreduce_mean(GRAD_PARAMETERS_X) end   -- 0: no contiguous buckets
 installs nn.sync_bn so that nn.SpatialBatchNormalization all-reduces its fp64 sums (sync-BN). ]]
 local ffi = require 'ffi'
 local abi = require 'catgan.ffi'

@@ -215,6 +215,12 @@ function Sequential:pairJoin()
    self.output = self._pnet:pair_join()
    return self.output
 end
+-- data parallelism: join the gradient buckets the planned backward started (self._bucket_overlap = true before the first pass); 0 = none
+-- travelled (per-module walk, or parameters that are not contiguous) and the host all-reduces the whole vector itself
+function Sequential:finishBuckets(comm)
+   if not (self._pnet and self._planned_last) then return 0 end
+   return self._pnet:finish_buckets(comm)
+end
 local function planned_backward(self, gradOutput, scale, acc)
    local gi = self._pnet:backward(to_device(gradOutput):materialise(), acc, scale)
    local first = self.modules[1]
