@@ -438,6 +438,7 @@ def main():
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-reference-order", action="store_true", help="skip the same-run timing of the reference's order of calls (kernel traces: the "
                     "trace tools analyse the LAST steps of the process)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the 1500-step sustained-rate leg of the default one-GPU line")
     ap.add_argument("--no-dp-dry-run", action="store_true", help="skip the data-parallel dry run of the default one-GPU line")
     ap.add_argument("--dp-dry-run", type=int, nargs="?", const=8, default=None, metavar="R",
                     help="one GPU: also time the per-rank step of an R-rank data-parallel job (sync-BN, gradient buckets, D's all-reduce under the "
@@ -572,12 +573,23 @@ def main():
                 }
             if args.config == 2:
                 res["roofline"]["step"].update({
-                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.86, "D forward": 0.85, "D backward + Adam": 1.15,
-                                         "D forward + data gradient (G step)": 1.09, "generator backward + Adam": 1.69},
+                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.88, "D forward": 0.83, "D backward + Adam": 1.14,
+                                         "D forward + data gradient (G step)": 1.07, "generator backward + Adam": 1.83},
                     "phases_note": "the generator's forward on N for the G step runs BESIDE the first two phases on its own hardware queue (cg_net_forward_pair), "
                                    "so it has no interval of its own and the intervals it shares are longer than they would be alone (0.55 / 0.53 ms in the reference order)",
                     "phases_source": "profiles/r06_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
-                                     "launches, 5.70 ms under the tracer; committed numbers, not measured in this run)"})
+                                     "launches, 5.73 ms under the tracer; committed numbers, not measured in this run)"})
+        # sustained rate: the same step for ~8 s (the timed region above lasts 0.1-0.3 s: a clock / thermal steady state does not show in it,
+        # and a monitor that samples the chip every few seconds never sees it busy)
+        if world == 1 and launch == "eager" and args.config == 2 and not args.no_sustained and not args.batch_per_gpu:
+            try:
+                n_sus = 1500
+                blocks = [time_steps(cg, S, data, N, n_sus // 5, 0) for _ in range(5)]
+                sms = sum(blocks) / len(blocks)
+                res["config"]["sustained"] = {"steps": n_sus, "ms_per_step": sms, "images_per_sec": 1e3 * N / sms, "over_headline": sms / ms,
+                                              "ms_per_step_blocks_of_300": blocks}
+            except Exception as e:                # noqa: BLE001
+                res["config"]["sustained"] = {"error": str(e)[:160]}
         # the reference's ORDER of calls (adversarial.lua:232-233 ... :185: the G-step's generator forward after D's update) in the same run:
         # what an unchanged adversarial.lua gets from the drop-in host; the headline issues the two generator forwards as one
         # cg_net_forward_pair (MODEL_G:forwardPair - six lines of adversarial.lua)

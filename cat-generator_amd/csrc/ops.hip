@@ -1106,16 +1106,23 @@ __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restric
         }
     }
     __syncthreads();
-    for (int c = tid; c < NC; c += 256) {                    // ... so sort every (short) bucket by output-pixel index
-        const int b = cstart[c], e = b + ccnt[c];
-        for (int i = b + 1; i < e; ++i) {
+    // ... so order every bucket by output-pixel index: an element's place is the number of smaller indices in its bucket (all threads, one
+    // element each - a bucket is short unless the transformer collapses, and then P^2 / 256 broadcast reads per thread still bound it;
+    // round 6: the insertion sort a single thread ran per bucket took 2-8 ms when every output pixel fell into one cell)
+    int* sorted = ccnt + NC;                                 // [P]
+    {
+        const int placed = cstart[NC];
+        for (int i = tid; i < placed; i += 256) {
             const int v = list[i];
-            int j = i - 1;
-            while (j >= b && list[j] > v) { list[j + 1] = list[j]; --j; }
-            list[j + 1] = v;
+            const int c = (ty0[v] + 1) * CW + tx0[v] + 1;
+            const int b = cstart[c], e = b + ccnt[c];
+            int rank = 0;
+            for (int j = b; j < e; ++j) rank += list[j] < v ? 1 : 0;
+            sorted[b + rank] = v;
         }
     }
     __syncthreads();
+    list = sorted;
     const float* gsample = gout + n * (long)P * C;
     const float* isample = img + (n % Nimg) * (long)Q * C;
     const int sub = tid & (G - 1), grp = tid / G, ngrp = 256 / G;
@@ -1157,6 +1164,9 @@ __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restric
         }
     }
     // ---- (B) image gradient of this workgroup's source pixels
+    constexpr int kHeavy = 64;                               // more taps than this on one source pixel: the whole workgroup sums them (below)
+    __shared__ float coop[256 * CACC * VW];
+    bool any_heavy = false;
     for (int j0 = 0; j0 < S; j0 += ngrp) {
         const int q = chunk * S + j0 + grp;
         if (!(j0 + grp < S && q < Q)) continue;
@@ -1168,6 +1178,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restric
         const int s2 = cstart[c00 + CW], n2 = ccnt[c00 + CW];
         const int s3 = cstart[c00 + CW + 1], n3 = ccnt[c00 + CW + 1];
         const int e1 = n0, e2 = n0 + n1, e3 = n0 + n1 + n2, total = e3 + n3;
+        if (total > kHeavy) { any_heavy = true; continue; }
         typedef BVec<VW> V;
         typename V::T acc[CACC];
 #pragma unroll
@@ -1205,6 +1216,74 @@ __global__ __launch_bounds__(256) void bilinear_bwd_det_k(const float* __restric
         for (int k = 0; k < CACC; ++k) {
             const int c = (sub + G * k) * VW;
             if (c < C) V::st(gimg + (n * Q + q) * C + c, acc[k]);
+        }
+    }
+    // A source pixel under a collapsed transformer (scale -> 0: every output pixel samples the same cell) collects up to P taps; one lane
+    // group summing them in a row is what made this kernel 75-750x slower there.  Such pixels are summed by the WHOLE workgroup: lane group r
+    // takes the taps r, r + ngrp, ... in bucket order, the ngrp partial sums are added in group order - a fixed order again, so the result
+    // is reproducible (it differs from the one-group order by fp32 re-association only, and only where more than kHeavy taps meet).
+    if (__syncthreads_or(any_heavy ? 1 : 0)) {
+        typedef BVec<VW> V;
+        for (int j = 0; j < S; ++j) {
+            const int q = chunk * S + j;
+            if (q >= Q) break;
+            const int y = q / Wi, x = q - y * Wi;
+            const int c00 = y * CW + x;
+            const int s0 = cstart[c00], n0 = ccnt[c00];
+            const int s1 = cstart[c00 + 1], n1 = ccnt[c00 + 1];
+            const int s2 = cstart[c00 + CW], n2 = ccnt[c00 + CW];
+            const int s3 = cstart[c00 + CW + 1], n3 = ccnt[c00 + CW + 1];
+            const int e1 = n0, e2 = n0 + n1, e3 = n0 + n1 + n2, total = e3 + n3;
+            if (total <= kHeavy) continue;                // uniform over the workgroup
+            typename V::T acc[CACC];
+#pragma unroll
+            for (int k = 0; k < CACC; ++k) acc[k] = V::zero();
+            for (int i0 = grp; i0 < total; i0 += 2 * ngrp) {     // two loads in flight per lane group
+                int ph[2];
+                float w[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = i0 + u * ngrp;
+                    if (i < total) {
+                        const int e = i < e1 ? s0 + i : (i < e2 ? s1 + i - e1 : (i < e3 ? s2 + i - e2 : s3 + i - e3));
+                        ph[u] = list[e];
+                        const float wy = (y == ty0[ph[u]]) ? twy[ph[u]] : 1.f - twy[ph[u]];
+                        const float wx = (x == tx0[ph[u]]) ? twx[ph[u]] : 1.f - twx[ph[u]];
+                        w[u] = wx * wy;
+                    } else {
+                        ph[u] = ph[0]; w[u] = 0.f;
+                    }
+                }
+                typename V::T g[2][CACC];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int k = 0; k < CACC; ++k) {
+                        const int c = (sub + G * k) * VW;
+                        g[u][k] = c < C ? V::ld(gsample + (long)ph[u] * C + c) : V::zero();
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int k = 0; k < CACC; ++k) V::fma(acc[k], w[u], g[u][k]);
+            }
+            __syncthreads();                               // the previous heavy pixel's partial sums have been read
+#pragma unroll
+            for (int k = 0; k < CACC; ++k) V::st(coop + (tid * CACC + k) * VW, acc[k]);
+            __syncthreads();
+            if (grp == 0) {
+                typename V::T tot[CACC];
+#pragma unroll
+                for (int k = 0; k < CACC; ++k) tot[k] = V::zero();
+                for (int r = 0; r < ngrp; ++r)
+#pragma unroll
+                    for (int k = 0; k < CACC; ++k) V::fma(tot[k], 1.f, V::ld(coop + ((r * G + sub) * CACC + k) * VW));
+#pragma unroll
+                for (int k = 0; k < CACC; ++k) {
+                    const int c = (sub + G * k) * VW;
+                    if (c < C) V::st(gimg + (n * Q + q) * C + c, tot[k]);
+                }
+            }
         }
     }
 }
@@ -1696,8 +1775,8 @@ int sampler_forward(void* stream, const float* img, const float* grid, float* ou
 int sampler_backward(void* stream, const float* img, const float* grid, const float* gout, float* gimg, float* ggrid, int N, int Nimg,
                      int Hi, int Wi, int C, int Ho, int Wo) {
     const long P = (long)Ho * Wo, Q = (long)Hi * Wi;
-    const size_t shb = ((size_t)5 * P + 2 * ((size_t)(Hi + 1) * (Wi + 1)) + 1) * 4;
-    if (shb <= 150 * 1024 && C <= 256 && N > 0) {   // deterministic gather form
+    const size_t shb = ((size_t)6 * P + 2 * ((size_t)(Hi + 1) * (Wi + 1)) + 1) * 4;
+    if (shb <= 140 * 1024 && C <= 256 && N > 0) {   // deterministic gather form
         const bool v4 = C % 4 == 0 && al16(img) && al16(gout) && al16(gimg);
         const int units = v4 ? C / 4 : C;                  // lane-sized channel units per pixel
         int G = 4;

@@ -17,7 +17,7 @@ t 300 "python bench.py --config 5 --no-dp-dry-run 2>>$E/${R}_bench_err.log" > $E
 echo "== traced step"; bash scripts/step_trace.sh ${R}ev > /dev/null 2>&1
 for f in eager_breakdown eager_timeline small_kernel_chains; do mv gpurun_out/${R}ev_$f.txt $E/${R}_$f.txt; done; head -3 $E/${R}_eager_breakdown.txt | cut -c1-300
 echo "== rocprofv3 --kernel-trace --stats of the bench command"
-(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOTD/gpurun_out/prof_stats" -o st -- bash -c "cd $ROOTD && exec python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-other-configs --no-dp-dry-run --no-reference-order" > "$ROOTD/$E/${R}_rocprof_stats_bench_line.json" 2>/dev/null < /dev/null)
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOTD/gpurun_out/prof_stats" -o st -- bash -c "cd $ROOTD && exec python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-other-configs --no-dp-dry-run --no-reference-order --no-sustained" > "$ROOTD/$E/${R}_rocprof_stats_bench_line.json" 2>/dev/null < /dev/null)
 f=$(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -45 "$f" > $E/${R}_rocprof_kernel_stats.csv
 g=$(find gpurun_out/prof_stats -name "*kernel_trace.csv" | head -1); [ -n "$g" ] && MINL=15 python scripts/trace_by_grid.py "$g" igemm_tng wino3 skinny igemm_nng wino_gemm_g > $E/${R}_roofline_launch_durations.txt
 rm -rf gpurun_out/prof_stats; head -8 $E/${R}_rocprof_kernel_stats.csv | cut -c1-160

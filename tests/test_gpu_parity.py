@@ -364,6 +364,43 @@ def test_shared_image_sampler_equals_one_launch_per_branch(cg, C, H):
         close(gg1.numpy(), gg_o, K=C, tol=2e-5, what="sampler gradGrid")
 
 
+@pytest.mark.parametrize("C,H", [(64, 16), (3, 32)])
+@pytest.mark.parametrize("scale", [0.0, 0.01, 0.1])
+def test_sampler_backward_under_a_collapsed_transformer(cg, C, H, scale):
+    """A localisation net that collapses (scale -> 0) maps every output pixel into ONE source cell: up to H*W taps in one bucket of the
+    deterministic gather backward (csrc/ops.hip, bilinear_bwd_det_k).  Round 6 found the step 40 % slower for 25 iterations of a long run
+    because of it (a single thread insertion-sorted the bucket, one lane group summed it: 2-8 ms instead of 11-28 us): buckets are now
+    ordered by rank in parallel and pixels with more than 64 taps are summed by the whole workgroup in a fixed order.  Against the oracle's
+    scatter, twice (bit-equal: the order is fixed), and bounded in time."""
+    import time
+    rs = np.random.RandomState(7)
+    N = 16
+    img = rs.randn(N, H, H, C).astype(f32)
+    ys, xs = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, H), indexing="ij")
+    grid = (np.stack([ys, xs], -1)[None].repeat(N, 0) * scale + rs.uniform(-0.3, 0.3, (N, 1, 1, 2))).astype(f32)
+    gout = rs.randn(N, H, H, C).astype(f32)
+    L, st = cg.lib(), cg.tensor.stream()
+    T = lambda a: cg.Tensor.from_numpy(a, "plain")
+    ti, tg, to = T(img), T(grid), T(gout)
+    runs = []
+    for _ in range(2):
+        gi, gg = cg.Tensor.empty((N, H, H, C)), cg.Tensor.empty((N, H, H, 2))
+        L.bilinear_sampler_backward(st, ti.ptr, tg.ptr, to.ptr, gi.ptr, gg.ptr, N, H, H, C, H, H)
+        runs.append((gi.numpy().copy(), gg.numpy().copy()))
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    gi_o, gg_o = O.bilinear_backward(img, grid, gout)
+    close(runs[0][0], gi_o, K=H * H, tol=1e-5, what="sampler gradInput, collapsed grid")       # up to H*W taps meet in one pixel
+    close(runs[0][1], gg_o, K=C, tol=2e-5, what="sampler gradGrid, collapsed grid")
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        L.bilinear_sampler_backward(st, ti.ptr, tg.ptr, to.ptr, gi.ptr, gg.ptr, N, H, H, C, H, H)
+    torch.cuda.synchronize()
+    assert (time.perf_counter() - t0) / 5 < 1.5e-3, "the collapsed-grid backward is slow again"
+
+
 def test_adam_and_fused_penalty_clamp(cg):
     rs = np.random.RandomState(6)
     n = 100003
