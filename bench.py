@@ -573,12 +573,12 @@ def main():
                 }
             if args.config == 2:
                 res["roofline"]["step"].update({
-                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.88, "D forward": 0.83, "D backward + Adam": 1.14,
-                                         "D forward + data gradient (G step)": 1.07, "generator backward + Adam": 1.83},
+                    "phases_ms_traced": {"generator forward on N/2 (fake images)": 0.92, "D forward": 0.85, "D backward + Adam": 1.13,
+                                         "D forward + data gradient (G step)": 1.07, "generator backward + Adam": 1.84},
                     "phases_note": "the generator's forward on N for the G step runs BESIDE the first two phases on its own hardware queue (cg_net_forward_pair), "
                                    "so it has no interval of its own and the intervals it shares are longer than they would be alone (0.55 / 0.53 ms in the reference order)",
                     "phases_source": "profiles/r06_eager_breakdown.txt (the last of three traced steps of `rocprofv3 --kernel-trace -- python bench.py`, eager "
-                                     "launches, 5.73 ms under the tracer; committed numbers, not measured in this run)"})
+                                     "launches, 5.79 ms under the tracer; committed numbers, not measured in this run)"})
         # sustained rate: the same step for ~8 s (the timed region above lasts 0.1-0.3 s: a clock / thermal steady state does not show in it,
         # and a monitor that samples the chip every few seconds never sees it busy)
         if world == 1 and launch == "eager" and args.config == 2 and not args.no_sustained and not args.batch_per_gpu:
