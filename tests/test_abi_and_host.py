@@ -156,3 +156,28 @@ def test_workspace_query_covers_the_position_major_plan_and_its_fallback(cg):
     finally:
         L.set_option(b"CG_PAD_SKIP", -1)
         L.set_option(b"CG_TN_SPLITS", -1)
+
+
+def test_bench_work_model_matches_the_survey_and_the_dispatch():
+    """bench.py::step_work is the numerator of every utilisation figure in the bench line.  Direct count: SURVEY.md 8d (F_G = 2592.4,
+    F_D = 374.0 MFLOP per image, W = 3.5 F_G + 5 F_D = 10.94 GFLOP per image at configs[1]).  Executed count: what the dispatch issues -
+    phase folding and the Winograd forms in G, and in D the padding taps the position-major kernels leave out (forward / data gradient:
+    the 7x7 layer; weight gradient: every plain layer with >= 10 % padding) and the fused-Winograd layers' 20 / 36."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    w2 = B.step_work(B.CONFIGS[2], 128)
+    assert abs(w2["F_G"] / 1e6 - 2592.4) < 0.1 and abs(w2["F_D"] / 1e6 - 374.0) < 0.1
+    assert abs(w2["W"] / 1e9 - 10.943) < 0.001
+    assert abs(w2["W_executed"] / 1e9 - 3.507) < 0.001
+    conv = lambda ci, co, k, ho: 2.0 * ci * co * k * k * ho * ho
+    share = lambda k, w: 1.0 - (sum(min(w - 1, x + k // 2) - max(0, x - k // 2) + 1 for x in range(w)) / (w * k)) ** 2
+    assert abs(share(7, 8) - 0.383) < 1e-3 and abs(share(5, 16) - 0.144) < 1e-3 and abs(share(3, 8) - 0.160) < 1e-3 and share(3, 16) < 0.10
+    fwd_skip = share(7, 8) * conv(128, 128, 7, 8) + 20 / 36 * (conv(64, 64, 3, 32) + 3 * conv(64, 64, 3, 16))
+    wg_skip = share(7, 8) * conv(128, 128, 7, 8) + share(5, 16) * conv(64, 128, 5, 16) + share(3, 8) * 3 * conv(64, 64, 3, 8)
+    assert abs(w2["D_skipped_per_pass"] - fwd_skip) < 1.0 and abs(w2["D_skipped_weight_gradient"] - wg_skip) < 1.0
+    for num, N in ((2, 128), (3, 256), (5, 64), (2, 16)):
+        w = B.step_work(B.CONFIGS[num], N)
+        assert 0 < w["W_executed"] < w["W"] and w["D_skipped_per_pass"] < w["F_D"] and w["D_skipped_weight_gradient"] < w["F_D"]
+    assert B.step_work(B.CONFIGS[2], 8)["D_skipped_weight_gradient"] == 0          # batch 8: no 16-image K tiles, nothing is skipped
