@@ -9,12 +9,14 @@ sys.path.insert(0, ROOT)
 cg = importlib.import_module("cat-generator_amd")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 cg.manual_seed(1)
-dims = (3, 32, 32)
-G, D = cg.models.create_G(dims, 100), cg.models.create_D(dims)
-S = cg.adversarial.State(dict(batchSize=128, seed=1), G, D)
+CONFIG = int(os.environ.get("CONFIG", "2"))             # BASELINE configs: 2 = G32up-c RGB batch 128, 3 = G32up grayscale batch 256, 5 = 64x64 RGB batch 64
+dims, NB = {2: ((3, 32, 32), 128), 3: ((1, 32, 32), 256), 5: ((3, 64, 64), 64)}[CONFIG]
+G = cg.models.create_G_decoder_upsampling32(dims, 100) if CONFIG == 3 else cg.models.create_G(dims, 100)
+D = cg.models.create_D(dims)
+S = cg.adversarial.State(dict(batchSize=NB, seed=1), G, D)
 data = cg.adversarial.TrainData(np.random.RandomState(100).rand(512, *dims).astype(np.float32))
 for _ in range(10):
-    cg.adversarial.iteration(S, data, 128)
+    cg.adversarial.iteration(S, data, NB)
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
 host = np.zeros(steps + 1)
@@ -24,7 +26,7 @@ K = int(os.environ.get("IN_FLIGHT", "0"))      # experiment: the host waits for 
 for i in range(steps):
     if K and i >= K:
         ev[i + 1 - K].synchronize()
-    cg.adversarial.iteration(S, data, 128)
+    cg.adversarial.iteration(S, data, NB)
     ev[i + 1].record()
     host[i + 1] = time.perf_counter() - t0
 torch.cuda.synchronize()
@@ -45,7 +47,7 @@ if len(sys.argv) > 2:      # second argument: profile the host over the iteratio
     for i in range(steps):
         if i == a:
             pr = cProfile.Profile(); pr.enable()
-        cg.adversarial.iteration(S, data, 128)
+        cg.adversarial.iteration(S, data, NB)
         if i == b - 1:
             pr.disable()
             pstats.Stats(pr).sort_stats("tottime").print_stats(14)
